@@ -1,0 +1,512 @@
+"""CPU oracle: NumPy restatement of RAiDER's tropospheric-delay hot path.
+
+*** TEST INFRASTRUCTURE - NOT PART OF THE PRODUCT. ***
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import this module,
+and only as the checker / reported baseline.  The product package `raider_amd` never imports it and
+fails loudly when its HIP library is missing.
+
+Parity status
+-------------
+Pinned against the reference itself: `oracle/refharness/gen_golden.py` imports the unmodified
+reference from /root/reference (in the build container), runs its `_build_cube`,
+`_build_cube_ray`, `build_ray`, `getTopOfAtmosphere`, `inc_hd_to_enu`, `enu2ecef`,
+`getZenithLookVecs`, `Conventional.__call__` arithmetic, the native `interpolate`,
+`interpolate_along_axis` and `makePoints*D` on seeded inputs and commits inputs+outputs under
+tests/golden/*.npz; `tests/test_oracle_golden.py` checks every function below against them.
+UNPINNED (stated in DESIGN.md): the WGS84<->ECEF arithmetic itself.  The reference calls
+pyproj/PROJ (`utilFcns.py:77-88`, `delay.py:238,252-253`), which is not installed in this image and
+is not under /root/reference; the formulas in `ecef2lla`/`lla2ecef` restate PROJ's published
+`cart` conversion (PROJ src/conversions/cart.cpp) and are pinned only by the three exact ECEF
+values of `test/test_delayFcns.py:86-99` and round trips.  isce3 look-vector generation is out of
+scope (look vectors are an input array).
+
+Every function cites the reference file:line (relative to /root/reference/) it follows.
+"""
+import numpy as np
+
+# ----------------------------------------------------------------------------------------------
+# constants  (tools/RAiDER/constants.py:12-23)
+# ----------------------------------------------------------------------------------------------
+_ZMIN = np.float64(-100)
+_ZREF = np.float64(26000)
+_STEP = np.float64(15.0)
+R_EARTH_MAX_WGS84 = 6378137
+R_EARTH_MIN_WGS84 = 6356752
+_CUBE_SPACING_IN_M = float(2000)
+
+# WGS84 ellipsoid as PROJ derives it from (a, rf)
+WGS84_A = 6378137.0
+WGS84_RF = 298.257223563
+WGS84_F = 1.0 / WGS84_RF
+WGS84_ES = 2.0 * WGS84_F - WGS84_F * WGS84_F          # first eccentricity squared
+WGS84_B = (1.0 - WGS84_F) * WGS84_A
+WGS84_E2S = WGS84_ES / (1.0 - WGS84_ES)               # second eccentricity squared
+DEG_TO_RAD = 0.017453292519943296
+RAD_TO_DEG = 57.295779513082321
+
+
+# ----------------------------------------------------------------------------------------------
+# geodesy
+# ----------------------------------------------------------------------------------------------
+def cosd(x):
+    """utilFcns.py:72-74"""
+    return np.cos(np.radians(x))
+
+
+def sind(x):
+    """utilFcns.py:67-69"""
+    return np.sin(np.radians(x))
+
+
+def lla2ecef(lat, lon, height):
+    """utilFcns.py:77-81 -> pyproj Transformer(4326->4978, always_xy) -> PROJ cart `cartesian()`.
+
+    Returns (x, y, z)."""
+    lam = np.asarray(lon, dtype=np.float64) * DEG_TO_RAD
+    phi = np.asarray(lat, dtype=np.float64) * DEG_TO_RAD
+    h = np.asarray(height, dtype=np.float64)
+    cosphi = np.cos(phi)
+    sinphi = np.sin(phi)
+    N = WGS84_A / np.sqrt(1.0 - WGS84_ES * sinphi * sinphi)
+    x = (N + h) * cosphi * np.cos(lam)
+    y = (N + h) * cosphi * np.sin(lam)
+    z = (N * (1.0 - WGS84_ES) + h) * sinphi
+    return x, y, z
+
+
+def ecef2lla(x, y, z):
+    """utilFcns.py:84-88 -> pyproj Transformer(4978->4326, always_xy) -> PROJ cart `geodetic()`.
+
+    Returns (lon_deg, lat_deg, h)  (always_xy order, as the reference's callers index it:
+    `pos_llh[2]` is the height, losreader.py:730-731)."""
+    x = np.asarray(x, dtype=np.float64)
+    y = np.asarray(y, dtype=np.float64)
+    z = np.asarray(z, dtype=np.float64)
+    p = np.hypot(x, y)
+    y_theta = z * WGS84_A
+    x_theta = p * WGS84_B
+    norm = np.hypot(y_theta, x_theta)
+    with np.errstate(invalid='ignore', divide='ignore'):
+        c = np.where(norm == 0, 1.0, x_theta / norm)
+        s = np.where(norm == 0, 0.0, y_theta / norm)
+        y_phi = z + WGS84_E2S * WGS84_B * s * s * s
+        x_phi = p - WGS84_ES * WGS84_A * c * c * c
+        norm_phi = np.hypot(y_phi, x_phi)
+        cosphi = np.where(norm_phi == 0, 1.0, x_phi / norm_phi)
+        sinphi = np.where(norm_phi == 0, 0.0, y_phi / norm_phi)
+        phi = np.arctan(y_phi / x_phi)
+        polar = x_phi <= 0
+        phi = np.where(polar, np.where(z >= 0, np.pi / 2, -np.pi / 2), phi)
+        cosphi = np.where(polar, 0.0, cosphi)
+        sinphi = np.where(polar, np.where(z >= 0, 1.0, -1.0), sinphi)
+        lam = np.arctan2(y, x)
+        h_reg = p / cosphi - WGS84_A / np.sqrt(1.0 - WGS84_ES * sinphi * sinphi)
+        r = np.hypot(WGS84_A * WGS84_A * cosphi, WGS84_B * WGS84_B * sinphi) / np.hypot(
+            WGS84_A * cosphi, WGS84_B * sinphi)
+        h = np.where(cosphi < 1e-6, np.abs(z) - r, h_reg)
+    return lam * RAD_TO_DEG, phi * RAD_TO_DEG, h
+
+
+def enu2ecef(east, north, up, lat0, lon0, h0):
+    """utilFcns.py:91-121 (h0 unused there too). Returns (...,3)."""
+    t = cosd(lat0) * up - sind(lat0) * north
+    w = sind(lat0) * up + cosd(lat0) * north
+    u = cosd(lon0) * t - sind(lon0) * east
+    v = sind(lon0) * t + cosd(lon0) * east
+    return np.stack((u, v, w), axis=-1)
+
+
+def ecef2enu(xyz, lat, lon, height):
+    """utilFcns.py:124-137."""
+    x, y, z = xyz[..., 0], xyz[..., 1], xyz[..., 2]
+    t = cosd(lon) * x + sind(lon) * y
+    e = -sind(lon) * x + cosd(lon) * y
+    n = -sind(lat) * t + cosd(lat) * z
+    u = cosd(lat) * t + sind(lat) * z
+    return np.stack((e, n, u), axis=-1)
+
+
+def inc_hd_to_enu(incidence, heading):
+    """losreader.py:374-396."""
+    if np.any(np.asarray(incidence) < 0):
+        raise ValueError('inc_hd_to_enu: Incidence angle cannot be less than 0')
+    east = sind(incidence) * cosd(heading + 90)
+    north = sind(incidence) * sind(heading + 90)
+    up = cosd(incidence)
+    return np.stack((east, north, up), axis=-1)
+
+
+def getZenithLookVecs(lats, lons, heights):
+    """losreader.py:302-316."""
+    x = np.cos(np.radians(lats)) * np.cos(np.radians(lons))
+    y = np.cos(np.radians(lats)) * np.sin(np.radians(lons))
+    z = np.sin(np.radians(lats))
+    return np.stack([x, y, z], axis=-1)
+
+
+def conventional_project(delays, LOS_enu):
+    """losreader.py:130-133 (`Conventional.__call__` tail)."""
+    if delays.shape == LOS_enu.shape:
+        return delays / LOS_enu
+    return delays / LOS_enu[..., -1]
+
+
+def look_vectors_from_inc_hd(inc, hd, lat, lon, ht):
+    """The duck-typed LOS used for goldens/bench: inc/heading -> ENU -> ECEF.
+
+    losreader.py:374-396 + utilFcns.py:91-121."""
+    enu = inc_hd_to_enu(inc, hd)
+    return enu2ecef(enu[..., 0], enu[..., 1], enu[..., 2], lat, lon, ht)
+
+
+# ----------------------------------------------------------------------------------------------
+# scipy RegularGridInterpolator (linear, bounds_error=False, fill_value=nan) restated
+#   call sites: delayFcns.py:55-56, delay.py:214,319,120-121
+#   algorithm: scipy/interpolate/_rgi.py:405-443,470-499,585-592 + _rgi_cython.find_indices (v1.15.3)
+# ----------------------------------------------------------------------------------------------
+class RGI:
+    """Rectilinear N-D (N<=3 used here) linear interpolator with scipy semantics.
+
+    `.grid` is exposed because delay.py:239 reads `interpolators[0].grid[2]`."""
+
+    def __init__(self, points, values, fill_value=np.nan):
+        grid = [np.asarray(p, dtype=np.float64) for p in points]
+        values = np.asarray(values)
+        # scipy flips descending axes (scipy _rgi.py `_check_points`)
+        for i, g in enumerate(grid):
+            if g.size > 1 and np.all(np.diff(g) < 0):
+                grid[i] = g[::-1].copy()
+                values = np.flip(values, axis=i)
+            elif g.size > 1 and not np.all(np.diff(g) > 0):
+                raise ValueError(f'The points in dimension {i} must be strictly ascending or descending')
+        self.grid = tuple(grid)
+        self.values = values
+        self.fill_value = fill_value
+
+    def __call__(self, xi):
+        xi = np.asarray(xi, dtype=np.float64)
+        nd = len(self.grid)
+        shp = xi.shape
+        xi = xi.reshape(-1, nd)
+        nans = np.any(np.isnan(xi), axis=-1)
+        oob = np.zeros(xi.shape[0], dtype=bool)
+        idx, t = [], []
+        for d, g in enumerate(self.grid):
+            x = xi[:, d]
+            oob |= x < g[0]
+            oob |= x > g[-1]
+            i = np.clip(np.searchsorted(g, x, side='right') - 1, 0, g.size - 2)
+            with np.errstate(invalid='ignore', divide='ignore'):
+                td = (x - g[i]) / (g[i + 1] - g[i])
+            idx.append(i)
+            t.append(td)
+        value = np.zeros(xi.shape[0], dtype=np.float64)
+        # hypercube corners in lexicographic order, last axis fastest (_rgi.py:490-498)
+        for corner in range(1 << nd):
+            bits = [(corner >> (nd - 1 - d)) & 1 for d in range(nd)]
+            weight = np.ones(xi.shape[0])
+            for d in range(nd):
+                weight = weight * (t[d] if bits[d] else (1 - t[d]))
+            edge = tuple(idx[d] + bits[d] for d in range(nd))
+            value = value + np.asarray(self.values[edge]) * weight
+        value[oob] = self.fill_value
+        value[nans] = np.nan
+        return value.reshape(shp[:-1])
+
+
+def getInterpolators(xs, ys, zs, wet_zyx, hydro_zyx):
+    """delayFcns.py:23-58 with the file read factored out: fields arrive in file order (z,y,x)
+    and are transposed to (y,x,z) (delayFcns.py:40-41)."""
+    wet = np.asarray(wet_zyx).transpose(1, 2, 0)
+    hydro = np.asarray(hydro_zyx).transpose(1, 2, 0)
+    return RGI((ys, xs, zs), wet), RGI((ys, xs, zs), hydro)
+
+
+# ----------------------------------------------------------------------------------------------
+# ray geometry
+# ----------------------------------------------------------------------------------------------
+def getTopOfAtmosphere(xyz, look_vecs, toaheight, factor=None):
+    """losreader.py:706-733."""
+    if factor is not None:
+        maxIter = 3
+    else:
+        maxIter = 10
+        factor = 1.0
+    pos = xyz + toaheight * look_vecs
+    for _ in range(maxIter):
+        pos_llh = ecef2lla(pos[..., 0], pos[..., 1], pos[..., 2])
+        pos = pos + look_vecs * ((toaheight - pos_llh[2]) / factor)[..., None]
+    return pos
+
+
+def ray_levels(model_zs, ht, zref):
+    """The slice-uniform part of build_ray (losreader.py:785-808): which model intervals
+    contribute and their clipped [low_ht, high_ht].  Returns list of (low_ht, high_ht)."""
+    model_zs = np.asarray(model_zs, dtype=np.float64)
+    out = []
+    for zz in range(model_zs.size - 1):
+        low_ht = model_zs[zz]
+        high_ht = model_zs[zz + 1]
+        if high_ht == model_zs[-1]:
+            high_ht = high_ht - 0.01
+        if (high_ht < ht) or (low_ht >= zref):
+            continue
+        if low_ht < ht:
+            low_ht = ht
+        if high_ht > zref:
+            high_ht = zref
+        if np.abs(high_ht - low_ht) < 1.0:
+            continue
+        out.append((float(low_ht), float(high_ht)))
+    return out
+
+
+def build_ray(model_zs, ht, xyz, LOS, MAX_TROPO_HEIGHT=_ZREF):
+    """losreader.py:772-835."""
+    low_xyz = None
+    high_xyz = None
+    cos_factor = None
+    ray_lengths, low_xyzs, high_xyzs = [], [], []
+    for low_ht, high_ht in ray_levels(model_zs, ht, MAX_TROPO_HEIGHT):
+        if high_xyz is not None:
+            low_xyz = high_xyz
+        else:
+            low_xyz = getTopOfAtmosphere(xyz, LOS, low_ht, factor=cos_factor)
+        high_xyz = getTopOfAtmosphere(xyz, LOS, high_ht, factor=cos_factor)
+        ray_length = np.linalg.norm(high_xyz - low_xyz, axis=-1)
+        if cos_factor is None:
+            cos_factor = (high_ht - low_ht) / ray_length
+        ray_lengths.append(ray_length)
+        low_xyzs.append(low_xyz)
+        high_xyzs.append(high_xyz)
+    if not ray_lengths:
+        return None, None, None
+    return np.stack(ray_lengths), np.stack(low_xyzs), np.stack(high_xyzs)
+
+
+def nparts_from_lengths(ray_lengths, MAX_SEGMENT_LENGTH=1000.0):
+    """delay.py:283 (max over the WHOLE slice; NaN poisons, as ndarray.max does)."""
+    K = ray_lengths.shape[0]
+    return np.ceil(ray_lengths.reshape(K, -1).max(1) / MAX_SEGMENT_LENGTH).astype(int) + 1
+
+
+# ----------------------------------------------------------------------------------------------
+# cube builders
+# ----------------------------------------------------------------------------------------------
+def build_cube(xpts, ypts, zpts, interpolators):
+    """delay.py:196-216 for model_crs == pts_crs (EPSG:4326 cube)."""
+    xx, yy = np.meshgrid(xpts, ypts)
+    zpts = np.asarray(zpts)
+    out = [np.zeros((zpts.size, len(ypts), len(xpts))) for _ in interpolators]
+    for ii, ht in enumerate(zpts):
+        pts = np.stack([yy, xx, np.full(yy.shape, ht)], axis=-1)
+        for mm, intp in enumerate(interpolators):
+            out[mm][ii, ...] = intp(pts)
+    return out
+
+
+def integrate_slice(model_zs, ray_lengths, low_xyzs, high_xyzs, nParts, interpolators, outSubs):
+    """delay.py:285-323: the sample loop for one slice (EPSG:4326 model cube)."""
+    zmin = np.array(model_zs).min()
+    zmax = np.array(model_zs).max()
+    for zz, nparts in enumerate(nParts):
+        fracs = np.linspace(0.0, 1.0, num=nparts)
+        for findex, ff in enumerate(fracs):
+            pts_xyz = low_xyzs[zz] + ff * (high_xyzs[zz] - low_xyzs[zz])
+            lon, lat, h = ecef2lla(pts_xyz[..., 0], pts_xyz[..., 1], pts_xyz[..., 2])
+            pts = np.stack((lat, lon, h), axis=-1)
+            if (pts[..., -1] < zmin).all():
+                pts[..., -1] = zmin
+            if (pts[..., -1] > zmax).all():
+                pts[..., -1] = zmax
+            wt = 0.5 if findex in [0, fracs.size - 1] else 1.0
+            wt = wt * (ray_lengths[zz] * 1.0e-6 / (nparts - 1.0))
+            for mm, out in enumerate(outSubs):
+                val = interpolators[mm](pts)
+                out += wt * val
+
+
+def build_cube_ray(xpts, ypts, zpts, look_fn, interpolators, MAX_SEGMENT_LENGTH=1000.0,
+                   MAX_TROPO_HEIGHT=_ZREF, nParts_override=None, return_nparts=False):
+    """delay.py:219-326 for an EPSG:4326 cube and EPSG:4326 query grid.
+
+    `look_fn(ht, llh, xyz, yy) -> (ny,nx,3)` plays `los.getLookVectors` (delay.py:270).
+    `nParts_override[hh]` (list per height level) replaces delay.py:283 - used to drive a shard with
+    the whole-slice nParts."""
+    model_zs = interpolators[0].grid[2]
+    xx, yy = np.meshgrid(xpts, ypts)
+    zpts = np.asarray(zpts)
+    outputArrs = [np.zeros((zpts.size, len(ypts), len(xpts))) for _ in interpolators]
+    all_nparts = []
+    for hh, ht in enumerate(zpts):
+        outSubs = [x[hh, ...] for x in outputArrs]
+        llh = [xx, yy, np.full(yy.shape, ht)]
+        xyz = np.stack(lla2ecef(llh[1], llh[0], llh[2]), axis=-1)
+        LOS = look_fn(ht, llh, xyz, yy)
+        ray_lengths, low_xyzs, high_xyzs = build_ray(model_zs, ht, xyz, LOS, MAX_TROPO_HEIGHT)
+        if ray_lengths is None and ht == zpts[-1]:
+            all_nparts.append(None)
+            continue
+        elif np.isnan(ray_lengths).all():
+            raise ValueError('geo2rdr did not converge. Check orbit coverage')
+        if nParts_override is not None:
+            nParts = np.asarray(nParts_override[hh])
+        else:
+            nParts = nparts_from_lengths(ray_lengths, MAX_SEGMENT_LENGTH)
+        all_nparts.append(nParts)
+        integrate_slice(model_zs, ray_lengths, low_xyzs, high_xyzs, nParts, interpolators, outSubs)
+    if return_nparts:
+        return outputArrs, all_nparts
+    return outputArrs
+
+
+def points_from_cube(lats, lons, hgts, xpts, ypts, zpts, wet_cube, hydro_cube):
+    """delay.py:110-121: second-stage interpolation of an output delay cube (z,y,x) to stations;
+    `getInterpolators(ds,'ztd')` on the output Dataset (delayFcns.py:37-41: kind!='total' picks
+    'wet'/'hydro', transposed to (y,x,z))."""
+    ifW, ifH = getInterpolators(xpts, ypts, zpts, wet_cube, hydro_cube)
+    pnts = np.stack([lats, lons, hgts], axis=-1)
+    return ifW(pnts), ifH(pnts)
+
+
+# ----------------------------------------------------------------------------------------------
+# temporal blend (cli/raider.py:817-819 + :877-888)
+# ----------------------------------------------------------------------------------------------
+def blend_cubes(w1, a1, w2, a2):
+    """`ds_out[var] = sum([wgt * ds[var] ...])` (cli/raider.py:817-819) = 0 + w1*a1 + w2*a2.
+
+    Under the reference's pinned numpy<2 (environment.yml:30) a float64 *scalar* weight times a
+    float32 array is computed in float32 (value-based casting), so `wet`/`hydro` stay f32 and
+    `*_total` stay f64.  Restated explicitly so the result does not depend on the numpy in use."""
+    dt_ = a1.dtype
+    return (dt_.type(w1) * a1 + dt_.type(w2) * a2).astype(dt_)
+
+
+def time_weights(t, t1, t2):
+    """cli/raider.py:877-888 (two-epoch linear weights), times in seconds."""
+    span = abs(t2 - t1)
+    return 1 - abs(t - t1) / span, 1 - abs(t2 - t) / span
+
+
+# ----------------------------------------------------------------------------------------------
+# native extension restatements
+# ----------------------------------------------------------------------------------------------
+def _bisect(grid, x):
+    """interpolate.h:23-38: first index with x < grid[i]  (== searchsorted side='right')."""
+    return np.searchsorted(grid, x, side='right')
+
+
+def native_interpolate(points, values, interp_points, fill_value=None):
+    """`RAiDER.interpolate.interpolate` (module.cpp:26-294; interpolate.h:78-118,
+    interpolate.cpp:18-258): N-D linear, hi = upper_bound index; with fill: hi<1 or hi>N-1 -> fill
+    (so a query ON the last node is filled); without fill: hi clamped to [1,N-1] (extrapolate).
+    value = sum(corner * prod(dist)) / prod(dx)   (1-D: y0 + slope*(x-x0))."""
+    points = [np.asarray(p, dtype=np.float64) for p in points]
+    values = np.asarray(values, dtype=np.float64)
+    q = np.asarray(interp_points, dtype=np.float64)
+    nd = len(points)
+    n = q.shape[0]
+    filled = np.zeros(n, dtype=bool)
+    lo, hi = [], []
+    for d, g in enumerate(points):
+        h = _bisect(g, q[:, d])
+        if fill_value is not None:
+            filled |= (h < 1) | (h > g.size - 1)
+        h = np.clip(h, 1, g.size - 1)
+        hi.append(h)
+        lo.append(h - 1)
+    if nd == 1:
+        g = points[0]
+        x0, x1 = g[lo[0]], g[hi[0]]
+        y0, y1 = values[lo[0]], values[hi[0]]
+        slope = (y1 - y0) / (x1 - x0)
+        out = y0 + slope * (q[:, 0] - x0)
+    else:
+        d0 = [q[:, d] - points[d][lo[d]] for d in range(nd)]   # dist to lower
+        d1 = [points[d][hi[d]] - q[:, d] for d in range(nd)]   # dist to upper
+        vol = np.ones(n)
+        for d in range(nd):
+            vol = vol * (points[d][hi[d]] - points[d][lo[d]])
+        if nd == 2:
+            z = lambda a, b: values[a, b]
+            out = (d1[0] * (z(lo[0], lo[1]) * d1[1] + z(lo[0], hi[1]) * d0[1]) +
+                   d0[0] * (z(hi[0], lo[1]) * d1[1] + z(hi[0], hi[1]) * d0[1])) / vol
+        elif nd == 3:
+            w = lambda a, b, c: values[a, b, c]
+            out = (d1[0] * (d1[1] * (d1[2] * w(lo[0], lo[1], lo[2]) + d0[2] * w(lo[0], lo[1], hi[2])) +
+                            d0[1] * (d1[2] * w(lo[0], hi[1], lo[2]) + d0[2] * w(lo[0], hi[1], hi[2]))) +
+                   d0[0] * (d1[1] * (d1[2] * w(hi[0], lo[1], lo[2]) + d0[2] * w(hi[0], lo[1], hi[2])) +
+                            d0[1] * (d1[2] * w(hi[0], hi[1], lo[2]) + d0[2] * w(hi[0], hi[1], hi[2])))) / vol
+        else:
+            out = np.zeros(n)
+            for j in range(1 << nd):
+                # interpolate.cpp:238-250: bit `dim` of j selects hi/lo of dimension dim
+                index = tuple(hi[d] if (j >> d) & 1 else lo[d] for d in range(nd))
+                term = values[index]
+                for d in range(nd):
+                    term = term * (d0[d] if (j >> d) & 1 else d1[d])
+                out = out + term
+            out = out / vol
+    if fill_value is not None:
+        out = np.where(filled, fill_value, out)
+    return out
+
+
+def native_interpolate_along_axis(points, values, interp_points, axis=-1, fill_value=None):
+    """`RAiDER.interpolate.interpolate_along_axis` (module.cpp:296-493, interpolate.cpp:260-332):
+    independent interpolate_1d (interpolate.h:78-118) along `axis` of same-shaped arrays."""
+    points = np.asarray(points, dtype=np.float64)
+    values = np.asarray(values, dtype=np.float64)
+    q = np.asarray(interp_points, dtype=np.float64)
+    axis = axis % points.ndim
+    P = np.moveaxis(points, axis, -1)
+    V = np.moveaxis(values, axis, -1)
+    Q = np.moveaxis(q, axis, -1)
+    lead = P.shape[:-1]
+    P2 = P.reshape(-1, P.shape[-1])
+    V2 = V.reshape(-1, V.shape[-1])
+    Q2 = Q.reshape(-1, Q.shape[-1])
+    out = np.empty_like(Q2)
+    for r in range(P2.shape[0]):
+        out[r] = native_interpolate((P2[r],), V2[r], Q2[r][:, None], fill_value)
+    return np.moveaxis(out.reshape(lead + (Q.shape[-1],)), -1, axis)
+
+
+def makePoints(max_len, Rays_SP, Rays_SLV, stepSize):
+    """makePoints.pyx:15-148 (0-D..3-D share one formula):
+    ray[..., k3, k4] = SP[..., k3] + basespace[k4]*SLV[..., k3], basespace = arange(0, max_len+step, step),
+    Npts = int(max_len//step) + (1 if max_len % step != 0 else 0)."""
+    SP = np.asarray(Rays_SP, dtype=np.float64)
+    SLV = np.asarray(Rays_SLV, dtype=np.float64)
+    if max_len % stepSize != 0:
+        Npts = int(max_len // stepSize) + 1
+    else:
+        Npts = int(max_len // stepSize)
+    basespace = np.arange(0, max_len + stepSize, stepSize)[:Npts]
+    return SP[..., :, None] + basespace * SLV[..., :, None]
+
+
+# ----------------------------------------------------------------------------------------------
+# synthetic workloads - shared by tests and bench so GPU and CPU see the
+# same seeded inputs
+# ----------------------------------------------------------------------------------------------
+def synthetic_cube(ny, nx, nz, seed=0, ztop=41000.0, y0=30.0, y1=36.0, x0=-121.0, x1=-113.0):
+    """SURVEY §8(d) "Synthetic cube": returns dict(xs, ys, zs, wet, hydro (z,y,x) f32,
+    wet_total, hydro_total (z,y,x) f64)."""
+    ys = np.linspace(y0, y1, ny)
+    xs = np.linspace(x0, x1, nx)
+    zs = np.round(-100 + ztop * np.linspace(0, 1, nz) ** 2, 3)
+    rng = np.random.default_rng(seed)
+    g_h = rng.standard_normal((ny, nx))
+    g_w = rng.standard_normal((ny, nx))
+    z3 = zs[:, None, None]
+    hydro = (270.0 * np.exp(-z3 / 8000.0) * (1 + 0.01 * g_h[None])).astype(np.float32)
+    wet = (60.0 * np.exp(-z3 / 2000.0) * (1 + 0.1 * g_w[None])).astype(np.float32)
+
+    def totals(f):
+        # weatherModel.py:389-403 `_getZTD`: total[l] = 1e-6 * trapz(f[l:], zs[l:])
+        f = f.astype(np.float64)
+        seg = 0.5 * (f[1:] + f[:-1]) * np.diff(zs)[:, None, None]
+        cum = np.concatenate([np.cumsum(seg[::-1], axis=0)[::-1], np.zeros((1,) + f.shape[1:])], axis=0)
+        return 1e-6 * cum
+    return dict(xs=xs, ys=ys, zs=zs, wet=wet, hydro=hydro, wet_total=totals(wet), hydro_total=totals(hydro))

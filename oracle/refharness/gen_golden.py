@@ -1,0 +1,374 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE (imported in place from /root/reference).
+
+TEST INFRASTRUCTURE; runs only in the build container (the reference does not exist on the GPU
+box).  Re-run with:   python oracle/refharness/gen_golden.py
+Needs oracle/_ref (oracle/build_ref.sh) for the reference's two native extensions.
+
+Each fixture stores the seeded INPUTS and the reference's OUTPUTS (data only - no reference source).
+The reference functions exercised (file:line under /root/reference/tools/RAiDER unless noted):
+  G1 makePoints0D..3D                      tools/bindings/utils/makePoints.pyx:15-148
+  G2 interpolate / interpolate_along_axis  tools/bindings/interpolate/src/module.cpp:26,296
+  G3 getTopOfAtmosphere, build_ray         losreader.py:706-733,772-835
+  G4 _build_cube                           delay.py:196-216
+  G5 _build_cube_ray (+G5b whole vs halves) delay.py:219-326
+  G6 inc_hd_to_enu, enu2ecef, ecef2enu, getZenithLookVecs, Conventional tail
+                                           losreader.py:374-396,302-316,130-133; utilFcns.py:91-137
+  (G7 time weights cli/raider.py:877-888: NOT generated - RAiDER.cli.raider imports h5py, absent here;
+   the two-line formula is restated in the oracle and pinned by its mean-of-epochs property only)
+  G8 tropo_delay point branch              delay.py:35-130
+pyproj/xarray/rasterio are build-owned stubs (oracle/refharness/stubs): geodetic<->ECEF arithmetic
+is therefore the stub's restatement of PROJ `cart`, not PROJ itself ("parity unpinned" for that
+one conversion; everything downstream of it is the reference's own code).
+"""
+import datetime as dt
+import sys
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+REPO = HERE.parent.parent
+sys.path.insert(0, str(HERE))
+sys.path.insert(0, str(REPO))
+
+import ref_import  # noqa: E402
+
+ref_import.import_reference()
+
+import scipy.interpolate  # noqa: E402
+import xarray as xr  # noqa: E402  (stub)
+import RAiDER.delay as rdelay  # noqa: E402
+import RAiDER.delayFcns as rdelayFcns  # noqa: E402
+import RAiDER.losreader as rlos  # noqa: E402
+import RAiDER.utilFcns as rutil  # noqa: E402
+from RAiDER.interpolate import interpolate as r_interpolate  # noqa: E402
+from RAiDER.interpolate import interpolate_along_axis as r_interp_axis  # noqa: E402
+from RAiDER import makePoints as r_mp  # noqa: E402
+from pyproj import CRS  # noqa: E402  (stub)
+
+from oracle.raider_oracle import synthetic_cube  # noqa: E402  (input generator only)
+
+GOLD = REPO / 'tests' / 'golden'
+GOLD.mkdir(parents=True, exist_ok=True)
+EPSG4326 = CRS.from_epsg(4326)
+
+
+def save(name, **arrs):
+    path = GOLD / f'{name}.npz'
+    np.savez_compressed(path, **arrs)
+    print(f'{name}: {path.stat().st_size/1024:.1f} KiB  keys={list(arrs)}')
+
+
+class ArrayLOS:
+    """Duck-typed LOS (protocol losreader.py:32-72) whose look vectors come from inc/heading via the
+    reference's own inc_hd_to_enu + enu2ecef."""
+
+    def __init__(self, inc, hd):
+        self.inc, self.hd = inc, hd
+
+    def getLookVectors(self, ht, llh, xyz, yy):
+        inc = np.broadcast_to(np.asarray(self.inc, dtype=float), yy.shape)
+        hd = np.broadcast_to(np.asarray(self.hd, dtype=float), yy.shape)
+        enu = rlos.inc_hd_to_enu(inc, hd)
+        return rutil.enu2ecef(enu[..., 0], enu[..., 1], enu[..., 2], llh[1], llh[0], llh[2])
+
+
+def scipy_interps(cube, kind):
+    """What getInterpolators (delayFcns.py:23-58) builds, minus the file read."""
+    w = cube['wet_total' if kind == 'total' else 'wet'].transpose(1, 2, 0)
+    h = cube['hydro_total' if kind == 'total' else 'hydro'].transpose(1, 2, 0)
+    mk = lambda v: scipy.interpolate.RegularGridInterpolator(
+        (cube['ys'], cube['xs'], cube['zs']), v, fill_value=np.nan, bounds_error=False)
+    return [mk(w), mk(h)]
+
+
+# ---------------------------------------------------------------------------------------------- G1
+def g1():
+    rng = np.random.default_rng(11)
+    out = {}
+    # inputs of test/test_util.py:49-128
+    out['a0_args'] = np.array([1000., 5.])
+    sp0, slv0 = np.array([0., 0., 0.]), np.array([0., 0., 1.])
+    out['a0_sp'], out['a0_slv'] = sp0, slv0
+    out['a0_out'] = r_mp.makePoints0D(1000., sp0, slv0, 5.)
+    sp1 = np.array([[0., 0., 0.], [0., 0., 0.]]); slv1 = np.array([[0., 0., 1.], [0., 1., 0.]])
+    out['a1_sp'], out['a1_slv'] = sp1, slv1
+    out['a1_out'] = r_mp.makePoints1D(1000., sp1, slv1, 5.)
+    sp2 = np.zeros((2, 2, 3)); slv2 = np.zeros((2, 2, 3))
+    slv2[0, 0, 0] = 1; slv2[0, 1, 1] = 1; slv2[1, 0, 2] = 1; slv2[1, 1, 0] = -1
+    out['a2_args'] = np.array([20., 5.])
+    out['a2_sp'], out['a2_slv'] = sp2, slv2
+    out['a2_out'] = r_mp.makePoints2D(20., sp2, slv2, 5)
+    sp3 = np.zeros((3, 3, 3, 3)); sp3[:, :, 1, 2] = 10; sp3[:, :, 2, 2] = 100
+    slv3 = np.zeros((3, 3, 3, 3)); slv3[0, :, :, 2] = 1; slv3[1, :, :, 1] = 1; slv3[2, :, :, 0] = 1
+    out['a3_args'] = np.array([100., 5.])
+    out['a3_sp'], out['a3_slv'] = sp3, slv3
+    out['a3_out'] = r_mp.makePoints3D(100., sp3, slv3, 5)
+    # the reference's own text golden (test/test_result_makePoints3D.txt) must agree
+    txt = np.loadtxt(ref_import.REF_ROOT / 'test' / 'test_result_makePoints3D.txt').reshape(3, 3, 3, 3, 20)
+    assert np.allclose(out['a3_out'], txt)
+    out['a3_txt'] = txt
+    # random, non-divisible length (exercises the +1 branch, makePoints.pyx:30-33)
+    spr = rng.normal(size=(5, 7, 3)) * 6.4e6; slvr = rng.normal(size=(5, 7, 3))
+    slvr /= np.linalg.norm(slvr, axis=-1, keepdims=True)
+    out['r2_args'] = np.array([12345.6, 15.0])
+    out['r2_sp'], out['r2_slv'] = spr, slvr
+    out['r2_out'] = r_mp.makePoints2D(12345.6, spr, slvr, 15.0)
+    save('g1_makepoints', **out)
+
+
+# ---------------------------------------------------------------------------------------------- G2
+def g2():
+    rng = np.random.default_rng(22)
+    out = {}
+    f = lambda x, y, z: x ** 2 + 3 * y - z
+    for nd in (1, 2, 3, 4):
+        grids = [np.sort(rng.uniform(-10, 10, size=n)) for n in (9, 7, 11, 5)[:nd]]
+        vals = rng.normal(size=tuple(g.size for g in grids))
+        q = np.stack([rng.uniform(g[0] - 2, g[-1] + 2, size=400) for g in grids], axis=-1)
+        # exact-node queries including first and LAST node (the C++ fills on the last node)
+        qn = np.stack([g[rng.integers(0, g.size, size=40)] for g in grids], axis=-1)
+        qn[0] = [g[0] for g in grids]
+        qn[1] = [g[-1] for g in grids]
+        q = np.concatenate([q, qn])
+        for k, g in enumerate(grids):
+            out[f'd{nd}_grid{k}'] = g
+        out[f'd{nd}_vals'] = vals
+        out[f'd{nd}_q'] = q
+        out[f'd{nd}_fill'] = r_interpolate(tuple(grids), vals, q, fill_value=np.nan, max_threads=1)
+        out[f'd{nd}_extrap'] = r_interpolate(tuple(grids), vals, q, max_threads=1)
+        out[f'd{nd}_fill7'] = r_interpolate(tuple(grids), vals, q, fill_value=7.0, max_threads=2)
+    # analytic 3-D case of test/test_interpolator.py (f = x^2 + 3y - z)
+    xs = np.linspace(0, 1000, 100); ys = np.linspace(0, 1000, 100); zs = np.linspace(0, 1000, 100)
+    vals = f(*np.meshgrid(xs, ys, zs, indexing='ij', sparse=True))
+    q = np.stack([rng.uniform(0, 1000, 2000) for _ in range(3)], axis=-1)
+    out['an3_q'] = q
+    out['an3_out'] = r_interpolate((xs, ys, zs), vals, q)
+    # interpolate_along_axis: random 3-D, each axis (axis 0 needs max_threads=1, module.cpp:332-335)
+    P = np.sort(rng.uniform(0, 100, size=(6, 5, 8)), axis=0)
+    for ax in (0, 1, 2):
+        Pa = np.sort(rng.uniform(0, 100, size=(6, 5, 8)), axis=ax)
+        Va = rng.normal(size=Pa.shape)
+        shp = list(Pa.shape); shp[ax] = 13
+        Qa = rng.uniform(-10, 110, size=shp)
+        out[f'ax{ax}_P'], out[f'ax{ax}_V'], out[f'ax{ax}_Q'] = Pa, Va, Qa
+        out[f'ax{ax}_fill'] = r_interp_axis(Pa, Va, Qa, axis=ax, fill_value=np.nan, max_threads=1)
+        out[f'ax{ax}_extrap'] = r_interp_axis(Pa, Va, Qa, axis=ax, max_threads=1)
+    save('g2_interpolate', **out)
+
+
+# ---------------------------------------------------------------------------------------------- G3
+def g3():
+    out = {}
+    lats = np.array([-3.75, 10.0, 33.5, 33.5, 55.0, 70.9])
+    lons = np.array([-120.0, -117.8, -60.0, 0.0, 45.5, 100.0, 179.0, -179.5])
+    lon2, lat2 = np.meshgrid(lons, lats)
+    incs = np.array([0, 20, 39, 55], dtype=float)
+    hds = np.array([-167.9, -12.1])
+    zs = np.round(-100 + 41000 * np.linspace(0, 1, 40) ** 2, 3)
+    out['lat'], out['lon'], out['model_zs'] = lat2, lon2, zs
+    out['incs'], out['hds'] = incs, hds
+    k = 0
+    for ht in (-500.0, 0.0, 2500.0):
+        xyz = np.stack(rutil.lla2ecef(lat2, lon2, np.full(lat2.shape, ht)), axis=-1)
+        out[f'xyz_ht{int(ht)}'] = xyz
+        for inc in incs:
+            for hd in hds:
+                los = ArrayLOS(inc, hd).getLookVectors(ht, [lon2, lat2, np.full(lat2.shape, ht)], xyz, lat2)
+                L, lo, hi = rlos.build_ray(zs, ht, xyz, los, 30000.0)
+                tag = f'ht{int(ht)}_inc{int(inc)}_hd{int(hd)}'
+                out[f'los_{tag}'] = los
+                out[f'len_{tag}'] = L
+                out[f'low_{tag}'] = lo[[0, 1, -1]]    # first two + last segment endpoints
+                out[f'high_{tag}'] = hi[[0, 1, -1]]
+                k += 1
+        # getTopOfAtmosphere directly, both iteration modes (losreader.py:717-721)
+        los = ArrayLOS(39.0, -167.9).getLookVectors(ht, [lon2, lat2, np.full(lat2.shape, ht)], xyz, lat2)
+        out[f'toa10_ht{int(ht)}'] = rlos.getTopOfAtmosphere(xyz, los, 15000.0)
+        out[f'toa3_ht{int(ht)}'] = rlos.getTopOfAtmosphere(xyz, los, 15000.0, factor=np.full(lat2.shape, 0.77))
+    # geodesy round trip table (stub pyproj arithmetic; recorded so drift is visible)
+    h = np.array([-500.0, 0.0, 1234.5, 40000.0])[:, None, None] + 0 * lat2
+    x, y, z = rutil.lla2ecef(lat2 + 0 * h, lon2 + 0 * h, h)
+    out['geo_xyz'] = np.stack([x, y, z], -1)
+    out['geo_llh'] = np.stack(rutil.ecef2lla(x, y, z), -1)
+    save('g3_rays', **out)
+
+
+# ---------------------------------------------------------------------------------------------- G4
+def g4():
+    cube = synthetic_cube(50, 50, 40, seed=0)
+    xpts = np.linspace(-119.5, -115.5, 100)
+    ypts = np.linspace(34.5, 31.5, 100)
+    zpts = np.array([0.0, 500.0, 1000.0])
+    wet, hydro = rdelay._build_cube(xpts, ypts, zpts, EPSG4326, EPSG4326, scipy_interps(cube, 'total'))
+    # a grid that pokes outside the cube (NaN fill) and hits exact nodes
+    xp2 = np.concatenate([[-121.5], cube['xs'][::7], [-112.9]])
+    yp2 = np.concatenate([[36.2], cube['ys'][::-9], [29.9]])
+    zp2 = np.array([-100.0, cube['zs'][5], 40900.0, 41000.0, -100.5])
+    wet2, hydro2 = rdelay._build_cube(xp2, yp2, zp2, EPSG4326, EPSG4326, scipy_interps(cube, 'total'))
+    save('g4_build_cube', cube_shape=np.array([50, 50, 40]), seed=np.array(0), xpts=xpts, ypts=ypts, zpts=zpts,
+         wet=wet, hydro=hydro, xp2=xp2, yp2=yp2, zp2=zp2, wet2=wet2, hydro2=hydro2)
+
+
+# ---------------------------------------------------------------------------------------------- G5
+def run_ray(cube, xpts, ypts, zpts, inc, hd, zref, maxseg=1000.0):
+    interps = scipy_interps(cube, 'pointwise')
+    # capture nParts by re-running build_ray exactly as delay.py:262-283 does
+    xx, yy = np.meshgrid(xpts, ypts)
+    nparts = []
+    for ht in zpts:
+        llh = [xx, yy, np.full(yy.shape, ht)]
+        xyz = np.stack(rutil.lla2ecef(llh[1], llh[0], llh[2]), axis=-1)
+        LOS = ArrayLOS(inc, hd).getLookVectors(ht, llh, xyz, yy)
+        L, _, _ = rlos.build_ray(interps[0].grid[2], ht, xyz, LOS, zref)
+        nparts.append(np.ceil(L.max((1, 2)) / maxseg).astype(int) + 1 if L is not None else np.zeros(0, int))
+    wet, hydro = rdelay._build_cube_ray(xpts, ypts, zpts, ArrayLOS(inc, hd), EPSG4326, EPSG4326, interps,
+                                        MAX_SEGMENT_LENGTH=maxseg, MAX_TROPO_HEIGHT=zref)
+    return wet, hydro, nparts
+
+
+def g5():
+    out = {}
+    cube = synthetic_cube(50, 50, 40, seed=0)
+    zref = cube['zs'].max() - 1           # delay.py:78,86-87
+    xpts = np.linspace(-119.5, -115.5, 32)
+    ypts = np.linspace(34.5, 31.5, 32)    # descending, llreader.py:191
+    zpts = np.array([0.0, 2500.0])
+    out['c1_xpts'], out['c1_ypts'], out['c1_zpts'], out['c1_zref'] = xpts, ypts, zpts, np.array(zref)
+    # (a) fixed inc/heading
+    wet, hydro, nparts = run_ray(cube, xpts, ypts, zpts, 39.0, -167.9, zref)
+    out['c1_fixed_wet'], out['c1_fixed_hydro'] = wet, hydro
+    for i, n in enumerate(nparts):
+        out[f'c1_fixed_nparts{i}'] = n
+    # (b) per-pixel inc (30..46 deg across columns, SURVEY §8d c3 recipe)
+    inc_pp = np.broadcast_to(30 + 16 * (np.arange(32) / 32.0), (32, 32)).copy()
+    out['c1_pp_inc'] = inc_pp
+    wet, hydro, nparts = run_ray(cube, xpts, ypts, zpts, inc_pp, -167.9, zref)
+    out['c1_pp_wet'], out['c1_pp_hydro'] = wet, hydro
+    for i, n in enumerate(nparts):
+        out[f'c1_pp_nparts{i}'] = n
+    # (c) default zref (_ZREF=26000) and a different MAX_SEGMENT_LENGTH, ascending heading
+    wet, hydro, nparts = run_ray(cube, xpts, ypts, np.array([100.0]), 20.0, -12.1, 26000.0, maxseg=500.0)
+    out['c1_z26_wet'], out['c1_z26_hydro'], out['c1_z26_nparts0'] = wet, hydro, nparts[0]
+    # (d) N==1 invariant: delay*1e6 == sum of ray lengths (test/test_synthetic.py:217-274)
+    cube1 = dict(cube); cube1['wet'] = np.ones_like(cube['wet']); cube1['hydro'] = np.ones_like(cube['hydro'])
+    xp = np.linspace(-119.5, -115.5, 8); yp = np.linspace(34.5, 31.5, 6)
+    wet, hydro, nparts = run_ray(cube1, xp, yp, zpts, 39.0, -167.9, zref)
+    out['c1_one_xpts'], out['c1_one_ypts'] = xp, yp
+    out['c1_one_wet'], out['c1_one_hydro'] = wet, hydro
+    # (e) rays leaving the cube laterally -> NaN (delay.py:321-323 commented out)
+    xe = np.linspace(-120.95, -113.05, 12); ye = np.linspace(35.95, 30.05, 10)
+    wet, hydro, nparts = run_ray(cube, xe, ye, np.array([0.0]), 45.0, -167.9, zref)
+    out['c1_edge_xpts'], out['c1_edge_ypts'] = xe, ye
+    out['c1_edge_wet'], out['c1_edge_hydro'], out['c1_edge_nparts0'] = wet, hydro, nparts[0]
+    # (f) ERA5-sized cube (regenerated from the seed in the tests), 16x16 rays
+    big = synthetic_cube(300, 300, 80, seed=0)
+    zrefb = big['zs'].max() - 1
+    xb = np.linspace(-119.5, -115.5, 16); yb = np.linspace(34.5, 31.5, 16)
+    inc_b = np.broadcast_to(30 + 16 * (np.arange(16) / 16.0), (16, 16)).copy()
+    wet, hydro, nparts = run_ray(big, xb, yb, np.array([0.0]), inc_b, -167.9, zrefb)
+    out['big_xpts'], out['big_ypts'], out['big_inc'], out['big_zref'] = xb, yb, inc_b, np.array(zrefb)
+    out['big_wet'], out['big_hydro'], out['big_nparts0'] = wet, hydro, nparts[0]
+    save('g5_build_cube_ray', **out)
+
+    # G5b: 64x64, inc 30..46 across columns, whole slice; halves must be driven with the WHOLE nParts
+    xpts = np.linspace(-119.5, -115.5, 64); ypts = np.linspace(34.5, 31.5, 64)
+    inc = np.broadcast_to(30 + 16 * (np.arange(64) / 64.0), (64, 64)).copy()
+    wet, hydro, nparts = run_ray(cube, xpts, ypts, np.array([0.0]), inc, -167.9, zref)
+    # what shard-local nParts would give (the reference run on each half separately)
+    wl, hl, npl = run_ray(cube, xpts[:32], ypts, np.array([0.0]), inc[:, :32], -167.9, zref)
+    wr, hr, npr = run_ray(cube, xpts[32:], ypts, np.array([0.0]), inc[:, 32:], -167.9, zref)
+    save('g5b_whole_vs_halves', xpts=xpts, ypts=ypts, inc=inc, zref=np.array(zref), wet=wet, hydro=hydro,
+         nparts=nparts[0], left_wet=wl, left_hydro=hl, left_nparts=npl[0],
+         right_wet=wr, right_hydro=hr, right_nparts=npr[0])
+    print('  G5b shard-local vs whole, max |d hydro| =',
+          max(np.abs(hl - hydro[:, :, :32]).max(), np.abs(hr - hydro[:, :, 32:]).max()))
+
+
+# ---------------------------------------------------------------------------------------------- G6
+def g6():
+    rng = np.random.default_rng(66)
+    out = {}
+    inc = rng.uniform(0, 60, size=(9, 11)); hd = rng.uniform(-180, 180, size=(9, 11))
+    lat = rng.uniform(-80, 80, size=(9, 11)); lon = rng.uniform(-180, 180, size=(9, 11))
+    enu = rlos.inc_hd_to_enu(inc, hd)
+    out.update(inc=inc, hd=hd, lat=lat, lon=lon, enu=enu)
+    out['ecef'] = rutil.enu2ecef(enu[..., 0], enu[..., 1], enu[..., 2], lat, lon, np.zeros_like(lat))
+    out['enu_back'] = rutil.ecef2enu(out['ecef'], lat, lon, np.zeros_like(lat))
+    out['zen'] = rlos.getZenithLookVecs(lat, lon, np.zeros_like(lat))
+    d = rng.uniform(2, 3, size=(9, 11))
+    out['delays'] = d
+    # Conventional.__call__ tail, losreader.py:130-133
+    out['proj_last'] = d / enu[..., -1]
+    out['cosd'] = rutil.cosd(hd); out['sind'] = rutil.sind(hd)
+    # exact ECEF values the reference test pins (test/test_delayFcns.py:86-99)
+    pts = rdelay.transformPoints(np.array([0., 0., 0.]), np.array([0., 90., 180.]), np.array([0., 0., 0.]),
+                                 4326, 4978)
+    out['tp_equator'] = pts
+    save('g6_los', **out)
+
+
+# ---------------------------------------------------------------------------------------------- G7
+def g7():
+    out = {}
+    try:
+        from RAiDER.cli.raider import get_weights_time_interp
+        t1 = dt.datetime(2020, 1, 1, 12); t2 = dt.datetime(2020, 1, 1, 13)
+        ws = []
+        for mins in (0, 15, 30, 45, 60):
+            ws.append(get_weights_time_interp([t1, t2], t1 + dt.timedelta(minutes=mins)))
+        out['weights'] = np.array(ws, dtype=np.float64)
+        out['minutes'] = np.array([0, 15, 30, 45, 60], dtype=np.float64)
+        print('  G7: weights from reference get_weights_time_interp')
+    except Exception as e:  # cli.raider drags in the whole product; fall back to the formula text
+        print('  G7: reference cli.raider not importable here:', repr(e)[:100])
+        out['weights'] = np.zeros((0, 2)); out['minutes'] = np.zeros(0)
+    save('g7_time_weights', **out)
+
+
+# ---------------------------------------------------------------------------------------------- G8
+class _Stations:
+    """Duck-typed non-BoundingBox AOI for the point branch of tropo_delay (delay.py:101-128):
+    needs xpts/ypts (delay.py:137-144), readLL, readZ."""
+
+    def __init__(self, lats, lons, hgts, xpts, ypts):
+        self._l, self._o, self._h = lats, lons, hgts
+        self.xpts, self.ypts = xpts, ypts
+
+    def readLL(self):
+        return self._l, self._o
+
+    def readZ(self):
+        return self._h
+
+
+def g8():
+    cube = synthetic_cube(50, 50, 40, seed=0)
+    ds = xr.Dataset(
+        data_vars={k: (['z', 'y', 'x'], cube[k]) for k in ('wet', 'hydro', 'wet_total', 'hydro_total')},
+        coords=dict(x=(['x'], cube['xs']), y=(['y'], cube['ys']), z=(['z'], cube['zs'])))
+    ds['proj'] = xr.DataArray(np.array(0), attrs={'crs_wkt': EPSG4326.to_wkt()})
+    xr.register_dataset('synthetic_c1.nc', ds)
+    rng = np.random.default_rng(88)
+    n = 1000
+    lats = rng.uniform(31.6, 34.4, n); lons = rng.uniform(-119.4, -115.6, n); hgts = rng.uniform(0, 3000, n)
+    xpts = np.linspace(-119.5, -115.5, 41); ypts = np.linspace(34.5, 31.5, 31)
+    hl = [0.0, 500.0, 1000.0, 2000.0, 3500.0]
+    aoi = _Stations(lats, lons, hgts, xpts, ypts)
+    wz, hz = rdelay.tropo_delay(dt.datetime(2020, 1, 1), 'synthetic_c1.nc', aoi, rlos.Zenith(), hl, 4326, None)
+    # ray-traced variant of the same two-stage path (duck LOS: not zenith, not projected)
+    class _RayLOS(ArrayLOS):
+        def is_Zenith(self): return False
+        def is_Projected(self): return False
+        def ray_trace(self): return True
+    aoi2 = _Stations(lats[:200], lons[:200], hgts[:200], xpts[::4], ypts[::3])
+    wr, hr = rdelay.tropo_delay(dt.datetime(2020, 1, 1), 'synthetic_c1.nc', aoi2, _RayLOS(39.0, -167.9), hl, 4326, None)
+    save('g8_points', lats=lats, lons=lons, hgts=hgts, xpts=xpts, ypts=ypts, height_levels=np.array(hl),
+         wet_zen=wz, hydro_zen=hz, xpts_ray=xpts[::4], ypts_ray=ypts[::3], wet_ray=wr, hydro_ray=hr)
+
+
+if __name__ == '__main__':
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g8']   # g7: cli.raider needs h5py (absent)
+    for w in which:
+        globals()[w]()

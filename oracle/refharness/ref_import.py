@@ -1,0 +1,44 @@
+"""Import the read-only reference (`/root/reference/tools/RAiDER`) IN PLACE, in this container only.
+
+TEST INFRASTRUCTURE.  Used by oracle/refharness/gen_golden.py (fixture generation) and by the
+optional `tests/test_oracle_vs_reference.py` (skipped when /root/reference is absent, i.e. on the GPU
+box).  Recipe = SURVEY.md App. B:
+  1. pre-seed sys.modules['RAiDER'] with a bare package whose __path__ points at the reference dir
+     (+ oracle/_ref/RAiDER for the two compiled native extensions) - bypasses
+     tools/RAiDER/__init__.py:7-10 (importlib.metadata.version of an uninstalled dist);
+  2. put the build-owned stubs of pyproj / xarray / rasterio (absent from this image) on sys.path;
+  3. point the reference logger at a temp dir (logger.py:59-86 would write debug.log into CWD).
+"""
+import os
+import sys
+import tempfile
+import types
+from pathlib import Path
+
+HERE = Path(__file__).resolve().parent
+REF_ROOT = Path(os.environ.get('RAIDER_REFERENCE', '/root/reference'))
+REF_PKG = REF_ROOT / 'tools' / 'RAiDER'
+REF_SO = HERE.parent / '_ref' / 'RAiDER'
+
+
+def available() -> bool:
+    return REF_PKG.is_dir()
+
+
+def import_reference():
+    """Returns the seeded `RAiDER` package object (reference modules importable as RAiDER.xxx)."""
+    if not available():
+        raise RuntimeError(f'reference not present at {REF_PKG}')
+    if 'RAiDER' in sys.modules and getattr(sys.modules['RAiDER'], '_oracle_seeded', False):
+        return sys.modules['RAiDER']
+    stubs = str(HERE / 'stubs')
+    if stubs not in sys.path:
+        sys.path.insert(0, stubs)
+    pkg = types.ModuleType('RAiDER')
+    pkg.__path__ = [str(REF_PKG), str(REF_SO)]
+    pkg.__version__ = '0.0-reference-in-place'
+    pkg._oracle_seeded = True
+    sys.modules['RAiDER'] = pkg
+    import RAiDER.cli.conf as conf  # noqa: E402
+    conf.setLoggerPath(Path(tempfile.mkdtemp(prefix='raider_ref_log_')))
+    return pkg

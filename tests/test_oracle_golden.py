@@ -1,0 +1,223 @@
+"""CPU: the oracle (oracle/raider_oracle.py) against the golden vectors produced by running the
+reference itself (oracle/refharness/gen_golden.py).  This is what pins the oracle."""
+import numpy as np
+import pytest
+
+from oracle import raider_oracle as O
+
+TOL = 1e-9   # metres; observed ~1e-13.  north_star tolerance for delays is 1e-6 m.
+
+
+def look_fn(inc, hd):
+    def f(ht, llh, xyz, yy):
+        i = np.broadcast_to(np.asarray(inc, float), yy.shape)
+        h = np.broadcast_to(np.asarray(hd, float), yy.shape)
+        return O.look_vectors_from_inc_hd(i, h, llh[1], llh[0], llh[2])
+    return f
+
+
+def interps(cube, kind):
+    sfx = '_total' if kind == 'total' else ''
+    return list(O.getInterpolators(cube['xs'], cube['ys'], cube['zs'], cube['wet' + sfx], cube['hydro' + sfx]))
+
+
+@pytest.fixture(scope='module')
+def c1():
+    return O.synthetic_cube(50, 50, 40, seed=0)
+
+
+def test_g1_makepoints(golden):
+    g = golden('g1_makepoints')
+    assert np.array_equal(O.makePoints(1000., g['a0_sp'], g['a0_slv'], 5.), g['a0_out'])
+    assert np.array_equal(O.makePoints(1000., g['a1_sp'], g['a1_slv'], 5.), g['a1_out'])
+    assert np.array_equal(O.makePoints(20., g['a2_sp'], g['a2_slv'], 5), g['a2_out'])
+    assert np.array_equal(O.makePoints(100., g['a3_sp'], g['a3_slv'], 5), g['a3_out'])
+    assert np.allclose(O.makePoints(100., g['a3_sp'], g['a3_slv'], 5), g['a3_txt'])
+    ml, st = g['r2_args']
+    assert np.array_equal(O.makePoints(ml, g['r2_sp'], g['r2_slv'], st), g['r2_out'])
+
+
+@pytest.mark.parametrize('nd', [1, 2, 3, 4])
+def test_g2_native_interpolate(golden, nd):
+    g = golden('g2_interpolate')
+    grids = [g[f'd{nd}_grid{k}'] for k in range(nd)]
+    vals, q = g[f'd{nd}_vals'], g[f'd{nd}_q']
+    np.testing.assert_allclose(O.native_interpolate(grids, vals, q, fill_value=np.nan), g[f'd{nd}_fill'],
+                               rtol=1e-13, atol=1e-13, equal_nan=True)
+    np.testing.assert_allclose(O.native_interpolate(grids, vals, q), g[f'd{nd}_extrap'], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(O.native_interpolate(grids, vals, q, fill_value=7.0), g[f'd{nd}_fill7'],
+                               rtol=1e-13, atol=1e-13)
+    # the last-node quirk: row 1 of the appended node queries sits on every last node
+    assert np.isnan(g[f'd{nd}_fill'][401])
+
+
+@pytest.mark.parametrize('ax', [0, 1, 2])
+def test_g2_along_axis(golden, ax):
+    g = golden('g2_interpolate')
+    P, V, Q = g[f'ax{ax}_P'], g[f'ax{ax}_V'], g[f'ax{ax}_Q']
+    np.testing.assert_allclose(O.native_interpolate_along_axis(P, V, Q, axis=ax, fill_value=np.nan),
+                               g[f'ax{ax}_fill'], rtol=1e-13, atol=1e-13, equal_nan=True)
+    np.testing.assert_allclose(O.native_interpolate_along_axis(P, V, Q, axis=ax), g[f'ax{ax}_extrap'],
+                               rtol=1e-12, atol=1e-12)
+
+
+def test_g3_rays(golden):
+    g = golden('g3_rays')
+    lat, lon, zs = g['lat'], g['lon'], g['model_zs']
+    for ht in (-500, 0, 2500):
+        xyz = np.stack(O.lla2ecef(lat, lon, np.full(lat.shape, float(ht))), -1)
+        np.testing.assert_allclose(xyz, g[f'xyz_ht{ht}'], rtol=0, atol=1e-8)
+        for inc in (0, 20, 39, 55):
+            for hd, hdt in ((-167.9, -167), (-12.1, -12)):
+                tag = f'ht{ht}_inc{inc}_hd{hdt}'
+                los = O.look_vectors_from_inc_hd(np.full(lat.shape, float(inc)), np.full(lat.shape, hd), lat, lon, float(ht))
+                np.testing.assert_allclose(los, g[f'los_{tag}'], rtol=0, atol=1e-15)
+                L, lo, hi = O.build_ray(zs, float(ht), xyz, los, 30000.0)
+                np.testing.assert_allclose(L, g[f'len_{tag}'], rtol=0, atol=1e-8)
+                np.testing.assert_allclose(lo[[0, 1, -1]], g[f'low_{tag}'], rtol=0, atol=1e-8)
+                np.testing.assert_allclose(hi[[0, 1, -1]], g[f'high_{tag}'], rtol=0, atol=1e-8)
+        los = O.look_vectors_from_inc_hd(np.full(lat.shape, 39.0), np.full(lat.shape, -167.9), lat, lon, float(ht))
+        np.testing.assert_allclose(O.getTopOfAtmosphere(xyz, los, 15000.0), g[f'toa10_ht{ht}'], atol=1e-8, rtol=0)
+        np.testing.assert_allclose(O.getTopOfAtmosphere(xyz, los, 15000.0, factor=np.full(lat.shape, 0.77)),
+                                   g[f'toa3_ht{ht}'], atol=1e-8, rtol=0)
+    llh = np.stack(O.ecef2lla(g['geo_xyz'][..., 0], g['geo_xyz'][..., 1], g['geo_xyz'][..., 2]), -1)
+    np.testing.assert_allclose(llh, g['geo_llh'], rtol=0, atol=1e-9)
+
+
+def test_g4_build_cube(golden, c1):
+    g = golden('g4_build_cube')
+    wet, hydro = O.build_cube(g['xpts'], g['ypts'], g['zpts'], interps(c1, 'total'))
+    np.testing.assert_allclose(wet, g['wet'], rtol=0, atol=1e-14)
+    np.testing.assert_allclose(hydro, g['hydro'], rtol=0, atol=1e-14)
+    wet2, hydro2 = O.build_cube(g['xp2'], g['yp2'], g['zp2'], interps(c1, 'total'))
+    assert np.isnan(g['wet2']).any() and not np.isnan(g['wet2']).all()
+    np.testing.assert_allclose(wet2, g['wet2'], rtol=0, atol=1e-14, equal_nan=True)
+    np.testing.assert_allclose(hydro2, g['hydro2'], rtol=0, atol=1e-14, equal_nan=True)
+
+
+def test_g5_build_cube_ray(golden, c1):
+    g = golden('g5_build_cube_ray')
+    zref = float(g['c1_zref'])
+    ip = interps(c1, 'pointwise')
+    for tag, inc in (('fixed', 39.0), ('pp', g['c1_pp_inc'])):
+        (wet, hydro), nparts = O.build_cube_ray(g['c1_xpts'], g['c1_ypts'], g['c1_zpts'], look_fn(inc, -167.9), ip,
+                                                MAX_TROPO_HEIGHT=zref, return_nparts=True)
+        for i in range(2):
+            assert np.array_equal(nparts[i], g[f'c1_{tag}_nparts{i}'])
+        np.testing.assert_allclose(wet, g[f'c1_{tag}_wet'], rtol=0, atol=TOL)
+        np.testing.assert_allclose(hydro, g[f'c1_{tag}_hydro'], rtol=0, atol=TOL)
+    (wet, hydro), nparts = O.build_cube_ray(g['c1_xpts'], g['c1_ypts'], np.array([100.0]), look_fn(20.0, -12.1), ip,
+                                            MAX_SEGMENT_LENGTH=500.0, MAX_TROPO_HEIGHT=26000.0, return_nparts=True)
+    assert np.array_equal(nparts[0], g['c1_z26_nparts0'])
+    np.testing.assert_allclose(wet, g['c1_z26_wet'], rtol=0, atol=TOL)
+    np.testing.assert_allclose(hydro, g['c1_z26_hydro'], rtol=0, atol=TOL)
+    # lateral exit -> NaN in exactly the same pixels
+    wet, hydro = O.build_cube_ray(g['c1_edge_xpts'], g['c1_edge_ypts'], np.array([0.0]), look_fn(45.0, -167.9), ip,
+                                  MAX_TROPO_HEIGHT=zref)
+    assert np.isnan(g['c1_edge_wet']).any() and not np.isnan(g['c1_edge_wet']).all()
+    np.testing.assert_allclose(wet, g['c1_edge_wet'], rtol=0, atol=TOL, equal_nan=True)
+    np.testing.assert_allclose(hydro, g['c1_edge_hydro'], rtol=0, atol=TOL, equal_nan=True)
+
+
+def test_g5_constant_refractivity_invariant(golden, c1):
+    """N==1  =>  delay*1e6 == sum of ray lengths (test/test_synthetic.py:217-274)."""
+    g = golden('g5_build_cube_ray')
+    cube1 = dict(c1); cube1['wet'] = np.ones_like(c1['wet']); cube1['hydro'] = np.ones_like(c1['hydro'])
+    zref = float(g['c1_zref'])
+    wet, hydro = O.build_cube_ray(g['c1_one_xpts'], g['c1_one_ypts'], g['c1_zpts'], look_fn(39.0, -167.9),
+                                  interps(cube1, 'pointwise'), MAX_TROPO_HEIGHT=zref)
+    np.testing.assert_allclose(wet, g['c1_one_wet'], rtol=0, atol=TOL)
+    xx, yy = np.meshgrid(g['c1_one_xpts'], g['c1_one_ypts'])
+    for i, ht in enumerate(g['c1_zpts']):
+        xyz = np.stack(O.lla2ecef(yy, xx, np.full(yy.shape, ht)), -1)
+        los = look_fn(39.0, -167.9)(ht, [xx, yy, np.full(yy.shape, ht)], xyz, yy)
+        L, _, _ = O.build_ray(c1['zs'], ht, xyz, los, zref)
+        np.testing.assert_allclose(wet[i] * 1e6, L.sum(0), rtol=1e-13)
+
+
+def test_g5_big_cube(golden):
+    g = golden('g5_build_cube_ray')
+    big = O.synthetic_cube(300, 300, 80, seed=0)
+    (wet, hydro), nparts = O.build_cube_ray(g['big_xpts'], g['big_ypts'], np.array([0.0]), look_fn(g['big_inc'], -167.9),
+                                            interps(big, 'pointwise'), MAX_TROPO_HEIGHT=float(g['big_zref']),
+                                            return_nparts=True)
+    assert np.array_equal(nparts[0], g['big_nparts0'])
+    np.testing.assert_allclose(wet, g['big_wet'], rtol=0, atol=TOL)
+    np.testing.assert_allclose(hydro, g['big_hydro'], rtol=0, atol=TOL)
+
+
+def test_g5b_halves_need_whole_slice_nparts(golden, c1):
+    """shards must be driven with the batch-global nParts."""
+    g = golden('g5b_whole_vs_halves')
+    ip = interps(c1, 'pointwise')
+    zref = float(g['zref'])
+    xp, yp, inc = g['xpts'], g['ypts'], g['inc']
+    for sl, side in ((slice(0, 32), 'left'), (slice(32, 64), 'right')):
+        wet, hydro = O.build_cube_ray(xp[sl], yp, np.array([0.0]), look_fn(inc[:, sl], -167.9), ip,
+                                      MAX_TROPO_HEIGHT=zref, nParts_override=[g['nparts']])
+        np.testing.assert_allclose(hydro, g['hydro'][:, :, sl], rtol=0, atol=TOL)
+        np.testing.assert_allclose(wet, g['wet'][:, :, sl], rtol=0, atol=TOL)
+        # and shard-local nParts reproduces the reference run on the half (which differs from the whole)
+        wet, hydro = O.build_cube_ray(xp[sl], yp, np.array([0.0]), look_fn(inc[:, sl], -167.9), ip, MAX_TROPO_HEIGHT=zref)
+        np.testing.assert_allclose(hydro, g[f'{side}_hydro'], rtol=0, atol=TOL)
+    assert np.abs(g['left_hydro'] - g['hydro'][:, :, :32]).max() > 1e-6
+
+
+def test_g6_los_tables(golden):
+    g = golden('g6_los')
+    enu = O.inc_hd_to_enu(g['inc'], g['hd'])
+    np.testing.assert_array_equal(enu, g['enu'])
+    ecef = O.enu2ecef(enu[..., 0], enu[..., 1], enu[..., 2], g['lat'], g['lon'], 0 * g['lat'])
+    np.testing.assert_array_equal(ecef, g['ecef'])
+    np.testing.assert_array_equal(O.ecef2enu(ecef, g['lat'], g['lon'], 0 * g['lat']), g['enu_back'])
+    np.testing.assert_array_equal(O.getZenithLookVecs(g['lat'], g['lon'], 0 * g['lat']), g['zen'])
+    np.testing.assert_array_equal(O.conventional_project(g['delays'], enu), g['proj_last'])
+    # the three ECEF values the reference test pins exactly (test/test_delayFcns.py:86-99):
+    # transformPoints returns (y, x, z)
+    x, y, z = O.lla2ecef(np.array([0., 0., 0.]), np.array([0., 90., 180.]), np.zeros(3))
+    np.testing.assert_allclose(np.stack([y, x, z], -1), g['tp_equator'], atol=1e-9)
+    np.testing.assert_allclose(np.stack([x, y, z], -1),
+                               [[6378137.0, 0, 0], [0, 6378137.0, 0], [-6378137.0, 0, 0]], atol=1e-9)
+    with pytest.raises(ValueError):
+        O.inc_hd_to_enu(np.array([-1.0]), np.array([0.0]))
+
+
+def test_g8_point_branch(golden, c1):
+    g = golden('g8_points')
+    hl = g['height_levels']
+    wet, hydro = O.build_cube(g['xpts'], g['ypts'], hl, interps(c1, 'total'))
+    w, h = O.points_from_cube(g['lats'], g['lons'], g['hgts'], g['xpts'], g['ypts'], hl, wet, hydro)
+    np.testing.assert_allclose(w, g['wet_zen'], rtol=0, atol=1e-13)
+    np.testing.assert_allclose(h, g['hydro_zen'], rtol=0, atol=1e-13)
+    zref = c1['zs'].max() - 1
+    wet, hydro = O.build_cube_ray(g['xpts_ray'], g['ypts_ray'], hl, look_fn(39.0, -167.9), interps(c1, 'pointwise'),
+                                  MAX_TROPO_HEIGHT=zref)
+    w, h = O.points_from_cube(g['lats'][:200], g['lons'][:200], g['hgts'][:200], g['xpts_ray'], g['ypts_ray'], hl, wet, hydro)
+    np.testing.assert_allclose(w, g['wet_ray'], rtol=0, atol=TOL)
+    np.testing.assert_allclose(h, g['hydro_ray'], rtol=0, atol=TOL)
+
+
+def test_rgi_matches_scipy_edges():
+    """Oracle RGI vs the real scipy (same third-party the reference calls): nodes, last node, NaN, outside,
+    f32 values, descending axis."""
+    from scipy.interpolate import RegularGridInterpolator
+    rng = np.random.default_rng(5)
+    ys = np.linspace(3, -2, 6); xs = np.sort(rng.uniform(0, 5, 7)); zs = np.array([0., 1., 3., 7.])
+    v = rng.normal(size=(6, 7, 4)).astype(np.float32)
+    sp = RegularGridInterpolator((ys, xs, zs), v, fill_value=np.nan, bounds_error=False)
+    mine = O.RGI((ys, xs, zs), v)
+    q = np.stack([rng.uniform(-2.5, 3.5, 500), rng.uniform(-0.5, 5.5, 500), rng.uniform(-1, 8, 500)], -1)
+    q[:6] = [[3, xs[0], 0], [-2, xs[-1], 7], [ys[2], xs[3], zs[1]], [np.nan, 1, 1], [0, 1, 7.0000001], [0, 1, 7]]
+    np.testing.assert_allclose(mine(q), sp(q), rtol=0, atol=1e-15, equal_nan=True)
+    assert mine(q).dtype == np.float64
+
+
+def test_time_weights_and_blend():
+    w1, w2 = O.time_weights(1800.0, 0.0, 3600.0)
+    assert (w1, w2) == (0.5, 0.5)
+    w1, w2 = O.time_weights(900.0, 0.0, 3600.0)
+    assert np.isclose(w1 + w2, 1) and np.isclose(w1, 0.75)
+    a = np.arange(6, dtype=np.float32); b = a[::-1].copy()
+    out = O.blend_cubes(0.5, a, 0.5, b)
+    assert out.dtype == np.float32 and np.allclose(out, 2.5)   # mean of epochs (test_temporal_interpolate.py)
+    assert O.blend_cubes(0.25, a.astype(np.float64), 0.75, b.astype(np.float64)).dtype == np.float64
