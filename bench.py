@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""bench.py - LOS rays/sec (wet+hydro slant delay) through an ERA5-sized cube on MI355X.
+
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on): ray-traced slant delay
+of a 4000x4000 SAR scene (16 M rays) as ONE slice at ht = 0 through the synthetic 300x300x80 cube of
+SURVEY.md §8(d), per-pixel ECEF look vectors (an input array resident in HBM), zref = max(zs)-1,
+MAX_SEGMENT_LENGTH = 1000 m.  One "step" = one pass of the hot path over that batch:
+   pass 1 (build_ray fused: per-level batch max of ray length)  ->  [N>1: all-reduce MAX over ranks]
+   pass 2 (trapezoid integration of wet+hydro along every ray).
+N GPUs: weak scaling - every rank traces its own rows x cols slab of a (N*rows) x cols scene; the cube is
+broadcast once over RCCL; the only data-path collective is the K-double MAX all-reduce that keeps nParts
+batch-global.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+REPO = Path(__file__).resolve().parent
+sys.path.insert(0, str(REPO))
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--rows', type=int, default=4000)
+    ap.add_argument('--cols', type=int, default=4000)
+    ap.add_argument('--cube', type=str, default='300x300x80')
+    ap.add_argument('--cpu-sample', type=int, default=224, help='edge of the square ray block timed on the CPU oracle (0 = skip)')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import raider_amd as R
+    from raider_amd.synthetic import synthetic_cube, scene_grid
+
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...')
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X (no CPU fallback)')
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    ctx = R.Context(local)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)     # library kernels run on torch's current stream
+
+    # ---- weather cube: generated on rank 0, broadcast once over RCCL/xGMI, packed on device -----------
+    ny, nx, nz = (int(v) for v in args.cube.split('x'))
+    if rank == 0:
+        c = synthetic_cube(ny, nx, nz, seed=0)
+        axes = torch.from_numpy(np.concatenate([c['ys'], c['xs'], c['zs']])).to(dev)
+        wet = torch.from_numpy(c['wet']).to(dev)
+        hyd = torch.from_numpy(c['hydro']).to(dev)
+    else:
+        axes = torch.empty(ny + nx + nz, dtype=torch.float64, device=dev)
+        wet = torch.empty((nz, ny, nx), dtype=torch.float32, device=dev)
+        hyd = torch.empty((nz, ny, nx), dtype=torch.float32, device=dev)
+    t_bcast = 0.0
+    if world > 1:
+        torch.cuda.synchronize(); dist.barrier()
+        t0 = time.perf_counter()
+        dist.broadcast(axes, 0); dist.broadcast(wet, 0); dist.broadcast(hyd, 0)
+        torch.cuda.synchronize()
+        t_bcast = time.perf_counter() - t0
+    ax = axes.cpu().numpy()
+    ys, xs, zs = ax[:ny], ax[ny:ny + nx], ax[ny + nx:]
+    cube = R.Cube(ys, xs, zs, wet, hyd, order='zyx', ctx=ctx)
+    zref = float(zs.max() - 1.0)                                 # delay.py:78,86-87
+    ht = 0.0
+
+    # ---- this rank's slab of the scene; look vectors generated on device, then used as an INPUT array ---
+    rows, cols = args.rows, args.cols
+    xpts, ypts, inc_cols, hd = scene_grid(rows, cols, row0=rank * rows, nrows=rows, total_rows=rows * world)
+    xpts_t = torch.from_numpy(xpts).to(dev); ypts_t = torch.from_numpy(ypts).to(dev)
+    inc_t = torch.from_numpy(np.ascontiguousarray(np.broadcast_to(inc_cols, (rows, cols)))).to(dev)
+    hd_t = torch.full((rows, cols), hd, dtype=torch.float64, device=dev)
+    los_t = R.Rays.grid(xpts_t, ypts_t, inc=inc_t, hd=hd_t).look_vectors(ctx)       # (rows, cols, 3) f64 in HBM
+    del inc_t, hd_t
+    rays = R.Rays.grid(xpts_t, ypts_t, los=los_t)
+    out_w = torch.empty((rows, cols), dtype=torch.float64, device=dev)
+    out_h = torch.empty_like(out_w)
+    n_rays = rows * cols
+
+    def step():
+        if world == 1:
+            cube.raytrace(rays, ht, zref, out=(out_w, out_h), want_nparts=False)       # fully asynchronous
+            return None
+        maxlen, flags = cube.ray_prepass(rays, ht, zref)
+        red = torch.from_numpy(np.concatenate([maxlen, [float(flags & 1), float(flags & 2), float(flags & 4), float(flags & 8)]])).to(dev)
+        dist.all_reduce(red, op=dist.ReduceOp.MAX)                                      # RCCL: K+4 doubles
+        red = red.cpu().numpy()
+        gflags = int(red[-4] > 0) * 1 + int(red[-3] > 0) * 2 + int(red[-2] > 0) * 4 + int(red[-1] > 0) * 8
+        nparts = R.nparts_from_maxlen(red[:-4])
+        cube.ray_march(rays, ht, zref, nparts, gflags, out=(out_w, out_h))
+        return nparts
+
+    # nParts / S for the roofline formula (one synchronous untimed call)
+    if world == 1:
+        _, _, nparts, flags = cube.raytrace(rays, ht, zref, out=(out_w, out_h), want_nparts=True)
+    else:
+        nparts = step()
+    S = int(np.sum(nparts)); K = int(len(nparts))
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    ctx.set_profiling(True)                                      # HIP event pairs around every kernel launch
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    n_pre, ms_pre = ctx.profile_get(0)
+    n_march, ms_march = ctx.profile_get(1)
+    ctx.set_profiling(False)
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    nan_frac = float(torch.isnan(out_h).double().mean().item())
+    mean_h = float(torch.nanmean(out_h).item()); mean_w = float(torch.nanmean(out_w).item())
+
+    if rank == 0:
+        total_rays = n_rays * world * args.steps
+        value = total_rays / dt
+        bytes_per_ray = 64 * S + 64                               # SURVEY.md §8(d) gather model
+        march_ms = ms_march / max(n_march, 1)
+        pre_ms = ms_pre / max(n_pre, 1)
+        achieved = bytes_per_ray * n_rays / (march_ms * 1e-3) / 1e9
+        res = {
+            'metric': 'LOS rays/sec (wet+hydro slant delay) through ERA5 cube; achieved HBM GB/s',
+            'value': value, 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': f'configs[2]: Raytracing LOS, {rows}x{cols} scene per GPU ({n_rays/1e6:.1f}M rays), one slice at ht=0, '
+                                   f'per-pixel ECEF look vectors, synthetic ERA5-sized {args.cube} f32 cube, zref=max(z)-1, MAX_SEGMENT_LENGTH=1000',
+                       'rays_per_gpu': n_rays, 'cube': args.cube, 'levels_K': K, 'samples_per_ray_S': S,
+                       'parallelism': f'rows sharded x{world}, cube broadcast over RCCL ({t_bcast*1e3:.1f} ms), MAX all-reduce of {K} doubles per step' if world > 1 else 'single GPU',
+                       'mean_hydro_m': mean_h, 'mean_wet_m': mean_w, 'nan_fraction': nan_frac},
+            'roofline': {'bound': 'hbm', 'kernel': 'ray_kernel<1> (march)', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                         'algorithmic_bytes_per_ray': bytes_per_ray, 'compulsory_bytes_per_ray': 64 + (ny * nx * nz * 8) / n_rays,
+                         'march_ms_avg': march_ms, 'prepass_ms_avg': pre_ms, 'launches_timed': n_march},
+        }
+        if world == 1 and args.cpu_sample > 0:
+            res['cpu_baseline'] = cpu_baseline(args, xpts, ypts, inc_cols, hd, nparts, zref, out_w, out_h)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, xpts, ypts, inc_cols, hd, nparts, zref, out_w, out_h):
+    """The oracle (NumPy port of the reference path, 1 thread) timed on a bounded block of the SAME scene,
+    driven with the whole-slice nParts; also reports |GPU - oracle| on that block."""
+    from oracle import raider_oracle as O
+    from raider_amd.synthetic import synthetic_cube
+    ny, nx, nz = (int(v) for v in args.cube.split('x'))
+    c = synthetic_cube(ny, nx, nz, seed=0)
+    n = min(args.cpu_sample, args.rows, args.cols)
+    r0 = (args.rows - n) // 2; c0 = (args.cols - n) // 2
+    xp = xpts[c0:c0 + n]; yp = ypts[r0:r0 + n]
+    inc = np.broadcast_to(inc_cols[c0:c0 + n], (n, n))
+    look = lambda ht, llh, xyz, yy: O.look_vectors_from_inc_hd(inc, np.full(yy.shape, hd), llh[1], llh[0], llh[2])
+    ip = list(O.getInterpolators(c['xs'], c['ys'], c['zs'], c['wet'], c['hydro']))
+    t0 = time.perf_counter()
+    w, h = O.build_cube_ray(xp, yp, np.array([0.0]), look, ip, MAX_TROPO_HEIGHT=zref, nParts_override=[nparts])
+    dt = time.perf_counter() - t0
+    gw = out_w[r0:r0 + n, c0:c0 + n].cpu().numpy(); gh = out_h[r0:r0 + n, c0:c0 + n].cpu().numpy()
+    err = float(max(np.nanmax(np.abs(gw - w[0])), np.nanmax(np.abs(gh - h[0]))))
+    return {'value': n * n / dt, 'unit': 'rays/s', 'cores': 1, 'kind': 'port',
+            'sample': f'{n}x{n} centre block of the same scene ({n*n} rays, {dt:.1f} s), NumPy oracle (oracle/raider_oracle.py), '
+                      f'whole-slice nParts; host has {os.cpu_count()} logical cores',
+            'gpu_vs_oracle_max_abs_m': err}
+
+
+if __name__ == '__main__':
+    main()

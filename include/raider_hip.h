@@ -1,0 +1,188 @@
+/* raider_hip.h - C ABI of libraider_hip.so, the MI355X (gfx950) engine behind RAiDER's delay hot path.
+ *
+ * Drop-in boundary: these are the entry points a RAiDER maintainer's ctypes binding would call in
+ * place of the reference's NumPy/scipy/pyproj hot loops and its two native extensions.  Every entry
+ * cites the reference interface it replaces (paths relative to the RAiDER repository root).
+ * INTEGRATION.md shows the reference-side ctypes stub.
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, no C++/torch types.  Every function returns an int status
+ *     (RDR_OK or a negative RDR_ERR_*); rdr_last_error() gives the message.
+ *   - the caller owns every buffer it passes; the library owns device memory behind the opaque
+ *     rdr_ctx / rdr_cube handles and never returns an allocation.
+ *   - `loc` says where the caller's arrays live: RDR_HOST (NumPy) - the library stages them through
+ *     its own device scratch and copies results back; RDR_DEVICE - pointers are HIP device pointers
+ *     (e.g. torch tensors), kernels are launched on the ctx stream and NOT synchronised.
+ *   - all floating point arrays are float64 unless a dtype argument says otherwise; angles in degrees,
+ *     lengths in metres; NaN is the in-band missing value exactly as in the reference.
+ *   - one ctx = one device + one stream; a ctx is not thread-safe, distinct ctxs are.
+ */
+#ifndef RAIDER_HIP_H
+#define RAIDER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RDR_OK 0
+#define RDR_ERR_INVALID (-1)    /* bad argument                -> TypeError / ValueError in the shim       */
+#define RDR_ERR_HIP (-2)        /* HIP runtime failure         -> RuntimeError                             */
+#define RDR_ERR_NODEVICE (-3)   /* no usable GPU               -> RuntimeError (product never falls back)  */
+#define RDR_ERR_ALL_NAN (-4)    /* every ray length is NaN     -> ValueError('geo2rdr did not converge...') delay.py:279-280 */
+#define RDR_ERR_NO_LEVELS (-5)  /* no model interval contributes: build_ray returns (None,None,None) losreader.py:832-833 */
+#define RDR_ERR_NAN_LENGTH (-6) /* some (not all) ray lengths NaN: the reference's nParts (delay.py:283) is undefined there */
+
+#define RDR_F32 0
+#define RDR_F64 1
+#define RDR_HOST 0
+#define RDR_DEVICE 1
+
+/* ray origin modes */
+#define RDR_ORIGIN_GRID 0 /* meshgrid(xpts, ypts) at height ht, row-major (ny,nx)  delay.py:242,262-267 */
+#define RDR_ORIGIN_LLH 1  /* per-ray lat[n], lon[n] at height ht                                   */
+#define RDR_ORIGIN_XYZ 2  /* per-ray ECEF xyz[n,3] (already at height ht)                          */
+/* look-vector modes */
+#define RDR_LOS_VEC 0      /* los[n,3] unit ECEF, ground->sensor: what los.getLookVectors returns, delay.py:270 */
+#define RDR_LOS_INC_HD 1   /* inc[n], hd[n] degrees -> inc_hd_to_enu + enu2ecef  losreader.py:374-396, utilFcns.py:91-121 */
+#define RDR_LOS_INC_HD_SCALAR 2 /* one inc0/hd0 for every ray                                       */
+#define RDR_LOS_ZENITH 3   /* getZenithLookVecs, losreader.py:302-316                               */
+
+/* flag bits returned by rdr_ray_prepass / consumed by rdr_ray_march */
+#define RDR_FLAG_ANY_NAN 1        /* some ray length is NaN                                          */
+#define RDR_FLAG_ANY_FINITE 2     /* some ray length is finite                                       */
+#define RDR_FLAG_FIRST_NOT_BELOW 4 /* some ray's first sample is NOT below min(model_zs)  (delay.py:306) */
+#define RDR_FLAG_LAST_NOT_ABOVE 8  /* some ray's last sample is NOT above max(model_zs)   (delay.py:310) */
+
+typedef struct rdr_ctx rdr_ctx;
+typedef struct rdr_cube rdr_cube;
+
+/* Ray batch = one (ny,nx) slice of _build_cube_ray at one height `ht` (delay.py:256-273). */
+typedef struct rdr_rays {
+    int64_t n;          /* number of rays (ny*nx in GRID mode)                                  */
+    int32_t origin_mode;
+    int32_t los_mode;
+    int64_t nx, ny;     /* GRID mode                                                            */
+    const double* xpts; /* GRID: [nx] lon deg                                                   */
+    const double* ypts; /* GRID: [ny] lat deg                                                   */
+    const double* lat;  /* LLH: [n]                                                             */
+    const double* lon;  /* LLH: [n]                                                             */
+    const double* xyz;  /* XYZ: [n,3]; with an inc/heading or zenith LOS lat/lon are needed too */
+    const double* los;  /* LOS_VEC: [n,3]                                                       */
+    const double* inc;  /* LOS_INC_HD: [n]                                                      */
+    const double* hd;   /* LOS_INC_HD: [n]                                                      */
+    double inc0, hd0;   /* LOS_INC_HD_SCALAR                                                    */
+    int32_t loc;        /* RDR_HOST / RDR_DEVICE for every pointer above                        */
+    int32_t _pad;
+} rdr_rays;
+
+/* ---- lifecycle ------------------------------------------------------------------------------- */
+int rdr_version(void);
+/* device < 0: use HIP's current device.  Fails with RDR_ERR_NODEVICE when there is no GPU. */
+int rdr_create(int device, rdr_ctx** out);
+void rdr_destroy(rdr_ctx* ctx);
+/* message of the last failure on this thread (ctx may be NULL) */
+const char* rdr_last_error(rdr_ctx* ctx);
+/* adopt an external hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = ctx's own */
+int rdr_set_stream(rdr_ctx* ctx, void* hip_stream);
+int rdr_synchronize(rdr_ctx* ctx);
+int rdr_device_info(rdr_ctx* ctx, char* name, int name_len, int* compute_units, int64_t* total_mem);
+/* profiling: while on, a HIP event pair brackets every kernel launch on the ctx stream (no sync).
+ * rdr_set_profiling(on) also resets the counters.  rdr_profile_get synchronises on the recorded
+ * events and returns how many launches of kernel kind `which` (0 ray prepass, 1 ray march, 2 interp,
+ * 3 other) were recorded and their summed duration in ms. */
+int rdr_set_profiling(rdr_ctx* ctx, int on);
+int rdr_profile_get(rdr_ctx* ctx, int which, int* count, float* total_ms);
+
+/* ---- weather cube ----------------------------------------------------------------------------
+ * Replaces getInterpolators (tools/RAiDER/delayFcns.py:23-58): the two fields of one processed weather
+ * model (`wet`/`hydro` f32, or `wet_total`/`hydro_total` f64) on a rectilinear (y,x,z) grid, wrapped
+ * with scipy-RegularGridInterpolator semantics (linear, bounds_error=False, fill_value=nan).
+ * wet/hydro: element [iy,ix,iz] at  base + iy*sy + ix*sx + iz*sz  (ELEMENT strides), so both the
+ * file order (z,y,x) (weatherModel.py:685-693) and the transposed (y,x,z) order are accepted without
+ * a host-side transpose.  Axes may be ascending or descending (scipy flips; so do we, on device).
+ * The device copy interleaves (wet,hydro) per cell, z fastest.  */
+int rdr_cube_create(rdr_ctx* ctx, const double* ys, int64_t ny, const double* xs, int64_t nx,
+                    const double* zs, int64_t nz, const void* wet, const void* hydro, int dtype,
+                    int64_t sy, int64_t sx, int64_t sz, int loc, rdr_cube** out);
+void rdr_cube_destroy(rdr_cube* cube);
+int rdr_cube_shape(const rdr_cube* cube, int64_t* ny, int64_t* nx, int64_t* nz, int* dtype);
+/* ascending copies of the axes as the interpolator's `.grid` exposes them (delay.py:239) */
+int rdr_cube_axes(const rdr_cube* cube, double* ys, double* xs, double* zs);
+/* temporal blend, cli/raider.py:817-819: out = w1*a + w2*b (f32 cubes blend in f32, f64 in f64) */
+int rdr_cube_blend(rdr_ctx* ctx, const rdr_cube* a, double w1, const rdr_cube* b, double w2, rdr_cube** out);
+/* copy the (blended) fields back, (y,x,z) C-order, dtype of the cube */
+int rdr_cube_read(rdr_ctx* ctx, const rdr_cube* cube, void* wet, void* hydro);
+
+/* ---- zenith / projected path -----------------------------------------------------------------
+ * scipy RegularGridInterpolator.__call__ on both fields (delay.py:214,120-121): pts[n,3] = (y,x,z). */
+int rdr_interp3(rdr_ctx* ctx, const rdr_cube* cube, const double* pts, int64_t n, double* wet,
+                double* hydro, int loc);
+/* _build_cube (delay.py:196-216) for model_crs == pts_crs: out[(iz*ny+iy)*nx+ix] = f(ypts[iy],xpts[ix],zpts[iz]) */
+int rdr_build_cube(rdr_ctx* ctx, const rdr_cube* cube, const double* xpts, int64_t nx, const double* ypts,
+                   int64_t ny, const double* zpts, int64_t nz, double* wet, double* hydro, int loc);
+/* Conventional.__call__ tail (losreader.py:130-133) with inc/heading rasters: out = delay / cos(inc) */
+int rdr_project_cosinc(rdr_ctx* ctx, double* wet, double* hydro, const double* inc, int64_t n, int loc);
+
+/* ---- ray-traced path --------------------------------------------------------------------------
+ * rdr_ray_levels: the slice-uniform part of build_ray (losreader.py:785-808).  lo/hi/kz need room for
+ * nz-1 entries; kz[k] = index of the model interval. Returns RDR_ERR_NO_LEVELS when K==0. */
+int rdr_ray_levels(const rdr_cube* cube, double ht, double zref, int32_t* K, double* lo, double* hi, int32_t* kz);
+/* Pass 1 (build_ray, losreader.py:772-835, fused - nothing materialised): per-level max ray length over
+ * the batch (what delay.py:283 reduces) and the RDR_FLAG_* bits.  maxlen (K doubles) and flags are HOST
+ * outputs (this call synchronises).  Multi-GPU callers all-reduce MAX(maxlen) / OR(flags) across ranks. */
+int rdr_ray_prepass(rdr_ctx* ctx, const rdr_cube* cube, const rdr_rays* rays, double ht, double zref,
+                    double* maxlen, int32_t* flags);
+/* nParts = ceil(maxlen/max_seg)+1 (delay.py:283) */
+int rdr_nparts(const double* maxlen, int32_t K, double max_seg, int32_t* nparts);
+/* Pass 2 (delay.py:285-323 + build_ray recomputed in registers): trapezoid integral of both fields along
+ * each ray with the GIVEN partition nparts[K] (host array) and clamp decision `flags`.
+ * wet/hydro: [n] outputs (overwritten, not accumulated), location = rays->loc. */
+int rdr_ray_march(rdr_ctx* ctx, const rdr_cube* cube, const rdr_rays* rays, double ht, double zref,
+                  const int32_t* nparts, int32_t flags, double* wet, double* hydro);
+/* One slice of _build_cube_ray (delay.py:256-323): prepass -> nParts on device -> march, no host
+ * round trip.  nparts_out (host, K entries, may be NULL) and flags_out (may be NULL) are filled after
+ * the launch (this forces a synchronisation; pass NULL for a fully asynchronous call with RDR_DEVICE).
+ * Returns RDR_ERR_ALL_NAN / RDR_ERR_NAN_LENGTH only when it synchronised. */
+int rdr_raytrace(rdr_ctx* ctx, const rdr_cube* cube, const rdr_rays* rays, double ht, double zref,
+                 double max_seg, double* wet, double* hydro, int32_t* nparts_out, int32_t* flags_out);
+
+/* Materialising variants for API parity on small inputs:
+ * getTopOfAtmosphere (losreader.py:706-733): factor==NULL -> 10 iterations with factor 1, else 3 */
+int rdr_top_of_atmosphere(rdr_ctx* ctx, const double* xyz, const double* los, int64_t n, double toaheight,
+                          const double* factor, double* pos, int loc);
+/* build_ray (losreader.py:772-835): ray_lengths[K,n], low[K,n,3], high[K,n,3] */
+int rdr_build_ray(rdr_ctx* ctx, const double* model_zs, int64_t nz, double ht, const double* xyz,
+                  const double* los, int64_t n, double zref, int32_t* K, double* lengths, double* low,
+                  double* high, int loc);
+
+/* ---- geodesy helpers (pyproj call sites utilFcns.py:77-88; LOS helpers losreader.py:302-316,374-396) */
+int rdr_lla2ecef(rdr_ctx* ctx, const double* lat, const double* lon, const double* h, int64_t n, double* xyz, int loc);
+int rdr_ecef2lla(rdr_ctx* ctx, const double* xyz, int64_t n, double* lon, double* lat, double* h, int loc);
+/* look vectors for a ray batch (any los_mode) -> los[n,3] */
+int rdr_look_vectors(rdr_ctx* ctx, const rdr_rays* rays, double ht, double* los);
+
+/* ---- the reference's two native extensions ----------------------------------------------------
+ * RAiDER.interpolate.interpolate (tools/bindings/interpolate/src/module.cpp:26-294, interpolate.cpp):
+ * N-D linear interpolation (ndim <= 8 on device), C-order values, interp_points[n,ndim].
+ * has_fill: queries with upper-bound index outside [1, N-1] (incl. ON the last node) get fill_value;
+ * else indices are clamped (linear extrapolation).  interpolate.h:23-74 */
+int rdr_interp_nd(rdr_ctx* ctx, int32_t ndim, const double* const* axes, const int64_t* axis_len,
+                  const double* values, const double* interp_points, int64_t n, int has_fill,
+                  double fill_value, double* out, int loc);
+/* RAiDER.interpolate.interpolate_along_axis (module.cpp:296-493, interpolate.cpp:260-332) on arrays made
+ * contiguous with the axis LAST: points/values [ncol, m], interp_points/out [ncol, mq]. */
+int rdr_interp_along_axis(rdr_ctx* ctx, const double* points, const double* values, int64_t ncol, int64_t m,
+                          const double* interp_points, int64_t mq, int has_fill, double fill_value,
+                          double* out, int loc);
+/* RAiDER.makePoints.makePoints{0,1,2,3}D (tools/bindings/utils/makePoints.pyx:15-148):
+ * out[r,3,npts] = sp[r,c] + (k*step)*slv[r,c]; npts = rdr_make_points_count(max_len, step) */
+int64_t rdr_make_points_count(double max_len, double step);
+int rdr_make_points(rdr_ctx* ctx, double max_len, const double* sp, const double* slv, int64_t nrays,
+                    double step, double* out, int loc);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAIDER_HIP_H */

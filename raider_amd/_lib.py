@@ -1,0 +1,194 @@
+"""ctypes binding of libraider_hip.so (C ABI: include/raider_hip.h).
+
+There is NO CPU fallback anywhere in this package: if the shared library is missing, or no MI355X
+is visible, every compute entry point raises RuntimeError.
+"""
+import ctypes as C
+import os
+import threading
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = Path(os.environ.get('RAIDER_HIP_LIB', _HERE / 'libraider_hip.so'))
+
+RDR_OK = 0
+RDR_ERR_INVALID, RDR_ERR_HIP, RDR_ERR_NODEVICE, RDR_ERR_ALL_NAN, RDR_ERR_NO_LEVELS, RDR_ERR_NAN_LENGTH = -1, -2, -3, -4, -5, -6
+RDR_F32, RDR_F64 = 0, 1
+RDR_HOST, RDR_DEVICE = 0, 1
+ORIGIN_GRID, ORIGIN_LLH, ORIGIN_XYZ = 0, 1, 2
+LOS_VEC, LOS_INC_HD, LOS_INC_HD_SCALAR, LOS_ZENITH = 0, 1, 2, 3
+FLAG_ANY_NAN, FLAG_ANY_FINITE, FLAG_FIRST_NOT_BELOW, FLAG_LAST_NOT_ABOVE = 1, 2, 4, 8
+
+c_dp = C.POINTER(C.c_double)
+c_ip = C.POINTER(C.c_int32)
+c_lp = C.POINTER(C.c_int64)
+
+
+class RdrRays(C.Structure):
+    _fields_ = [
+        ('n', C.c_int64), ('origin_mode', C.c_int32), ('los_mode', C.c_int32),
+        ('nx', C.c_int64), ('ny', C.c_int64),
+        ('xpts', C.c_void_p), ('ypts', C.c_void_p), ('lat', C.c_void_p), ('lon', C.c_void_p),
+        ('xyz', C.c_void_p), ('los', C.c_void_p), ('inc', C.c_void_p), ('hd', C.c_void_p),
+        ('inc0', C.c_double), ('hd0', C.c_double), ('loc', C.c_int32), ('_pad', C.c_int32),
+    ]
+
+
+class NoLevels(Exception):
+    """build_ray would return (None, None, None) (losreader.py:832-833)."""
+
+
+_lib = None
+_lock = threading.Lock()
+
+# every symbol include/raider_hip.h declares: (name, restype, argtypes)
+_VP = C.c_void_p
+SYMBOLS = [
+    ('rdr_version', C.c_int, []),
+    ('rdr_create', C.c_int, [C.c_int, C.POINTER(_VP)]),
+    ('rdr_destroy', None, [_VP]),
+    ('rdr_last_error', C.c_char_p, [_VP]),
+    ('rdr_set_stream', C.c_int, [_VP, _VP]),
+    ('rdr_synchronize', C.c_int, [_VP]),
+    ('rdr_device_info', C.c_int, [_VP, C.c_char_p, C.c_int, C.POINTER(C.c_int), c_lp]),
+    ('rdr_set_profiling', C.c_int, [_VP, C.c_int]),
+    ('rdr_profile_get', C.c_int, [_VP, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_float)]),
+    ('rdr_cube_create', C.c_int, [_VP, _VP, C.c_int64, _VP, C.c_int64, _VP, C.c_int64, _VP, _VP, C.c_int,
+                                  C.c_int64, C.c_int64, C.c_int64, C.c_int, C.POINTER(_VP)]),
+    ('rdr_cube_destroy', None, [_VP]),
+    ('rdr_cube_shape', C.c_int, [_VP, c_lp, c_lp, c_lp, C.POINTER(C.c_int)]),
+    ('rdr_cube_axes', C.c_int, [_VP, _VP, _VP, _VP]),
+    ('rdr_cube_blend', C.c_int, [_VP, _VP, C.c_double, _VP, C.c_double, C.POINTER(_VP)]),
+    ('rdr_cube_read', C.c_int, [_VP, _VP, _VP, _VP]),
+    ('rdr_interp3', C.c_int, [_VP, _VP, _VP, C.c_int64, _VP, _VP, C.c_int]),
+    ('rdr_build_cube', C.c_int, [_VP, _VP, _VP, C.c_int64, _VP, C.c_int64, _VP, C.c_int64, _VP, _VP, C.c_int]),
+    ('rdr_project_cosinc', C.c_int, [_VP, _VP, _VP, _VP, C.c_int64, C.c_int]),
+    ('rdr_ray_levels', C.c_int, [_VP, C.c_double, C.c_double, c_ip, _VP, _VP, _VP]),
+    ('rdr_ray_prepass', C.c_int, [_VP, _VP, C.POINTER(RdrRays), C.c_double, C.c_double, _VP, c_ip]),
+    ('rdr_nparts', C.c_int, [_VP, C.c_int32, C.c_double, _VP]),
+    ('rdr_ray_march', C.c_int, [_VP, _VP, C.POINTER(RdrRays), C.c_double, C.c_double, _VP, C.c_int32, _VP, _VP]),
+    ('rdr_raytrace', C.c_int, [_VP, _VP, C.POINTER(RdrRays), C.c_double, C.c_double, C.c_double, _VP, _VP, _VP, c_ip]),
+    ('rdr_top_of_atmosphere', C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_double, _VP, _VP, C.c_int]),
+    ('rdr_build_ray', C.c_int, [_VP, _VP, C.c_int64, C.c_double, _VP, _VP, C.c_int64, C.c_double, c_ip, _VP, _VP, _VP, C.c_int]),
+    ('rdr_lla2ecef', C.c_int, [_VP, _VP, _VP, _VP, C.c_int64, _VP, C.c_int]),
+    ('rdr_ecef2lla', C.c_int, [_VP, _VP, C.c_int64, _VP, _VP, _VP, C.c_int]),
+    ('rdr_look_vectors', C.c_int, [_VP, C.POINTER(RdrRays), C.c_double, _VP]),
+    ('rdr_interp_nd', C.c_int, [_VP, C.c_int32, C.POINTER(_VP), c_lp, _VP, _VP, C.c_int64, C.c_int, C.c_double, _VP, C.c_int]),
+    ('rdr_interp_along_axis', C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_int64, _VP, C.c_int64, C.c_int, C.c_double, _VP, C.c_int]),
+    ('rdr_make_points_count', C.c_int64, [C.c_double, C.c_double]),
+    ('rdr_make_points', C.c_int, [_VP, C.c_double, _VP, _VP, C.c_int64, C.c_double, _VP, C.c_int]),
+]
+
+
+def load():
+    """dlopen the HIP library (does not need a GPU) and declare every prototype."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not LIB_PATH.exists():
+            raise RuntimeError(
+                f'raider_amd: HIP library {LIB_PATH} is missing - build it with '
+                f'`python -c "import __graft_entry__ as g; g.build()"` (hipcc --offload-arch=gfx950). '
+                'There is no CPU fallback.')
+        lib = C.CDLL(str(LIB_PATH))
+        for name, res, args in SYMBOLS:
+            fn = getattr(lib, name)      # AttributeError if the .so does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+        return lib
+
+
+def last_error(ctx=None):
+    msg = load().rdr_last_error(ctx)
+    return msg.decode() if msg else ''
+
+
+def check(rc, ctx=None, exc_invalid=ValueError):
+    """Map C status codes onto the exception classes the reference raises."""
+    if rc == RDR_OK:
+        return
+    msg = last_error(ctx)
+    if rc == RDR_ERR_INVALID:
+        raise exc_invalid(msg)
+    if rc == RDR_ERR_ALL_NAN:
+        raise ValueError(msg)                      # delay.py:279-280
+    if rc == RDR_ERR_NAN_LENGTH:
+        raise ValueError(msg)                      # delay.py:283 -> np.linspace(num<0) ValueError in the reference
+    if rc == RDR_ERR_NO_LEVELS:
+        raise NoLevels(msg)
+    raise RuntimeError(f'raider_amd HIP engine error {rc}: {msg}')
+
+
+class Context:
+    """One device + one stream.  `Context.default()` is the process-wide lazily created context."""
+
+    _default = None
+
+    def __init__(self, device=-1):
+        lib = load()
+        h = C.c_void_p()
+        rc = lib.rdr_create(int(device), C.byref(h))
+        if rc != RDR_OK:
+            raise RuntimeError(f'raider_amd: cannot create a GPU context ({last_error()}). '
+                               'raider_amd needs an AMD MI355X (gfx950); there is no CPU fallback.')
+        self.handle = h
+        self.lib = lib
+
+    @classmethod
+    def default(cls):
+        if cls._default is None:
+            dev = int(os.environ.get('RAIDER_HIP_DEVICE', os.environ.get('LOCAL_RANK', '-1')))
+            cls._default = cls(dev)
+        return cls._default
+
+    def set_stream(self, stream_handle):
+        check(self.lib.rdr_set_stream(self.handle, C.c_void_p(stream_handle or 0)), self.handle)
+
+    def synchronize(self):
+        check(self.lib.rdr_synchronize(self.handle), self.handle)
+
+    def device_info(self):
+        name = C.create_string_buffer(256)
+        cus = C.c_int()
+        mem = C.c_int64()
+        check(self.lib.rdr_device_info(self.handle, name, 256, C.byref(cus), C.byref(mem)), self.handle)
+        return name.value.decode(), cus.value, mem.value
+
+    def set_profiling(self, on=True):
+        check(self.lib.rdr_set_profiling(self.handle, int(bool(on))), self.handle)
+
+    def profile_get(self, which):
+        """(launch count, total ms) of kernel kind `which` since set_profiling(True)."""
+        n = C.c_int()
+        ms = C.c_float()
+        check(self.lib.rdr_profile_get(self.handle, int(which), C.byref(n), C.byref(ms)), self.handle)
+        return n.value, float(ms.value)
+
+    def __del__(self):
+        try:
+            if getattr(self, 'handle', None) and self is not Context._default:
+                self.lib.rdr_destroy(self.handle)
+        except Exception:
+            pass
+
+
+def f64(a):
+    """C-contiguous float64 view/copy (what py::array::c_style forces, module.cpp:27-29)."""
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def ptr(a):
+    """void* of a NumPy array, a torch tensor (data_ptr), an int address, or None."""
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data_as(C.c_void_p)
+    if isinstance(a, int):
+        return C.c_void_p(a)
+    if hasattr(a, 'data_ptr'):
+        return C.c_void_p(a.data_ptr())
+    raise TypeError(f'cannot take a pointer of {type(a)}')

@@ -1,0 +1,1105 @@
+// libraider_hip.so - C ABI (include/raider_hip.h) + the remaining kernels.  gfx950 only.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC raider_hip.hip -o libraider_hip.so
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/raider_hip.h"
+#include "raider_kernels.h"
+
+using namespace rdr;
+
+// ------------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+enum { SLOT_IN0 = 0, SLOT_IN1, SLOT_IN2, SLOT_IN3, SLOT_IN4, SLOT_IN5, SLOT_OUT0, SLOT_OUT1, SLOT_OUT2, SLOT_AUX, NSLOT };
+
+struct rdr_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    int num_cus = 256;
+    size_t total_mem = 0;
+    std::string name;
+    bool profiling = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> evs[4];   // HIP event pairs around every launch, per kernel kind
+    size_t ev_used[4] = {0, 0, 0, 0};
+    DevBuf slot[NSLOT];
+    unsigned long long* d_maxlen = nullptr;   // [MAX_LEVELS]
+    int* d_flags = nullptr;                   // [1]
+    int* d_nparts = nullptr;                  // [MAX_LEVELS]
+    std::string err;
+};
+
+struct rdr_cube {
+    rdr_ctx* ctx = nullptr;
+    int64_t ny = 0, nx = 0, nz = 0;
+    int dtype = RDR_F32;
+    void* d_vals = nullptr;     // interleaved (wet,hydro), (y,x,z) z fastest
+    double* d_axes = nullptr;   // ys | xs | zs ascending
+    std::vector<double> ys, xs, zs;
+    int uni[3] = {0, 0, 0};
+    double inv_d[3] = {0, 0, 0};
+};
+
+static int fail(rdr_ctx* ctx, int code, const std::string& msg) {
+    g_err = msg;
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+#define HIPCHECK(ctx, expr)                                                                         \
+    do {                                                                                            \
+        hipError_t _e = (expr);                                                                     \
+        if (_e != hipSuccess)                                                                       \
+            return fail(ctx, RDR_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));      \
+    } while (0)
+
+static int ensure(rdr_ctx* ctx, int s, size_t bytes, void** out) {
+    DevBuf& b = ctx->slot[s];
+    if (b.cap < bytes) {
+        if (b.p) { HIPCHECK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHECK(ctx, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+        size_t cap = std::max(bytes, (size_t)1 << 16);
+        HIPCHECK(ctx, hipMalloc(&b.p, cap));
+        b.cap = cap;
+    }
+    *out = b.p;
+    return RDR_OK;
+}
+
+// input staging: host -> scratch slot (synchronous w.r.t. host buffer), device -> passthrough
+static int stage_in(rdr_ctx* ctx, int s, const void* src, size_t bytes, int loc, const void** dev) {
+    if (!src) { *dev = nullptr; return RDR_OK; }
+    if (loc == RDR_DEVICE) { *dev = src; return RDR_OK; }
+    void* d;
+    int rc = ensure(ctx, s, bytes, &d);
+    if (rc) return rc;
+    HIPCHECK(ctx, hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    *dev = d;
+    return RDR_OK;
+}
+
+static int stage_out(rdr_ctx* ctx, int s, void* dst, size_t bytes, int loc, void** dev) {
+    if (loc == RDR_DEVICE) { *dev = dst; return RDR_OK; }
+    return ensure(ctx, s, bytes, dev);
+}
+
+static int finish_out(rdr_ctx* ctx, void* dst, const void* dev, size_t bytes, int loc) {
+    if (loc == RDR_DEVICE || !dst) return RDR_OK;
+    HIPCHECK(ctx, hipMemcpyAsync(dst, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    return RDR_OK;
+}
+
+struct KTimer {
+    rdr_ctx* c; int which; hipEvent_t stop = nullptr;
+    KTimer(rdr_ctx* ctx, int w) : c(ctx), which(w) {
+        if (!c->profiling) return;
+        auto& v = c->evs[which];
+        if (c->ev_used[which] == v.size()) {
+            hipEvent_t a = nullptr, b = nullptr;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+            v.emplace_back(a, b);
+        }
+        auto& pr = v[c->ev_used[which]++];
+        (void)hipEventRecord(pr.first, c->stream);
+        stop = pr.second;
+    }
+    ~KTimer() { if (stop) (void)hipEventRecord(stop, c->stream); }
+};
+
+static inline int grid_for(int64_t n, int block, int max_blocks) {
+    int64_t g = (n + block - 1) / block;
+    return (int)std::max<int64_t>(1, std::min<int64_t>(g, max_blocks));
+}
+
+// ------------------------------------------------------------------------------------------------
+// small kernels
+// ------------------------------------------------------------------------------------------------
+template <typename T, typename T2>
+__global__ void pack_cube_kernel(const T* __restrict__ wet, const T* __restrict__ hyd, T2* __restrict__ dst,
+                                 int64_t ny, int64_t nx, int64_t nz, int64_t sy, int64_t sx, int64_t sz,
+                                 int fy, int fx, int fz) {
+    const int64_t total = ny * nx * nz;
+    for (int64_t o = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t iz = o % nz, r = o / nz, ix = r % nx, iy = r / nx;
+        const int64_t jy = fy ? ny - 1 - iy : iy, jx = fx ? nx - 1 - ix : ix, jz = fz ? nz - 1 - iz : iz;
+        const int64_t s = jy * sy + jx * sx + jz * sz;
+        T2 v; v.x = wet[s]; v.y = hyd[s];
+        dst[o] = v;
+    }
+}
+
+template <typename T, typename T2>
+__global__ void unpack_cube_kernel(const T2* __restrict__ src, T* __restrict__ wet, T* __restrict__ hyd, int64_t total) {
+    for (int64_t o = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x) {
+        const T2 v = src[o]; wet[o] = v.x; hyd[o] = v.y;
+    }
+}
+
+// cli/raider.py:817-819: sum([w*ds[var]]) = 0 + w1*a + w2*b in the array dtype (numpy<2 value-based casting)
+template <typename T, typename T2>
+__global__ void blend_kernel(const T2* __restrict__ a, T w1, const T2* __restrict__ b, T w2, T2* __restrict__ out, int64_t total) {
+    for (int64_t o = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x) {
+        const T2 va = a[o], vb = b[o];
+        T2 r;
+        {
+#pragma clang fp contract(off)
+            const T p = w1 * va.x, q = w2 * vb.x; r.x = p + q;
+            const T p2 = w1 * va.y, q2 = w2 * vb.y; r.y = p2 + q2;
+        }
+        out[o] = r;
+    }
+}
+
+// A4/A5: scipy RGI at packed points (n,3) = (y,x,z)
+template <typename T2>
+__global__ __launch_bounds__(256) void interp_points_kernel(CubeView<T2> c, const double* __restrict__ pts, int64_t n,
+                                                            double* __restrict__ wet, double* __restrict__ hyd) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double* s_y = reinterpret_cast<double*>(smem_raw);
+    double* s_x = s_y + c.ny;
+    double* s_z = s_x + c.nx;
+    for (int i = threadIdx.x; i < c.ny + c.nx + c.nz; i += blockDim.x) s_y[i] = c.axes[i];
+    __syncthreads();
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double y = pts[3 * i], x = pts[3 * i + 1], z = pts[3 * i + 2];
+        double w, h;
+        trilinear(c, s_y, s_x, s_z, y, x, z, -1, w, h);
+        wet[i] = w; hyd[i] = h;
+    }
+}
+
+// _build_cube (delay.py:196-216): points generated on the fly from (xpts, ypts, zpts)
+template <typename T2>
+__global__ __launch_bounds__(256) void build_cube_kernel(CubeView<T2> c, const double* __restrict__ xpts, int64_t nx,
+                                                         const double* __restrict__ ypts, int64_t ny,
+                                                         const double* __restrict__ zpts, int64_t nz,
+                                                         double* __restrict__ wet, double* __restrict__ hyd) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double* s_y = reinterpret_cast<double*>(smem_raw);
+    double* s_x = s_y + c.ny;
+    double* s_z = s_x + c.nx;
+    for (int i = threadIdx.x; i < c.ny + c.nx + c.nz; i += blockDim.x) s_y[i] = c.axes[i];
+    __syncthreads();
+    const int64_t n = nx * ny * nz;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t ix = i % nx, r = i / nx, iy = r % ny, iz = r / ny;
+        double w, h;
+        trilinear(c, s_y, s_x, s_z, ypts[iy], xpts[ix], zpts[iz], -1, w, h);
+        wet[i] = w; hyd[i] = h;
+    }
+}
+
+__global__ void project_kernel(double* wet, double* hyd, const double* __restrict__ inc, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double up = cos(inc[i] * DEG_TO_RAD);   // inc_hd_to_enu(...)[..., -1] = cosd(inc)
+        wet[i] = wet[i] / up; hyd[i] = hyd[i] / up;
+    }
+}
+
+__global__ void lla2ecef_kernel(const double* __restrict__ lat, const double* __restrict__ lon, const double* __restrict__ h,
+                                int64_t n, double* __restrict__ xyz) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        double x, y, z; lla2ecef(lat[i], lon[i], h[i], x, y, z);
+        xyz[3 * i] = x; xyz[3 * i + 1] = y; xyz[3 * i + 2] = z;
+    }
+}
+
+__global__ void ecef2lla_kernel(const double* __restrict__ xyz, int64_t n, double* __restrict__ lon, double* __restrict__ lat,
+                                double* __restrict__ h) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        double lo, la, hh; ecef2lla(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], lo, la, hh);
+        lon[i] = lo; lat[i] = la; h[i] = hh;
+    }
+}
+
+__global__ void look_kernel(RayParams P, double* __restrict__ los) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < P.n; i += (int64_t)gridDim.x * blockDim.x) {
+        double lat, lon;
+        if (P.origin_mode == 0) { lat = P.ypts[i / P.nx]; lon = P.xpts[i % P.nx]; }
+        else { lat = P.lat[i]; lon = P.lon[i]; }
+        double u, v, w;
+        if (P.los_mode == 0) { u = P.los[3 * i]; v = P.los[3 * i + 1]; w = P.los[3 * i + 2]; }
+        else if (P.los_mode == 1) inc_hd_to_ecef(P.inc[i], P.hd[i], lat, lon, u, v, w);
+        else if (P.los_mode == 2) inc_hd_to_ecef(P.inc0, P.hd0, lat, lon, u, v, w);
+        else {
+            double sla, cla, slo, clo;
+            sincos(lat * DEG_TO_RAD, &sla, &cla); sincos(lon * DEG_TO_RAD, &slo, &clo);
+            u = cla * clo; v = cla * slo; w = sla;
+        }
+        los[3 * i] = u; los[3 * i + 1] = v; los[3 * i + 2] = w;
+    }
+}
+
+__global__ void toa_kernel(const double* __restrict__ xyz, const double* __restrict__ los, int64_t n, double h,
+                           const double* __restrict__ factor, double* __restrict__ pos) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        double px, py, pz;
+        toa_newton(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], los[3 * i], los[3 * i + 1], los[3 * i + 2], h,
+                   factor ? 3 : 10, factor ? factor[i] : 1.0, px, py, pz);
+        pos[3 * i] = px; pos[3 * i + 1] = py; pos[3 * i + 2] = pz;
+    }
+}
+
+// build_ray materialised (losreader.py:772-835): levels passed in a small device table
+__global__ void build_ray_kernel(const double* __restrict__ xyz, const double* __restrict__ los, int64_t n, int K,
+                                 const double* __restrict__ lo_hi, double* __restrict__ lengths, double* __restrict__ low,
+                                 double* __restrict__ high) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double ox = xyz[3 * i], oy = xyz[3 * i + 1], oz = xyz[3 * i + 2];
+        const double lx = los[3 * i], ly = los[3 * i + 1], lz = los[3 * i + 2];
+        double hx = 0, hy = 0, hz = 0, cosf = 1.0;
+        for (int k = 0; k < K; ++k) {
+            const double lo = lo_hi[k], hi = lo_hi[K + k];
+            double bx, by, bz;
+            if (k == 0) toa_newton(ox, oy, oz, lx, ly, lz, lo, 10, 1.0, bx, by, bz);
+            else { bx = hx; by = hy; bz = hz; }
+            toa_newton(ox, oy, oz, lx, ly, lz, hi, k == 0 ? 10 : 3, cosf, hx, hy, hz);
+            const double dx = hx - bx, dy = hy - by, dz = hz - bz;
+            const double L = sqrt(dx * dx + dy * dy + dz * dz);
+            if (k == 0) cosf = (hi - lo) / L;
+            lengths[(int64_t)k * n + i] = L;
+            double* pl = low + ((int64_t)k * n + i) * 3; pl[0] = bx; pl[1] = by; pl[2] = bz;
+            double* ph = high + ((int64_t)k * n + i) * 3; ph[0] = hx; ph[1] = hy; ph[2] = hz;
+        }
+    }
+}
+
+// ---- native extension kernels -------------------------------------------------------------------
+// interpolate.h:23-38 bisect_left: first index with x < a[i]
+__device__ __forceinline__ int upper_bound_idx(const double* a, int n, double x) {
+    int left = 0, right = n;
+    while (right != left) {
+        const int mid = (left + right) / 2;
+        if (x < a[mid]) right = mid; else left = mid + 1;
+    }
+    return right;
+}
+
+struct NdParams {
+    int ndim;
+    int64_t len[8];
+    int64_t off[8];      // offset of axis d inside `axes`
+    int64_t stride[8];   // C-order element strides of `values`
+};
+
+__global__ void interp_nd_kernel(NdParams P, const double* __restrict__ axes, const double* __restrict__ values,
+                                 const double* __restrict__ q, int64_t n, int has_fill, double fill, double* __restrict__ out) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int lo[8], hi[8];
+        double d0[8], d1[8];
+        double vol = 1.0;
+        bool filled = false;
+        for (int d = 0; d < P.ndim; ++d) {
+            const double* g = axes + P.off[d];
+            const int N = (int)P.len[d];
+            const double x = q[i * P.ndim + d];
+            int h = upper_bound_idx(g, N, x);
+            if (has_fill) { if (h < 1 || h > N - 1) { filled = true; } }
+            h = min(max(h, 1), N - 1);
+            hi[d] = h; lo[d] = h - 1;
+            const double x0 = g[h - 1], x1 = g[h];
+            vol *= x1 - x0;
+            d0[d] = x - x0; d1[d] = x1 - x;
+        }
+        if (filled) { out[i] = fill; continue; }
+        double r;
+        {
+#pragma clang fp contract(off)
+        if (P.ndim == 1) {
+            const double* g = axes + P.off[0];
+            const double x0 = g[lo[0]], x1 = g[hi[0]], y0 = values[lo[0]], y1 = values[hi[0]];
+            const double slope = (y1 - y0) / (x1 - x0);                                   // interpolate.h:115-116
+            r = y0 + slope * (q[i] - x0);
+        } else if (P.ndim == 2) {
+            const int64_t s0 = P.stride[0];
+            const double z00 = values[lo[0] * s0 + lo[1]], z01 = values[lo[0] * s0 + hi[1]];
+            const double z10 = values[hi[0] * s0 + lo[1]], z11 = values[hi[0] * s0 + hi[1]];
+            r = (d1[0] * (z00 * d1[1] + z01 * d0[1]) + d0[0] * (z10 * d1[1] + z11 * d0[1])) / vol;   // interpolate.cpp:78-81
+        } else if (P.ndim == 3) {
+            const int64_t s0 = P.stride[0], s1 = P.stride[1];
+            const double w000 = values[lo[0] * s0 + lo[1] * s1 + lo[2]], w001 = values[lo[0] * s0 + lo[1] * s1 + hi[2]];
+            const double w010 = values[lo[0] * s0 + hi[1] * s1 + lo[2]], w011 = values[lo[0] * s0 + hi[1] * s1 + hi[2]];
+            const double w100 = values[hi[0] * s0 + lo[1] * s1 + lo[2]], w101 = values[hi[0] * s0 + lo[1] * s1 + hi[2]];
+            const double w110 = values[hi[0] * s0 + hi[1] * s1 + lo[2]], w111 = values[hi[0] * s0 + hi[1] * s1 + hi[2]];
+            r = (d1[0] * (d1[1] * (d1[2] * w000 + d0[2] * w001) + d0[1] * (d1[2] * w010 + d0[2] * w011)) +
+                 d0[0] * (d1[1] * (d1[2] * w100 + d0[2] * w101) + d0[1] * (d1[2] * w110 + d0[2] * w111))) / vol;   // interpolate.cpp:164-174
+        } else {
+            r = 0.0;
+            for (int j = 0; j < (1 << P.ndim); ++j) {                                      // interpolate.cpp:236-252
+                int64_t idx = 0;
+                double term = 1.0;
+                for (int d = 0; d < P.ndim; ++d) idx += (int64_t)(((j >> d) & 1) ? hi[d] : lo[d]) * P.stride[d];
+                term = values[idx];
+                for (int d = 0; d < P.ndim; ++d) term *= ((j >> d) & 1) ? d0[d] : d1[d];
+                r += term;
+            }
+            r /= vol;
+        }
+        }
+        out[i] = r;
+    }
+}
+
+// interpolate_1d along the last axis of [ncol, m] (interpolate.h:78-118)
+__global__ void along_axis_kernel(const double* __restrict__ xs, const double* __restrict__ ys, int64_t ncol, int64_t m,
+                                  const double* __restrict__ q, int64_t mq, int has_fill, double fill, double* __restrict__ out) {
+    const int64_t total = ncol * mq;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t col = t / mq;
+        const double* g = xs + col * m;
+        const double* v = ys + col * m;
+        const double x = q[t];
+        int h = upper_bound_idx(g, (int)m, x);
+        if (has_fill && (h < 1 || h > m - 1)) { out[t] = fill; continue; }
+        h = min(max(h, 1), (int)m - 1);
+        const double x0 = g[h - 1], x1 = g[h], y0 = v[h - 1], y1 = v[h];
+        {
+#pragma clang fp contract(off)
+            const double slope = (y1 - y0) / (x1 - x0); out[t] = y0 + slope * (x - x0);
+        }
+    }
+}
+
+// makePoints.pyx:35-40: ray[r,c,k] = SP[r,c] + basespace[k]*SLV[r,c], basespace = arange(0, max_len+step, step)
+__global__ void make_points_kernel(const double* __restrict__ sp, const double* __restrict__ slv, int64_t nrays, int64_t npts,
+                                   double step, double* __restrict__ out) {
+    const int64_t total = nrays * 3 * npts;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t k = t % npts, rc = t / npts;
+        {
+#pragma clang fp contract(off)
+            const double b = (double)k * step; const double p = b * slv[rc]; out[t] = sp[rc] + p;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+// (definitions below get C linkage from their extern "C" declarations in include/raider_hip.h)
+
+int rdr_version(void) { return 100; }
+
+const char* rdr_last_error(rdr_ctx* ctx) { return (ctx && !ctx->err.empty()) ? ctx->err.c_str() : g_err.c_str(); }
+
+int rdr_create(int device, rdr_ctx** out) {
+    if (!out) return fail(nullptr, RDR_ERR_INVALID, "rdr_create: out is NULL");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(nullptr, RDR_ERR_NODEVICE, std::string("rdr_create: no HIP device available (") +
+                    (e != hipSuccess ? hipGetErrorString(e) : "device count 0") + "); raider_amd has no CPU fallback");
+    if (device < 0) { if (hipGetDevice(&device) != hipSuccess) device = 0; }
+    if (device >= count) return fail(nullptr, RDR_ERR_INVALID, "rdr_create: device index out of range");
+    rdr_ctx* c = new rdr_ctx();
+    c->device = device;
+    HIPCHECK(nullptr, hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHECK(nullptr, hipGetDeviceProperties(&prop, device));
+    c->num_cus = prop.multiProcessorCount;
+    c->total_mem = prop.totalGlobalMem;
+    c->name = prop.name;
+    if (c->name.empty()) c->name = std::string("AMD ") + prop.gcnArchName;   // amdgpu.ids may be absent on the box
+    HIPCHECK(nullptr, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    HIPCHECK(nullptr, hipMalloc((void**)&c->d_maxlen, MAX_LEVELS * sizeof(unsigned long long)));
+    HIPCHECK(nullptr, hipMalloc((void**)&c->d_flags, sizeof(int)));
+    HIPCHECK(nullptr, hipMalloc((void**)&c->d_nparts, MAX_LEVELS * sizeof(int)));
+    *out = c;
+    return RDR_OK;
+}
+
+void rdr_destroy(rdr_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& b : c->slot) if (b.p) (void)hipFree(b.p);
+    if (c->d_maxlen) (void)hipFree(c->d_maxlen);
+    if (c->d_flags) (void)hipFree(c->d_flags);
+    if (c->d_nparts) (void)hipFree(c->d_nparts);
+    for (auto& v : c->evs) for (auto& pr : v) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+int rdr_set_stream(rdr_ctx* c, void* s) {
+    if (!c) return fail(nullptr, RDR_ERR_INVALID, "ctx is NULL");
+    c->stream = s ? (hipStream_t)s : c->own_stream;
+    return RDR_OK;
+}
+
+int rdr_synchronize(rdr_ctx* c) {
+    if (!c) return fail(nullptr, RDR_ERR_INVALID, "ctx is NULL");
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    return RDR_OK;
+}
+
+int rdr_device_info(rdr_ctx* c, char* name, int name_len, int* cus, int64_t* mem) {
+    if (!c) return fail(nullptr, RDR_ERR_INVALID, "ctx is NULL");
+    if (name && name_len > 0) { std::strncpy(name, c->name.c_str(), name_len - 1); name[name_len - 1] = 0; }
+    if (cus) *cus = c->num_cus;
+    if (mem) *mem = (int64_t)c->total_mem;
+    return RDR_OK;
+}
+
+int rdr_set_profiling(rdr_ctx* c, int on) {
+    if (!c) return fail(nullptr, RDR_ERR_INVALID, "ctx is NULL");
+    c->profiling = on != 0;
+    for (auto& u : c->ev_used) u = 0;
+    return RDR_OK;
+}
+
+int rdr_profile_get(rdr_ctx* c, int which, int* count, float* total_ms) {
+    if (!c || which < 0 || which > 3 || !count || !total_ms) return fail(c, RDR_ERR_INVALID, "rdr_profile_get: bad argument");
+    float tot = 0;
+    for (size_t i = 0; i < c->ev_used[which]; ++i) {
+        float ms = 0;
+        HIPCHECK(c, hipEventSynchronize(c->evs[which][i].second));
+        HIPCHECK(c, hipEventElapsedTime(&ms, c->evs[which][i].first, c->evs[which][i].second));
+        tot += ms;
+    }
+    *count = (int)c->ev_used[which];
+    *total_ms = tot;
+    return RDR_OK;
+}
+
+// ---- cube ---------------------------------------------------------------------------------------
+static int axis_check(const double* g, int64_t n, int* flip) {
+    if (n < 2) return -1;
+    bool asc = true, desc = true;
+    for (int64_t i = 1; i < n; ++i) {
+        if (!(g[i] > g[i - 1])) asc = false;
+        if (!(g[i] < g[i - 1])) desc = false;
+    }
+    if (!asc && !desc) return -1;
+    *flip = desc ? 1 : 0;
+    return 0;
+}
+
+static void axis_uniformity(const std::vector<double>& g, int* uni, double* inv_d) {
+    const int64_t n = (int64_t)g.size();
+    const double span = g[n - 1] - g[0];
+    *inv_d = (double)(n - 1) / span;
+    double worst = 0;
+    for (int64_t i = 0; i < n; ++i) worst = std::max(worst, std::fabs((g[i] - g[0]) * (*inv_d) - (double)i));
+    *uni = worst < 0.25 ? 1 : 0;   // guess lands within +-1 cell; fix-up loops make it exact
+}
+
+template <typename T2>
+static CubeView<T2> make_view(const rdr_cube* q) {
+    CubeView<T2> v;
+    v.v = (const T2*)q->d_vals;
+    v.axes = q->d_axes;
+    v.ny = (int)q->ny; v.nx = (int)q->nx; v.nz = (int)q->nz;
+    v.y_lo = q->ys.front(); v.y_hi = q->ys.back();
+    v.x_lo = q->xs.front(); v.x_hi = q->xs.back();
+    v.z_lo = q->zs.front(); v.z_hi = q->zs.back();
+    v.inv_dy = q->inv_d[0]; v.inv_dx = q->inv_d[1]; v.inv_dz = q->inv_d[2];
+    v.uni_y = q->uni[0]; v.uni_x = q->uni[1]; v.uni_z = q->uni[2];
+    return v;
+}
+
+static size_t axes_smem(const rdr_cube* q) { return (size_t)(q->ny + q->nx + q->nz) * sizeof(double); }
+
+static int cube_alloc(rdr_ctx* c, rdr_cube* q) {
+    const size_t esz = q->dtype == RDR_F32 ? 8 : 16;
+    const size_t total = (size_t)q->ny * q->nx * q->nz;
+    HIPCHECK(c, hipMalloc(&q->d_vals, total * esz));
+    HIPCHECK(c, hipMalloc((void**)&q->d_axes, (size_t)(q->ny + q->nx + q->nz) * sizeof(double)));
+    std::vector<double> ax;
+    ax.insert(ax.end(), q->ys.begin(), q->ys.end());
+    ax.insert(ax.end(), q->xs.begin(), q->xs.end());
+    ax.insert(ax.end(), q->zs.begin(), q->zs.end());
+    HIPCHECK(c, hipMemcpy(q->d_axes, ax.data(), ax.size() * sizeof(double), hipMemcpyHostToDevice));
+    axis_uniformity(q->ys, &q->uni[0], &q->inv_d[0]);
+    axis_uniformity(q->xs, &q->uni[1], &q->inv_d[1]);
+    axis_uniformity(q->zs, &q->uni[2], &q->inv_d[2]);
+    return RDR_OK;
+}
+
+int rdr_cube_create(rdr_ctx* c, const double* ys, int64_t ny, const double* xs, int64_t nx, const double* zs, int64_t nz,
+                    const void* wet, const void* hydro, int dtype, int64_t sy, int64_t sx, int64_t sz, int loc,
+                    rdr_cube** out) {
+    if (!c || !out || !ys || !xs || !zs || !wet || !hydro) return fail(c, RDR_ERR_INVALID, "rdr_cube_create: NULL argument");
+    if (dtype != RDR_F32 && dtype != RDR_F64) return fail(c, RDR_ERR_INVALID, "rdr_cube_create: dtype must be RDR_F32 or RDR_F64");
+    if (nz > MAX_LEVELS) return fail(c, RDR_ERR_INVALID, "rdr_cube_create: more than 512 z levels");
+    if (ny + nx + nz > 7000) return fail(c, RDR_ERR_INVALID, "rdr_cube_create: axes too long for the LDS-resident axis table");
+    int fy, fx, fz;
+    if (axis_check(ys, ny, &fy) || axis_check(xs, nx, &fx) || axis_check(zs, nz, &fz))
+        return fail(c, RDR_ERR_INVALID, "The points in each dimension must be strictly ascending or descending (and >= 2)");
+    HIPCHECK(c, hipSetDevice(c->device));
+    rdr_cube* q = new rdr_cube();
+    q->ctx = c; q->ny = ny; q->nx = nx; q->nz = nz; q->dtype = dtype;
+    q->ys.assign(ys, ys + ny); q->xs.assign(xs, xs + nx); q->zs.assign(zs, zs + nz);
+    if (fy) std::reverse(q->ys.begin(), q->ys.end());
+    if (fx) std::reverse(q->xs.begin(), q->xs.end());
+    if (fz) std::reverse(q->zs.begin(), q->zs.end());
+    int rc = cube_alloc(c, q);
+    if (rc) { rdr_cube_destroy(q); return rc; }
+    const size_t total = (size_t)ny * nx * nz;
+    const size_t esz = dtype == RDR_F32 ? 4 : 8;
+    // span of the strided source (non-negative strides)
+    if (sy < 0 || sx < 0 || sz < 0) { rdr_cube_destroy(q); return fail(c, RDR_ERR_INVALID, "rdr_cube_create: negative strides not supported"); }
+    const size_t span = (size_t)((ny - 1) * sy + (nx - 1) * sx + (nz - 1) * sz + 1);
+    const void *dw, *dh;
+    rc = stage_in(c, SLOT_IN0, wet, span * esz, loc, &dw); if (rc) { rdr_cube_destroy(q); return rc; }
+    rc = stage_in(c, SLOT_IN1, hydro, span * esz, loc, &dh); if (rc) { rdr_cube_destroy(q); return rc; }
+    const int g = grid_for((int64_t)total, 256, c->num_cus * 8);
+    if (dtype == RDR_F32)
+        hipLaunchKernelGGL((pack_cube_kernel<float, float2>), dim3(g), dim3(256), 0, c->stream, (const float*)dw, (const float*)dh,
+                           (float2*)q->d_vals, ny, nx, nz, sy, sx, sz, fy, fx, fz);
+    else
+        hipLaunchKernelGGL((pack_cube_kernel<double, double2>), dim3(g), dim3(256), 0, c->stream, (const double*)dw, (const double*)dh,
+                           (double2*)q->d_vals, ny, nx, nz, sy, sx, sz, fy, fx, fz);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { rdr_cube_destroy(q); return fail(c, RDR_ERR_HIP, hipGetErrorString(e)); }
+    if (loc == RDR_HOST) { e = hipStreamSynchronize(c->stream); if (e != hipSuccess) { rdr_cube_destroy(q); return fail(c, RDR_ERR_HIP, hipGetErrorString(e)); } }
+    *out = q;
+    return RDR_OK;
+}
+
+void rdr_cube_destroy(rdr_cube* q) {
+    if (!q) return;
+    if (q->ctx) { (void)hipSetDevice(q->ctx->device); (void)hipStreamSynchronize(q->ctx->stream); }
+    if (q->d_vals) (void)hipFree(q->d_vals);
+    if (q->d_axes) (void)hipFree(q->d_axes);
+    delete q;
+}
+
+int rdr_cube_shape(const rdr_cube* q, int64_t* ny, int64_t* nx, int64_t* nz, int* dtype) {
+    if (!q) return fail(nullptr, RDR_ERR_INVALID, "cube is NULL");
+    if (ny) *ny = q->ny; if (nx) *nx = q->nx; if (nz) *nz = q->nz; if (dtype) *dtype = q->dtype;
+    return RDR_OK;
+}
+
+int rdr_cube_axes(const rdr_cube* q, double* ys, double* xs, double* zs) {
+    if (!q) return fail(nullptr, RDR_ERR_INVALID, "cube is NULL");
+    if (ys) std::copy(q->ys.begin(), q->ys.end(), ys);
+    if (xs) std::copy(q->xs.begin(), q->xs.end(), xs);
+    if (zs) std::copy(q->zs.begin(), q->zs.end(), zs);
+    return RDR_OK;
+}
+
+int rdr_cube_blend(rdr_ctx* c, const rdr_cube* a, double w1, const rdr_cube* b, double w2, rdr_cube** out) {
+    if (!c || !a || !b || !out) return fail(c, RDR_ERR_INVALID, "rdr_cube_blend: NULL argument");
+    if (a->ny != b->ny || a->nx != b->nx || a->nz != b->nz || a->dtype != b->dtype || a->ys != b->ys || a->xs != b->xs || a->zs != b->zs)
+        return fail(c, RDR_ERR_INVALID, "rdr_cube_blend: cubes are not on the same grid / dtype");
+    HIPCHECK(c, hipSetDevice(c->device));
+    rdr_cube* q = new rdr_cube();
+    q->ctx = c; q->ny = a->ny; q->nx = a->nx; q->nz = a->nz; q->dtype = a->dtype;
+    q->ys = a->ys; q->xs = a->xs; q->zs = a->zs;
+    int rc = cube_alloc(c, q);
+    if (rc) { rdr_cube_destroy(q); return rc; }
+    const int64_t total = a->ny * a->nx * a->nz;
+    const int g = grid_for(total, 256, c->num_cus * 8);
+    {
+        KTimer t(c, 3);
+        if (a->dtype == RDR_F32)
+            hipLaunchKernelGGL((blend_kernel<float, float2>), dim3(g), dim3(256), 0, c->stream, (const float2*)a->d_vals, (float)w1,
+                               (const float2*)b->d_vals, (float)w2, (float2*)q->d_vals, total);
+        else
+            hipLaunchKernelGGL((blend_kernel<double, double2>), dim3(g), dim3(256), 0, c->stream, (const double2*)a->d_vals, w1,
+                               (const double2*)b->d_vals, w2, (double2*)q->d_vals, total);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { rdr_cube_destroy(q); return fail(c, RDR_ERR_HIP, hipGetErrorString(e)); }
+    *out = q;
+    return RDR_OK;
+}
+
+int rdr_cube_read(rdr_ctx* c, const rdr_cube* q, void* wet, void* hydro) {
+    if (!c || !q || !wet || !hydro) return fail(c, RDR_ERR_INVALID, "rdr_cube_read: NULL argument");
+    HIPCHECK(c, hipSetDevice(c->device));
+    const int64_t total = q->ny * q->nx * q->nz;
+    const size_t esz = q->dtype == RDR_F32 ? 4 : 8;
+    void *dw, *dh;
+    int rc = ensure(c, SLOT_OUT0, total * esz, &dw); if (rc) return rc;
+    rc = ensure(c, SLOT_OUT1, total * esz, &dh); if (rc) return rc;
+    const int g = grid_for(total, 256, c->num_cus * 8);
+    if (q->dtype == RDR_F32)
+        hipLaunchKernelGGL((unpack_cube_kernel<float, float2>), dim3(g), dim3(256), 0, c->stream, (const float2*)q->d_vals, (float*)dw, (float*)dh, total);
+    else
+        hipLaunchKernelGGL((unpack_cube_kernel<double, double2>), dim3(g), dim3(256), 0, c->stream, (const double2*)q->d_vals, (double*)dw, (double*)dh, total);
+    HIPCHECK(c, hipGetLastError());
+    HIPCHECK(c, hipMemcpyAsync(wet, dw, total * esz, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(hydro, dh, total * esz, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    return RDR_OK;
+}
+
+// ---- zenith / projected ---------------------------------------------------------------------------
+int rdr_interp3(rdr_ctx* c, const rdr_cube* q, const double* pts, int64_t n, double* wet, double* hydro, int loc) {
+    if (!c || !q || (n > 0 && (!pts || !wet || !hydro))) return fail(c, RDR_ERR_INVALID, "rdr_interp3: NULL argument");
+    if (n == 0) return RDR_OK;
+    HIPCHECK(c, hipSetDevice(c->device));
+    const void* dp; void *dw, *dh;
+    int rc = stage_in(c, SLOT_IN0, pts, (size_t)n * 24, loc, &dp); if (rc) return rc;
+    rc = stage_out(c, SLOT_OUT0, wet, (size_t)n * 8, loc, &dw); if (rc) return rc;
+    rc = stage_out(c, SLOT_OUT1, hydro, (size_t)n * 8, loc, &dh); if (rc) return rc;
+    const int g = grid_for(n, 256, c->num_cus * 8);
+    {
+        KTimer t(c, 2);
+        if (q->dtype == RDR_F32)
+            hipLaunchKernelGGL((interp_points_kernel<float2>), dim3(g), dim3(256), axes_smem(q), c->stream, make_view<float2>(q),
+                               (const double*)dp, n, (double*)dw, (double*)dh);
+        else
+            hipLaunchKernelGGL((interp_points_kernel<double2>), dim3(g), dim3(256), axes_smem(q), c->stream, make_view<double2>(q),
+                               (const double*)dp, n, (double*)dw, (double*)dh);
+    }
+    HIPCHECK(c, hipGetLastError());
+    rc = finish_out(c, wet, dw, (size_t)n * 8, loc); if (rc) return rc;
+    rc = finish_out(c, hydro, dh, (size_t)n * 8, loc); if (rc) return rc;
+    if (loc == RDR_HOST) HIPCHECK(c, hipStreamSynchronize(c->stream));
+    return RDR_OK;
+}
+
+int rdr_build_cube(rdr_ctx* c, const rdr_cube* q, const double* xpts, int64_t nx, const double* ypts, int64_t ny,
+                   const double* zpts, int64_t nz, double* wet, double* hydro, int loc) {
+    if (!c || !q || !xpts || !ypts || !zpts || !wet || !hydro) return fail(c, RDR_ERR_INVALID, "rdr_build_cube: NULL argument");
+    const int64_t n = nx * ny * nz;
+    if (n == 0) return RDR_OK;
+    HIPCHECK(c, hipSetDevice(c->device));
+    const void *dx, *dy, *dz; void *dw, *dh;
+    int rc = stage_in(c, SLOT_IN0, xpts, (size_t)nx * 8, loc, &dx); if (rc) return rc;
+    rc = stage_in(c, SLOT_IN1, ypts, (size_t)ny * 8, loc, &dy); if (rc) return rc;
+    rc = stage_in(c, SLOT_IN2, zpts, (size_t)nz * 8, loc, &dz); if (rc) return rc;
+    rc = stage_out(c, SLOT_OUT0, wet, (size_t)n * 8, loc, &dw); if (rc) return rc;
+    rc = stage_out(c, SLOT_OUT1, hydro, (size_t)n * 8, loc, &dh); if (rc) return rc;
+    const int g = grid_for(n, 256, c->num_cus * 8);
+    {
+        KTimer t(c, 2);
+        if (q->dtype == RDR_F32)
+            hipLaunchKernelGGL((build_cube_kernel<float2>), dim3(g), dim3(256), axes_smem(q), c->stream, make_view<float2>(q),
+                               (const double*)dx, nx, (const double*)dy, ny, (const double*)dz, nz, (double*)dw, (double*)dh);
+        else
+            hipLaunchKernelGGL((build_cube_kernel<double2>), dim3(g), dim3(256), axes_smem(q), c->stream, make_view<double2>(q),
+                               (const double*)dx, nx, (const double*)dy, ny, (const double*)dz, nz, (double*)dw, (double*)dh);
+    }
+    HIPCHECK(c, hipGetLastError());
+    rc = finish_out(c, wet, dw, (size_t)n * 8, loc); if (rc) return rc;
+    rc = finish_out(c, hydro, dh, (size_t)n * 8, loc); if (rc) return rc;
+    if (loc == RDR_HOST) HIPCHECK(c, hipStreamSynchronize(c->stream));
+    return RDR_OK;
+}
+
+int rdr_project_cosinc(rdr_ctx* c, double* wet, double* hydro, const double* inc, int64_t n, int loc) {
+    if (!c || !wet || !hydro || !inc) return fail(c, RDR_ERR_INVALID, "rdr_project_cosinc: NULL argument");
+    if (n == 0) return RDR_OK;
+    HIPCHECK(c, hipSetDevice(c->device));
+    const void *di, *dwi, *dhi;
+    int rc = stage_in(c, SLOT_IN0, inc, (size_t)n * 8, loc, &di); if (rc) return rc;
+    rc = stage_in(c, SLOT_OUT0, wet, (size_t)n * 8, loc, &dwi); if (rc) return rc;
+    rc = stage_in(c, SLOT_OUT1, hydro, (size_t)n * 8, loc, &dhi); if (rc) return rc;
+    hipLaunchKernelGGL(project_kernel, dim3(grid_for(n, 256, c->num_cus * 8)), dim3(256), 0, c->stream, (double*)dwi, (double*)dhi,
+                       (const double*)di, n);
+    HIPCHECK(c, hipGetLastError());
+    rc = finish_out(c, wet, dwi, (size_t)n * 8, loc); if (rc) return rc;
+    rc = finish_out(c, hydro, dhi, (size_t)n * 8, loc); if (rc) return rc;
+    if (loc == RDR_HOST) HIPCHECK(c, hipStreamSynchronize(c->stream));
+    return RDR_OK;
+}
+
+// ---- rays -------------------------------------------------------------------------------------------
+static int levels_host(const std::vector<double>& zs, double ht, double zref, std::vector<double>& lo, std::vector<double>& hi,
+                       std::vector<int>& kz) {
+    const int nz = (int)zs.size();
+    const double ztop = zs[nz - 1];
+    for (int zz = 0; zz < nz - 1; ++zz) {
+        double l = zs[zz], h = zs[zz + 1];
+        if (h == ztop) h -= 0.01;
+        if (h < ht || l >= zref) continue;
+        if (l < ht) l = ht;
+        if (h > zref) h = zref;
+        if (std::fabs(h - l) < 1.0) continue;
+        lo.push_back(l); hi.push_back(h); kz.push_back(zz);
+    }
+    return (int)lo.size();
+}
+
+int rdr_ray_levels(const rdr_cube* q, double ht, double zref, int32_t* K, double* lo, double* hi, int32_t* kz) {
+    if (!q || !K) return fail(nullptr, RDR_ERR_INVALID, "rdr_ray_levels: NULL argument");
+    std::vector<double> l, h; std::vector<int> z;
+    *K = levels_host(q->zs, ht, zref, l, h, z);
+    if (lo) std::copy(l.begin(), l.end(), lo);
+    if (hi) std::copy(h.begin(), h.end(), hi);
+    if (kz) std::copy(z.begin(), z.end(), kz);
+    if (*K == 0) return fail(q->ctx, RDR_ERR_NO_LEVELS, "no weather-model interval contributes to the ray integral (build_ray -> None)");
+    return RDR_OK;
+}
+
+int rdr_nparts(const double* maxlen, int32_t K, double max_seg, int32_t* nparts) {
+    if (!maxlen || !nparts) return fail(nullptr, RDR_ERR_INVALID, "rdr_nparts: NULL argument");
+    for (int k = 0; k < K; ++k) nparts[k] = (int32_t)std::ceil(maxlen[k] / max_seg) + 1;   // delay.py:283
+    return RDR_OK;
+}
+
+static int check_rays(rdr_ctx* c, const rdr_rays* r) {
+    if (!r) return fail(c, RDR_ERR_INVALID, "rays is NULL");
+    if (r->n < 0) return fail(c, RDR_ERR_INVALID, "rays->n negative");
+    if (r->origin_mode == RDR_ORIGIN_GRID) {
+        if (!r->xpts || !r->ypts || r->nx * r->ny != r->n) return fail(c, RDR_ERR_INVALID, "GRID rays need xpts, ypts and n == nx*ny");
+    } else if (r->origin_mode == RDR_ORIGIN_LLH) {
+        if (!r->lat || !r->lon) return fail(c, RDR_ERR_INVALID, "LLH rays need lat and lon");
+    } else if (r->origin_mode == RDR_ORIGIN_XYZ) {
+        if (!r->xyz) return fail(c, RDR_ERR_INVALID, "XYZ rays need xyz");
+        if (r->los_mode != RDR_LOS_VEC && (!r->lat || !r->lon)) return fail(c, RDR_ERR_INVALID, "XYZ rays with inc/heading or zenith LOS need lat and lon too");
+    } else return fail(c, RDR_ERR_INVALID, "unknown origin_mode");
+    if (r->los_mode == RDR_LOS_VEC) { if (!r->los) return fail(c, RDR_ERR_INVALID, "LOS_VEC needs los"); }
+    else if (r->los_mode == RDR_LOS_INC_HD) { if (!r->inc || !r->hd) return fail(c, RDR_ERR_INVALID, "LOS_INC_HD needs inc and hd"); }
+    else if (r->los_mode != RDR_LOS_INC_HD_SCALAR && r->los_mode != RDR_LOS_ZENITH) return fail(c, RDR_ERR_INVALID, "unknown los_mode");
+    return RDR_OK;
+}
+
+// stage every ray array the mode needs; fills P
+static int stage_rays(rdr_ctx* c, const rdr_rays* r, RayParams& P) {
+    std::memset(&P, 0, sizeof(P));
+    P.n = r->n; P.origin_mode = r->origin_mode; P.los_mode = r->los_mode; P.nx = r->nx; P.ny = r->ny;
+    P.inc0 = r->inc0; P.hd0 = r->hd0;
+    const int loc = r->loc;
+    const void* d;
+    int rc;
+    if (r->origin_mode == RDR_ORIGIN_GRID) {
+        rc = stage_in(c, SLOT_IN0, r->xpts, (size_t)r->nx * 8, loc, &d); if (rc) return rc; P.xpts = (const double*)d;
+        rc = stage_in(c, SLOT_IN1, r->ypts, (size_t)r->ny * 8, loc, &d); if (rc) return rc; P.ypts = (const double*)d;
+    } else {
+        rc = stage_in(c, SLOT_IN0, r->lat, (size_t)r->n * 8, loc, &d); if (rc) return rc; P.lat = (const double*)d;
+        rc = stage_in(c, SLOT_IN1, r->lon, (size_t)r->n * 8, loc, &d); if (rc) return rc; P.lon = (const double*)d;
+        if (r->origin_mode == RDR_ORIGIN_XYZ) { rc = stage_in(c, SLOT_IN2, r->xyz, (size_t)r->n * 24, loc, &d); if (rc) return rc; P.xyz = (const double*)d; }
+    }
+    if (r->los_mode == RDR_LOS_VEC) { rc = stage_in(c, SLOT_IN3, r->los, (size_t)r->n * 24, loc, &d); if (rc) return rc; P.los = (const double*)d; }
+    else if (r->los_mode == RDR_LOS_INC_HD) {
+        rc = stage_in(c, SLOT_IN4, r->inc, (size_t)r->n * 8, loc, &d); if (rc) return rc; P.inc = (const double*)d;
+        rc = stage_in(c, SLOT_IN5, r->hd, (size_t)r->n * 8, loc, &d); if (rc) return rc; P.hd = (const double*)d;
+    }
+    if (r->origin_mode == RDR_ORIGIN_GRID) {
+        P.tiles_x = (int)((r->nx + TILE - 1) / TILE);
+        P.ntiles = (int64_t)P.tiles_x * ((r->ny + TILE - 1) / TILE);
+    } else {
+        P.tiles_x = 1;
+        P.ntiles = (r->n + BLOCK - 1) / BLOCK;
+    }
+    P.maxlen_bits = c->d_maxlen; P.flags = c->d_flags;
+    return RDR_OK;
+}
+
+static size_t ray_smem(const rdr_cube* q) {
+    return (size_t)(q->ny + q->nx + q->nz) * 8 + (size_t)q->nz * 8 * 3 + (size_t)q->nz * 4 * 2 + 16;
+}
+
+static int ray_grid(rdr_ctx* c, int64_t ntiles) {
+    int64_t g = std::min<int64_t>(ntiles, (int64_t)c->num_cus * 8);
+    g = std::max<int64_t>(8, (g + 7) / 8 * 8);   // multiple of 8 (one share per XCD)
+    return (int)g;
+}
+
+template <int MODE>
+static int launch_ray(rdr_ctx* c, const rdr_cube* q, const RayParams& P) {
+    const int g = ray_grid(c, P.ntiles);
+    KTimer t(c, MODE);
+    if (q->dtype == RDR_F32)
+        hipLaunchKernelGGL((ray_kernel<MODE, float2>), dim3(g), dim3(BLOCK), ray_smem(q), c->stream, make_view<float2>(q), P);
+    else
+        hipLaunchKernelGGL((ray_kernel<MODE, double2>), dim3(g), dim3(BLOCK), ray_smem(q), c->stream, make_view<double2>(q), P);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(c, RDR_ERR_HIP, std::string("ray_kernel launch: ") + hipGetErrorString(e));
+    return RDR_OK;
+}
+
+static int flags_to_status(rdr_ctx* c, int flags) {
+    if (!(flags & RDR_FLAG_ANY_FINITE)) return fail(c, RDR_ERR_ALL_NAN, "geo2rdr did not converge. Check orbit coverage");
+    if (flags & RDR_FLAG_ANY_NAN) return fail(c, RDR_ERR_NAN_LENGTH, "some ray lengths are NaN: the number of integration parts (delay.py:283) is undefined");
+    return RDR_OK;
+}
+
+int rdr_ray_prepass(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, double ht, double zref, double* maxlen, int32_t* flags) {
+    if (!c || !q || !maxlen) return fail(c, RDR_ERR_INVALID, "rdr_ray_prepass: NULL argument");
+    int rc = check_rays(c, r); if (rc) return rc;
+    std::vector<double> lo, hi; std::vector<int> kz;
+    const int K = levels_host(q->zs, ht, zref, lo, hi, kz);
+    if (K == 0) return fail(c, RDR_ERR_NO_LEVELS, "no weather-model interval contributes to the ray integral (build_ray -> None)");
+    HIPCHECK(c, hipSetDevice(c->device));
+    RayParams P;
+    rc = stage_rays(c, r, P); if (rc) return rc;
+    P.ht = ht; P.zref = zref; P.max_seg = 1000.0;
+    HIPCHECK(c, hipMemsetAsync(c->d_maxlen, 0, MAX_LEVELS * sizeof(unsigned long long), c->stream));
+    HIPCHECK(c, hipMemsetAsync(c->d_flags, 0, sizeof(int), c->stream));
+    if (r->n > 0) { rc = launch_ray<0>(c, q, P); if (rc) return rc; }
+    int f = 0;
+    HIPCHECK(c, hipMemcpyAsync(maxlen, c->d_maxlen, (size_t)K * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(&f, c->d_flags, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    if (flags) *flags = f;
+    return RDR_OK;
+}
+
+int rdr_ray_march(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, double ht, double zref, const int32_t* nparts, int32_t flags,
+                  double* wet, double* hydro) {
+    if (!c || !q || !nparts || !wet || !hydro) return fail(c, RDR_ERR_INVALID, "rdr_ray_march: NULL argument");
+    int rc = check_rays(c, r); if (rc) return rc;
+    std::vector<double> lo, hi; std::vector<int> kz;
+    const int K = levels_host(q->zs, ht, zref, lo, hi, kz);
+    if (K == 0) return fail(c, RDR_ERR_NO_LEVELS, "no weather-model interval contributes to the ray integral (build_ray -> None)");
+    for (int k = 0; k < K; ++k) if (nparts[k] < 1 || nparts[k] > (1 << 24)) return fail(c, RDR_ERR_INVALID, "rdr_ray_march: nparts out of range");
+    if (r->n == 0) return RDR_OK;
+    HIPCHECK(c, hipSetDevice(c->device));
+    RayParams P;
+    rc = stage_rays(c, r, P); if (rc) return rc;
+    P.ht = ht; P.zref = zref; P.max_seg = 1000.0;
+    HIPCHECK(c, hipMemcpyAsync(c->d_nparts, nparts, (size_t)K * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    int f = flags;
+    HIPCHECK(c, hipMemcpyAsync(c->d_flags, &f, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));   // nparts / f are caller / stack memory
+    P.nparts_override = c->d_nparts;
+    void *dw, *dh;
+    rc = stage_out(c, SLOT_OUT0, wet, (size_t)r->n * 8, r->loc, &dw); if (rc) return rc;
+    rc = stage_out(c, SLOT_OUT1, hydro, (size_t)r->n * 8, r->loc, &dh); if (rc) return rc;
+    P.wet = (double*)dw; P.hyd = (double*)dh;
+    rc = launch_ray<1>(c, q, P); if (rc) return rc;
+    rc = finish_out(c, wet, dw, (size_t)r->n * 8, r->loc); if (rc) return rc;
+    rc = finish_out(c, hydro, dh, (size_t)r->n * 8, r->loc); if (rc) return rc;
+    if (r->loc == RDR_HOST) HIPCHECK(c, hipStreamSynchronize(c->stream));
+    return RDR_OK;
+}
+
+int rdr_raytrace(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, double ht, double zref, double max_seg, double* wet,
+                 double* hydro, int32_t* nparts_out, int32_t* flags_out) {
+    if (!c || !q || !wet || !hydro) return fail(c, RDR_ERR_INVALID, "rdr_raytrace: NULL argument");
+    if (!(max_seg > 0)) return fail(c, RDR_ERR_INVALID, "rdr_raytrace: MAX_SEGMENT_LENGTH must be positive");
+    int rc = check_rays(c, r); if (rc) return rc;
+    std::vector<double> lo, hi; std::vector<int> kz;
+    const int K = levels_host(q->zs, ht, zref, lo, hi, kz);
+    if (K == 0) return fail(c, RDR_ERR_NO_LEVELS, "no weather-model interval contributes to the ray integral (build_ray -> None)");
+    if (r->n == 0) return RDR_OK;
+    HIPCHECK(c, hipSetDevice(c->device));
+    RayParams P;
+    rc = stage_rays(c, r, P); if (rc) return rc;
+    P.ht = ht; P.zref = zref; P.max_seg = max_seg;
+    void *dw, *dh;
+    rc = stage_out(c, SLOT_OUT0, wet, (size_t)r->n * 8, r->loc, &dw); if (rc) return rc;
+    rc = stage_out(c, SLOT_OUT1, hydro, (size_t)r->n * 8, r->loc, &dh); if (rc) return rc;
+    P.wet = (double*)dw; P.hyd = (double*)dh;
+    HIPCHECK(c, hipMemsetAsync(c->d_maxlen, 0, MAX_LEVELS * sizeof(unsigned long long), c->stream));
+    HIPCHECK(c, hipMemsetAsync(c->d_flags, 0, sizeof(int), c->stream));
+    rc = launch_ray<0>(c, q, P); if (rc) return rc;
+    rc = launch_ray<1>(c, q, P); if (rc) return rc;
+    rc = finish_out(c, wet, dw, (size_t)r->n * 8, r->loc); if (rc) return rc;
+    rc = finish_out(c, hydro, dh, (size_t)r->n * 8, r->loc); if (rc) return rc;
+    const bool need_sync = r->loc == RDR_HOST || nparts_out || flags_out;
+    if (need_sync) {
+        std::vector<double> ml(K);
+        int f = 0;
+        HIPCHECK(c, hipMemcpyAsync(ml.data(), c->d_maxlen, (size_t)K * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHECK(c, hipMemcpyAsync(&f, c->d_flags, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHECK(c, hipStreamSynchronize(c->stream));
+        if (nparts_out) rdr_nparts(ml.data(), K, max_seg, nparts_out);
+        if (flags_out) *flags_out = f;
+        return flags_to_status(c, f);
+    }
+    return RDR_OK;
+}
+
+int rdr_top_of_atmosphere(rdr_ctx* c, const double* xyz, const double* los, int64_t n, double h, const double* factor, double* pos, int loc) {
+    if (!c || !xyz || !los || !pos) return fail(c, RDR_ERR_INVALID, "rdr_top_of_atmosphere: NULL argument");
+    if (n == 0) return RDR_OK;
+    HIPCHECK(c, hipSetDevice(c->device));
+    const void *dx, *dl, *df; void* dp;
+    int rc = stage_in(c, SLOT_IN0, xyz, (size_t)n * 24, loc, &dx); if (rc) return rc;
+    rc = stage_in(c, SLOT_IN1, los, (size_t)n * 24, loc, &dl); if (rc) return rc;
+    rc = stage_in(c, SLOT_IN2, factor, (size_t)n * 8, loc, &df); if (rc) return rc;
+    rc = stage_out(c, SLOT_OUT0, pos, (size_t)n * 24, loc, &dp); if (rc) return rc;
+    hipLaunchKernelGGL(toa_kernel, dim3(grid_for(n, 256, c->num_cus * 8)), dim3(256), 0, c->stream, (const double*)dx, (const double*)dl, n, h,
+                       (const double*)df, (double*)dp);
+    HIPCHECK(c, hipGetLastError());
+    rc = finish_out(c, pos, dp, (size_t)n * 24, loc); if (rc) return rc;
+    if (loc == RDR_HOST) HIPCHECK(c, hipStreamSynchronize(c->stream));
+    return RDR_OK;
+}
+
+int rdr_build_ray(rdr_ctx* c, const double* model_zs, int64_t nz, double ht, const double* xyz, const double* los, int64_t n,
+                  double zref, int32_t* K_out, double* lengths, double* low, double* high, int loc) {
+    if (!c || !model_zs || !xyz || !los || !K_out) return fail(c, RDR_ERR_INVALID, "rdr_build_ray: NULL argument");
+    if (nz < 2) return fail(c, RDR_ERR_INVALID, "rdr_build_ray: need at least 2 model levels");
+    std::vector<double> zs(model_zs, model_zs + nz), lo, hi; std::vector<int> kz;
+    const int K = levels_host(zs, ht, zref, lo, hi, kz);
+    *K_out = K;
+    if (K == 0) return fail(c, RDR_ERR_NO_LEVELS, "no weather-model interval contributes to the ray integral (build_ray -> None)");
+    if (!lengths || !low || !high) return RDR_OK;   // size query
+    if (n == 0) return RDR_OK;
+    HIPCHECK(c, hipSetDevice(c->device));
+    const void *dx, *dl; void *dlen, *dlo, *dhi, *dtab;
+    int rc = stage_in(c, SLOT_IN0, xyz, (size_t)n * 24, loc, &dx); if (rc) return rc;
+    rc = stage_in(c, SLOT_IN1, los, (size_t)n * 24, loc, &dl); if (rc) return rc;
+    rc = stage_out(c, SLOT_OUT0, lengths, (size_t)K * n * 8, loc, &dlen); if (rc) return rc;
+    rc = stage_out(c, SLOT_OUT1, low, (size_t)K * n * 24, loc, &dlo); if (rc) return rc;
+    rc = stage_out(c, SLOT_OUT2, high, (size_t)K * n * 24, loc, &dhi); if (rc) return rc;
+    rc = ensure(c, SLOT_AUX, (size_t)2 * K * 8, &dtab); if (rc) return rc;
+    std::vector<double> tab(lo); tab.insert(tab.end(), hi.begin(), hi.end());
+    HIPCHECK(c, hipMemcpyAsync(dtab, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    hipLaunchKernelGGL(build_ray_kernel, dim3(grid_for(n, 256, c->num_cus * 8)), dim3(256), 0, c->stream, (const double*)dx, (const double*)dl, n, K,
+                       (const double*)dtab, (double*)dlen, (double*)dlo, (double*)dhi);
+    HIPCHECK(c, hipGetLastError());
+    rc = finish_out(c, lengths, dlen, (size_t)K * n * 8, loc); if (rc) return rc;
+    rc = finish_out(c, low, dlo, (size_t)K * n * 24, loc); if (rc) return rc;
+    rc = finish_out(c, high, dhi, (size_t)K * n * 24, loc); if (rc) return rc;
+    if (loc == RDR_HOST) HIPCHECK(c, hipStreamSynchronize(c->stream));
+    return RDR_OK;
+}
+
+// ---- geodesy ------------------------------------------------------------------------------------------
+int rdr_lla2ecef(rdr_ctx* c, const double* lat, const double* lon, const double* h, int64_t n, double* xyz, int loc) {
+    if (!c || !lat || !lon || !h || !xyz) return fail(c, RDR_ERR_INVALID, "rdr_lla2ecef: NULL argument");
+    if (n == 0) return RDR_OK;
+    HIPCHECK(c, hipSetDevice(c->device));
+    const void *a, *b, *d; void* o;
+    int rc = stage_in(c, SLOT_IN0, lat, (size_t)n * 8, loc, &a); if (rc) return rc;
+    rc = stage_in(c, SLOT_IN1, lon, (size_t)n * 8, loc, &b); if (rc) return rc;
+    rc = stage_in(c, SLOT_IN2, h, (size_t)n * 8, loc, &d); if (rc) return rc;
+    rc = stage_out(c, SLOT_OUT0, xyz, (size_t)n * 24, loc, &o); if (rc) return rc;
+    hipLaunchKernelGGL(lla2ecef_kernel, dim3(grid_for(n, 256, c->num_cus * 8)), dim3(256), 0, c->stream, (const double*)a, (const double*)b,
+                       (const double*)d, n, (double*)o);
+    HIPCHECK(c, hipGetLastError());
+    rc = finish_out(c, xyz, o, (size_t)n * 24, loc); if (rc) return rc;
+    if (loc == RDR_HOST) HIPCHECK(c, hipStreamSynchronize(c->stream));
+    return RDR_OK;
+}
+
+int rdr_ecef2lla(rdr_ctx* c, const double* xyz, int64_t n, double* lon, double* lat, double* h, int loc) {
+    if (!c || !xyz || !lon || !lat || !h) return fail(c, RDR_ERR_INVALID, "rdr_ecef2lla: NULL argument");
+    if (n == 0) return RDR_OK;
+    HIPCHECK(c, hipSetDevice(c->device));
+    const void* a; void *o0, *o1, *o2;
+    int rc = stage_in(c, SLOT_IN0, xyz, (size_t)n * 24, loc, &a); if (rc) return rc;
+    rc = stage_out(c, SLOT_OUT0, lon, (size_t)n * 8, loc, &o0); if (rc) return rc;
+    rc = stage_out(c, SLOT_OUT1, lat, (size_t)n * 8, loc, &o1); if (rc) return rc;
+    rc = stage_out(c, SLOT_OUT2, h, (size_t)n * 8, loc, &o2); if (rc) return rc;
+    hipLaunchKernelGGL(ecef2lla_kernel, dim3(grid_for(n, 256, c->num_cus * 8)), dim3(256), 0, c->stream, (const double*)a, n, (double*)o0,
+                       (double*)o1, (double*)o2);
+    HIPCHECK(c, hipGetLastError());
+    rc = finish_out(c, lon, o0, (size_t)n * 8, loc); if (rc) return rc;
+    rc = finish_out(c, lat, o1, (size_t)n * 8, loc); if (rc) return rc;
+    rc = finish_out(c, h, o2, (size_t)n * 8, loc); if (rc) return rc;
+    if (loc == RDR_HOST) HIPCHECK(c, hipStreamSynchronize(c->stream));
+    return RDR_OK;
+}
+
+int rdr_look_vectors(rdr_ctx* c, const rdr_rays* r, double ht, double* los) {
+    (void)ht;
+    if (!c || !los) return fail(c, RDR_ERR_INVALID, "rdr_look_vectors: NULL argument");
+    int rc = check_rays(c, r); if (rc) return rc;
+    if (r->origin_mode == RDR_ORIGIN_XYZ && (!r->lat || !r->lon) && r->los_mode != RDR_LOS_VEC)
+        return fail(c, RDR_ERR_INVALID, "rdr_look_vectors: lat/lon required");
+    if (r->n == 0) return RDR_OK;
+    HIPCHECK(c, hipSetDevice(c->device));
+    RayParams P;
+    rc = stage_rays(c, r, P); if (rc) return rc;
+    void* o;
+    rc = stage_out(c, SLOT_OUT0, los, (size_t)r->n * 24, r->loc, &o); if (rc) return rc;
+    hipLaunchKernelGGL(look_kernel, dim3(grid_for(r->n, 256, c->num_cus * 8)), dim3(256), 0, c->stream, P, (double*)o);
+    HIPCHECK(c, hipGetLastError());
+    rc = finish_out(c, los, o, (size_t)r->n * 24, r->loc); if (rc) return rc;
+    if (r->loc == RDR_HOST) HIPCHECK(c, hipStreamSynchronize(c->stream));
+    return RDR_OK;
+}
+
+// ---- native extensions ------------------------------------------------------------------------------------
+int rdr_interp_nd(rdr_ctx* c, int32_t ndim, const double* const* axes, const int64_t* axis_len, const double* values,
+                  const double* q, int64_t n, int has_fill, double fill, double* out, int loc) {
+    if (!c || !axes || !axis_len || !values || (n > 0 && (!q || !out))) return fail(c, RDR_ERR_INVALID, "rdr_interp_nd: NULL argument");
+    if (ndim < 1 || ndim > 8) return fail(c, RDR_ERR_INVALID, "rdr_interp_nd: 1 <= ndim <= 8 supported on device");
+    if (n == 0) return RDR_OK;
+    HIPCHECK(c, hipSetDevice(c->device));
+    NdParams P; std::memset(&P, 0, sizeof(P));
+    P.ndim = ndim;
+    int64_t tot_axes = 0, nvals = 1;
+    for (int d = 0; d < ndim; ++d) {
+        if (axis_len[d] < 2) return fail(c, RDR_ERR_INVALID, "rdr_interp_nd: every axis needs >= 2 points");
+        P.len[d] = axis_len[d]; P.off[d] = tot_axes; tot_axes += axis_len[d]; nvals *= axis_len[d];
+    }
+    int64_t s = 1;
+    for (int d = ndim - 1; d >= 0; --d) { P.stride[d] = s; s *= axis_len[d]; }
+    // axes are always host-side tuples of small 1-D arrays in the reference API; accept device too
+    void* dax;
+    int rc = ensure(c, SLOT_AUX, (size_t)tot_axes * 8, &dax); if (rc) return rc;
+    for (int d = 0; d < ndim; ++d)
+        HIPCHECK(c, hipMemcpyAsync((double*)dax + P.off[d], axes[d], (size_t)axis_len[d] * 8,
+                                   loc == RDR_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, c->stream));
+    const void *dv, *dq; void* dout;
+    rc = stage_in(c, SLOT_IN0, values, (size_t)nvals * 8, loc, &dv); if (rc) return rc;
+    rc = stage_in(c, SLOT_IN1, q, (size_t)n * ndim * 8, loc, &dq); if (rc) return rc;
+    rc = stage_out(c, SLOT_OUT0, out, (size_t)n * 8, loc, &dout); if (rc) return rc;
+    {
+        KTimer t(c, 2);
+        hipLaunchKernelGGL(interp_nd_kernel, dim3(grid_for(n, 256, c->num_cus * 8)), dim3(256), 0, c->stream, P, (const double*)dax,
+                           (const double*)dv, (const double*)dq, n, has_fill, fill, (double*)dout);
+    }
+    HIPCHECK(c, hipGetLastError());
+    rc = finish_out(c, out, dout, (size_t)n * 8, loc); if (rc) return rc;
+    if (loc == RDR_HOST) HIPCHECK(c, hipStreamSynchronize(c->stream));
+    return RDR_OK;
+}
+
+int rdr_interp_along_axis(rdr_ctx* c, const double* points, const double* values, int64_t ncol, int64_t m, const double* q,
+                          int64_t mq, int has_fill, double fill, double* out, int loc) {
+    if (!c || !points || !values || !q || !out) return fail(c, RDR_ERR_INVALID, "rdr_interp_along_axis: NULL argument");
+    if (m < 2) return fail(c, RDR_ERR_INVALID, "rdr_interp_along_axis: axis needs >= 2 points");
+    if (ncol * mq == 0) return RDR_OK;
+    HIPCHECK(c, hipSetDevice(c->device));
+    const void *dp, *dv, *dq; void* dout;
+    int rc = stage_in(c, SLOT_IN0, points, (size_t)ncol * m * 8, loc, &dp); if (rc) return rc;
+    rc = stage_in(c, SLOT_IN1, values, (size_t)ncol * m * 8, loc, &dv); if (rc) return rc;
+    rc = stage_in(c, SLOT_IN2, q, (size_t)ncol * mq * 8, loc, &dq); if (rc) return rc;
+    rc = stage_out(c, SLOT_OUT0, out, (size_t)ncol * mq * 8, loc, &dout); if (rc) return rc;
+    hipLaunchKernelGGL(along_axis_kernel, dim3(grid_for(ncol * mq, 256, c->num_cus * 8)), dim3(256), 0, c->stream, (const double*)dp,
+                       (const double*)dv, ncol, m, (const double*)dq, mq, has_fill, fill, (double*)dout);
+    HIPCHECK(c, hipGetLastError());
+    rc = finish_out(c, out, dout, (size_t)ncol * mq * 8, loc); if (rc) return rc;
+    if (loc == RDR_HOST) HIPCHECK(c, hipStreamSynchronize(c->stream));
+    return RDR_OK;
+}
+
+int64_t rdr_make_points_count(double max_len, double step) {
+    // makePoints.pyx:30-33: Npts = int(max_len//step) (+1 if max_len % step != 0); python float // and %
+    if (!(step > 0) || !(max_len >= 0)) return -1;
+    double mod = std::fmod(max_len, step);
+    double div = (max_len - mod) / step;
+    double fl = std::floor(div);
+    if (div - fl > 0.5) fl += 1.0;
+    return (int64_t)fl + (mod != 0.0 ? 1 : 0);
+}
+
+int rdr_make_points(rdr_ctx* c, double max_len, const double* sp, const double* slv, int64_t nrays, double step, double* out, int loc) {
+    if (!c || !sp || !slv || !out) return fail(c, RDR_ERR_INVALID, "rdr_make_points: NULL argument");
+    const int64_t npts = rdr_make_points_count(max_len, step);
+    if (npts < 0) return fail(c, RDR_ERR_INVALID, "rdr_make_points: need max_len >= 0 and step > 0");
+    if (nrays * npts == 0) return RDR_OK;
+    HIPCHECK(c, hipSetDevice(c->device));
+    const void *ds, *dl; void* dout;
+    int rc = stage_in(c, SLOT_IN0, sp, (size_t)nrays * 24, loc, &ds); if (rc) return rc;
+    rc = stage_in(c, SLOT_IN1, slv, (size_t)nrays * 24, loc, &dl); if (rc) return rc;
+    rc = stage_out(c, SLOT_OUT0, out, (size_t)nrays * 3 * npts * 8, loc, &dout); if (rc) return rc;
+    {
+        KTimer t(c, 3);
+        hipLaunchKernelGGL(make_points_kernel, dim3(grid_for(nrays * 3 * npts, 256, c->num_cus * 8)), dim3(256), 0, c->stream,
+                           (const double*)ds, (const double*)dl, nrays, npts, step, (double*)dout);
+    }
+    HIPCHECK(c, hipGetLastError());
+    rc = finish_out(c, out, dout, (size_t)nrays * 3 * npts * 8, loc); if (rc) return rc;
+    if (loc == RDR_HOST) HIPCHECK(c, hipStreamSynchronize(c->stream));
+    return RDR_OK;
+}
+

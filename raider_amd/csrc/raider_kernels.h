@@ -1,0 +1,300 @@
+// Device-side building blocks of libraider_hip (gfx950 / CDNA4 only).
+//
+//   CubeView + trilinear()  : scipy RegularGridInterpolator(linear, fill=nan) on the interleaved
+//                             (wet,hydro) cube          [delayFcns.py:55-56, scipy _rgi.py:405-499]
+//   toa_newton()            : getTopOfAtmosphere        [losreader.py:706-733]
+//   ray_kernel<MODE>        : build_ray fused with the per-level trapezoid of _build_cube_ray
+//                             [losreader.py:772-835, delay.py:283-323]; MODE 0 = pass 1 (per-level
+//                             batch max of ray length + clamp/NaN flags), MODE 1 = pass 2 (integrate)
+//
+// Design notes (MI355X):
+//   * one ray per lane, 64-lane wavefronts, 256-thread workgroups = one 16x16 pixel tile of the
+//     scene: neighbouring rays walk the same few cube columns, so their gathers hit the same
+//     L1/L2 lines; the per-level loop bounds are batch-uniform, so a wave never diverges.
+//   * the cube is stored (y,x,z) with z fastest and (wet,hydro) interleaved per cell: the two z
+//     neighbours of both fields of one column are ONE contiguous 16 B (f32) / 32 B (f64) read.
+//   * grid axes + the level table + the per-level partition live in LDS (a few KB), filled once
+//     per workgroup; nothing per-level is ever materialised in HBM (the reference materialises
+//     K x N x 56 B).
+//   * persistent grid (a few workgroups per CU) walking tiles with an XCD-aware mapping so that the 32
+//     CUs sharing one L2 work on one contiguous band of the scene.
+//   * no MFMA: this is a gather + transcendental-heavy fp64 integrate, there is no contraction.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "geodesy.h"
+
+namespace rdr {
+
+constexpr int TILE = 16;         // 16x16 pixel tile per workgroup (GRID mode)
+constexpr int BLOCK = TILE * TILE;
+constexpr int MAX_LEVELS = 512;  // model intervals (ERA5 has 144)
+
+template <typename T2>
+struct CubeView {
+    const T2* v;          // [(iy*nx+ix)*nz+iz] -> (wet, hydro)
+    const double* axes;   // ys[ny] | xs[nx] | zs[nz]   (ascending)
+    int ny, nx, nz;
+    double y_lo, y_hi, x_lo, x_hi, z_lo, z_hi;   // axis end points (bounds test)
+    double inv_dy, inv_dx, inv_dz;               // (n-1)/(g[n-1]-g[0]) for the uniform-axis index guess
+    int uni_y, uni_x, uni_z;                     // axis is (nearly) uniform: guess is within +-1 cell
+};
+
+__device__ __forceinline__ double qnan() { return __longlong_as_double(0x7ff8000000000000LL); }
+
+// index i with g[i] <= x < g[i+1], clamped to [0, n-2] (last cell closed) - scipy find_indices.
+__device__ __forceinline__ int find_cell(const double* g, int n, double x, double g0, double inv_d, int uniform) {
+    int i;
+    if (uniform) {
+        i = (int)((x - g0) * inv_d);
+        i = min(max(i, 0), n - 2);
+        while (i > 0 && x < g[i]) --i;
+        while (i < n - 2 && x >= g[i + 1]) ++i;
+    } else {
+        int lo = 0, hi = n;   // first index with x < g[idx]
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (x < g[mid]) hi = mid; else lo = mid + 1;
+        }
+        i = min(max(lo - 1, 0), n - 2);
+    }
+    return i;
+}
+
+__device__ __forceinline__ int find_cell_hint(const double* g, int n, double x, int hint) {
+    int i = min(max(hint, 0), n - 2);
+    while (i > 0 && x < g[i]) --i;
+    while (i < n - 2 && x >= g[i + 1]) ++i;
+    return i;
+}
+
+__device__ __forceinline__ void ld2(const float2* p, double& a, double& b) { const float2 t = *p; a = (double)t.x; b = (double)t.y; }
+__device__ __forceinline__ void ld2(const double2* p, double& a, double& b) { const double2 t = *p; a = t.x; b = t.y; }
+
+// scipy linear RGI on both fields.  sy/sx/sz: the axes (LDS or global).  zhint >= 0: start the z search
+// at that interval (ray marcher knows the model interval), else use the uniform guess / bisection.
+template <typename T2>
+__device__ __forceinline__ void trilinear(const CubeView<T2>& c, const double* sy, const double* sx, const double* sz,
+                                          double y, double x, double z, int zhint, double& wet, double& hyd) {
+    // out of bounds (x < g[0] or x > g[-1]) -> fill_value nan; nan coordinate -> nan   (_rgi.py:437-442,585-592)
+    const bool inside = (y >= c.y_lo) && (y <= c.y_hi) && (x >= c.x_lo) && (x <= c.x_hi) && (z >= c.z_lo) && (z <= c.z_hi);
+    if (!inside) { wet = qnan(); hyd = qnan(); return; }
+    const int iy = find_cell(sy, c.ny, y, c.y_lo, c.inv_dy, c.uni_y);
+    const int ix = find_cell(sx, c.nx, x, c.x_lo, c.inv_dx, c.uni_x);
+    const int iz = zhint >= 0 ? find_cell_hint(sz, c.nz, z, zhint) : find_cell(sz, c.nz, z, c.z_lo, c.inv_dz, c.uni_z);
+    const double ty = (y - sy[iy]) / (sy[iy + 1] - sy[iy]);
+    const double tx = (x - sx[ix]) / (sx[ix + 1] - sx[ix]);
+    const double tz = (z - sz[iz]) / (sz[iz + 1] - sz[iz]);
+    const T2* p00 = c.v + ((int64_t)iy * c.nx + ix) * c.nz + iz;   // (y0,x0)
+    const T2* p01 = p00 + c.nz;                                    // (y0,x1)
+    const T2* p10 = p00 + (int64_t)c.nx * c.nz;                    // (y1,x0)
+    const T2* p11 = p10 + c.nz;                                    // (y1,x1)
+    double w[8], h[8];
+    ld2(p00, w[0], h[0]); ld2(p00 + 1, w[1], h[1]);
+    ld2(p01, w[2], h[2]); ld2(p01 + 1, w[3], h[3]);
+    ld2(p10, w[4], h[4]); ld2(p10 + 1, w[5], h[5]);
+    ld2(p11, w[6], h[6]); ld2(p11 + 1, w[7], h[7]);
+    const double wy0 = 1.0 - ty, wx0 = 1.0 - tx, wz0 = 1.0 - tz;
+    // weight = ((1*wy)*wx)*wz, corners in lexicographic (y,x,z) order, value = 0 + sum   (_rgi.py:490-498)
+    const double a00 = wy0 * wx0, a01 = wy0 * tx, a10 = ty * wx0, a11 = ty * tx;
+    const double k0 = a00 * wz0, k1 = a00 * tz, k2 = a01 * wz0, k3 = a01 * tz;
+    const double k4 = a10 * wz0, k5 = a10 * tz, k6 = a11 * wz0, k7 = a11 * tz;
+    double sw = 0.0, sh = 0.0;
+    sw += w[0] * k0; sh += h[0] * k0;
+    sw += w[1] * k1; sh += h[1] * k1;
+    sw += w[2] * k2; sh += h[2] * k2;
+    sw += w[3] * k3; sh += h[3] * k3;
+    sw += w[4] * k4; sh += h[4] * k4;
+    sw += w[5] * k5; sh += h[5] * k5;
+    sw += w[6] * k6; sh += h[6] * k6;
+    sw += w[7] * k7; sh += h[7] * k7;
+    wet = sw; hyd = sh;
+}
+
+// getTopOfAtmosphere (losreader.py:706-733): pos = xyz + h*los; repeat: pos += los*((h - height(pos))/factor)
+__device__ __forceinline__ void toa_newton(double ox, double oy, double oz, double lx, double ly, double lz,
+                                           double h, int iters, double factor, double& px, double& py, double& pz) {
+    px = ox + h * lx; py = oy + h * ly; pz = oz + h * lz;
+    for (int it = 0; it < iters; ++it) {
+        const double hgt = ecef_height(px, py, pz);
+        const double step = (h - hgt) / factor;
+        px = px + lx * step; py = py + ly * step; pz = pz + lz * step;
+    }
+}
+
+struct RayParams {
+    // geometry
+    int64_t n;
+    int origin_mode, los_mode;
+    int64_t nx, ny;
+    const double* xpts; const double* ypts;
+    const double* lat; const double* lon; const double* xyz;
+    const double* los; const double* inc; const double* hd;
+    double inc0, hd0;
+    // slice
+    double ht, zref, max_seg;
+    // batch-global state
+    unsigned long long* maxlen_bits;   // [MAX_LEVELS] per-level max ray length (bit pattern of a non-negative double)
+    int* flags;                        // RDR_FLAG_* bits (OR-reduced)
+    const int* nparts_override;        // [K] or nullptr -> ceil(maxlen/max_seg)+1
+    // outputs
+    double* wet; double* hyd;
+    // tiling
+    int64_t ntiles; int tiles_x;
+};
+
+// The slice-uniform level table of build_ray (losreader.py:785-808), computed by one thread into LDS.
+__device__ inline int build_levels(const double* zs, int nz, double ht, double zref, double* s_lo, double* s_hi, int* s_kz) {
+    int K = 0;
+    const double ztop = zs[nz - 1];
+    for (int zz = 0; zz < nz - 1; ++zz) {
+        double lo = zs[zz], hi = zs[zz + 1];
+        if (hi == ztop) hi -= 0.01;
+        if (hi < ht || lo >= zref) continue;
+        if (lo < ht) lo = ht;
+        if (hi > zref) hi = zref;
+        if (fabs(hi - lo) < 1.0) continue;
+        if (K < MAX_LEVELS) { s_lo[K] = lo; s_hi[K] = hi; s_kz[K] = zz; }
+        ++K;
+    }
+    return min(K, MAX_LEVELS);
+}
+
+__device__ __forceinline__ double wave_max(double v) {
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+// MODE 0: prepass (per-level batch max + flags).  MODE 1: march (integrate).
+template <int MODE, typename T2>
+__global__ __launch_bounds__(BLOCK) void ray_kernel(CubeView<T2> c, RayParams P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double* s_y = reinterpret_cast<double*>(smem_raw);
+    double* s_x = s_y + c.ny;
+    double* s_z = s_x + c.nx;
+    double* s_lo = s_z + c.nz;
+    double* s_hi = s_lo + c.nz;
+    unsigned long long* s_max = reinterpret_cast<unsigned long long*>(s_hi + c.nz);   // [nz] (MODE 0)
+    int* s_kz = reinterpret_cast<int*>(s_max + c.nz);
+    int* s_np = s_kz + c.nz;
+    int* s_K = s_np + c.nz;
+
+    const int tid = threadIdx.x;
+    for (int i = tid; i < c.ny + c.nx + c.nz; i += BLOCK) s_y[i] = c.axes[i];
+    __syncthreads();
+    if (tid == 0) *s_K = build_levels(s_z, c.nz, P.ht, P.zref, s_lo, s_hi, s_kz);
+    __syncthreads();
+    const int K = *s_K;
+    if (MODE == 0) {
+        for (int k = tid; k < K; k += BLOCK) s_max[k] = 0ULL;
+    } else {
+        for (int k = tid; k < K; k += BLOCK) {
+            int np;
+            if (P.nparts_override) np = P.nparts_override[k];
+            else np = (int)ceil(__longlong_as_double((long long)P.maxlen_bits[k]) / P.max_seg) + 1;   // delay.py:283
+            s_np[k] = np;
+        }
+    }
+    __syncthreads();
+    int flags_in = 0;
+    if (MODE == 1) flags_in = *P.flags;
+    const bool clamp_lo = MODE == 1 && !(flags_in & 4);   // ALL first samples below zmin  (delay.py:306-307)
+    const bool clamp_hi = MODE == 1 && !(flags_in & 8);   // ALL last samples above zmax   (delay.py:310-311)
+    int my_flags = 0;
+
+    // persistent walk over tiles; XCD-aware: workgroup b runs on XCD b%8 -> give each XCD one contiguous band
+    const int nb = gridDim.x;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = nb >> 3;
+    const int64_t chunk = (P.ntiles + 7) / 8;
+    for (int64_t tt = slot; tt < chunk; tt += nslot) {
+        const int64_t t = (int64_t)xcd * chunk + tt;
+        if (t >= P.ntiles) break;
+        int64_t i; int64_t row = 0, col = 0; bool active;
+        if (P.origin_mode == 0) {
+            const int64_t ty = t / P.tiles_x, tx = t - ty * P.tiles_x;
+            row = ty * TILE + (tid >> 4); col = tx * TILE + (tid & 15);
+            active = row < P.ny && col < P.nx;
+            i = row * P.nx + col;
+        } else {
+            i = t * BLOCK + tid;
+            active = i < P.n;
+        }
+        // ---- origin: llh -> ECEF (delay.py:262-267)
+        double lat = 0, lon = 0, ox = qnan(), oy = qnan(), oz = qnan();
+        if (active) {
+            if (P.origin_mode == 0) { lat = P.ypts[row]; lon = P.xpts[col]; }
+            else if (P.lat) { lat = P.lat[i]; lon = P.lon[i]; }
+            if (P.origin_mode == 2) { ox = P.xyz[3 * i]; oy = P.xyz[3 * i + 1]; oz = P.xyz[3 * i + 2]; }
+            else lla2ecef(lat, lon, P.ht, ox, oy, oz);
+        }
+        // ---- look vector (delay.py:270)
+        double lx = qnan(), ly = qnan(), lz = qnan();
+        if (active) {
+            if (P.los_mode == 0) { lx = P.los[3 * i]; ly = P.los[3 * i + 1]; lz = P.los[3 * i + 2]; }
+            else if (P.los_mode == 1) inc_hd_to_ecef(P.inc[i], P.hd[i], lat, lon, lx, ly, lz);
+            else if (P.los_mode == 2) inc_hd_to_ecef(P.inc0, P.hd0, lat, lon, lx, ly, lz);
+            else {   // zenith (losreader.py:302-316)
+                double sla, cla, slo, clo;
+                sincos(lat * DEG_TO_RAD, &sla, &cla); sincos(lon * DEG_TO_RAD, &slo, &clo);
+                lx = cla * clo; ly = cla * slo; lz = sla;
+            }
+        }
+        double hx = 0, hy = 0, hz = 0, cosf = 1.0;
+        double acc_w = 0.0, acc_h = 0.0;
+        for (int k = 0; k < K; ++k) {
+            const double lo = s_lo[k], hi = s_hi[k];
+            double bx, by, bz;
+            if (k == 0) toa_newton(ox, oy, oz, lx, ly, lz, lo, 10, 1.0, bx, by, bz);   // cos_factor None: 10 iterations
+            else { bx = hx; by = hy; bz = hz; }                                          // reuse previous top (losreader.py:811-812)
+            toa_newton(ox, oy, oz, lx, ly, lz, hi, k == 0 ? 10 : 3, cosf, hx, hy, hz);
+            const double dx = hx - bx, dy = hy - by, dz = hz - bz;
+            const double L = sqrt(dx * dx + dy * dy + dz * dz);                         // np.linalg.norm, losreader.py:821
+            if (k == 0) cosf = (hi - lo) / L;                                           // losreader.py:824-825
+            if (MODE == 0) {
+                // NaN poisons the max exactly as ndarray.max does (delay.py:283): tracked via flags
+                if (active) my_flags |= (L != L) ? 1 : 2;
+                double m = (active && L == L) ? L : 0.0;
+                m = wave_max(m);
+                if ((tid & 63) == 0) atomicMax(&s_max[k], (unsigned long long)__double_as_longlong(m));
+                if (k == 0 && active) {          // first sample: low + 0*(high-low)
+                    const double h0 = ecef_height(bx + 0.0 * dx, by + 0.0 * dy, bz + 0.0 * dz);
+                    if (!(h0 < c.z_lo)) my_flags |= 4;
+                }
+                if (k == K - 1 && active) {      // last sample: low + 1*(high-low)
+                    const double h1 = ecef_height(bx + 1.0 * dx, by + 1.0 * dy, bz + 1.0 * dz);
+                    if (!(h1 > c.z_hi)) my_flags |= 8;
+                }
+            } else {
+                const int np = s_np[k];
+                const double nm1 = (double)np - 1.0;
+                const double step = 1.0 / nm1;                       // np.linspace(0,1,np) (delay.py:287)
+                const double segw = (L * 1.0e-6) / nm1;              // delay.py:315
+                const int kz = s_kz[k];
+                for (int j = 0; j < np; ++j) {
+                    const double f = (j == np - 1) ? 1.0 : (double)j * step;
+                    const double qx = bx + f * dx, qy = by + f * dy, qz = bz + f * dz;   // delay.py:292
+                    double plon, plat, ph;
+                    ecef2lla(qx, qy, qz, plon, plat, ph);                                 // delay.py:295
+                    if (clamp_lo && k == 0 && j == 0) ph = c.z_lo;
+                    if (clamp_hi && k == K - 1 && j == np - 1) ph = c.z_hi;
+                    double vw, vh;
+                    trilinear(c, s_y, s_x, s_z, plat, plon, ph, kz, vw, vh);              // delay.py:298,319
+                    const double wt = ((j == 0 || j == np - 1) ? 0.5 : 1.0) * segw;       // delay.py:314-315
+                    acc_w += wt * vw; acc_h += wt * vh;                                   // delay.py:323
+                }
+            }
+        }
+        if (MODE == 1 && active) { P.wet[i] = acc_w; P.hyd[i] = acc_h; }
+    }
+    if (MODE == 0) {
+        __syncthreads();
+        for (int k = tid; k < K; k += BLOCK) atomicMax(&P.maxlen_bits[k], s_max[k]);
+        // OR-reduce flags: wave ballot then one atomic per wave
+        int f = my_flags;
+        for (int off = 32; off > 0; off >>= 1) f |= __shfl_xor(f, off, 64);
+        if ((tid & 63) == 0 && f) atomicOr(P.flags, f);
+    }
+}
+
+}  // namespace rdr

@@ -1,0 +1,282 @@
+"""Thin object layer over the C ABI: device-resident weather cubes and ray batches.
+
+Everything here only marshals arguments; all arithmetic happens in the HIP kernels
+(raider_amd/csrc).  NumPy arrays are staged by the library (RDR_HOST); objects exposing
+`data_ptr()` (torch tensors on the GPU) are passed through as device pointers (RDR_DEVICE).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+from ._lib import Context, check, f64, ptr
+
+
+def _is_dev(a):
+    return hasattr(a, 'data_ptr')
+
+
+class Cube:
+    """Both fields of one processed weather model on the GPU, with scipy-RGI semantics.
+
+    Replaces the pair of scipy interpolators getInterpolators returns (delayFcns.py:23-58)."""
+
+    def __init__(self, ys, xs, zs, wet, hydro, order='yxz', ctx=None):
+        """wet/hydro: arrays of identical shape/dtype (f32 or f64); order 'yxz' (interpolator order)
+        or 'zyx' (file order, weatherModel.py:685-693) - no host transpose is made."""
+        self.ctx = ctx or Context.default()
+        self.handle = None
+        ys, xs, zs = f64(ys), f64(xs), f64(zs)
+        dev = _is_dev(wet)
+        if not dev:
+            wet = np.asarray(wet)
+            hydro = np.asarray(hydro)
+            if wet.dtype not in (np.float32, np.float64):
+                wet = wet.astype(np.float64)
+            hydro = np.asarray(hydro, dtype=wet.dtype)
+            wet = np.ascontiguousarray(wet)
+            hydro = np.ascontiguousarray(hydro)
+            dt = L.RDR_F32 if wet.dtype == np.float32 else L.RDR_F64
+            shape = wet.shape
+        else:
+            import torch
+            dt = L.RDR_F32 if wet.dtype == torch.float32 else L.RDR_F64
+            shape = tuple(wet.shape)
+            assert wet.is_contiguous() and hydro.is_contiguous()
+        ny, nx, nz = ys.size, xs.size, zs.size
+        if order == 'yxz':
+            want = (ny, nx, nz)
+            sy, sx, sz = nx * nz, nz, 1
+        elif order == 'zyx':
+            want = (nz, ny, nx)
+            sy, sx, sz = nx, 1, ny * nx
+        else:
+            raise ValueError("order must be 'yxz' or 'zyx'")
+        if tuple(shape) != want or tuple(hydro.shape) != want:
+            raise ValueError(f'There are {want} points in the grid but values have shape {tuple(shape)}')
+        h = C.c_void_p()
+        check(self.ctx.lib.rdr_cube_create(self.ctx.handle, ptr(ys), ny, ptr(xs), nx, ptr(zs), nz, ptr(wet), ptr(hydro), dt,
+                                           sy, sx, sz, L.RDR_DEVICE if dev else L.RDR_HOST, C.byref(h)), self.ctx.handle)
+        self.handle = h
+        self.dtype = np.float32 if dt == L.RDR_F32 else np.float64
+        self.shape = (ny, nx, nz)
+        gy, gx, gz = np.empty(ny), np.empty(nx), np.empty(nz)
+        check(self.ctx.lib.rdr_cube_axes(h, ptr(gy), ptr(gx), ptr(gz)))
+        self.grid = (gy, gx, gz)       # ascending, as scipy exposes `.grid` (delay.py:239)
+
+    @classmethod
+    def _from_handle(cls, ctx, h):
+        self = cls.__new__(cls)
+        self.ctx, self.handle = ctx, h
+        ny, nx, nz, dt = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int()
+        check(ctx.lib.rdr_cube_shape(h, C.byref(ny), C.byref(nx), C.byref(nz), C.byref(dt)))
+        self.shape = (ny.value, nx.value, nz.value)
+        self.dtype = np.float32 if dt.value == L.RDR_F32 else np.float64
+        gy, gx, gz = np.empty(ny.value), np.empty(nx.value), np.empty(nz.value)
+        check(ctx.lib.rdr_cube_axes(h, ptr(gy), ptr(gx), ptr(gz)))
+        self.grid = (gy, gx, gz)
+        return self
+
+    def blend(self, w1, other, w2):
+        """cli/raider.py:817-819: w1*self + w2*other on the device."""
+        h = C.c_void_p()
+        check(self.ctx.lib.rdr_cube_blend(self.ctx.handle, self.handle, float(w1), other.handle, float(w2), C.byref(h)), self.ctx.handle)
+        return Cube._from_handle(self.ctx, h)
+
+    def read(self):
+        wet = np.empty(self.shape, dtype=self.dtype)
+        hydro = np.empty(self.shape, dtype=self.dtype)
+        check(self.ctx.lib.rdr_cube_read(self.ctx.handle, self.handle, ptr(wet), ptr(hydro)), self.ctx.handle)
+        return wet, hydro
+
+    # ---- zenith / projected ------------------------------------------------------------------
+    def interp(self, pts):
+        """scipy RGI __call__ on both fields; pts[...,3] = (y,x,z).  Returns (wet, hydro) f64."""
+        if _is_dev(pts):
+            import torch
+            n = pts.numel() // 3
+            wet = torch.empty(pts.shape[:-1], dtype=torch.float64, device=pts.device)
+            hyd = torch.empty_like(wet)
+            check(self.ctx.lib.rdr_interp3(self.ctx.handle, self.handle, ptr(pts), n, ptr(wet), ptr(hyd), L.RDR_DEVICE), self.ctx.handle)
+            return wet, hyd
+        pts = np.asarray(pts)
+        if pts.shape[-1] != 3:
+            raise ValueError(f'The requested sample points xi have dimension {pts.shape[-1]} but this '
+                             'RegularGridInterpolator has dimension 3')
+        p = f64(pts).reshape(-1, 3)
+        wet = np.empty(p.shape[0]); hyd = np.empty(p.shape[0])
+        check(self.ctx.lib.rdr_interp3(self.ctx.handle, self.handle, ptr(p), p.shape[0], ptr(wet), ptr(hyd), L.RDR_HOST), self.ctx.handle)
+        return wet.reshape(pts.shape[:-1]), hyd.reshape(pts.shape[:-1])
+
+    def build_cube(self, xpts, ypts, zpts, out=None):
+        """_build_cube (delay.py:196-216): (wet, hydro) of shape (nz, ny, nx)."""
+        if _is_dev(xpts):
+            import torch
+            nx, ny, nz = xpts.numel(), ypts.numel(), zpts.numel()
+            wet, hyd = out if out is not None else (torch.empty((nz, ny, nx), dtype=torch.float64, device=xpts.device),
+                                                    torch.empty((nz, ny, nx), dtype=torch.float64, device=xpts.device))
+            check(self.ctx.lib.rdr_build_cube(self.ctx.handle, self.handle, ptr(xpts), nx, ptr(ypts), ny, ptr(zpts), nz,
+                                              ptr(wet), ptr(hyd), L.RDR_DEVICE), self.ctx.handle)
+            return wet, hyd
+        x, y, z = f64(xpts).ravel(), f64(ypts).ravel(), f64(np.atleast_1d(zpts)).ravel()
+        wet = np.empty((z.size, y.size, x.size)); hyd = np.empty_like(wet)
+        check(self.ctx.lib.rdr_build_cube(self.ctx.handle, self.handle, ptr(x), x.size, ptr(y), y.size, ptr(z), z.size,
+                                          ptr(wet), ptr(hyd), L.RDR_HOST), self.ctx.handle)
+        return wet, hyd
+
+    # ---- rays ------------------------------------------------------------------------------------
+    def ray_levels(self, ht, zref):
+        """(lo, hi, kz) of the contributing model intervals (losreader.py:785-808); raises NoLevels."""
+        nz = self.shape[2]
+        K = C.c_int32()
+        lo, hi, kz = np.empty(nz), np.empty(nz), np.empty(nz, dtype=np.int32)
+        check(self.ctx.lib.rdr_ray_levels(self.handle, float(ht), float(zref), C.byref(K), ptr(lo), ptr(hi), ptr(kz)), self.ctx.handle)
+        return lo[:K.value].copy(), hi[:K.value].copy(), kz[:K.value].copy()
+
+    def ray_prepass(self, rays, ht, zref):
+        K = len(self.ray_levels(ht, zref)[0])
+        maxlen = np.zeros(K)
+        flags = C.c_int32()
+        check(self.ctx.lib.rdr_ray_prepass(self.ctx.handle, self.handle, C.byref(rays.struct), float(ht), float(zref), ptr(maxlen),
+                                           C.byref(flags)), self.ctx.handle)
+        return maxlen, flags.value
+
+    def ray_march(self, rays, ht, zref, nparts, flags, out=None):
+        nparts = np.ascontiguousarray(nparts, dtype=np.int32)
+        wet, hyd = out if out is not None else rays.empty_outputs()
+        check(self.ctx.lib.rdr_ray_march(self.ctx.handle, self.handle, C.byref(rays.struct), float(ht), float(zref), ptr(nparts),
+                                         int(flags), ptr(wet), ptr(hyd)), self.ctx.handle)
+        return wet, hyd
+
+    def raytrace(self, rays, ht, zref, max_seg=1000.0, out=None, want_nparts=True):
+        """One slice of _build_cube_ray (delay.py:256-323).  Returns (wet, hydro, nparts, flags);
+        nparts/flags are None when want_nparts is False (fully asynchronous for device arrays)."""
+        wet, hyd = out if out is not None else rays.empty_outputs()
+        if want_nparts:
+            K = len(self.ray_levels(ht, zref)[0])
+            nparts = np.zeros(K, dtype=np.int32)
+            flags = C.c_int32()
+            check(self.ctx.lib.rdr_raytrace(self.ctx.handle, self.handle, C.byref(rays.struct), float(ht), float(zref), float(max_seg),
+                                            ptr(wet), ptr(hyd), ptr(nparts), C.byref(flags)), self.ctx.handle)
+            return wet, hyd, nparts, flags.value
+        check(self.ctx.lib.rdr_raytrace(self.ctx.handle, self.handle, C.byref(rays.struct), float(ht), float(zref), float(max_seg),
+                                        ptr(wet), ptr(hyd), None, None), self.ctx.handle)
+        return wet, hyd, None, None
+
+    def __del__(self):
+        try:
+            if getattr(self, 'handle', None):
+                self.ctx.lib.rdr_cube_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+class Rays:
+    """One ray batch = one (ny,nx) slice at one height (delay.py:256-273).  Keeps references to the
+    arrays it points at."""
+
+    def __init__(self):
+        self.struct = L.RdrRays()
+        self._keep = []
+        self.shape = ()
+        self._torch_device = None
+
+    def _set(self, field, arr):
+        if arr is None:
+            return
+        if _is_dev(arr):
+            self._torch_device = arr.device
+            assert arr.is_contiguous()
+            self._keep.append(arr)
+            setattr(self.struct, field, arr.data_ptr())
+        else:
+            a = f64(arr)
+            self._keep.append(a)
+            setattr(self.struct, field, a.ctypes.data)
+
+    @classmethod
+    def grid(cls, xpts, ypts, los=None, inc=None, hd=None, zenith=False):
+        """Origins on meshgrid(xpts, ypts) (delay.py:242).  LOS: `los` (ny,nx,3) ECEF unit vectors, or
+        inc/hd (scalars or (ny,nx) arrays, degrees), or zenith."""
+        r = cls()
+        nx = xpts.numel() if _is_dev(xpts) else np.size(xpts)
+        ny = ypts.numel() if _is_dev(ypts) else np.size(ypts)
+        r.struct.origin_mode = L.ORIGIN_GRID
+        r.struct.nx, r.struct.ny, r.struct.n = nx, ny, nx * ny
+        r._set('xpts', xpts); r._set('ypts', ypts)
+        r.shape = (ny, nx)
+        r._set_los(los, inc, hd, zenith)
+        return r
+
+    @classmethod
+    def points(cls, lat=None, lon=None, xyz=None, los=None, inc=None, hd=None, zenith=False):
+        """Arbitrary ray list: lat/lon (deg) at the slice height, or ECEF xyz (n,3)."""
+        r = cls()
+        if xyz is not None:
+            r.struct.origin_mode = L.ORIGIN_XYZ
+            n = (xyz.numel() if _is_dev(xyz) else np.size(xyz)) // 3
+            r.shape = tuple(xyz.shape[:-1])
+            r._set('xyz', xyz)
+            r._set('lat', lat); r._set('lon', lon)
+        else:
+            r.struct.origin_mode = L.ORIGIN_LLH
+            n = lat.numel() if _is_dev(lat) else np.size(lat)
+            r.shape = tuple(lat.shape) if hasattr(lat, 'shape') else (n,)
+            r._set('lat', lat); r._set('lon', lon)
+        r.struct.n = n
+        r._set_los(los, inc, hd, zenith)
+        return r
+
+    def _set_los(self, los, inc, hd, zenith):
+        n = self.struct.n
+        if los is not None:
+            cnt = los.numel() if _is_dev(los) else np.size(los)
+            if cnt != 3 * n:
+                raise ValueError(f'look vectors must have shape {self.shape + (3,)}')
+            self.struct.los_mode = L.LOS_VEC
+            self._set('los', los)
+        elif zenith:
+            self.struct.los_mode = L.LOS_ZENITH
+        elif inc is not None:
+            if np.ndim(inc) == 0 and np.ndim(hd) == 0 and not _is_dev(inc):
+                if float(inc) < 0:
+                    raise ValueError('inc_hd_to_enu: Incidence angle cannot be less than 0')
+                self.struct.los_mode = L.LOS_INC_HD_SCALAR
+                self.struct.inc0, self.struct.hd0 = float(inc), float(hd)
+            else:
+                if not _is_dev(inc):
+                    inc = np.broadcast_to(np.asarray(inc, dtype=np.float64), self.shape)
+                    hd = np.broadcast_to(np.asarray(hd, dtype=np.float64), self.shape)
+                    if np.any(inc < 0):
+                        raise ValueError('inc_hd_to_enu: Incidence angle cannot be less than 0')
+                self.struct.los_mode = L.LOS_INC_HD
+                self._set('inc', inc); self._set('hd', hd)
+        else:
+            raise ValueError('a ray batch needs look vectors, inc/heading, or zenith=True')
+        self.struct.loc = L.RDR_DEVICE if self._torch_device is not None else L.RDR_HOST
+
+    def empty_outputs(self):
+        if self._torch_device is not None:
+            import torch
+            return (torch.empty(self.shape, dtype=torch.float64, device=self._torch_device),
+                    torch.empty(self.shape, dtype=torch.float64, device=self._torch_device))
+        return np.empty(self.shape), np.empty(self.shape)
+
+    def look_vectors(self, ctx=None):
+        ctx = ctx or Context.default()
+        if self._torch_device is not None:
+            import torch
+            out = torch.empty(self.shape + (3,), dtype=torch.float64, device=self._torch_device)
+        else:
+            out = np.empty(self.shape + (3,))
+        check(ctx.lib.rdr_look_vectors(ctx.handle, C.byref(self.struct), 0.0, ptr(out)), ctx.handle)
+        return out
+
+
+def nparts_from_maxlen(maxlen, max_seg=1000.0):
+    """delay.py:283."""
+    maxlen = f64(maxlen)
+    out = np.empty(maxlen.size, dtype=np.int32)
+    check(L.load().rdr_nparts(ptr(maxlen), maxlen.size, float(max_seg), ptr(out)))
+    return out

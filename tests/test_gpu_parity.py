@@ -1,0 +1,156 @@
+"""GPU parity: the HIP engine (through the C ABI) against the oracle and the reference goldens."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import raider_oracle as O
+
+TOL = 1e-6     # metres - the north_star tolerance for wet/hydro delays (observed: ~1e-12)
+TIGHT = 1e-9
+
+
+@pytest.fixture(scope='module')
+def R():
+    import raider_amd
+    return raider_amd
+
+
+@pytest.fixture(scope='module')
+def c1():
+    return O.synthetic_cube(50, 50, 40, seed=0)
+
+
+@pytest.fixture(scope='module')
+def cubes(R, c1):
+    pw = R.Cube(c1['ys'], c1['xs'], c1['zs'], c1['wet'], c1['hydro'], order='zyx')
+    tot = R.Cube(c1['ys'], c1['xs'], c1['zs'], c1['wet_total'], c1['hydro_total'], order='zyx')
+    return pw, tot
+
+
+def test_interp3_matches_scipy_semantics(R):
+    from scipy.interpolate import RegularGridInterpolator
+    rng = np.random.default_rng(5)
+    ys = np.linspace(3, -2, 6); xs = np.sort(rng.uniform(0, 5, 7)); zs = np.array([0., 1., 3., 7.])
+    for dt in (np.float32, np.float64):
+        w = rng.normal(size=(6, 7, 4)).astype(dt); h = rng.normal(size=(6, 7, 4)).astype(dt)
+        cube = R.Cube(ys, xs, zs, w, h, order='yxz')
+        q = np.stack([rng.uniform(-2.5, 3.5, 5000), rng.uniform(-0.5, 5.5, 5000), rng.uniform(-1, 8, 5000)], -1)
+        q[:6] = [[3, xs[0], 0], [-2, xs[-1], 7], [ys[2], xs[3], zs[1]], [np.nan, 1, 1], [0, 1, 7.0000001], [0, 1, 7]]
+        gw, gh = cube.interp(q)
+        sw = RegularGridInterpolator((ys, xs, zs), w, fill_value=np.nan, bounds_error=False)(q)
+        sh = RegularGridInterpolator((ys, xs, zs), h, fill_value=np.nan, bounds_error=False)(q)
+        np.testing.assert_allclose(gw, sw, rtol=0, atol=1e-14, equal_nan=True)
+        np.testing.assert_allclose(gh, sh, rtol=0, atol=1e-14, equal_nan=True)
+        assert np.isnan(gw[3]) and np.isnan(gw[4]) and not np.isnan(gw[5])
+
+
+def test_cube_roundtrip_and_orders(R, c1):
+    a = R.Cube(c1['ys'], c1['xs'], c1['zs'], c1['wet'], c1['hydro'], order='zyx')
+    w, h = a.read()
+    assert np.array_equal(w, c1['wet'].transpose(1, 2, 0)) and np.array_equal(h, c1['hydro'].transpose(1, 2, 0))
+    b = R.Cube(c1['ys'][::-1], c1['xs'], c1['zs'], np.ascontiguousarray(w[::-1]), np.ascontiguousarray(h[::-1]), order='yxz')
+    w2, _ = b.read()
+    assert np.array_equal(w2, w)           # descending axis flipped on device, like scipy
+    assert np.array_equal(b.grid[0], c1['ys'])
+
+
+def test_g4_build_cube(R, golden, cubes):
+    g = golden('g4_build_cube')
+    _, tot = cubes
+    wet, hydro = tot.build_cube(g['xpts'], g['ypts'], g['zpts'])
+    np.testing.assert_allclose(wet, g['wet'], rtol=0, atol=1e-14)
+    np.testing.assert_allclose(hydro, g['hydro'], rtol=0, atol=1e-14)
+    wet2, hydro2 = tot.build_cube(g['xp2'], g['yp2'], g['zp2'])
+    np.testing.assert_allclose(wet2, g['wet2'], rtol=0, atol=1e-14, equal_nan=True)
+    np.testing.assert_allclose(hydro2, g['hydro2'], rtol=0, atol=1e-14, equal_nan=True)
+
+
+@pytest.mark.parametrize('tag', ['fixed', 'pp'])
+def test_g5_raytrace_c1(R, golden, cubes, tag):
+    g = golden('g5_build_cube_ray')
+    pw, _ = cubes
+    zref = float(g['c1_zref'])
+    inc = 39.0 if tag == 'fixed' else g['c1_pp_inc']
+    for i, ht in enumerate(g['c1_zpts']):
+        rays = R.Rays.grid(g['c1_xpts'], g['c1_ypts'], inc=inc, hd=-167.9)
+        wet, hyd, nparts, flags = pw.raytrace(rays, ht, zref)
+        assert np.array_equal(nparts, g[f'c1_{tag}_nparts{i}'])
+        np.testing.assert_allclose(wet, g[f'c1_{tag}_wet'][i], rtol=0, atol=TIGHT)
+        np.testing.assert_allclose(hyd, g[f'c1_{tag}_hydro'][i], rtol=0, atol=TIGHT)
+
+
+def test_g5_los_vector_input_and_maxseg(R, golden, cubes):
+    g = golden('g5_build_cube_ray')
+    pw, _ = cubes
+    xx, yy = np.meshgrid(g['c1_xpts'], g['c1_ypts'])
+    los = O.look_vectors_from_inc_hd(np.full(yy.shape, 20.0), np.full(yy.shape, -12.1), yy, xx, 100.0)
+    rays = R.Rays.grid(g['c1_xpts'], g['c1_ypts'], los=los)
+    wet, hyd, nparts, _ = pw.raytrace(rays, 100.0, 26000.0, max_seg=500.0)
+    assert np.array_equal(nparts, g['c1_z26_nparts0'])
+    np.testing.assert_allclose(wet, g['c1_z26_wet'][0], rtol=0, atol=TIGHT)
+    np.testing.assert_allclose(hyd, g['c1_z26_hydro'][0], rtol=0, atol=TIGHT)
+
+
+def test_g5_lateral_exit_nan(R, golden, cubes):
+    g = golden('g5_build_cube_ray')
+    pw, _ = cubes
+    rays = R.Rays.grid(g['c1_edge_xpts'], g['c1_edge_ypts'], inc=45.0, hd=-167.9)
+    wet, hyd, nparts, _ = pw.raytrace(rays, 0.0, float(g['c1_zref']))
+    assert np.array_equal(nparts, g['c1_edge_nparts0'])
+    assert np.array_equal(np.isnan(wet), np.isnan(g['c1_edge_wet'][0]))
+    np.testing.assert_allclose(wet, g['c1_edge_wet'][0], rtol=0, atol=TIGHT, equal_nan=True)
+    np.testing.assert_allclose(hyd, g['c1_edge_hydro'][0], rtol=0, atol=TIGHT, equal_nan=True)
+
+
+def test_g5_constant_refractivity_invariant(R, golden, c1):
+    g = golden('g5_build_cube_ray')
+    ones = np.ones_like(c1['wet'])
+    cube = R.Cube(c1['ys'], c1['xs'], c1['zs'], ones, ones, order='zyx')
+    zref = float(g['c1_zref'])
+    xx, yy = np.meshgrid(g['c1_one_xpts'], g['c1_one_ypts'])
+    for i, ht in enumerate(g['c1_zpts']):
+        rays = R.Rays.grid(g['c1_one_xpts'], g['c1_one_ypts'], inc=39.0, hd=-167.9)
+        wet, hyd, _, _ = cube.raytrace(rays, ht, zref)
+        np.testing.assert_allclose(wet, g['c1_one_wet'][i], rtol=0, atol=TIGHT)
+        xyz = np.stack(O.lla2ecef(yy, xx, np.full(yy.shape, ht)), -1)
+        los = O.look_vectors_from_inc_hd(np.full(yy.shape, 39.0), np.full(yy.shape, -167.9), yy, xx, ht)
+        Lk, _, _ = O.build_ray(c1['zs'], ht, xyz, los, zref)
+        np.testing.assert_allclose(wet * 1e6, Lk.sum(0), rtol=1e-12)     # delay*1e6 == sum of ray lengths
+
+
+def test_g5_big_cube(R, golden):
+    g = golden('g5_build_cube_ray')
+    big = O.synthetic_cube(300, 300, 80, seed=0)
+    cube = R.Cube(big['ys'], big['xs'], big['zs'], big['wet'], big['hydro'], order='zyx')
+    rays = R.Rays.grid(g['big_xpts'], g['big_ypts'], inc=g['big_inc'], hd=-167.9)
+    wet, hyd, nparts, _ = cube.raytrace(rays, 0.0, float(g['big_zref']))
+    assert np.array_equal(nparts, g['big_nparts0'])
+    np.testing.assert_allclose(wet, g['big_wet'][0], rtol=0, atol=TIGHT)
+    np.testing.assert_allclose(hyd, g['big_hydro'][0], rtol=0, atol=TIGHT)
+
+
+def test_g5b_shards_need_global_nparts(R, golden, cubes):
+    g = golden('g5b_whole_vs_halves')
+    pw, _ = cubes
+    zref = float(g['zref'])
+    xp, yp, inc = g['xpts'], g['ypts'], g['inc']
+    whole = R.Rays.grid(xp, yp, inc=inc, hd=-167.9)
+    maxlen, flags = pw.ray_prepass(whole, 0.0, zref)
+    nparts = R.nparts_from_maxlen(maxlen)
+    assert np.array_equal(nparts, g['nparts'])
+    mls = []
+    for sl in (slice(0, 32), slice(32, 64)):
+        rays = R.Rays.grid(xp[sl], yp, inc=np.ascontiguousarray(inc[:, sl]), hd=-167.9)
+        ml, fl = pw.ray_prepass(rays, 0.0, zref)
+        mls.append(ml)
+        wet, hyd = pw.ray_march(rays, 0.0, zref, nparts, flags)
+        np.testing.assert_allclose(hyd, g['hydro'][0][:, sl], rtol=0, atol=TIGHT)
+        np.testing.assert_allclose(wet, g['wet'][0][:, sl], rtol=0, atol=TIGHT)
+    assert np.array_equal(np.maximum(*mls), maxlen)       # MAX all-reduce of shard maxima == whole-slice maxima
+    # shard-local partition reproduces the reference run on the half, which differs from the whole by > 1e-6 m
+    rays = R.Rays.grid(xp[:32], yp, inc=np.ascontiguousarray(inc[:, :32]), hd=-167.9)
+    wet, hyd, npl, _ = pw.raytrace(rays, 0.0, zref)
+    assert np.array_equal(npl, g['left_nparts'])
+    np.testing.assert_allclose(hyd, g['left_hydro'][0], rtol=0, atol=TIGHT)
+    assert np.abs(hyd - g['hydro'][0][:, :32]).max() > 1e-6
