@@ -1,0 +1,368 @@
+"""RAiDER tropospheric delay calculation on MI355X - the drop-in for tools/RAiDER/delay.py.
+
+Same functions, signatures and quirks as the reference module:
+  tropo_delay (delay.py:35-130), _get_delays_on_cube (:133-193), _build_cube (:196-216),
+  _build_cube_ray (:219-326), writeResultsToXarray (:329-401), transformPoints (:404-436);
+`getDelays` is kept as a legacy alias of `tropo_delay`.
+Host code only orchestrates; every gather / ray march happens in the HIP kernels (raider_amd/csrc).
+"""
+import datetime as dt
+import os
+
+import numpy as np
+
+from ._lib import NoLevels
+from .constants import _ZREF
+from .delayFcns import FieldInterpolator, getInterpolators, _load_fields
+from .engine import Cube, Rays
+from .logger import logger
+from .utilFcns import ecef2lla, lla2ecef
+
+try:  # optional: only needed for CRSs other than EPSG:4326 / EPSG:4978
+    import pyproj
+except ImportError:  # pragma: no cover - pyproj is absent from the build image
+    pyproj = None
+
+
+# ------------------------------------------------------------------------------------------------
+# CRS helpers (the reference uses pyproj.CRS objects; EPSG ints / 'EPSG:xxxx' strings are enough here)
+# ------------------------------------------------------------------------------------------------
+def _epsg(crs):
+    """EPSG code of a CRS-like (int, 'EPSG:4326', '4326', pyproj.CRS, object with to_epsg) or None."""
+    if crs is None:
+        return None
+    if isinstance(crs, (int, np.integer)):
+        return int(crs)
+    if isinstance(crs, str):
+        s = crs.split(':')[-1]
+        try:
+            return int(s)
+        except ValueError:
+            if pyproj is not None:
+                return pyproj.CRS(crs).to_epsg()
+            return None
+    if hasattr(crs, 'to_epsg'):
+        return crs.to_epsg()
+    return None
+
+
+def _same_crs(a, b):
+    ea, eb = _epsg(a), _epsg(b)
+    if ea is not None and eb is not None:
+        return ea == eb
+    return a == b
+
+
+def _is_4326(crs):
+    return _epsg(crs) == 4326
+
+
+# ------------------------------------------------------------------------------------------------
+# small containers (the AOI / Dataset providers themselves are outside the hot path)
+# ------------------------------------------------------------------------------------------------
+class GridAOI:
+    """Array-backed stand-in for llreader.BoundingBox / Geocube: output grid nodes only."""
+
+    def __init__(self, xpts, ypts, heights=None):
+        self.xpts = np.asarray(xpts, dtype=np.float64)
+        self.ypts = np.asarray(ypts, dtype=np.float64)
+        self._heights = heights
+
+    def type(self):
+        return 'bounding_box' if self._heights is None else 'Geocube'
+
+    def readZ(self):
+        return self._heights
+
+
+class PointsAOI:
+    """Array-backed stand-in for llreader.StationFile / RasterRDR: query points + the intermediate grid."""
+
+    def __init__(self, lats, lons, hgts, xpts=None, ypts=None):
+        self._lats, self._lons, self._hgts = (np.asarray(a, dtype=np.float64) for a in (lats, lons, hgts))
+        if xpts is not None:
+            self.xpts = np.asarray(xpts, dtype=np.float64)
+            self.ypts = np.asarray(ypts, dtype=np.float64)
+
+    def type(self):
+        return 'station_file'
+
+    def readLL(self):
+        return self._lats, self._lons
+
+    def readZ(self):
+        return self._hgts
+
+    # llreader.py:173-191 (EPSG:4326 only): grid from the bounding box of the points
+    def set_output_spacing(self, ll_res=None):
+        self._spacing = ll_res
+
+    def set_output_xygrid(self, dst_crs=4326):
+        S, N = np.nanmin(self._lats), np.nanmax(self._lats)
+        W, E = np.nanmin(self._lons), np.nanmax(self._lons)
+        sp = self._spacing
+        self.xpts = np.arange(W, E + sp, sp)
+        self.ypts = np.arange(N, S - sp, -sp)
+
+
+class DelayCube:
+    """What writeResultsToXarray returns when xarray is not installed: the same variables/coords,
+    readable by getInterpolators (`.variables[name][:]`)."""
+
+    def __init__(self, variables, attrs):
+        self.variables = variables
+        self.attrs = attrs
+
+    def __getitem__(self, k):
+        return self.variables[k]
+
+    def __getattr__(self, k):
+        try:
+            return self.__dict__['variables'][k]
+        except KeyError:
+            raise AttributeError(k)
+
+
+def _is_cube_aoi(aoi):
+    """delay.py:98 `isinstance(aoi, (BoundingBox, Geocube))`, duck-typed on AOI.type() (llreader.py:50-51,316,373)."""
+    t = getattr(aoi, 'type', None)
+    t = t() if callable(t) else t
+    return t in ('bounding_box', 'Geocube')
+
+
+def _is_geocube(aoi):
+    t = getattr(aoi, 'type', None)
+    t = t() if callable(t) else t
+    return t == 'Geocube'
+
+
+# ------------------------------------------------------------------------------------------------
+# interpolator plumbing
+# ------------------------------------------------------------------------------------------------
+def _cube_of(interpolators):
+    """(Cube, field index per interpolator).  Accepts this package's FieldInterpolators, or ANY objects with
+    scipy's `.grid` / `.values` (e.g. the scipy RGIs the reference builds): their data is uploaded once and
+    cached on the first object - the arithmetic still runs on the GPU, never in scipy."""
+    first = interpolators[0]
+    if all(isinstance(i, FieldInterpolator) for i in interpolators) and all(i.cube is first.cube for i in interpolators):
+        return first.cube, [i.field for i in interpolators]
+    if len(interpolators) > 2:
+        raise ValueError('at most two interpolators (wet, hydro) are supported')
+    cached = getattr(first, '_raider_amd_cube', None)
+    if cached is not None:
+        return cached, list(range(len(interpolators)))
+    grid = first.grid
+    a = np.asarray(first.values)
+    b = np.asarray(interpolators[-1].values)
+    cube = Cube(grid[0], grid[1], grid[2], a, b.astype(a.dtype, copy=False), order='yxz')
+    try:
+        first._raider_amd_cube = cube
+    except AttributeError:
+        pass
+    return cube, list(range(len(interpolators)))
+
+
+# ------------------------------------------------------------------------------------------------
+# public API
+# ------------------------------------------------------------------------------------------------
+def tropo_delay(datetime, weather_model_file, aoi, los, height_levels=None, out_proj=4326, zref=None):
+    """delay.py:35-130: ZTD, projected STD, or ray-traced STD on an AOI.
+
+    weather_model_file: path to a processed weather-model NetCDF, an xarray.Dataset, or a mapping with
+    x, y, z, wet, hydro, wet_total, hydro_total (file order (z,y,x)) and optionally a 'proj' entry.
+    Returns (Dataset-like, None) for cube AOIs, else (wetDelay, hydroDelay) at the query points."""
+    crs = out_proj
+    var, get = _load_fields(weather_model_file)
+    # CRS of the weather model (delay.py:66-73)
+    wm_proj = None
+    try:
+        wkt = var['proj'].attrs['crs_wkt']
+        wm_proj = pyproj.CRS.from_wkt(wkt) if pyproj is not None else (4326 if ('WGS 84' in wkt and 'PROJCRS' not in wkt) or wkt.endswith('4326') else wkt)
+    except (KeyError, AttributeError, TypeError):
+        logger.warning("WARNING: I can't find a CRS in the weather model file, so I will assume you are using WGS84")
+        wm_proj = 4326
+
+    wm_levels = get('z')
+    toa = wm_levels.max() - 1                                   # delay.py:78
+    if height_levels is None:
+        height_levels = aoi.readZ() if _is_geocube(aoi) else wm_levels
+    if zref is None:
+        zref = toa
+    if zref > toa:
+        zref = toa
+        logger.warning(f'Requested integration height (zref) is higher than top of weather model. Forcing to top ({toa}).')
+
+    ds = _get_delays_on_cube(datetime, weather_model_file, wm_proj, aoi, height_levels, los, crs, zref)
+    if _is_cube_aoi(aoi):
+        return ds, None
+
+    # point branch (delay.py:101-128): interpolate the output cube to the query points
+    lats, lons = aoi.readLL()
+    hgts = aoi.readZ()
+    pnts = transformPoints(lats, lons, hgts, 4326, out_proj)
+    try:
+        ifWet, ifHydro = getInterpolators(ds, 'ztd')
+    except RuntimeError:
+        raise RuntimeError(f'Failed to get weather model {weather_model_file} interpolators.')
+    wetDelay = ifWet(pnts)
+    hydroDelay = ifHydro(pnts)
+    if los.is_Projected():
+        los.setTime(datetime)
+        los.setPoints(lats, lons, hgts)
+        wetDelay = los(wetDelay)
+        hydroDelay = los(hydroDelay)
+    return wetDelay, hydroDelay
+
+
+getDelays = tropo_delay   # legacy name used by BASELINE.json's north_star
+
+
+def _get_delays_on_cube(datetime, weather_model_file, wm_proj, aoi, heights, los, crs, zref, nproc=1):
+    """delay.py:133-193."""
+    zpts = np.array(heights)
+    try:
+        aoi.xpts
+    except AttributeError:
+        _, get = _load_fields(weather_model_file)
+        x_spacing = np.diff(get('x')).mean()
+        y_spacing = np.diff(get('y')).mean()
+        aoi.set_output_spacing(ll_res=np.min([x_spacing, y_spacing]))
+        aoi.set_output_xygrid(crs)
+
+    if los.is_Zenith() or los.is_Projected():
+        # NB: a projected LOS on a cube AOI yields ZENITH delays, exactly like the reference
+        out_type = 'zenith' if los.is_Zenith() else 'slant - projected'
+        ifWet, ifHydro = getInterpolators(weather_model_file, 'total')
+        wetDelay, hydroDelay = _build_cube(aoi.xpts, aoi.ypts, zpts, wm_proj, crs, [ifWet, ifHydro])
+    else:
+        out_type = 'slant - raytracing'
+        ifWet, ifHydro = getInterpolators(weather_model_file, kind='pointwise', shared=(nproc > 1))
+        if nproc == 1:
+            wetDelay, hydroDelay = _build_cube_ray(aoi.xpts, aoi.ypts, zpts, los, wm_proj, crs, [ifWet, ifHydro],
+                                                   MAX_TROPO_HEIGHT=zref)
+        else:
+            raise NotImplementedError     # delay.py:178-185 (multi-GPU: see raider_amd.distributed)
+
+    if np.isnan(wetDelay).any() or np.isnan(hydroDelay).any():
+        logger.critical('There are missing delay values. Check your inputs.')
+
+    return writeResultsToXarray(datetime, aoi.xpts, aoi.ypts, zpts, crs, wetDelay, hydroDelay, weather_model_file, out_type)
+
+
+def _build_cube(xpts, ypts, zpts, model_crs, pts_crs, interpolators):
+    """delay.py:196-216: zenith / projected cube, one trilinear gather of both fields per node."""
+    cube, fields = _cube_of(interpolators)
+    zpts = np.asarray(zpts)
+    if _same_crs(model_crs, pts_crs):
+        res = cube.build_cube(xpts, ypts, zpts)            # points generated on the fly in the kernel
+        return [res[f] for f in fields]
+    xx, yy = np.meshgrid(xpts, ypts)
+    outputArrs = [np.zeros((zpts.size, len(ypts), len(xpts))) for _ in interpolators]
+    for ii, ht in enumerate(zpts):
+        pts = transformPoints(yy, xx, np.full(yy.shape, ht), pts_crs, model_crs)    # delay.py:207-209
+        res = cube.interp(pts)
+        for mm, f in enumerate(fields):
+            outputArrs[mm][ii, ...] = res[f]
+    return outputArrs
+
+
+def _build_cube_ray(xpts, ypts, zpts, los, model_crs, pts_crs, interpolators, outputArrs=None,
+                    MAX_SEGMENT_LENGTH=1000.0, MAX_TROPO_HEIGHT=_ZREF):
+    """delay.py:219-326: ray-traced cube.  One fused GPU pass pair per height slice:
+    pass 1 = build_ray's per-level ray lengths reduced to the slice maximum (-> nParts, delay.py:283),
+    pass 2 = Newton level intersections + ECEF->geodetic + trilinear gather + trapezoid, per ray."""
+    if not _is_4326(model_crs):
+        raise NotImplementedError('ray tracing through projected (e.g. HRRR Lambert) cubes is not built yet '
+                                  '(SURVEY.md §8f); the weather cube must be on an EPSG:4326 lat/lon grid')
+    cube, fields = _cube_of(interpolators)
+    xpts = np.asarray(xpts, dtype=np.float64)
+    ypts = np.asarray(ypts, dtype=np.float64)
+    zpts = np.asarray(zpts)
+    output_created_here = False
+    if outputArrs is None:
+        output_created_here = True
+        outputArrs = [np.zeros((zpts.size, ypts.size, xpts.size)) for _ in interpolators]
+
+    grid_is_ll = _is_4326(pts_crs)
+    for hh, ht in enumerate(zpts):
+        logger.info(f'Processing slice {hh + 1} / {len(zpts)}: {ht}')
+        if grid_is_ll and hasattr(los, 'ray_batch'):
+            rays = los.ray_batch(xpts, ypts)                               # look vectors made / read on the device
+        else:
+            xx, yy = np.meshgrid(xpts, ypts)
+            if grid_is_ll:
+                llh = [xx, yy, np.full(yy.shape, ht)]
+            else:                                                          # delay.py:262-263
+                p = transformPoints(yy, xx, np.full(yy.shape, ht), pts_crs, 4326)
+                llh = [p[..., 1], p[..., 0], p[..., 2]]
+            xyz = np.stack(lla2ecef(llh[1], llh[0], llh[2]), axis=-1)      # delay.py:267
+            LOS = los.getLookVectors(ht, llh, xyz, yy)                     # delay.py:270
+            if grid_is_ll:
+                rays = Rays.grid(xpts, ypts, los=LOS)
+            else:
+                rays = Rays.points(lat=llh[1], lon=llh[0], los=LOS)
+        try:
+            wet, hyd, _nparts, _flags = cube.raytrace(rays, ht, MAX_TROPO_HEIGHT, MAX_SEGMENT_LENGTH)
+        except NoLevels:
+            if ht == zpts[-1]:                                             # delay.py:276-277
+                continue
+            raise TypeError("ufunc 'isnan' not supported for the input types (build_ray returned None)")   # delay.py:279
+        res = (wet, hyd)
+        for mm, f in enumerate(fields):
+            outputArrs[mm][hh, ...] += res[f].reshape(ypts.size, xpts.size)
+    if output_created_here:
+        return outputArrs
+
+
+def writeResultsToXarray(datetime, xpts, ypts, zpts, crs, wetDelay, hydroDelay, weather_model_file, out_type):
+    """delay.py:329-401.  Returns an xarray.Dataset when xarray is installed, else a DelayCube with the
+    same variables (`wet`, `hydro` on (z,y,x); coords x, y, z; attrs)."""
+    source = os.path.basename(weather_model_file) if isinstance(weather_model_file, (str, os.PathLike)) else 'in-memory'
+    attrs = dict(Conventions='CF-1.7', title='RAiDER geo cube', source=source,
+                 history=str(dt.datetime.now(tz=dt.timezone.utc)) + ' RAiDER',
+                 description=f'RAiDER geo cube - {out_type}',
+                 reference_time=datetime.strftime('%Y%m%dT%H:%M:%S') if hasattr(datetime, 'strftime') else str(datetime))
+    degrees = _is_4326(crs)
+    try:
+        import xarray as xr
+    except ImportError:
+        return DelayCube(dict(wet=np.asarray(wetDelay), hydro=np.asarray(hydroDelay), x=np.asarray(xpts), y=np.asarray(ypts),
+                              z=np.asarray(zpts), crs=np.array(-2147483647)), attrs)
+    ds = xr.Dataset(
+        data_vars=dict(
+            wet=(['z', 'y', 'x'], wetDelay, {'units': 'm', 'description': f'wet {out_type} delay', 'grid_mapping': 'crs'}),
+            hydro=(['z', 'y', 'x'], hydroDelay, {'units': 'm', 'description': f'hydrostatic {out_type} delay', 'grid_mapping': 'crs'})),
+        coords=dict(x=(['x'], xpts), y=(['y'], ypts), z=(['z'], zpts)), attrs=attrs)
+    ds['crs'] = -2147483647
+    if pyproj is not None:
+        for k, v in pyproj.CRS(crs).to_cf().items():
+            ds.crs.attrs[k] = v
+    ds.z.attrs.update(axis='Z', units='m', description='height above ellipsoid')
+    if degrees:
+        ds.y.attrs.update(units='degrees_north', standard_name='latitude', long_name='latitude')
+        ds.x.attrs.update(units='degrees_east', standard_name='longitude', long_name='longitude')
+    else:
+        ds.y.attrs.update(axis='Y', standard_name='projection_y_coordinate', long_name='y-coordinate in projected coordinate system', units='m')
+        ds.x.attrs.update(axis='X', standard_name='projection_x_coordinate', long_name='x-coordinate in projected coordinate system', units='m')
+    return ds
+
+
+def transformPoints(lats, lons, hgts, old_proj, new_proj):
+    """delay.py:404-436: (lat, lon, h) in `old_proj` -> stacked (y, x, z) in `new_proj`.
+    EPSG:4326 <-> EPSG:4978 run on the GPU; anything else needs pyproj (as in the reference)."""
+    eo, en = _epsg(old_proj), _epsg(new_proj)
+    lats, lons, hgts = np.broadcast_arrays(np.asarray(lats, dtype=np.float64), np.asarray(lons, dtype=np.float64),
+                                           np.asarray(hgts, dtype=np.float64))
+    if eo is not None and eo == en:
+        return np.stack([lats, lons, hgts], axis=-1)
+    if eo == 4326 and en == 4978:
+        x, y, z = lla2ecef(lats, lons, hgts)
+        return np.stack([y, x, z], axis=-1)
+    if eo == 4978 and en == 4326:
+        lon, lat, h = ecef2lla(lons, lats, hgts)          # always_xy: x = "lons" argument, y = "lats" argument
+        return np.stack([lat, lon, h], axis=-1)
+    if pyproj is None:
+        raise NotImplementedError(f'transformPoints {old_proj} -> {new_proj} needs pyproj (only EPSG:4326 <-> EPSG:4978 are built in)')
+    t = pyproj.Transformer.from_crs(old_proj, new_proj, always_xy=True)
+    res = t.transform(lons, lats, hgts)
+    return np.stack([res[1], res[0], res[2]], axis=-1)

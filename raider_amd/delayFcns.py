@@ -1,0 +1,90 @@
+"""`getInterpolators` of the delay path (tools/RAiDER/delayFcns.py:23-58).
+
+Returns two interpolator objects with scipy's `RegularGridInterpolator` call semantics (linear,
+bounds_error=False, fill_value=nan) and a `.grid` attribute (delay.py:239 reads `interpolators[0].grid[2]`),
+both views of ONE device-resident `Cube` (wet and hydro interleaved, gathered together)."""
+from pathlib import Path
+
+import numpy as np
+
+from .engine import Cube
+
+
+class FieldInterpolator:
+    """One field (0 = wet, 1 = hydro) of a device cube, callable like scipy's RGI."""
+
+    def __init__(self, cube, field):
+        self.cube = cube
+        self.field = field
+        self.grid = cube.grid
+        self.fill_value = np.nan
+        self.bounds_error = False
+        self.method = 'linear'
+        self._sibling = None
+        self._cache = None
+
+    @property
+    def values(self):
+        return self.cube.read()[self.field]
+
+    @staticmethod
+    def _sig(pts):
+        flat = pts.reshape(-1)
+        step = max(1, flat.size // 16)
+        return (pts.shape, pts.dtype.str, flat[::step][:17].tobytes())
+
+    def __call__(self, xi):
+        """Both fields are gathered in one kernel launch; the sibling interpolator reuses the result when it
+        is called next with the same points (the reference loops `for intp in interpolators: intp(pts)`,
+        delay.py:213-214,318-319)."""
+        pts = np.asarray(xi, dtype=np.float64)
+        sig = self._sig(pts)
+        if self._cache is not None and self._cache[0] == sig and self._cache[1] is xi:
+            out = self._cache[2]
+            self._cache = None
+            return out
+        wet, hyd = self.cube.interp(pts)
+        if self._sibling is not None:
+            self._sibling._cache = (sig, xi, hyd if self.field == 0 else wet)
+        return wet if self.field == 0 else hyd
+
+
+def _load_fields(wm_file):
+    """Pull x, y, z and the four fields out of a path / xarray.Dataset / mapping."""
+    if isinstance(wm_file, (str, Path)):
+        try:
+            import xarray as xr
+            ds = xr.load_dataset(wm_file)
+        except ImportError:
+            from scipy.io import netcdf_file     # NetCDF-3 only
+            with netcdf_file(str(wm_file), 'r', mmap=False) as f:
+                ds = {k: np.array(v[:]) for k, v in f.variables.items()}
+    else:
+        ds = wm_file
+    var = ds.variables if hasattr(ds, 'variables') else ds
+    get = lambda k: np.array(var[k][:])
+    return var, get
+
+
+def getInterpolators(wm_file, kind='pointwise', shared=False, ctx=None):
+    """delayFcns.py:23-58.  `wm_file`: processed weather-model NetCDF path, an xarray.Dataset, or any mapping
+    with x, y, z and wet/hydro (`kind != 'total'`) or wet_total/hydro_total (`kind == 'total'`) in file
+    order (z, y, x).  `shared` is accepted and ignored (device memory is shared by construction)."""
+    var, get = _load_fields(wm_file)
+    xs, ys, zs = get('x'), get('y'), get('z')
+    wet = get('wet_total' if kind == 'total' else 'wet')
+    hydro = get('hydro_total' if kind == 'total' else 'hydro')
+    if np.any(np.isnan(wet)) or np.any(np.isnan(hydro)):
+        from .logger import logger
+        logger.critical('Weather model contains NaNs!')
+    cube = Cube(ys, xs, zs, wet, hydro, order='zyx', ctx=ctx)      # no host transpose (delayFcns.py:40-41 does one)
+    ifWet, ifHydro = FieldInterpolator(cube, 0), FieldInterpolator(cube, 1)
+    ifWet._sibling, ifHydro._sibling = ifHydro, ifWet
+    return ifWet, ifHydro
+
+
+def interpolators_from_cube(cube):
+    """Wrap an existing device `Cube` (e.g. a blended one) as the (ifWet, ifHydro) pair."""
+    a, b = FieldInterpolator(cube, 0), FieldInterpolator(cube, 1)
+    a._sibling, b._sibling = b, a
+    return a, b

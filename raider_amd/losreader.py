@@ -1,0 +1,226 @@
+"""Line-of-sight types and ray geometry of the delay path (tools/RAiDER/losreader.py).
+
+Same duck-typed LOS protocol as the reference (`is_Zenith`, `is_Projected`, `ray_trace`, `setPoints`,
+`setTime`, `__call__`, `getLookVectors`; losreader.py:32-72,89,110,219).  isce3 (orbit -> look vector,
+losreader.py:219-255) is outside this build's scope: `Raytracing` here is
+ARRAY-BACKED - per-pixel look vectors or incidence/heading - and the geometry kernels
+(getTopOfAtmosphere, build_ray) run on the GPU."""
+import ctypes as C
+from abc import ABC
+
+import numpy as np
+
+from . import _lib as L
+from ._lib import Context, check, f64, ptr
+from .constants import _ZREF
+from .utilFcns import cosd, enu2ecef, sind
+
+
+class LOS(ABC):
+    """losreader.py:32-72."""
+
+    def __init__(self):
+        self._lats, self._lons, self._heights = None, None, None
+        self._look_vecs = None
+        self._ray_trace = False
+        self._is_zenith = False
+        self._is_projected = False
+        self._time = None
+
+    def setPoints(self, lats, lons=None, heights=None):
+        """losreader.py:42-60."""
+        if (lats is None) and (self._lats is None):
+            raise RuntimeError("You haven't given any point locations yet")
+        if lons is None:
+            llh = lats
+            self._lats, self._lons, self._heights = llh[..., 0], llh[..., 1], llh[..., 2]
+        elif heights is None:
+            self._lats, self._lons = lats, lons
+            self._heights = np.zeros((len(lats), 1))
+        else:
+            self._lats, self._lons, self._heights = lats, lons, heights
+
+    def setTime(self, datetime):
+        self._time = datetime
+
+    def is_Zenith(self):
+        return self._is_zenith
+
+    def is_Projected(self):
+        return self._is_projected
+
+    def ray_trace(self):
+        return self._ray_trace
+
+
+class Zenith(LOS):
+    """losreader.py:75-91."""
+
+    def __init__(self):
+        super().__init__()
+        self._is_zenith = True
+
+    def setLookVectors(self):
+        if self._lats is None:
+            raise ValueError('Target points not set')
+        if self._look_vecs is None:
+            self._look_vecs = getZenithLookVecs(self._lats, self._lons, self._heights)
+
+    def __call__(self, delays):
+        return delays
+
+
+class Conventional(LOS):
+    """Zenith delay projected with 1/cos(inc) (losreader.py:94-133).
+
+    `filename` may be an ISCE-style 2-band LOS raster path (needs rasterio, like the reference) or -
+    array-backed extension - `inc`/`heading` rasters given directly.  The orbit-file branch
+    (losreader.py:122-128) needs isce3 and is out of scope here."""
+
+    def __init__(self, filename=None, los_convention='isce', time=None, pad=600, inc=None, heading=None):
+        super().__init__()
+        self._file = filename
+        self._time = time
+        self._pad = pad
+        self._is_projected = True
+        self._convention = los_convention
+        self._inc = None if inc is None else np.asarray(inc, dtype=np.float64)
+        self._hd = None if heading is None else np.asarray(heading, dtype=np.float64)
+        if self._convention.lower() != 'isce':
+            raise NotImplementedError()
+
+    def _enu(self):
+        if self._inc is not None:
+            hd = self._hd if self._hd is not None else np.zeros_like(self._inc)
+            return inc_hd_to_enu(self._inc, hd)
+        if self._file is None:
+            raise ValueError('LOS file not set')
+        try:
+            import rasterio
+        except ImportError as e:
+            raise ImportError('reading an ISCE LOS raster needs rasterio; pass inc=/heading= arrays instead') from e
+        with rasterio.open(self._file) as src:
+            data = src.read()
+        return inc_hd_to_enu(*data)
+
+    def __call__(self, delays):
+        """losreader.py:110-133."""
+        if self._lats is None:
+            raise ValueError('Target points not set')
+        if self._file is None and self._inc is None:
+            raise ValueError('LOS file not set')
+        LOS_enu = self._enu()
+        delays = np.asarray(delays)
+        if delays.shape == LOS_enu.shape:
+            return delays / LOS_enu
+        return delays / LOS_enu[..., -1]
+
+
+class Raytracing(LOS):
+    """Full ray tracing (losreader.py:136-255), array-backed.
+
+    Give EITHER `look_vectors` (ny,nx,3) ECEF unit vectors ground->sensor (what the reference's
+    getLookVectors returns, delay.py:270; reused for every height slice) OR `inc`/`heading` (deg, scalars or
+    (ny,nx) rasters) from which the kernels derive the vectors per pixel (inc_hd_to_enu + enu2ecef).
+    A statevector file (`filename=`) would need isce3's geo2rdr and raises ImportError like the reference
+    does when isce3 is missing (losreader.py:176-177)."""
+
+    def __init__(self, filename=None, los_convention='isce', time=None, look_dir='right', pad=600,
+                 look_vectors=None, inc=None, heading=None):
+        if filename is not None and look_vectors is None and inc is None:
+            raise ImportError('isce3 is required for orbit-based look vectors; raider_amd.Raytracing takes '
+                              'look_vectors= or inc=/heading= arrays instead')
+        super().__init__()
+        self._ray_trace = True
+        self._file = filename
+        self._time = time
+        self._pad = pad
+        self._convention = los_convention
+        if self._convention.lower() != 'isce':
+            raise NotImplementedError()
+        if look_dir.lower() not in ('right', 'left'):
+            raise RuntimeError(f'Unknown look direction: {look_dir}')
+        self._look_dir = look_dir.lower()
+        self._lv = None if look_vectors is None else np.ascontiguousarray(look_vectors, dtype=np.float64)
+        self._inc = inc
+        self._hd = heading if heading is not None else (0.0 if inc is not None else None)
+        if self._lv is None and self._inc is None:
+            raise ValueError('Raytracing needs look_vectors= or inc=/heading=')
+
+    def getLookDirection(self):
+        return self._look_dir
+
+    def ray_batch(self, xpts, ypts):
+        """Engine fast path: a `Rays` batch whose look vectors are generated / read on the device."""
+        from .engine import Rays
+        if self._lv is not None:
+            return Rays.grid(xpts, ypts, los=self._lv)
+        return Rays.grid(xpts, ypts, inc=self._inc, hd=self._hd)
+
+    def getLookVectors(self, ht, llh, xyz, yy):
+        """delay.py:270 protocol: (ny,nx,3) unit ECEF vectors."""
+        if self._lv is not None:
+            if self._lv.shape != yy.shape + (3,):
+                raise ValueError(f'look_vectors have shape {self._lv.shape}, expected {yy.shape + (3,)}')
+            return self._lv
+        inc = np.broadcast_to(np.asarray(self._inc, dtype=np.float64), yy.shape)
+        hd = np.broadcast_to(np.asarray(self._hd, dtype=np.float64), yy.shape)
+        enu = inc_hd_to_enu(inc, hd)
+        return enu2ecef(enu[..., 0], enu[..., 1], enu[..., 2], llh[1], llh[0], llh[2])
+
+
+def getZenithLookVecs(lats, lons, heights):
+    """losreader.py:302-316."""
+    x = np.cos(np.radians(lats)) * np.cos(np.radians(lons))
+    y = np.cos(np.radians(lats)) * np.sin(np.radians(lons))
+    z = np.sin(np.radians(lats))
+    return np.stack([x, y, z], axis=-1)
+
+
+def inc_hd_to_enu(incidence, heading):
+    """losreader.py:374-396."""
+    if np.any(np.asarray(incidence) < 0):
+        raise ValueError('inc_hd_to_enu: Incidence angle cannot be less than 0')
+    east = sind(incidence) * cosd(heading + 90)
+    north = sind(incidence) * sind(heading + 90)
+    up = cosd(incidence)
+    return np.stack((east, north, up), axis=-1)
+
+
+def getTopOfAtmosphere(xyz, look_vecs, toaheight, factor=None):
+    """losreader.py:706-733 on the GPU: Newton intersection of rays with the height surface `toaheight`
+    (10 iterations with factor 1 if `factor` is None, else 3 iterations with the per-pixel factor)."""
+    xyz = np.asarray(xyz, dtype=np.float64)
+    shp = xyz.shape
+    x = f64(xyz).reshape(-1, 3)
+    l = f64(np.broadcast_to(look_vecs, shp)).reshape(-1, 3)
+    n = x.shape[0]
+    fac = None if factor is None else f64(np.broadcast_to(factor, shp[:-1])).ravel()
+    pos = np.empty((n, 3))
+    ctx = Context.default()
+    check(ctx.lib.rdr_top_of_atmosphere(ctx.handle, ptr(x), ptr(l), n, float(toaheight), ptr(fac), ptr(pos), L.RDR_HOST), ctx.handle)
+    return pos.reshape(shp)
+
+
+def build_ray(model_zs, ht, xyz, LOS, MAX_TROPO_HEIGHT=_ZREF):
+    """losreader.py:772-835 on the GPU: (ray_lengths (K,...), low_xyzs (K,...,3), high_xyzs (K,...,3)) or
+    (None, None, None) when no model interval contributes.  (The ray tracer proper never materialises
+    these - it fuses this computation into the integration kernel.)"""
+    model_zs = f64(model_zs).ravel()
+    xyz = np.asarray(xyz, dtype=np.float64)
+    shp = xyz.shape[:-1]
+    x = f64(xyz).reshape(-1, 3)
+    l = f64(np.broadcast_to(LOS, xyz.shape)).reshape(-1, 3)
+    n = x.shape[0]
+    ctx = Context.default()
+    K = C.c_int32()
+    rc = ctx.lib.rdr_build_ray(ctx.handle, ptr(model_zs), model_zs.size, float(ht), ptr(x), ptr(l), n, float(MAX_TROPO_HEIGHT),
+                               C.byref(K), None, None, None, L.RDR_HOST)
+    if rc == L.RDR_ERR_NO_LEVELS:
+        return None, None, None
+    check(rc, ctx.handle)
+    k = K.value
+    lengths, low, high = np.empty((k, n)), np.empty((k, n, 3)), np.empty((k, n, 3))
+    check(ctx.lib.rdr_build_ray(ctx.handle, ptr(model_zs), model_zs.size, float(ht), ptr(x), ptr(l), n, float(MAX_TROPO_HEIGHT),
+                                C.byref(K), ptr(lengths), ptr(low), ptr(high), L.RDR_HOST), ctx.handle)
+    return lengths.reshape((k,) + shp), low.reshape((k,) + shp + (3,)), high.reshape((k,) + shp + (3,))

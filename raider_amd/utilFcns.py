@@ -1,0 +1,73 @@
+"""Geodesy helpers of the delay path (tools/RAiDER/utilFcns.py:55-137).
+
+lla2ecef / ecef2lla run on the GPU (the reference goes through pyproj/PROJ, utilFcns.py:77-88);
+the ENU rotations and degree trig are the same few NumPy expressions the reference uses and are kept
+on the host because the reference's callers use them on tiny arrays outside the hot loops (inside the
+ray kernels the same conversions are fused on-device, csrc/geodesy.h)."""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import Context, check, f64, ptr, RDR_HOST
+
+
+def projectDelays(delay, inc):
+    """utilFcns.py:55-59."""
+    if np.any(np.asarray(inc) == 90):
+        raise ZeroDivisionError
+    return delay / cosd(inc)
+
+
+def sind(x):
+    """utilFcns.py:67-69."""
+    return np.sin(np.radians(x))
+
+
+def cosd(x):
+    """utilFcns.py:72-74."""
+    return np.cos(np.radians(x))
+
+
+def lla2ecef(lat, lon, height):
+    """utilFcns.py:77-81 - returns the (x, y, z) tuple pyproj's always_xy transform returns."""
+    lat, lon, height = np.broadcast_arrays(np.asarray(lat, dtype=np.float64), np.asarray(lon, dtype=np.float64),
+                                           np.asarray(height, dtype=np.float64))
+    shp = lat.shape
+    ctx = Context.default()
+    la, lo, hh = f64(lat).ravel(), f64(lon).ravel(), f64(height).ravel()
+    xyz = np.empty((la.size, 3))
+    check(ctx.lib.rdr_lla2ecef(ctx.handle, ptr(la), ptr(lo), ptr(hh), la.size, ptr(xyz), RDR_HOST), ctx.handle)
+    return xyz[:, 0].reshape(shp), xyz[:, 1].reshape(shp), xyz[:, 2].reshape(shp)
+
+
+def ecef2lla(x, y, z):
+    """utilFcns.py:84-88 - returns (lon, lat, height) (always_xy order)."""
+    x, y, z = np.broadcast_arrays(np.asarray(x, dtype=np.float64), np.asarray(y, dtype=np.float64), np.asarray(z, dtype=np.float64))
+    shp = x.shape
+    xyz = np.ascontiguousarray(np.stack([x.ravel(), y.ravel(), z.ravel()], axis=-1))
+    ctx = Context.default()
+    n = xyz.shape[0]
+    lon, lat, h = np.empty(n), np.empty(n), np.empty(n)
+    check(ctx.lib.rdr_ecef2lla(ctx.handle, ptr(xyz), n, ptr(lon), ptr(lat), ptr(h), RDR_HOST), ctx.handle)
+    return lon.reshape(shp), lat.reshape(shp), h.reshape(shp)
+
+
+def enu2ecef(east, north, up, lat0, lon0, h0):
+    """utilFcns.py:91-121: rotate a local ENU vector at (lat0, lon0) into ECEF; h0 is unused there too."""
+    slat, clat, slon, clon = sind(lat0), cosd(lat0), sind(lon0), cosd(lon0)
+    t = clat * up - slat * north
+    w = slat * up + clat * north
+    u = clon * t - slon * east
+    v = slon * t + clon * east
+    return np.stack((u, v, w), axis=-1)
+
+
+def ecef2enu(xyz, lat, lon, height):
+    """utilFcns.py:124-137."""
+    x, y, z = xyz[..., 0], xyz[..., 1], xyz[..., 2]
+    slat, clat, slon, clon = sind(lat), cosd(lat), sind(lon), cosd(lon)
+    t = clon * x + slon * y
+    e = -slon * x + clon * y
+    n = -slat * t + clat * z
+    u = clat * t + slat * z
+    return np.stack((e, n, u), axis=-1)

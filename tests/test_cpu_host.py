@@ -1,0 +1,120 @@
+"""CPU: C-ABI library loads and exports every declared symbol; host-side logic; loud failure without a GPU;
+the product never imports the oracle."""
+import ctypes
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+REPO = Path(__file__).resolve().parent.parent
+
+
+@pytest.fixture(scope='module')
+def built():
+    import __graft_entry__ as g
+    g.build()
+    import raider_amd
+    return raider_amd
+
+
+def test_library_exports_every_header_symbol(built):
+    from raider_amd import _lib
+    hdr = (REPO / 'include' / 'raider_hip.h').read_text()
+    hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
+    declared = set(re.findall(r'\b(rdr_[a-z0-9_]+)\s*\(', hdr))
+    assert len(declared) >= 30
+    lib = ctypes.CDLL(str(_lib.LIB_PATH))
+    for name in declared:
+        assert hasattr(lib, name), f'{name} declared in include/raider_hip.h but not exported'
+    bound = {s[0] for s in _lib.SYMBOLS}
+    assert declared == bound, f'header vs ctypes table mismatch: {declared ^ bound}'
+    assert _lib.load().rdr_version() >= 100
+
+
+def test_rays_struct_layout_matches_header(built):
+    from raider_amd import _lib
+    # 8 + 4 + 4 + 8 + 8 + 8*8 + 8 + 8 + 4 + 4
+    assert ctypes.sizeof(_lib.RdrRays) == 120
+
+
+def test_no_gpu_fails_loudly(built):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('a GPU is present')
+    from raider_amd import Context
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        Context(0)
+    from scipy.interpolate import RegularGridInterpolator
+    from raider_amd.delay import _build_cube
+    ax = np.arange(3.0)
+    rgi = RegularGridInterpolator((ax, ax, ax), np.zeros((3, 3, 3)))
+    with pytest.raises(RuntimeError, match='no CPU fallback'):          # scipy objects are uploaded, never evaluated
+        _build_cube(ax, ax, np.zeros(1), 4326, 4326, [rgi, rgi])
+
+
+def test_missing_library_fails_loudly(built, monkeypatch, tmp_path):
+    from raider_amd import _lib
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'LIB_PATH', tmp_path / 'nope.so')
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        _lib.load()
+
+
+def test_product_never_imports_oracle():
+    for p in (REPO / 'raider_amd').rglob('*.py'):
+        txt = p.read_text()
+        assert 'oracle' not in re.sub(r'#.*', '', txt).replace('SURVEY', ''), f'{p} mentions the oracle'
+    for p in (REPO / 'raider_amd' / 'csrc').iterdir():
+        assert 'oracle' not in p.read_text(errors='ignore') or p.suffix == '.so'
+
+
+def test_host_helpers_match_oracle():
+    from oracle import raider_oracle as O
+    from raider_amd.losreader import getZenithLookVecs, inc_hd_to_enu
+    from raider_amd.utilFcns import cosd, ecef2enu, enu2ecef, sind
+    rng = np.random.default_rng(1)
+    inc = rng.uniform(0, 60, 50); hd = rng.uniform(-180, 180, 50); lat = rng.uniform(-80, 80, 50); lon = rng.uniform(-180, 180, 50)
+    assert np.array_equal(inc_hd_to_enu(inc, hd), O.inc_hd_to_enu(inc, hd))
+    enu = inc_hd_to_enu(inc, hd)
+    e = enu2ecef(enu[:, 0], enu[:, 1], enu[:, 2], lat, lon, 0)
+    np.testing.assert_allclose(e, O.enu2ecef(enu[:, 0], enu[:, 1], enu[:, 2], lat, lon, 0), rtol=0, atol=1e-16)
+    np.testing.assert_allclose(ecef2enu(e, lat, lon, 0), enu, rtol=0, atol=1e-15)          # round trip (test/test_util.py:390-495)
+    assert np.array_equal(getZenithLookVecs(lat, lon, 0), O.getZenithLookVecs(lat, lon, 0))
+    assert cosd(60.0) == pytest.approx(0.5) and sind(30.0) == pytest.approx(0.5)
+    with pytest.raises(ValueError):
+        inc_hd_to_enu(np.array([-1.0]), np.array([0.0]))
+
+
+def test_los_protocol():
+    from raider_amd.losreader import Conventional, Raytracing, Zenith
+    z = Zenith(); c = Conventional(inc=np.array([30.0])); r = Raytracing(inc=35.0, heading=-168.0)
+    assert z.is_Zenith() and not z.is_Projected() and not z.ray_trace()
+    assert c.is_Projected() and not c.is_Zenith()
+    assert r.ray_trace() and not r.is_Zenith() and not r.is_Projected()
+    with pytest.raises(ImportError):
+        Raytracing('orbit.EOF')                       # isce3-based path, as the reference without isce3
+    with pytest.raises(RuntimeError):
+        Raytracing(inc=1.0, look_dir='up')
+    with pytest.raises(NotImplementedError):
+        Conventional(los_convention='roipac')
+    with pytest.raises(RuntimeError):
+        Zenith().setPoints(None)
+    z.setPoints(np.zeros((4, 3)))
+    assert z._heights.shape == (4,)
+
+
+def test_make_points_count(built):
+    from raider_amd import _lib
+    lib = _lib.load()
+    for ml, st in ((1000., 5.), (20., 5.), (100., 5.), (12345.6, 15.0), (7.0, 2.0), (0.0, 1.0), (1.0, 0.3)):
+        ref = int(ml // st) + (1 if ml % st != 0 else 0)            # makePoints.pyx:30-33
+        assert lib.rdr_make_points_count(ml, st) == ref
+
+
+def test_synthetic_matches_oracle_recipe():
+    from oracle import raider_oracle as O
+    from raider_amd.synthetic import synthetic_cube
+    a = synthetic_cube(20, 24, 12, seed=3); b = O.synthetic_cube(20, 24, 12, seed=3)
+    for k in a:
+        assert np.array_equal(a[k], b[k])

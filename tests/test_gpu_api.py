@@ -1,0 +1,227 @@
+"""GPU: the reference-API shim (raider_amd.delay / losreader / delayFcns / interpolate / makePoints /
+utilFcns) against the golden vectors generated from the reference, through the C ABI."""
+import datetime as dt
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import raider_oracle as O
+
+TIGHT = 1e-9
+
+
+@pytest.fixture(scope='module')
+def c1():
+    return O.synthetic_cube(50, 50, 40, seed=0)
+
+
+# ---- native extensions ---------------------------------------------------------------------------
+def test_g1_makepoints(golden):
+    from raider_amd.makePoints import makePoints0D, makePoints1D, makePoints2D, makePoints3D
+    g = golden('g1_makepoints')
+    assert np.array_equal(makePoints0D(1000., g['a0_sp'], g['a0_slv'], 5.), g['a0_out'])
+    assert np.array_equal(makePoints1D(1000., g['a1_sp'], g['a1_slv'], 5.), g['a1_out'])
+    assert np.array_equal(makePoints2D(20., g['a2_sp'], g['a2_slv'], 5), g['a2_out'])
+    out3 = makePoints3D(100., g['a3_sp'], g['a3_slv'], 5)
+    assert out3.ndim == 5 and np.array_equal(out3, g['a3_out']) and np.allclose(out3, g['a3_txt'])
+    ml, st = g['r2_args']
+    assert np.array_equal(makePoints2D(ml, g['r2_sp'], g['r2_slv'], st), g['r2_out'])    # bit-exact
+    with pytest.raises(ValueError):
+        makePoints1D(10., np.zeros(3), np.zeros(3), 1.)
+
+
+@pytest.mark.parametrize('nd', [1, 2, 3, 4])
+def test_g2_interpolate(golden, nd):
+    from raider_amd.interpolate import interpolate
+    g = golden('g2_interpolate')
+    grids = tuple(g[f'd{nd}_grid{k}'] for k in range(nd))
+    vals, q = g[f'd{nd}_vals'], g[f'd{nd}_q']
+    np.testing.assert_allclose(interpolate(grids, vals, q, fill_value=np.nan), g[f'd{nd}_fill'], rtol=1e-13, atol=1e-13, equal_nan=True)
+    np.testing.assert_allclose(interpolate(grids, vals, q), g[f'd{nd}_extrap'], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(interpolate(grids, vals, q, fill_value=7.0, max_threads=2), g[f'd{nd}_fill7'], rtol=1e-13, atol=1e-13)
+    assert np.isnan(interpolate(grids, vals, q, fill_value=np.nan)[401])     # on-the-last-node quirk
+
+
+def test_g2_analytic_and_errors(golden):
+    from raider_amd.interpolate import interpolate
+    from raider_amd.interpolator import RegularGridInterpolator
+    g = golden('g2_interpolate')
+    f = lambda x, y, z: x ** 2 + 3 * y - z
+    xs = np.linspace(0, 1000, 100)
+    vals = f(*np.meshgrid(xs, xs, xs, indexing='ij', sparse=True))
+    np.testing.assert_allclose(interpolate((xs, xs, xs), vals, g['an3_q']), g['an3_out'], rtol=0, atol=1e-9)
+    it = RegularGridInterpolator((xs, xs, xs), vals)
+    np.testing.assert_allclose(it(g['an3_q'].reshape(40, 50, 3)), g['an3_out'].reshape(40, 50), rtol=0, atol=1e-9)
+    # reference tests test_basic / test_1d_out_of_bounds / test_1d_fill_value (test/test_interpolator.py:329-365)
+    assert interpolate((np.array([0, 1]),), np.array([0, 1]), np.array([[0.5]]), max_threads=1, assume_sorted=True) == np.array([0.5])
+    assert interpolate((np.array([0, 1]),), np.array([0, 1]), np.array([[100]])) == np.array([100])
+    assert np.all(np.isnan(interpolate((np.array([0, 1]),), np.array([0, 1]), np.array([[100]]), fill_value=np.nan)))
+    with pytest.raises(TypeError):
+        interpolate(points=(np.zeros((10,)), np.zeros((5,))), values=np.zeros((1,)), interp_points=np.zeros((1,)))
+
+
+@pytest.mark.parametrize('ax', [0, 1, 2])
+def test_g2_along_axis(golden, ax):
+    from raider_amd.interpolate import interpolate_along_axis
+    g = golden('g2_interpolate')
+    P, V, Q = g[f'ax{ax}_P'], g[f'ax{ax}_V'], g[f'ax{ax}_Q']
+    np.testing.assert_allclose(interpolate_along_axis(P, V, Q, axis=ax, fill_value=np.nan, max_threads=1), g[f'ax{ax}_fill'],
+                               rtol=1e-13, atol=1e-13, equal_nan=True)
+    np.testing.assert_allclose(interpolate_along_axis(P, V, Q, axis=ax, max_threads=1), g[f'ax{ax}_extrap'], rtol=1e-12, atol=1e-12)
+    if ax == 0:
+        with pytest.raises(RuntimeError):
+            interpolate_along_axis(P, V, Q, axis=0, max_threads=8)
+
+
+# ---- geometry ------------------------------------------------------------------------------------
+def test_g3_toa_and_build_ray(golden):
+    from raider_amd.losreader import build_ray, getTopOfAtmosphere
+    from raider_amd.utilFcns import ecef2lla, lla2ecef
+    g = golden('g3_rays')
+    lat, lon, zs = g['lat'], g['lon'], g['model_zs']
+    for ht in (-500, 0, 2500):
+        xyz = np.stack(lla2ecef(lat, lon, np.full(lat.shape, float(ht))), -1)
+        np.testing.assert_allclose(xyz, g[f'xyz_ht{ht}'], rtol=0, atol=1e-8)
+        for inc in (0, 20, 39, 55):
+            for hdt in (-167, -12):
+                tag = f'ht{ht}_inc{inc}_hd{hdt}'
+                L, lo, hi = build_ray(zs, float(ht), g[f'xyz_ht{ht}'], g[f'los_{tag}'], 30000.0)
+                np.testing.assert_allclose(L, g[f'len_{tag}'], rtol=0, atol=1e-7)
+                np.testing.assert_allclose(lo[[0, 1, -1]], g[f'low_{tag}'], rtol=0, atol=1e-7)
+                np.testing.assert_allclose(hi[[0, 1, -1]], g[f'high_{tag}'], rtol=0, atol=1e-7)
+        los = g[f'los_ht{ht}_inc39_hd-167']
+        np.testing.assert_allclose(getTopOfAtmosphere(g[f'xyz_ht{ht}'], los, 15000.0), g[f'toa10_ht{ht}'], rtol=0, atol=1e-7)
+        np.testing.assert_allclose(getTopOfAtmosphere(g[f'xyz_ht{ht}'], los, 15000.0, factor=np.full(lat.shape, 0.77)),
+                                   g[f'toa3_ht{ht}'], rtol=0, atol=1e-7)
+    assert build_ray(zs, 50000.0, g['xyz_ht0'], g['los_ht0_inc39_hd-167'], 30000.0) == (None, None, None)
+    lo_, la_, h_ = ecef2lla(g['geo_xyz'][..., 0], g['geo_xyz'][..., 1], g['geo_xyz'][..., 2])
+    np.testing.assert_allclose(np.stack([lo_, la_, h_], -1), g['geo_llh'], rtol=0, atol=1e-8)
+
+
+def test_g6_los_tables(golden):
+    from raider_amd import Rays
+    from raider_amd.delay import transformPoints
+    from raider_amd.losreader import Conventional, Zenith, getZenithLookVecs, inc_hd_to_enu
+    from raider_amd.utilFcns import ecef2enu, enu2ecef
+    g = golden('g6_los')
+    enu = inc_hd_to_enu(g['inc'], g['hd'])
+    np.testing.assert_allclose(enu, g['enu'], rtol=0, atol=1e-16)
+    np.testing.assert_allclose(enu2ecef(enu[..., 0], enu[..., 1], enu[..., 2], g['lat'], g['lon'], 0 * g['lat']), g['ecef'], rtol=0, atol=1e-15)
+    np.testing.assert_allclose(ecef2enu(g['ecef'], g['lat'], g['lon'], 0), g['enu_back'], rtol=0, atol=1e-15)
+    np.testing.assert_allclose(getZenithLookVecs(g['lat'], g['lon'], 0), g['zen'], rtol=0, atol=1e-16)
+    # the device-side look-vector generation (what the ray kernels use)
+    dev = Rays.points(lat=g['lat'], lon=g['lon'], inc=g['inc'], hd=g['hd']).look_vectors()
+    np.testing.assert_allclose(dev, g['ecef'], rtol=0, atol=1e-14)
+    devz = Rays.points(lat=g['lat'], lon=g['lon'], zenith=True).look_vectors()
+    np.testing.assert_allclose(devz, g['zen'], rtol=0, atol=1e-14)
+    conv = Conventional(inc=g['inc'], heading=g['hd'])
+    conv.setPoints(g['lat'], g['lon'], 0 * g['lat'])
+    np.testing.assert_allclose(conv(g['delays']), g['proj_last'], rtol=1e-15)
+    assert Zenith()(g['delays']) is g['delays']
+    with pytest.raises(ValueError):
+        Conventional(inc=g['inc'])(g['delays'])                       # 'Target points not set'
+    np.testing.assert_allclose(transformPoints(np.zeros(3), np.array([0., 90., 180.]), np.zeros(3), 4326, 4978), g['tp_equator'], atol=1e-9)
+
+
+# ---- the tropo_delay flow --------------------------------------------------------------------------
+def _wm(c1):
+    return dict(x=c1['xs'], y=c1['ys'], z=c1['zs'], wet=c1['wet'], hydro=c1['hydro'], wet_total=c1['wet_total'], hydro_total=c1['hydro_total'])
+
+
+def test_g8_tropo_delay_point_branch(golden, c1):
+    from raider_amd.delay import PointsAOI, tropo_delay
+    from raider_amd.losreader import Raytracing, Zenith
+    g = golden('g8_points')
+    hl = list(g['height_levels'])
+    aoi = PointsAOI(g['lats'], g['lons'], g['hgts'], g['xpts'], g['ypts'])
+    wz, hz = tropo_delay(dt.datetime(2020, 1, 1), _wm(c1), aoi, Zenith(), hl, 4326, None)
+    np.testing.assert_allclose(wz, g['wet_zen'], rtol=0, atol=1e-13)
+    np.testing.assert_allclose(hz, g['hydro_zen'], rtol=0, atol=1e-13)
+    aoi2 = PointsAOI(g['lats'][:200], g['lons'][:200], g['hgts'][:200], g['xpts_ray'], g['ypts_ray'])
+    wr, hr = tropo_delay(dt.datetime(2020, 1, 1), _wm(c1), aoi2, Raytracing(inc=39.0, heading=-167.9), hl, 4326, None)
+    np.testing.assert_allclose(wr, g['wet_ray'], rtol=0, atol=TIGHT)
+    np.testing.assert_allclose(hr, g['hydro_ray'], rtol=0, atol=TIGHT)
+
+
+def test_tropo_delay_cube_branch_and_projected_quirk(golden, c1):
+    """Cube AOI returns (Dataset-like, None); a Conventional LOS on a cube AOI gives ZENITH delays;
+    on a point AOI it divides by cos(inc) (delay.py:124-128)."""
+    from raider_amd.delay import GridAOI, PointsAOI, tropo_delay, getDelays
+    from raider_amd.losreader import Conventional, Zenith
+    g4 = golden('g4_build_cube')
+    aoi = GridAOI(g4['xpts'], g4['ypts'])
+    ds, none = tropo_delay(dt.datetime(2020, 1, 1), _wm(c1), aoi, Zenith(), list(g4['zpts']))
+    assert none is None
+    np.testing.assert_allclose(np.asarray(ds['wet'][:]), g4['wet'], rtol=0, atol=1e-14)
+    np.testing.assert_allclose(np.asarray(ds['hydro'][:]), g4['hydro'], rtol=0, atol=1e-14)
+    ds2, _ = getDelays(dt.datetime(2020, 1, 1), _wm(c1), aoi, Conventional(inc=np.full((100, 100), 35.0)), list(g4['zpts']))
+    np.testing.assert_allclose(np.asarray(ds2['hydro'][:]), g4['hydro'], rtol=0, atol=1e-14)     # NOT divided by cos(inc)
+    g8 = golden('g8_points')
+    pa = PointsAOI(g8['lats'], g8['lons'], g8['hgts'], g8['xpts'], g8['ypts'])
+    inc = np.full(g8['lats'].shape, 35.0)
+    wz, hz = tropo_delay(dt.datetime(2020, 1, 1), _wm(c1), pa, Conventional(inc=inc, heading=0 * inc), list(g8['height_levels']))
+    np.testing.assert_allclose(hz, g8['hydro_zen'] / np.cos(np.radians(35.0)), rtol=1e-14)
+
+
+def test_build_cube_ray_reference_signature(golden, c1):
+    """_build_cube_ray with a duck-typed LOS object and with scipy interpolators handed in (uploaded, not evaluated
+    on the CPU); in-place accumulation into outputArrs (delay.py:245-248,325-326); top slice with no levels stays 0."""
+    from scipy.interpolate import RegularGridInterpolator
+    from raider_amd.delay import _build_cube_ray
+    g = golden('g5_build_cube_ray')
+
+    class DuckLOS:
+        def getLookVectors(self, ht, llh, xyz, yy):
+            return O.look_vectors_from_inc_hd(np.full(yy.shape, 39.0), np.full(yy.shape, -167.9), llh[1], llh[0], llh[2])
+
+    mk = lambda v: RegularGridInterpolator((c1['ys'], c1['xs'], c1['zs']), v.transpose(1, 2, 0), fill_value=np.nan, bounds_error=False)
+    interps = [mk(c1['wet']), mk(c1['hydro'])]
+    zref = float(g['c1_zref'])
+    wet, hydro = _build_cube_ray(g['c1_xpts'], g['c1_ypts'], g['c1_zpts'], DuckLOS(), 4326, 4326, interps, MAX_TROPO_HEIGHT=zref)
+    np.testing.assert_allclose(wet, g['c1_fixed_wet'], rtol=0, atol=TIGHT)
+    np.testing.assert_allclose(hydro, g['c1_fixed_hydro'], rtol=0, atol=TIGHT)
+    outs = [np.ones_like(wet), np.ones_like(hydro)]
+    assert _build_cube_ray(g['c1_xpts'], g['c1_ypts'], g['c1_zpts'], DuckLOS(), 4326, 4326, interps, outputArrs=outs, MAX_TROPO_HEIGHT=zref) is None
+    np.testing.assert_allclose(outs[1], 1 + g['c1_fixed_hydro'], rtol=0, atol=TIGHT)
+    # heights: last one above zref -> slice stays zero; a non-last one -> TypeError as in the reference
+    z2 = np.array([0.0, zref + 10.0])
+    w2, h2 = _build_cube_ray(g['c1_xpts'][:4], g['c1_ypts'][:4], z2, DuckLOS(), 4326, 4326, interps, MAX_TROPO_HEIGHT=zref)
+    assert np.all(w2[1] == 0) and np.all(h2[0] > 0)
+    with pytest.raises(TypeError):
+        _build_cube_ray(g['c1_xpts'][:4], g['c1_ypts'][:4], z2[::-1], DuckLOS(), 4326, 4326, interps, MAX_TROPO_HEIGHT=zref)
+
+
+def test_nan_look_vectors(c1):
+    """All-NaN look vectors -> ValueError('geo2rdr did not converge...') (delay.py:279-280)."""
+    import raider_amd as R
+    cube = R.Cube(c1['ys'], c1['xs'], c1['zs'], c1['wet'], c1['hydro'], order='zyx')
+    xp = np.linspace(-119, -116, 8); yp = np.linspace(34, 32, 6)
+    los = np.full((6, 8, 3), np.nan)
+    with pytest.raises(ValueError, match='geo2rdr did not converge'):
+        cube.raytrace(R.Rays.grid(xp, yp, los=los), 0.0, 30000.0)
+
+
+def test_temporal_blend(c1):
+    """Two-epoch blend on device (cli/raider.py:817-819): f32 stays f32, mean of epochs at the centre time
+    (test/test_temporal_interpolate.py), and delays are linear in the cube."""
+    import raider_amd as R
+    c2 = O.synthetic_cube(50, 50, 40, seed=1)
+    a = R.Cube(c1['ys'], c1['xs'], c1['zs'], c1['wet'], c1['hydro'], order='zyx')
+    b = R.Cube(c2['ys'], c2['xs'], c2['zs'], c2['wet'], c2['hydro'], order='zyx')
+    w1, w2 = O.time_weights(900.0, 0.0, 3600.0)
+    m = a.blend(w1, b, w2)
+    bw, bh = m.read()
+    assert bw.dtype == np.float32
+    assert np.array_equal(bw, O.blend_cubes(w1, c1['wet'], w2, c2['wet']).transpose(1, 2, 0))      # bit-exact f32 arithmetic
+    assert np.array_equal(bh, O.blend_cubes(w1, c1['hydro'], w2, c2['hydro']).transpose(1, 2, 0))
+    half = a.blend(0.5, b, 0.5)
+    xp = np.linspace(-119, -116, 16); yp = np.linspace(34, 32, 12)
+    rays = lambda: R.Rays.grid(xp, yp, inc=35.0, hd=-167.9)
+    zref = c1['zs'].max() - 1
+    wa, ha, _, _ = a.raytrace(rays(), 0.0, zref)
+    wb, hb, _, _ = b.raytrace(rays(), 0.0, zref)
+    wm_, hm_, _, _ = half.raytrace(rays(), 0.0, zref)
+    np.testing.assert_allclose(hm_, 0.5 * (ha + hb), rtol=0, atol=5e-7)       # f32 rounding of the blended cube
+    np.testing.assert_allclose(wm_, 0.5 * (wa + wb), rtol=0, atol=5e-7)
