@@ -36,13 +36,14 @@ def main():
     ap.add_argument('--rows', type=int, default=4000)
     ap.add_argument('--cols', type=int, default=4000)
     ap.add_argument('--cube', type=str, default='300x300x80')
-    ap.add_argument('--cpu-sample', type=int, default=224, help='edge of the square ray block timed on the CPU oracle (0 = skip)')
+    ap.add_argument('--cpu-sample', type=int, default=640, help='edge of the square ray block timed on the CPU oracle (0 = skip)')
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     import raider_amd as R
     from raider_amd.synthetic import synthetic_cube, scene_grid
+    from raider_amd import distributed as D
 
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -102,13 +103,7 @@ def main():
         if world == 1:
             cube.raytrace(rays, ht, zref, out=(out_w, out_h), want_nparts=False)       # fully asynchronous
             return None
-        maxlen, flags = cube.ray_prepass(rays, ht, zref)
-        red = torch.from_numpy(np.concatenate([maxlen, [float(flags & 1), float(flags & 2), float(flags & 4), float(flags & 8)]])).to(dev)
-        dist.all_reduce(red, op=dist.ReduceOp.MAX)                                      # RCCL: K+4 doubles
-        red = red.cpu().numpy()
-        gflags = int(red[-4] > 0) * 1 + int(red[-3] > 0) * 2 + int(red[-2] > 0) * 4 + int(red[-1] > 0) * 8
-        nparts = R.nparts_from_maxlen(red[:-4])
-        cube.ray_march(rays, ht, zref, nparts, gflags, out=(out_w, out_h))
+        _, _, nparts = D.raytrace_slab(cube, rays, ht, zref, out=(out_w, out_h), device=dev)    # pass 1 -> RCCL MAX all-reduce (K+4 doubles) -> pass 2
         return nparts
 
     # nParts / S for the roofline formula (one synchronous untimed call)

@@ -1,0 +1,94 @@
+"""CPU, world_size 2, gloo: the N>1 host path (row sharding + the MAX all-reduce that keeps nParts batch-global).
+The per-shard arithmetic is played by the oracle here (no GPU in this container); the collective logic under test
+is raider_amd.distributed, exactly what bench.py / multi-GPU callers use."""
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+REPO = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(REPO))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from oracle import raider_oracle as O
+        from raider_amd import distributed as D
+        from raider_amd.engine import nparts_from_maxlen
+        g = np.load(REPO / 'tests' / 'golden' / 'g5b_whole_vs_halves.npz')
+        # cube broadcast from rank 0
+        fields = None
+        if rank == 0:
+            c = O.synthetic_cube(50, 50, 40, seed=0)
+            fields = {k: c[k] for k in ('xs', 'ys', 'zs', 'wet', 'hydro')}
+        got = {k: v.numpy() for k, v in D.broadcast_cube_fields(fields, src=0).items()}
+        ip = list(O.getInterpolators(got['xs'], got['ys'], got['zs'], got['wet'], got['hydro']))
+        zref = float(g['zref'])
+        # column shard here (the golden halves are column halves); shard_rows is exercised on the column count
+        c0, nc = D.shard_rows(64, world, rank)
+        xp, yp, inc = g['xpts'][c0:c0 + nc], g['ypts'], g['inc'][:, c0:c0 + nc]
+        xx, yy = np.meshgrid(xp, yp)
+        xyz = np.stack(O.lla2ecef(yy, xx, np.zeros_like(yy)), -1)
+        los = O.look_vectors_from_inc_hd(inc, np.full(yy.shape, -167.9), yy, xx, 0.0)
+        L, lo, hi = O.build_ray(got['zs'], 0.0, xyz, los, zref)
+        local_max = L.reshape(L.shape[0], -1).max(1)
+        maxlen, flags = D.reduce_partition(local_max, 2 | 4 | 8)
+        D.check_partition_flags(flags)
+        nparts = nparts_from_maxlen(maxlen)
+        local_nparts = nparts_from_maxlen(local_max)
+        look = lambda ht, llh, xyz_, yy_: los
+        wet, hyd = O.build_cube_ray(xp, yp, np.array([0.0]), look, ip, MAX_TROPO_HEIGHT=zref, nParts_override=[nparts])
+        err = max(np.abs(hyd[0] - g['hydro'][0][:, c0:c0 + nc]).max(), np.abs(wet[0] - g['wet'][0][:, c0:c0 + nc]).max())
+        q.put((rank, bool(np.array_equal(nparts, g['nparts'])), bool(np.array_equal(local_nparts, g['nparts'])), float(err), int(flags)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_partition_allreduce():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, global_ok, local_same, err, flags in res:
+        assert global_ok, 'all-reduced nParts must equal the whole-slice nParts of the reference'
+        assert err < 1e-9, f'rank {rank}: shard driven by the global partition differs from the whole-slice reference by {err}'
+        assert flags == (2 | 4 | 8)
+    assert not all(r[2] for r in res), 'at least one shard-local partition must differ (otherwise the test is vacuous)'
+
+
+def test_shard_rows_cover_exactly():
+    from raider_amd.distributed import shard_rows
+    for ny in (1, 7, 64, 4000, 10000):
+        for world in (1, 2, 3, 8):
+            blocks = [shard_rows(ny, world, r) for r in range(world)]
+            assert blocks[0][0] == 0 and sum(b[1] for b in blocks) == ny
+            for (a0, an), (b0, bn) in zip(blocks, blocks[1:]):
+                assert a0 + an == b0
+            assert max(b[1] for b in blocks) - min(b[1] for b in blocks) <= 1
+
+
+def test_reduce_partition_single_process_passthrough():
+    from raider_amd.distributed import check_partition_flags, reduce_partition
+    m, f = reduce_partition(np.array([1.0, 2.0]), 6)
+    assert np.array_equal(m, [1.0, 2.0]) and f == 6
+    with pytest.raises(ValueError, match='geo2rdr did not converge'):
+        check_partition_flags(1)
+    with pytest.raises(ValueError):
+        check_partition_flags(3)
