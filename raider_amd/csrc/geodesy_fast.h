@@ -1,0 +1,134 @@
+// Device-only "light fp64" geodesy for the ray kernels (gfx950).
+//
+// Same FUNCTIONS as geodesy.h (PROJ `cart` inverse: single-pass Bowring latitude, h = p/cos(phi) - N,
+// lon = atan2(y,x)), evaluated with cheaper instruction sequences:
+//   * 1/sqrt and 1/x come from v_rsq_f64 / v_rcp_f64 + Newton-Raphson steps instead of the correctly
+//     rounded sqrt()/div expansions (each ~4x the instructions); two NR steps leave <= ~1 ulp, which is
+//     the same rounding noise the CPU reference has (|dh| ~ 1e-9 m on 6.4e6 m coordinates);
+//   * latitude / longitude of a ray sample are computed RELATIVE to the ray origin (whose geodetic
+//     coordinates are the kernel's exact inputs): sin(phi-phi0) and sin(lam-lam0) come from 2 FMAs each
+//     and the angle from a 5-term asin series (|angle| < 0.05 rad, i.e. < 300 km from the origin; larger
+//     angles take the generic atan2 path).  No atan/atan2 per sample, and less cancellation than
+//     re-deriving a 6-digit longitude from scratch.
+// Accuracy is pinned by tests/test_gpu_parity.py (rdr_ecef2lla / rdr_top_of_atmosphere / ray tracing
+// against the oracle: heights to 2e-8 m, angles to 1e-12 deg, delays to 1e-9 m).
+#pragma once
+#include "geodesy.h"
+
+namespace rdr {
+
+template <int NR>
+__device__ __forceinline__ double rsq_nr(double a) {
+    double y = __builtin_amdgcn_rsq(a);
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        const double t = a * y;
+        const double e = fma(-t, y, 1.0);
+        y = fma(0.5 * y, e, y);
+    }
+    return y;
+}
+
+template <int NR>
+__device__ __forceinline__ double rcp_nr(double b) {
+    double r = __builtin_amdgcn_rcp(b);
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        const double e = fma(-b, r, 1.0);
+        r = fma(r, e, r);
+    }
+    return r;
+}
+
+// Out-of-line generic paths (poles, centre of the Earth, NaN, samples > ~300 km from the ray origin): rare, so
+// keep their registers (atan/atan2/sqrt/div expansions) out of the hot loops.
+__device__ __noinline__ double ecef_height_slow(double x, double y, double z) { return ecef_height(x, y, z); }
+__device__ __noinline__ void ecef2lla_slow(double x, double y, double z, double* lon_deg, double* lat_deg, double* h) {
+    double a, b, c;
+    ecef2lla(x, y, z, a, b, c);
+    *lon_deg = a; *lat_deg = b; *h = c;
+}
+
+constexpr double E2S_B = WGS84_E2S * WGS84_B;
+constexpr double ES_A = WGS84_ES * WGS84_A;
+
+struct GeoF {
+    double p, rp;          // hypot(x,y) and its reciprocal
+    double x_phi, y_phi;   // Bowring numerator / denominator of tan(phi)
+    double r;              // 1/hypot(x_phi, y_phi):  cos(phi) = x_phi*r, sin(phi) = y_phi*r
+    double h;              // ellipsoidal height
+    bool regular;          // false -> caller must use the generic (slow) path
+};
+
+__device__ __forceinline__ GeoF geo_fast(double x, double y, double z) {
+    GeoF g;
+    const double p2 = fma(x, x, y * y);
+    g.rp = rsq_nr<2>(p2);
+    g.p = p2 * g.rp;
+    const double xt = g.p * WGS84_B, yt = z * WGS84_A;
+    const double rn = rsq_nr<1>(fma(xt, xt, yt * yt));
+    const double c = xt * rn, s = yt * rn;
+    g.y_phi = fma(E2S_B, s * s * s, z);
+    g.x_phi = fma(-ES_A, c * c * c, g.p);
+    const double n2 = fma(g.x_phi, g.x_phi, g.y_phi * g.y_phi);
+    g.r = rsq_nr<2>(n2);
+    const double sphi = g.y_phi * g.r;
+    const double w = fma(-WGS84_ES * sphi, sphi, 1.0);
+    // h = p / cos(phi) - a / sqrt(1 - es sin^2(phi)),  1/cos(phi) = hypot(x_phi,y_phi) / x_phi
+    g.h = fma(g.p * (n2 * g.r), rcp_nr<2>(g.x_phi), -WGS84_A * rsq_nr<2>(w));
+    g.regular = (g.x_phi * g.r >= 1e-6) && (p2 > 1.0);
+    return g;
+}
+
+__device__ __forceinline__ double height_fast(double x, double y, double z) {
+    const GeoF g = geo_fast(x, y, z);
+    if (!g.regular) return ecef_height_slow(x, y, z);   // poles / centre of the Earth / NaN: PROJ's special branches
+    return g.h;
+}
+
+// asin(s) for |s| <= 0.05 (truncation < 1e-17 rad)
+__device__ __forceinline__ double asin_small(double s) {
+    const double s2 = s * s;
+    double q = fma(s2, 35.0 / 1152.0, 5.0 / 112.0);
+    q = fma(s2, q, 3.0 / 40.0);
+    q = fma(s2, q, 1.0 / 6.0);
+    return fma(s * s2, q, s);
+}
+
+// Geodetic frame of the ray origin: everything the per-sample delta formulas need.
+struct RayBase {
+    double lat0, lon0;     // degrees (kernel inputs, exact)
+    double s0, c0;         // sin/cos(lat0)
+    double sl0, cl0;       // sin/cos(lon0)
+};
+
+__device__ __forceinline__ RayBase make_base(double lat_deg, double lon_deg) {
+    RayBase b;
+    b.lat0 = lat_deg; b.lon0 = lon_deg;
+    sincos(lat_deg * DEG_TO_RAD, &b.s0, &b.c0);
+    sincos(lon_deg * DEG_TO_RAD, &b.sl0, &b.cl0);
+    return b;
+}
+
+// ECEF -> (lon deg, lat deg, h) near the ray origin.
+__device__ __forceinline__ void ecef2lla_fast(const RayBase& b, double x, double y, double z,
+                                              double& lon_deg, double& lat_deg, double& h) {
+    const GeoF g = geo_fast(x, y, z);
+    const double sphi = g.y_phi * g.r, cphi = g.x_phi * g.r;
+    const double sd = fma(sphi, b.c0, -cphi * b.s0);                 // sin(phi - phi0)
+    const double cd = fma(cphi, b.c0, sphi * b.s0);                  // cos(phi - phi0)
+    const double sl = fma(b.cl0, y, -b.sl0 * x) * g.rp;              // sin(lam - lam0)
+    const double cl = fma(b.cl0, x, b.sl0 * y);                      // cos(lam - lam0) * p
+    if (!g.regular || !(fabs(sd) < 0.05) || !(fabs(sl) < 0.05) || !(cd > 0.0) || !(cl > 0.0)) {   // far from the origin / polar / NaN
+        ecef2lla_slow(x, y, z, &lon_deg, &lat_deg, &h);
+        return;
+    }
+    lat_deg = fma(asin_small(sd), RAD_TO_DEG, b.lat0);
+    double lon = fma(asin_small(sl), RAD_TO_DEG, b.lon0);
+    if (lon > 180.0) lon -= 360.0;                                    // PROJ returns lam in (-180, 180]
+    else if (lon < -180.0) lon += 360.0;
+    lon_deg = lon;
+    h = g.h;
+}
+
+}  // namespace rdr

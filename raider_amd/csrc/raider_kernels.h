@@ -24,6 +24,7 @@
 #include <stdint.h>
 
 #include "geodesy.h"
+#include "geodesy_fast.h"
 
 namespace rdr {
 
@@ -74,7 +75,9 @@ __device__ __forceinline__ void ld2(const double2* p, double& a, double& b) { co
 
 // scipy linear RGI on both fields.  sy/sx/sz: the axes (LDS or global).  zhint >= 0: start the z search
 // at that interval (ray marcher knows the model interval), else use the uniform guess / bisection.
-template <typename T2>
+// RECIP: cell-width reciprocals follow the axes in the table (sy[ny+nx+nz + i]); the ray kernel uses them to turn
+// the three divisions per sample into multiplications (1 ulp difference in the weights).
+template <typename T2, bool RECIP = false>
 __device__ __forceinline__ void trilinear(const CubeView<T2>& c, const double* sy, const double* sx, const double* sz,
                                           double y, double x, double z, int zhint, double& wet, double& hyd) {
     // out of bounds (x < g[0] or x > g[-1]) -> fill_value nan; nan coordinate -> nan   (_rgi.py:437-442,585-592)
@@ -83,9 +86,17 @@ __device__ __forceinline__ void trilinear(const CubeView<T2>& c, const double* s
     const int iy = find_cell(sy, c.ny, y, c.y_lo, c.inv_dy, c.uni_y);
     const int ix = find_cell(sx, c.nx, x, c.x_lo, c.inv_dx, c.uni_x);
     const int iz = zhint >= 0 ? find_cell_hint(sz, c.nz, z, zhint) : find_cell(sz, c.nz, z, c.z_lo, c.inv_dz, c.uni_z);
-    const double ty = (y - sy[iy]) / (sy[iy + 1] - sy[iy]);
-    const double tx = (x - sx[ix]) / (sx[ix + 1] - sx[ix]);
-    const double tz = (z - sz[iz]) / (sz[iz + 1] - sz[iz]);
+    double ty, tx, tz;
+    if (RECIP) {
+        const int na = c.ny + c.nx + c.nz;
+        ty = (y - sy[iy]) * sy[na + iy];
+        tx = (x - sx[ix]) * sx[na + ix];
+        tz = (z - sz[iz]) * sz[na + iz];
+    } else {
+        ty = (y - sy[iy]) / (sy[iy + 1] - sy[iy]);
+        tx = (x - sx[ix]) / (sx[ix + 1] - sx[ix]);
+        tz = (z - sz[iz]) / (sz[iz + 1] - sz[iz]);
+    }
     const T2* p00 = c.v + ((int64_t)iy * c.nx + ix) * c.nz + iz;   // (y0,x0)
     const T2* p01 = p00 + c.nz;                                    // (y0,x1)
     const T2* p10 = p00 + (int64_t)c.nx * c.nz;                    // (y1,x0)
@@ -120,6 +131,17 @@ __device__ __forceinline__ void toa_newton(double ox, double oy, double oz, doub
         const double hgt = ecef_height(px, py, pz);
         const double step = (h - hgt) / factor;
         px = px + lx * step; py = py + ly * step; pz = pz + lz * step;
+    }
+}
+
+// Same iteration with the light-fp64 height and the step scaled by a precomputed 1/factor (ray kernels).
+__device__ __forceinline__ void toa_newton_fast(double ox, double oy, double oz, double lx, double ly, double lz,
+                                                double h, int iters, double inv_factor, double& px, double& py, double& pz) {
+    px = fma(h, lx, ox); py = fma(h, ly, oy); pz = fma(h, lz, oz);
+    for (int it = 0; it < iters; ++it) {
+        const double hgt = height_fast(px, py, pz);
+        const double step = (h - hgt) * inv_factor;
+        px = fma(lx, step, px); py = fma(ly, step, py); pz = fma(lz, step, pz);
     }
 }
 
@@ -170,10 +192,11 @@ __device__ __forceinline__ double wave_max(double v) {
 template <int MODE, typename T2>
 __global__ __launch_bounds__(BLOCK) void ray_kernel(CubeView<T2> c, RayParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    double* s_y = reinterpret_cast<double*>(smem_raw);
+    const int na = c.ny + c.nx + c.nz;
+    double* s_y = reinterpret_cast<double*>(smem_raw);   // [ys | xs | zs | 1/dy | 1/dx | 1/dz]
     double* s_x = s_y + c.ny;
     double* s_z = s_x + c.nx;
-    double* s_lo = s_z + c.nz;
+    double* s_lo = s_y + 2 * na;
     double* s_hi = s_lo + c.nz;
     unsigned long long* s_max = reinterpret_cast<unsigned long long*>(s_hi + c.nz);   // [nz] (MODE 0)
     int* s_kz = reinterpret_cast<int*>(s_max + c.nz);
@@ -181,8 +204,12 @@ __global__ __launch_bounds__(BLOCK) void ray_kernel(CubeView<T2> c, RayParams P)
     int* s_K = s_np + c.nz;
 
     const int tid = threadIdx.x;
-    for (int i = tid; i < c.ny + c.nx + c.nz; i += BLOCK) s_y[i] = c.axes[i];
+    for (int i = tid; i < na; i += BLOCK) s_y[i] = c.axes[i];
     __syncthreads();
+    for (int i = tid; i < na; i += BLOCK) {
+        const bool last = (i == c.ny - 1) || (i == c.ny + c.nx - 1) || (i == na - 1);
+        s_y[na + i] = last ? 0.0 : 1.0 / (s_y[i + 1] - s_y[i]);
+    }
     if (tid == 0) *s_K = build_levels(s_z, c.nz, P.ht, P.zref, s_lo, s_hi, s_kz);
     __syncthreads();
     const int K = *s_K;
@@ -225,9 +252,12 @@ __global__ __launch_bounds__(BLOCK) void ray_kernel(CubeView<T2> c, RayParams P)
         if (active) {
             if (P.origin_mode == 0) { lat = P.ypts[row]; lon = P.xpts[col]; }
             else if (P.lat) { lat = P.lat[i]; lon = P.lon[i]; }
-            if (P.origin_mode == 2) { ox = P.xyz[3 * i]; oy = P.xyz[3 * i + 1]; oz = P.xyz[3 * i + 2]; }
-            else lla2ecef(lat, lon, P.ht, ox, oy, oz);
+            if (P.origin_mode == 2) {
+                ox = P.xyz[3 * i]; oy = P.xyz[3 * i + 1]; oz = P.xyz[3 * i + 2];
+                if (!P.lat) { double h0_; ecef2lla(ox, oy, oz, lon, lat, h0_); }   // frame for the delta lat/lon formulas
+            } else lla2ecef(lat, lon, P.ht, ox, oy, oz);
         }
+        const RayBase base = make_base(lat, lon);
         // ---- look vector (delay.py:270)
         double lx = qnan(), ly = qnan(), lz = qnan();
         if (active) {
@@ -240,17 +270,18 @@ __global__ __launch_bounds__(BLOCK) void ray_kernel(CubeView<T2> c, RayParams P)
                 lx = cla * clo; ly = cla * slo; lz = sla;
             }
         }
-        double hx = 0, hy = 0, hz = 0, cosf = 1.0;
+        double hx = 0, hy = 0, hz = 0, inv_cosf = 1.0;
         double acc_w = 0.0, acc_h = 0.0;
         for (int k = 0; k < K; ++k) {
             const double lo = s_lo[k], hi = s_hi[k];
             double bx, by, bz;
-            if (k == 0) toa_newton(ox, oy, oz, lx, ly, lz, lo, 10, 1.0, bx, by, bz);   // cos_factor None: 10 iterations
-            else { bx = hx; by = hy; bz = hz; }                                          // reuse previous top (losreader.py:811-812)
-            toa_newton(ox, oy, oz, lx, ly, lz, hi, k == 0 ? 10 : 3, cosf, hx, hy, hz);
+            if (k == 0) toa_newton_fast(ox, oy, oz, lx, ly, lz, lo, 10, 1.0, bx, by, bz);   // cos_factor None: 10 iterations
+            else { bx = hx; by = hy; bz = hz; }                                               // reuse previous top (losreader.py:811-812)
+            toa_newton_fast(ox, oy, oz, lx, ly, lz, hi, k == 0 ? 10 : 3, inv_cosf, hx, hy, hz);
             const double dx = hx - bx, dy = hy - by, dz = hz - bz;
-            const double L = sqrt(dx * dx + dy * dy + dz * dz);                         // np.linalg.norm, losreader.py:821
-            if (k == 0) cosf = (hi - lo) / L;                                           // losreader.py:824-825
+            const double L2 = fma(dx, dx, fma(dy, dy, dz * dz));
+            const double L = L2 * rsq_nr<2>(L2);                                        // np.linalg.norm, losreader.py:821
+            if (k == 0) inv_cosf = L / (hi - lo);                                       // 1/cos_factor, losreader.py:824-825
             if (MODE == 0) {
                 // NaN poisons the max exactly as ndarray.max does (delay.py:283): tracked via flags
                 if (active) my_flags |= (L != L) ? 1 : 2;
@@ -258,28 +289,28 @@ __global__ __launch_bounds__(BLOCK) void ray_kernel(CubeView<T2> c, RayParams P)
                 m = wave_max(m);
                 if ((tid & 63) == 0) atomicMax(&s_max[k], (unsigned long long)__double_as_longlong(m));
                 if (k == 0 && active) {          // first sample: low + 0*(high-low)
-                    const double h0 = ecef_height(bx + 0.0 * dx, by + 0.0 * dy, bz + 0.0 * dz);
+                    const double h0 = height_fast(bx + 0.0 * dx, by + 0.0 * dy, bz + 0.0 * dz);
                     if (!(h0 < c.z_lo)) my_flags |= 4;
                 }
                 if (k == K - 1 && active) {      // last sample: low + 1*(high-low)
-                    const double h1 = ecef_height(bx + 1.0 * dx, by + 1.0 * dy, bz + 1.0 * dz);
+                    const double h1 = height_fast(bx + 1.0 * dx, by + 1.0 * dy, bz + 1.0 * dz);
                     if (!(h1 > c.z_hi)) my_flags |= 8;
                 }
             } else {
                 const int np = s_np[k];
                 const double nm1 = (double)np - 1.0;
-                const double step = 1.0 / nm1;                       // np.linspace(0,1,np) (delay.py:287)
-                const double segw = (L * 1.0e-6) / nm1;              // delay.py:315
+                const double step = 1.0 / nm1;                       // np.linspace(0,1,np) (delay.py:287); uniform -> scalar-ish
+                const double segw = (L * 1.0e-6) * step;             // delay.py:315 (L*1e-6/(np-1))
                 const int kz = s_kz[k];
                 for (int j = 0; j < np; ++j) {
                     const double f = (j == np - 1) ? 1.0 : (double)j * step;
-                    const double qx = bx + f * dx, qy = by + f * dy, qz = bz + f * dz;   // delay.py:292
+                    const double qx = fma(f, dx, bx), qy = fma(f, dy, by), qz = fma(f, dz, bz);   // delay.py:292
                     double plon, plat, ph;
-                    ecef2lla(qx, qy, qz, plon, plat, ph);                                 // delay.py:295
+                    ecef2lla_fast(base, qx, qy, qz, plon, plat, ph);                      // delay.py:295
                     if (clamp_lo && k == 0 && j == 0) ph = c.z_lo;
                     if (clamp_hi && k == K - 1 && j == np - 1) ph = c.z_hi;
                     double vw, vh;
-                    trilinear(c, s_y, s_x, s_z, plat, plon, ph, kz, vw, vh);              // delay.py:298,319
+                    trilinear<T2, true>(c, s_y, s_x, s_z, plat, plon, ph, kz, vw, vh);   // delay.py:298,319
                     const double wt = ((j == 0 || j == np - 1) ? 0.5 : 1.0) * segw;       // delay.py:314-315
                     acc_w += wt * vw; acc_h += wt * vh;                                   // delay.py:323
                 }
