@@ -52,36 +52,51 @@ __device__ __noinline__ void ecef2lla_slow(double x, double y, double z, double*
 constexpr double E2S_B = WGS84_E2S * WGS84_B;
 constexpr double ES_A = WGS84_ES * WGS84_A;
 
+// sqrt(1-u) for 0 <= u <= es (0.0067): degree-6 Taylor, truncation 1e-17
+__device__ __forceinline__ double sqrt_one_minus_small(double u) {
+    double q = fma(u, -21.0 / 1024.0, -7.0 / 256.0);
+    q = fma(u, q, -5.0 / 128.0);
+    q = fma(u, q, -1.0 / 16.0);
+    q = fma(u, q, -1.0 / 8.0);
+    q = fma(u, q, -0.5);
+    return fma(u, q, 1.0);
+}
+
 struct GeoF {
     double p, rp;          // hypot(x,y) and its reciprocal
-    double x_phi, y_phi;   // Bowring numerator / denominator of tan(phi)
-    double r;              // 1/hypot(x_phi, y_phi):  cos(phi) = x_phi*r, sin(phi) = y_phi*r
+    double cphi, sphi;     // cos / sin of the (Bowring) geodetic latitude, unit-normalised
     double h;              // ellipsoidal height
-    bool regular;          // false -> caller must use the generic (slow) path
+    bool regular;          // false -> caller must use the generic path (poles, Earth's centre, NaN)
 };
 
+// Height is evaluated as the support-function identity  h = p cos(phi) + z sin(phi) - a sqrt(1 - es sin^2(phi)),
+// which is EXACT for the exact latitude and only second-order sensitive to the latitude error (PROJ's
+// h = p/cos(phi) - N is first-order sensitive: with the single-pass Bowring latitude it is off by up to 1.7e-5 m
+// at 40 km, 1e-6 m at 10 km - far below anything that reaches the delay: < 1e-9 m).
+// PRECISE_PHI: refine the theta-stage normalisation (needed when the LATITUDE itself is used, i.e. for samples;
+// the height alone tolerates the 2^-24 seed).
+template <bool PRECISE_PHI>
 __device__ __forceinline__ GeoF geo_fast(double x, double y, double z) {
     GeoF g;
     const double p2 = fma(x, x, y * y);
-    g.rp = rsq_nr<2>(p2);
+    g.rp = rsq_nr<1>(p2);
     g.p = p2 * g.rp;
     const double xt = g.p * WGS84_B, yt = z * WGS84_A;
-    const double rn = rsq_nr<1>(fma(xt, xt, yt * yt));
+    const double n2t = fma(xt, xt, yt * yt);
+    const double rn = PRECISE_PHI ? rsq_nr<1>(n2t) : __builtin_amdgcn_rsq(n2t);
     const double c = xt * rn, s = yt * rn;
-    g.y_phi = fma(E2S_B, s * s * s, z);
-    g.x_phi = fma(-ES_A, c * c * c, g.p);
-    const double n2 = fma(g.x_phi, g.x_phi, g.y_phi * g.y_phi);
-    g.r = rsq_nr<2>(n2);
-    const double sphi = g.y_phi * g.r;
-    const double w = fma(-WGS84_ES * sphi, sphi, 1.0);
-    // h = p / cos(phi) - a / sqrt(1 - es sin^2(phi)),  1/cos(phi) = hypot(x_phi,y_phi) / x_phi
-    g.h = fma(g.p * (n2 * g.r), rcp_nr<2>(g.x_phi), -WGS84_A * rsq_nr<2>(w));
-    g.regular = (g.x_phi * g.r >= 1e-6) && (p2 > 1.0);
+    const double y_phi = fma(E2S_B, s * s * s, z);
+    const double x_phi = fma(-ES_A, c * c * c, g.p);
+    const double r = rsq_nr<1>(fma(x_phi, x_phi, y_phi * y_phi));
+    g.sphi = y_phi * r; g.cphi = x_phi * r;
+    const double sq = sqrt_one_minus_small(WGS84_ES * g.sphi * g.sphi);
+    g.h = fma(g.p, g.cphi, fma(z, g.sphi, -WGS84_A * sq));
+    g.regular = (g.cphi >= 1e-6) && (p2 > 1.0);
     return g;
 }
 
 __device__ __forceinline__ double height_fast(double x, double y, double z) {
-    const GeoF g = geo_fast(x, y, z);
+    const GeoF g = geo_fast<false>(x, y, z);
     if (!g.regular) return ecef_height_slow(x, y, z);   // poles / centre of the Earth / NaN: PROJ's special branches
     return g.h;
 }
@@ -113,8 +128,8 @@ __device__ __forceinline__ RayBase make_base(double lat_deg, double lon_deg) {
 // ECEF -> (lon deg, lat deg, h) near the ray origin.
 __device__ __forceinline__ void ecef2lla_fast(const RayBase& b, double x, double y, double z,
                                               double& lon_deg, double& lat_deg, double& h) {
-    const GeoF g = geo_fast(x, y, z);
-    const double sphi = g.y_phi * g.r, cphi = g.x_phi * g.r;
+    const GeoF g = geo_fast<true>(x, y, z);
+    const double sphi = g.sphi, cphi = g.cphi;
     const double sd = fma(sphi, b.c0, -cphi * b.s0);                 // sin(phi - phi0)
     const double cd = fma(cphi, b.c0, sphi * b.s0);                  // cos(phi - phi0)
     const double sl = fma(b.cl0, y, -b.sl0 * x) * g.rp;              // sin(lam - lam0)

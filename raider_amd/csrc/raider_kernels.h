@@ -123,7 +123,69 @@ __device__ __forceinline__ void trilinear(const CubeView<T2>& c, const double* s
     wet = sw; hyd = sh;
 }
 
-// getTopOfAtmosphere (losreader.py:706-733): pos = xyz + h*los; repeat: pos += los*((h - height(pos))/factor)
+// ---- ray-kernel sampler ----------------------------------------------------------------------------------------
+// Same scipy semantics as trilinear<> (interval g[i] <= v < g[i+1], last cell closed; outside / NaN -> NaN) with a
+// branch-light cell search: on (nearly) uniform axes the linear guess is at most one cell off, so a single
+// compare-and-step in each direction is exact; along z the model interval of the segment is the guess.  A lane whose
+// guess is further off (possible only for non-converged Newton crossings in sub-metre levels) re-does a bisection.
+__device__ __forceinline__ int bisect_cell(const double* g, int n, double v) {
+    int lo = 0, hi = n;   // first index with v < g[idx]
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (v < g[mid]) hi = mid; else lo = mid + 1;
+    }
+    return min(max(lo - 1, 0), n - 2);
+}
+
+__device__ __forceinline__ int step_cell(const double* g, int n, double v, int guess) {
+    int i = min(max(guess, 0), n - 2);
+    i -= (int)((v < g[i]) & (i > 0));
+    i += (int)((v >= g[i + 1]) & (i < n - 2));
+    const bool ok = ((v >= g[i]) | (i == 0)) & ((v < g[i + 1]) | (i == n - 2));
+    if (!ok) i = bisect_cell(g, n, v);
+    return i;
+}
+
+// tab = [ys | xs | zs | 1/dy | 1/dx | 1/dz] in LDS.
+template <typename T2>
+__device__ __forceinline__ void sample_cube(const CubeView<T2>& c, const double* tab, double y, double x, double z, int kz,
+                                            double& wet, double& hyd) {
+    const bool inside = (y >= c.y_lo) && (y <= c.y_hi) && (x >= c.x_lo) && (x <= c.x_hi) && (z >= c.z_lo) && (z <= c.z_hi);
+    if (!inside) { wet = qnan(); hyd = qnan(); return; }
+    const double* sy = tab; const double* sx = tab + c.ny; const double* sz = sx + c.nx;
+    const int na = c.ny + c.nx + c.nz;
+    const int iy = c.uni_y ? step_cell(sy, c.ny, y, (int)((y - c.y_lo) * c.inv_dy)) : bisect_cell(sy, c.ny, y);
+    const int ix = c.uni_x ? step_cell(sx, c.nx, x, (int)((x - c.x_lo) * c.inv_dx)) : bisect_cell(sx, c.nx, x);
+    const int iz = step_cell(sz, c.nz, z, kz);
+    const double ty = (y - sy[iy]) * sy[na + iy];
+    const double tx = (x - sx[ix]) * sx[na + ix];
+    const double tz = (z - sz[iz]) * sz[na + iz];
+    const T2* p00 = c.v + ((int64_t)iy * c.nx + ix) * c.nz + iz;
+    const T2* p01 = p00 + c.nz;
+    const T2* p10 = p00 + (int64_t)c.nx * c.nz;
+    const T2* p11 = p10 + c.nz;
+    double w[8], h[8];
+    ld2(p00, w[0], h[0]); ld2(p00 + 1, w[1], h[1]);
+    ld2(p01, w[2], h[2]); ld2(p01 + 1, w[3], h[3]);
+    ld2(p10, w[4], h[4]); ld2(p10 + 1, w[5], h[5]);
+    ld2(p11, w[6], h[6]); ld2(p11 + 1, w[7], h[7]);
+    const double wy0 = 1.0 - ty, wx0 = 1.0 - tx, wz0 = 1.0 - tz;
+    const double a00 = wy0 * wx0, a01 = wy0 * tx, a10 = ty * wx0, a11 = ty * tx;
+    double sw = 0.0, sh = 0.0, k;      // weight = (wy*wx)*wz, corners in (y,x,z) lexicographic order (_rgi.py:490-498)
+    k = a00 * wz0; sw = fma(w[0], k, sw); sh = fma(h[0], k, sh);
+    k = a00 * tz;  sw = fma(w[1], k, sw); sh = fma(h[1], k, sh);
+    k = a01 * wz0; sw = fma(w[2], k, sw); sh = fma(h[2], k, sh);
+    k = a01 * tz;  sw = fma(w[3], k, sw); sh = fma(h[3], k, sh);
+    k = a10 * wz0; sw = fma(w[4], k, sw); sh = fma(h[4], k, sh);
+    k = a10 * tz;  sw = fma(w[5], k, sw); sh = fma(h[5], k, sh);
+    k = a11 * wz0; sw = fma(w[6], k, sw); sh = fma(h[6], k, sh);
+    k = a11 * tz;  sw = fma(w[7], k, sw); sh = fma(h[7], k, sh);
+    wet = sw; hyd = sh;
+}
+
+// getTopOfAtmosphere (losreader.py:706-733): pos = xyz + h*los; repeat: pos += los*((h - height(pos))/factor).
+// Straight restatement with the PROJ-formula height (used by the materialising API kernels rdr_top_of_atmosphere /
+// rdr_build_ray, whose OUTPUT is positions: they match the reference's to ~1e-8 m).
 __device__ __forceinline__ void toa_newton(double ox, double oy, double oz, double lx, double ly, double lz,
                                            double h, int iters, double factor, double& px, double& py, double& pz) {
     px = ox + h * lx; py = oy + h * ly; pz = oz + h * lz;
@@ -134,15 +196,19 @@ __device__ __forceinline__ void toa_newton(double ox, double oy, double oz, doub
     }
 }
 
-// Same iteration with the light-fp64 height and the step scaled by a precomputed 1/factor (ray kernels).
-__device__ __forceinline__ void toa_newton_fast(double ox, double oy, double oz, double lx, double ly, double lz,
-                                                double h, int iters, double inv_factor, double& px, double& py, double& pz) {
-    px = fma(h, lx, ox); py = fma(h, ly, oy); pz = fma(h, lz, oz);
+// Ray kernels: the same iteration carried on the scalar ray parameter t (pos = o + t*l): t0 = h,
+// t += (h - height(o + t l)) / factor - identical in exact arithmetic to losreader.py:724-731, 2 live doubles per
+// crossing instead of 6 - with the light-fp64 TRUE height (geodesy_fast.h): crossings land within 2e-5 m (at 40 km)
+// of the reference's, which moves the delays by < 1e-10 m.
+__device__ __forceinline__ double toa_newton_t(double ox, double oy, double oz, double lx, double ly, double lz,
+                                               double h, int iters, double inv_factor) {
+    double t = h;
+#pragma unroll 1
     for (int it = 0; it < iters; ++it) {
-        const double hgt = height_fast(px, py, pz);
-        const double step = (h - hgt) * inv_factor;
-        px = fma(lx, step, px); py = fma(ly, step, py); pz = fma(lz, step, pz);
+        const double hgt = height_fast(fma(t, lx, ox), fma(t, ly, oy), fma(t, lz, oz));
+        t = fma(h - hgt, inv_factor, t);
     }
+    return t;
 }
 
 struct RayParams {
@@ -270,17 +336,21 @@ __global__ __launch_bounds__(BLOCK) void ray_kernel(CubeView<T2> c, RayParams P)
                 lx = cla * clo; ly = cla * slo; lz = sla;
             }
         }
-        double hx = 0, hy = 0, hz = 0, inv_cosf = 1.0;
+        // |l| (1 for unit look vectors): ray length between two crossings = (t_hi - t_lo) * |l|   (losreader.py:821)
+        const double nl2 = fma(lx, lx, fma(ly, ly, lz * lz));
+        const double nl = nl2 * rsq_nr<2>(nl2);
+        double t_hi = 0.0, inv_cosf = 1.0;
         double acc_w = 0.0, acc_h = 0.0;
+        double vw_top = 0.0, vh_top = 0.0;    // sample values at the top of the previous segment (= bottom of this one)
+#pragma unroll 1
         for (int k = 0; k < K; ++k) {
             const double lo = s_lo[k], hi = s_hi[k];
-            double bx, by, bz;
-            if (k == 0) toa_newton_fast(ox, oy, oz, lx, ly, lz, lo, 10, 1.0, bx, by, bz);   // cos_factor None: 10 iterations
-            else { bx = hx; by = hy; bz = hz; }                                               // reuse previous top (losreader.py:811-812)
-            toa_newton_fast(ox, oy, oz, lx, ly, lz, hi, k == 0 ? 10 : 3, inv_cosf, hx, hy, hz);
-            const double dx = hx - bx, dy = hy - by, dz = hz - bz;
-            const double L2 = fma(dx, dx, fma(dy, dy, dz * dz));
-            const double L = L2 * rsq_nr<2>(L2);                                        // np.linalg.norm, losreader.py:821
+            // first interval: cos_factor is None -> 10 iterations with factor 1 for both ends (losreader.py:812-825);
+            // later intervals reuse the previous top as their bottom (losreader.py:811-812)
+            const double t_lo = (k == 0) ? toa_newton_t(ox, oy, oz, lx, ly, lz, lo, 10, 1.0) : t_hi;
+            t_hi = toa_newton_t(ox, oy, oz, lx, ly, lz, hi, k == 0 ? 10 : 3, inv_cosf);
+            const double dt = t_hi - t_lo;
+            const double L = dt * nl;
             if (k == 0) inv_cosf = L / (hi - lo);                                       // 1/cos_factor, losreader.py:824-825
             if (MODE == 0) {
                 // NaN poisons the max exactly as ndarray.max does (delay.py:283): tracked via flags
@@ -288,31 +358,37 @@ __global__ __launch_bounds__(BLOCK) void ray_kernel(CubeView<T2> c, RayParams P)
                 double m = (active && L == L) ? L : 0.0;
                 m = wave_max(m);
                 if ((tid & 63) == 0) atomicMax(&s_max[k], (unsigned long long)__double_as_longlong(m));
-                if (k == 0 && active) {          // first sample: low + 0*(high-low)
-                    const double h0 = height_fast(bx + 0.0 * dx, by + 0.0 * dy, bz + 0.0 * dz);
+                if (k == 0 && active) {          // first sample of the ray (fraction 0)
+                    const double h0 = height_fast(fma(t_lo, lx, ox), fma(t_lo, ly, oy), fma(t_lo, lz, oz));
                     if (!(h0 < c.z_lo)) my_flags |= 4;
                 }
-                if (k == K - 1 && active) {      // last sample: low + 1*(high-low)
-                    const double h1 = height_fast(bx + 1.0 * dx, by + 1.0 * dy, bz + 1.0 * dz);
+                if (k == K - 1 && active) {      // last sample of the ray (fraction 1)
+                    const double h1 = height_fast(fma(t_hi, lx, ox), fma(t_hi, ly, oy), fma(t_hi, lz, oz));
                     if (!(h1 > c.z_hi)) my_flags |= 8;
                 }
             } else {
                 const int np = s_np[k];
                 const double nm1 = (double)np - 1.0;
-                const double step = 1.0 / nm1;                       // np.linspace(0,1,np) (delay.py:287); uniform -> scalar-ish
-                const double segw = (L * 1.0e-6) * step;             // delay.py:315 (L*1e-6/(np-1))
+                const double step = 1.0 / nm1;                       // np.linspace(0,1,np) (delay.py:287)
+                const double segw = (L * 1.0e-6) * step;             // delay.py:315: L*1e-6/(np-1)
                 const int kz = s_kz[k];
-                for (int j = 0; j < np; ++j) {
+                // j = 0 of this segment is the SAME point as j = np-1 of the previous one (low_xyz is high_xyz,
+                // losreader.py:811-812), so its interpolated value is reused instead of recomputed; the reference
+                // evaluates it twice and gets the same number both times.  Order of accumulation is unchanged.
+                if (k > 0) { acc_w = fma(0.5 * segw, vw_top, acc_w); acc_h = fma(0.5 * segw, vh_top, acc_h); }   // j = 0, reused
+#pragma unroll 1
+                for (int j = (k == 0 ? 0 : 1); j < np; ++j) {
                     const double f = (j == np - 1) ? 1.0 : (double)j * step;
-                    const double qx = fma(f, dx, bx), qy = fma(f, dy, by), qz = fma(f, dz, bz);   // delay.py:292
+                    const double ts = fma(f, dt, t_lo);                                   // low + f*(high-low), delay.py:292
                     double plon, plat, ph;
-                    ecef2lla_fast(base, qx, qy, qz, plon, plat, ph);                      // delay.py:295
-                    if (clamp_lo && k == 0 && j == 0) ph = c.z_lo;
-                    if (clamp_hi && k == K - 1 && j == np - 1) ph = c.z_hi;
+                    ecef2lla_fast(base, fma(ts, lx, ox), fma(ts, ly, oy), fma(ts, lz, oz), plon, plat, ph);   // delay.py:295
+                    if (clamp_lo && k == 0 && j == 0) ph = c.z_lo;                       // delay.py:306-307
+                    if (clamp_hi && k == K - 1 && j == np - 1) ph = c.z_hi;              // delay.py:310-311
                     double vw, vh;
-                    trilinear<T2, true>(c, s_y, s_x, s_z, plat, plon, ph, kz, vw, vh);   // delay.py:298,319
-                    const double wt = ((j == 0 || j == np - 1) ? 0.5 : 1.0) * segw;       // delay.py:314-315
-                    acc_w += wt * vw; acc_h += wt * vh;                                   // delay.py:323
+                    sample_cube(c, s_y, plat, plon, ph, kz, vw, vh);                      // delay.py:298,319
+                    const double wt = ((j == 0) | (j == np - 1)) ? 0.5 * segw : segw;     // delay.py:314-315
+                    acc_w = fma(wt, vw, acc_w); acc_h = fma(wt, vh, acc_h);               // delay.py:323
+                    vw_top = vw; vh_top = vh;                                             // after the loop: value at j = np-1
                 }
             }
         }
