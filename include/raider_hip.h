@@ -93,6 +93,11 @@ int rdr_device_info(rdr_ctx* ctx, char* name, int name_len, int* compute_units, 
  * events and returns how many launches of kernel kind `which` (0 ray prepass, 1 ray march, 2 interp,
  * 3 other) were recorded and their summed duration in ms. */
 int rdr_set_profiling(rdr_ctx* ctx, int on);
+/* Ray pass 1 hands each ray's set-up (origin, look vector, origin frame) and its K+1 level-crossing parameters to
+ * pass 2 through an HBM workspace of 8*(14+K) bytes per ray (712 B/ray for an 80-level cube; 11.4 GB for 16 M rays).
+ * `bytes` caps it (default 48 GiB of the 288 GB, and never more than half of the free memory); larger batches are
+ * integrated in chunks.  Env override at rdr_create: RAIDER_HIP_WORKSPACE_BYTES. */
+int rdr_set_workspace_limit(rdr_ctx* ctx, int64_t bytes);
 int rdr_profile_get(rdr_ctx* ctx, int which, int* count, float* total_ms);
 
 /* ---- weather cube ----------------------------------------------------------------------------

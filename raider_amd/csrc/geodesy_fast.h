@@ -40,15 +40,6 @@ __device__ __forceinline__ double rcp_nr(double b) {
     return r;
 }
 
-// Out-of-line generic paths (poles, centre of the Earth, NaN, samples > ~300 km from the ray origin): rare, so
-// keep their registers (atan/atan2/sqrt/div expansions) out of the hot loops.
-__device__ __noinline__ double ecef_height_slow(double x, double y, double z) { return ecef_height(x, y, z); }
-__device__ __noinline__ void ecef2lla_slow(double x, double y, double z, double* lon_deg, double* lat_deg, double* h) {
-    double a, b, c;
-    ecef2lla(x, y, z, a, b, c);
-    *lon_deg = a; *lat_deg = b; *h = c;
-}
-
 constexpr double E2S_B = WGS84_E2S * WGS84_B;
 constexpr double ES_A = WGS84_ES * WGS84_A;
 
@@ -95,16 +86,16 @@ __device__ __forceinline__ GeoF geo_fast(double x, double y, double z) {
     return g;
 }
 
-__device__ __forceinline__ double height_fast(double x, double y, double z) {
-    const GeoF g = geo_fast<false>(x, y, z);
-    if (!g.regular) return ecef_height_slow(x, y, z);   // poles / centre of the Earth / NaN: PROJ's special branches
-    return g.h;
+// Height along a ray that passed the static classification (never near a pole / the Earth's centre).
+__device__ __forceinline__ double height_fast_nocheck(double x, double y, double z) {
+    return geo_fast<false>(x, y, z).h;
 }
 
-// asin(s) for |s| <= 0.05 (truncation < 1e-17 rad)
+// asin(s): odd series through s^11; truncation < 3e-17 rad for |s| <= 0.05, 4e-12 rad (2.5e-5 m) at |s| = 0.13
 __device__ __forceinline__ double asin_small(double s) {
     const double s2 = s * s;
-    double q = fma(s2, 35.0 / 1152.0, 5.0 / 112.0);
+    double q = fma(s2, 63.0 / 2816.0, 35.0 / 1152.0);
+    q = fma(s2, q, 5.0 / 112.0);
     q = fma(s2, q, 3.0 / 40.0);
     q = fma(s2, q, 1.0 / 6.0);
     return fma(s * s2, q, s);
@@ -125,19 +116,13 @@ __device__ __forceinline__ RayBase make_base(double lat_deg, double lon_deg) {
     return b;
 }
 
-// ECEF -> (lon deg, lat deg, h) near the ray origin.
-__device__ __forceinline__ void ecef2lla_fast(const RayBase& b, double x, double y, double z,
+// ECEF -> (lon deg, lat deg, h) of a point within ~0.13 rad of the ray origin (guaranteed by the per-ray static
+// classification in crossings_kernel; rays that fail it never come here).
+__device__ __forceinline__ void ecef2lla_near(const RayBase& b, double x, double y, double z,
                                               double& lon_deg, double& lat_deg, double& h) {
     const GeoF g = geo_fast<true>(x, y, z);
-    const double sphi = g.sphi, cphi = g.cphi;
-    const double sd = fma(sphi, b.c0, -cphi * b.s0);                 // sin(phi - phi0)
-    const double cd = fma(cphi, b.c0, sphi * b.s0);                  // cos(phi - phi0)
+    const double sd = fma(g.sphi, b.c0, -g.cphi * b.s0);             // sin(phi - phi0)
     const double sl = fma(b.cl0, y, -b.sl0 * x) * g.rp;              // sin(lam - lam0)
-    const double cl = fma(b.cl0, x, b.sl0 * y);                      // cos(lam - lam0) * p
-    if (!g.regular || !(fabs(sd) < 0.05) || !(fabs(sl) < 0.05) || !(cd > 0.0) || !(cl > 0.0)) {   // far from the origin / polar / NaN
-        ecef2lla_slow(x, y, z, &lon_deg, &lat_deg, &h);
-        return;
-    }
     lat_deg = fma(asin_small(sd), RAD_TO_DEG, b.lat0);
     double lon = fma(asin_small(sl), RAD_TO_DEG, b.lon0);
     if (lon > 180.0) lon -= 360.0;                                    // PROJ returns lam in (-180, 180]

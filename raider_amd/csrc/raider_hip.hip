@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -40,6 +41,11 @@ struct rdr_ctx {
     unsigned long long* d_maxlen = nullptr;   // [MAX_LEVELS]
     int* d_flags = nullptr;                   // [1]
     int* d_nparts = nullptr;                  // [MAX_LEVELS]
+    int* d_nslow = nullptr;                   // [1] rays sent to the generic kernels by the last pass 1
+    DevBuf ws;                                // pass 1 -> pass 2 workspace (field-major ray records)
+    size_t ws_limit = (size_t)48 << 30;       // cap on that workspace; bigger batches are marched in chunks
+    // which ray batch the stored records belong to (a later rdr_ray_march reuses them only for the identical batch)
+    struct { const void* cube = nullptr; int64_t n = -1; double ht = 0, zref = 0; const void* a = nullptr; const void* b = nullptr; const void* c = nullptr; int K = 0; bool valid = false; } wsig;
     std::string err;
 };
 
@@ -419,6 +425,9 @@ int rdr_create(int device, rdr_ctx** out) {
     HIPCHECK(nullptr, hipMalloc((void**)&c->d_maxlen, MAX_LEVELS * sizeof(unsigned long long)));
     HIPCHECK(nullptr, hipMalloc((void**)&c->d_flags, sizeof(int)));
     HIPCHECK(nullptr, hipMalloc((void**)&c->d_nparts, MAX_LEVELS * sizeof(int)));
+    HIPCHECK(nullptr, hipMalloc((void**)&c->d_nslow, sizeof(int)));
+    HIPCHECK(nullptr, hipMemset(c->d_nslow, 0, sizeof(int)));
+    if (const char* e = std::getenv("RAIDER_HIP_WORKSPACE_BYTES")) c->ws_limit = (size_t)std::strtoull(e, nullptr, 10);
     *out = c;
     return RDR_OK;
 }
@@ -431,6 +440,8 @@ void rdr_destroy(rdr_ctx* c) {
     if (c->d_maxlen) (void)hipFree(c->d_maxlen);
     if (c->d_flags) (void)hipFree(c->d_flags);
     if (c->d_nparts) (void)hipFree(c->d_nparts);
+    if (c->d_nslow) (void)hipFree(c->d_nslow);
+    if (c->ws.p) (void)hipFree(c->ws.p);
     for (auto& v : c->evs) for (auto& pr : v) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -453,6 +464,13 @@ int rdr_device_info(rdr_ctx* c, char* name, int name_len, int* cus, int64_t* mem
     if (name && name_len > 0) { std::strncpy(name, c->name.c_str(), name_len - 1); name[name_len - 1] = 0; }
     if (cus) *cus = c->num_cus;
     if (mem) *mem = (int64_t)c->total_mem;
+    return RDR_OK;
+}
+
+int rdr_set_workspace_limit(rdr_ctx* c, int64_t bytes) {
+    if (!c || bytes < (int64_t)1 << 20) return fail(c, RDR_ERR_INVALID, "rdr_set_workspace_limit: need at least 1 MiB");
+    c->ws_limit = (size_t)bytes;
+    c->wsig.valid = false;
     return RDR_OK;
 }
 
@@ -793,6 +811,7 @@ static int stage_rays(rdr_ctx* c, const rdr_rays* r, RayParams& P) {
         P.ntiles = (r->n + BLOCK - 1) / BLOCK;
     }
     P.maxlen_bits = c->d_maxlen; P.flags = c->d_flags;
+    P.ws = nullptr; P.nslots = 0; P.tile_begin = 0; P.tile_count = P.ntiles; P.nslow = c->d_nslow;
     return RDR_OK;
 }
 
@@ -806,16 +825,100 @@ static int ray_grid(rdr_ctx* c, int64_t ntiles) {
     return (int)g;
 }
 
-template <int MODE>
-static int launch_ray(rdr_ctx* c, const rdr_cube* q, const RayParams& P) {
-    const int g = ray_grid(c, P.ntiles);
-    KTimer t(c, MODE);
+static int ws_fields(int K) { return WS_T + K + 1; }
+
+// Largest number of tiles whose records fit the workspace limit / half of the free device memory.
+static int64_t ws_chunk_tiles(rdr_ctx* c, int K) {
+    const size_t per_tile = (size_t)ws_fields(K) * BLOCK * sizeof(double);
+    size_t free_b = 0, total_b = 0;
+    size_t budget = c->ws_limit;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = std::min(budget, std::max(c->ws.cap, free_b / 2 + c->ws.cap));
+    return (int64_t)std::max<size_t>(1, budget / per_tile);
+}
+
+static int ws_reserve(rdr_ctx* c, int64_t tiles, int K, double** out) {
+    const size_t need = (size_t)tiles * BLOCK * ws_fields(K) * sizeof(double);
+    if (c->ws.cap < need) {
+        if (c->ws.p) { HIPCHECK(c, hipStreamSynchronize(c->stream)); HIPCHECK(c, hipFree(c->ws.p)); c->ws.p = nullptr; c->ws.cap = 0; }
+        HIPCHECK(c, hipMalloc(&c->ws.p, need));
+        c->ws.cap = need;
+    }
+    *out = (double*)c->ws.p;
+    return RDR_OK;
+}
+
+static void wsig_set(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, double ht, double zref, int K, bool valid) {
+    c->wsig.cube = q; c->wsig.n = r->n; c->wsig.ht = ht; c->wsig.zref = zref; c->wsig.K = K; c->wsig.valid = valid;
+    c->wsig.a = r->origin_mode == RDR_ORIGIN_GRID ? (const void*)r->xpts : (r->origin_mode == RDR_ORIGIN_XYZ ? (const void*)r->xyz : (const void*)r->lat);
+    c->wsig.b = r->origin_mode == RDR_ORIGIN_GRID ? (const void*)r->ypts : (const void*)r->lon;
+    c->wsig.c = r->los_mode == RDR_LOS_VEC ? (const void*)r->los : (const void*)r->inc;
+}
+
+static bool wsig_match(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, double ht, double zref, int K) {
+    if (!c->wsig.valid || c->wsig.cube != q || c->wsig.n != r->n || c->wsig.ht != ht || c->wsig.zref != zref || c->wsig.K != K) return false;
+    if (r->loc != RDR_DEVICE) return false;   // host arrays may have been rewritten in place between the two calls
+    const void* a = r->origin_mode == RDR_ORIGIN_GRID ? (const void*)r->xpts : (r->origin_mode == RDR_ORIGIN_XYZ ? (const void*)r->xyz : (const void*)r->lat);
+    const void* b = r->origin_mode == RDR_ORIGIN_GRID ? (const void*)r->ypts : (const void*)r->lon;
+    const void* cc = r->los_mode == RDR_LOS_VEC ? (const void*)r->los : (const void*)r->inc;
+    return a == c->wsig.a && b == c->wsig.b && cc == c->wsig.c;
+}
+
+// pass 1 over tiles [tb, tb+tc): optional reduction (P.maxlen_bits != null) and/or record store (P.ws != null)
+static int launch_crossings(rdr_ctx* c, const rdr_cube* q, RayParams P, int64_t tb, int64_t tc) {
+    P.tile_begin = tb; P.tile_count = tc; P.nslots = tc * BLOCK;
+    const int g = ray_grid(c, tc);
+    HIPCHECK(c, hipMemsetAsync(c->d_nslow, 0, sizeof(int), c->stream));
+    {
+        KTimer t(c, 0);
+        if (q->dtype == RDR_F32)
+            hipLaunchKernelGGL((crossings_kernel<float2, false>), dim3(g), dim3(BLOCK), ray_smem(q), c->stream, make_view<float2>(q), P);
+        else
+            hipLaunchKernelGGL((crossings_kernel<double2, false>), dim3(g), dim3(BLOCK), ray_smem(q), c->stream, make_view<double2>(q), P);
+    }
+    // generic-geodesy mop-up of the rays the classification rejected (returns at once when there are none)
     if (q->dtype == RDR_F32)
-        hipLaunchKernelGGL((ray_kernel<MODE, float2>), dim3(g), dim3(BLOCK), ray_smem(q), c->stream, make_view<float2>(q), P);
+        hipLaunchKernelGGL((crossings_kernel<float2, true>), dim3(g), dim3(BLOCK), ray_smem(q), c->stream, make_view<float2>(q), P);
     else
-        hipLaunchKernelGGL((ray_kernel<MODE, double2>), dim3(g), dim3(BLOCK), ray_smem(q), c->stream, make_view<double2>(q), P);
+        hipLaunchKernelGGL((crossings_kernel<double2, true>), dim3(g), dim3(BLOCK), ray_smem(q), c->stream, make_view<double2>(q), P);
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(c, RDR_ERR_HIP, std::string("ray_kernel launch: ") + hipGetErrorString(e));
+    if (e != hipSuccess) return fail(c, RDR_ERR_HIP, std::string("crossings_kernel launch: ") + hipGetErrorString(e));
+    return RDR_OK;
+}
+
+static int launch_march(rdr_ctx* c, const rdr_cube* q, RayParams P, int64_t tb, int64_t tc) {
+    P.tile_begin = tb; P.tile_count = tc; P.nslots = tc * BLOCK;
+    const int g = ray_grid(c, tc);
+    {
+        KTimer t(c, 1);
+        if (q->dtype == RDR_F32)
+            hipLaunchKernelGGL((march_kernel<float2, false>), dim3(g), dim3(BLOCK), ray_smem(q), c->stream, make_view<float2>(q), P);
+        else
+            hipLaunchKernelGGL((march_kernel<double2, false>), dim3(g), dim3(BLOCK), ray_smem(q), c->stream, make_view<double2>(q), P);
+    }
+    if (q->dtype == RDR_F32)
+        hipLaunchKernelGGL((march_kernel<float2, true>), dim3(g), dim3(BLOCK), ray_smem(q), c->stream, make_view<float2>(q), P);
+    else
+        hipLaunchKernelGGL((march_kernel<double2, true>), dim3(g), dim3(BLOCK), ray_smem(q), c->stream, make_view<double2>(q), P);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(c, RDR_ERR_HIP, std::string("march_kernel launch: ") + hipGetErrorString(e));
+    return RDR_OK;
+}
+
+// pass 2 for the whole batch when no valid records are around: chunked (pass-1-store, pass-2) pairs
+static int march_chunked(rdr_ctx* c, const rdr_cube* q, const RayParams& P0, int K) {
+    const int64_t chunk = std::min<int64_t>(P0.ntiles, ws_chunk_tiles(c, K));
+    double* ws;
+    int rc = ws_reserve(c, chunk, K, &ws); if (rc) return rc;
+    for (int64_t tb = 0; tb < P0.ntiles; tb += chunk) {
+        const int64_t tc = std::min<int64_t>(chunk, P0.ntiles - tb);
+        RayParams P = P0;
+        P.ws = ws;
+        unsigned long long* keep = P.maxlen_bits;
+        P.maxlen_bits = nullptr;                      // store only, no reduction
+        rc = launch_crossings(c, q, P, tb, tc); if (rc) return rc;
+        P.maxlen_bits = keep;
+        rc = launch_march(c, q, P, tb, tc); if (rc) return rc;
+    }
     return RDR_OK;
 }
 
@@ -837,7 +940,14 @@ int rdr_ray_prepass(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, double ht,
     P.ht = ht; P.zref = zref; P.max_seg = 1000.0;
     HIPCHECK(c, hipMemsetAsync(c->d_maxlen, 0, MAX_LEVELS * sizeof(unsigned long long), c->stream));
     HIPCHECK(c, hipMemsetAsync(c->d_flags, 0, sizeof(int), c->stream));
-    if (r->n > 0) { rc = launch_ray<0>(c, q, P); if (rc) return rc; }
+    c->wsig.valid = false;
+    if (r->n > 0) {
+        // keep the ray records for the rdr_ray_march that normally follows (same device arrays, whole batch fits)
+        const bool keep = r->loc == RDR_DEVICE && P.ntiles <= ws_chunk_tiles(c, K);
+        if (keep) { rc = ws_reserve(c, P.ntiles, K, &P.ws); if (rc) return rc; }
+        rc = launch_crossings(c, q, P, 0, P.ntiles); if (rc) return rc;
+        if (keep) wsig_set(c, q, r, ht, zref, K, true);
+    }
     int f = 0;
     HIPCHECK(c, hipMemcpyAsync(maxlen, c->d_maxlen, (size_t)K * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHECK(c, hipMemcpyAsync(&f, c->d_flags, sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -856,6 +966,7 @@ int rdr_ray_march(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, double ht, d
     for (int k = 0; k < K; ++k) if (nparts[k] < 1 || nparts[k] > (1 << 24)) return fail(c, RDR_ERR_INVALID, "rdr_ray_march: nparts out of range");
     if (r->n == 0) return RDR_OK;
     HIPCHECK(c, hipSetDevice(c->device));
+    const bool reuse = wsig_match(c, q, r, ht, zref, K);
     RayParams P;
     rc = stage_rays(c, r, P); if (rc) return rc;
     P.ht = ht; P.zref = zref; P.max_seg = 1000.0;
@@ -868,7 +979,10 @@ int rdr_ray_march(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, double ht, d
     rc = stage_out(c, SLOT_OUT0, wet, (size_t)r->n * 8, r->loc, &dw); if (rc) return rc;
     rc = stage_out(c, SLOT_OUT1, hydro, (size_t)r->n * 8, r->loc, &dh); if (rc) return rc;
     P.wet = (double*)dw; P.hyd = (double*)dh;
-    rc = launch_ray<1>(c, q, P); if (rc) return rc;
+    if (reuse) { P.ws = (double*)c->ws.p; rc = launch_march(c, q, P, 0, P.ntiles); }
+    else rc = march_chunked(c, q, P, K);
+    c->wsig.valid = false;
+    if (rc) return rc;
     rc = finish_out(c, wet, dw, (size_t)r->n * 8, r->loc); if (rc) return rc;
     rc = finish_out(c, hydro, dh, (size_t)r->n * 8, r->loc); if (rc) return rc;
     if (r->loc == RDR_HOST) HIPCHECK(c, hipStreamSynchronize(c->stream));
@@ -894,8 +1008,18 @@ int rdr_raytrace(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, double ht, do
     P.wet = (double*)dw; P.hyd = (double*)dh;
     HIPCHECK(c, hipMemsetAsync(c->d_maxlen, 0, MAX_LEVELS * sizeof(unsigned long long), c->stream));
     HIPCHECK(c, hipMemsetAsync(c->d_flags, 0, sizeof(int), c->stream));
-    rc = launch_ray<0>(c, q, P); if (rc) return rc;
-    rc = launch_ray<1>(c, q, P); if (rc) return rc;
+    c->wsig.valid = false;
+    if (P.ntiles <= ws_chunk_tiles(c, K)) {
+        // whole batch fits: pass 1 reduces AND stores the ray records, pass 2 streams them back
+        rc = ws_reserve(c, P.ntiles, K, &P.ws); if (rc) return rc;
+        rc = launch_crossings(c, q, P, 0, P.ntiles); if (rc) return rc;
+        rc = launch_march(c, q, P, 0, P.ntiles); if (rc) return rc;
+    } else {
+        // pass 1 (reduction only) over everything, then chunked (store, march) pairs
+        P.ws = nullptr;
+        rc = launch_crossings(c, q, P, 0, P.ntiles); if (rc) return rc;
+        rc = march_chunked(c, q, P, K); if (rc) return rc;
+    }
     rc = finish_out(c, wet, dw, (size_t)r->n * 8, r->loc); if (rc) return rc;
     rc = finish_out(c, hydro, dh, (size_t)r->n * 8, r->loc); if (rc) return rc;
     const bool need_sync = r->loc == RDR_HOST || nparts_out || flags_out;

@@ -199,17 +199,30 @@ __device__ __forceinline__ void toa_newton(double ox, double oy, double oz, doub
 // Ray kernels: the same iteration carried on the scalar ray parameter t (pos = o + t*l): t0 = h,
 // t += (h - height(o + t l)) / factor - identical in exact arithmetic to losreader.py:724-731, 2 live doubles per
 // crossing instead of 6 - with the light-fp64 TRUE height (geodesy_fast.h): crossings land within 2e-5 m (at 40 km)
-// of the reference's, which moves the delays by < 1e-10 m.
+// of the reference's, which moves the delays by < 1e-10 m.  SLOW = the generic PROJ-formula height, used by the
+// *_kernel<T2, true> instantiations that mop up the rare rays the static classification rejects.
+template <bool SLOW>
+__device__ __forceinline__ double height_sel(double x, double y, double z) {
+    return SLOW ? ecef_height(x, y, z) : height_fast_nocheck(x, y, z);
+}
+
+template <bool SLOW>
 __device__ __forceinline__ double toa_newton_t(double ox, double oy, double oz, double lx, double ly, double lz,
                                                double h, int iters, double inv_factor) {
     double t = h;
 #pragma unroll 1
     for (int it = 0; it < iters; ++it) {
-        const double hgt = height_fast(fma(t, lx, ox), fma(t, ly, oy), fma(t, lz, oz));
+        const double hgt = height_sel<SLOW>(fma(t, lx, ox), fma(t, ly, oy), fma(t, lz, oz));
         t = fma(h - hgt, inv_factor, t);
     }
     return t;
 }
+
+// Workspace record handed from pass 1 (crossings_kernel) to pass 2 (march_kernel): one column per ray SLOT
+// (slot = local tile * 256 + thread), field-major so every field access is a perfectly coalesced 512 B per wave:
+//   ws[f * nslots + slot],  f = 0..2 origin ECEF | 3..5 look vector | 6 lat0 | 7 lon0 | 8..11 sin/cos lat0, sin/cos lon0
+//                           | 12 fast_ok | 13 .. 13+K  ray parameter t of the K+1 level crossings
+constexpr int WS_ORIGIN = 0, WS_LOS = 3, WS_LAT0 = 6, WS_LON0 = 7, WS_S0 = 8, WS_C0 = 9, WS_SL0 = 10, WS_CL0 = 11, WS_FAST = 12, WS_T = 13;
 
 struct RayParams {
     // geometry
@@ -223,12 +236,16 @@ struct RayParams {
     // slice
     double ht, zref, max_seg;
     // batch-global state
-    unsigned long long* maxlen_bits;   // [MAX_LEVELS] per-level max ray length (bit pattern of a non-negative double)
+    unsigned long long* maxlen_bits;   // [MAX_LEVELS] per-level max ray length (bit pattern of a non-negative double); nullptr: no reduction
     int* flags;                        // RDR_FLAG_* bits (OR-reduced)
     const int* nparts_override;        // [K] or nullptr -> ceil(maxlen/max_seg)+1
+    int* nslow;                        // number of rays the static classification sent to the generic (slow) kernels
+    // pass 1 -> pass 2 workspace (this launch covers tiles [tile_begin, tile_begin + tile_count))
+    double* ws; int64_t nslots;
+    int64_t tile_begin, tile_count;
     // outputs
     double* wet; double* hyd;
-    // tiling
+    // tiling of the whole batch
     int64_t ntiles; int tiles_x;
 };
 
@@ -249,61 +266,98 @@ __device__ inline int build_levels(const double* zs, int nz, double ht, double z
     return min(K, MAX_LEVELS);
 }
 
-__device__ __forceinline__ double wave_max(double v) {
-    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+// max over the 64 lanes of a wave, DPP only (no LDS round trips): row (16 lanes) butterflies, then the two
+// row-broadcast steps of gfx9 wave64; the result is valid in lane 63.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_max_step(double v) {
+    const long long b = __double_as_longlong(v);
+    int lo = (int)(b & 0xffffffffLL), hi = (int)(b >> 32);
+    // unselected / out-of-range lanes keep their own value (old = src, bound_ctrl off)
+    const int lo2 = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
+    const int hi2 = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
+    const double o = __longlong_as_double(((long long)hi2 << 32) | (unsigned int)lo2);
+    return fmax(v, o);
+}
+__device__ __forceinline__ double wave_max_lane63(double v) {
+    v = dpp_max_step<0x111, 0xf>(v);   // row_shr:1
+    v = dpp_max_step<0x112, 0xf>(v);   // row_shr:2
+    v = dpp_max_step<0x114, 0xf>(v);   // row_shr:4
+    v = dpp_max_step<0x118, 0xf>(v);   // row_shr:8   -> lane 15 of every row holds the row max
+    v = dpp_max_step<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+    v = dpp_max_step<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave max
     return v;
 }
 
-// MODE 0: prepass (per-level batch max + flags).  MODE 1: march (integrate).
-template <int MODE, typename T2>
-__global__ __launch_bounds__(BLOCK) void ray_kernel(CubeView<T2> c, RayParams P) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int na = c.ny + c.nx + c.nz;
-    double* s_y = reinterpret_cast<double*>(smem_raw);   // [ys | xs | zs | 1/dy | 1/dx | 1/dz]
-    double* s_x = s_y + c.ny;
-    double* s_z = s_x + c.nx;
-    double* s_lo = s_y + 2 * na;
-    double* s_hi = s_lo + c.nz;
-    unsigned long long* s_max = reinterpret_cast<unsigned long long*>(s_hi + c.nz);   // [nz] (MODE 0)
-    int* s_kz = reinterpret_cast<int*>(s_max + c.nz);
-    int* s_np = s_kz + c.nz;
-    int* s_K = s_np + c.nz;
+// Shared LDS layout of the two ray kernels.
+struct RaySmem {
+    double* tab;            // [ys | xs | zs | 1/dy | 1/dx | 1/dz]
+    double* lo; double* hi; // level table
+    unsigned long long* mx; // per-level block max (pass 1)
+    int* kz; int* np; int* K;
+};
+__device__ __forceinline__ RaySmem carve_smem(unsigned char* raw, int ny, int nx, int nz) {
+    RaySmem m;
+    const int na = ny + nx + nz;
+    m.tab = reinterpret_cast<double*>(raw);
+    m.lo = m.tab + 2 * na;
+    m.hi = m.lo + nz;
+    m.mx = reinterpret_cast<unsigned long long*>(m.hi + nz);
+    m.kz = reinterpret_cast<int*>(m.mx + nz);
+    m.np = m.kz + nz;
+    m.K = m.np + nz;
+    return m;
+}
 
+template <typename T2>
+__device__ __forceinline__ int fill_tables(const CubeView<T2>& c, const RaySmem& m, double ht, double zref) {
+    const int na = c.ny + c.nx + c.nz;
     const int tid = threadIdx.x;
-    for (int i = tid; i < na; i += BLOCK) s_y[i] = c.axes[i];
+    for (int i = tid; i < na; i += BLOCK) m.tab[i] = c.axes[i];
     __syncthreads();
     for (int i = tid; i < na; i += BLOCK) {
         const bool last = (i == c.ny - 1) || (i == c.ny + c.nx - 1) || (i == na - 1);
-        s_y[na + i] = last ? 0.0 : 1.0 / (s_y[i + 1] - s_y[i]);
+        m.tab[na + i] = last ? 0.0 : 1.0 / (m.tab[i + 1] - m.tab[i]);
     }
-    if (tid == 0) *s_K = build_levels(s_z, c.nz, P.ht, P.zref, s_lo, s_hi, s_kz);
+    if (tid == 0) *m.K = build_levels(m.tab + c.ny + c.nx, c.nz, ht, zref, m.lo, m.hi, m.kz);
     __syncthreads();
-    const int K = *s_K;
-    if (MODE == 0) {
-        for (int k = tid; k < K; k += BLOCK) s_max[k] = 0ULL;
-    } else {
-        for (int k = tid; k < K; k += BLOCK) {
-            int np;
-            if (P.nparts_override) np = P.nparts_override[k];
-            else np = (int)ceil(__longlong_as_double((long long)P.maxlen_bits[k]) / P.max_seg) + 1;   // delay.py:283
-            s_np[k] = np;
-        }
-    }
-    __syncthreads();
-    int flags_in = 0;
-    if (MODE == 1) flags_in = *P.flags;
-    const bool clamp_lo = MODE == 1 && !(flags_in & 4);   // ALL first samples below zmin  (delay.py:306-307)
-    const bool clamp_hi = MODE == 1 && !(flags_in & 8);   // ALL last samples above zmax   (delay.py:310-311)
-    int my_flags = 0;
+    return *m.K;
+}
 
-    // persistent walk over tiles; XCD-aware: workgroup b runs on XCD b%8 -> give each XCD one contiguous band
-    const int nb = gridDim.x;
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = nb >> 3;
-    const int64_t chunk = (P.ntiles + 7) / 8;
-    for (int64_t tt = slot; tt < chunk; tt += nslot) {
-        const int64_t t = (int64_t)xcd * chunk + tt;
-        if (t >= P.ntiles) break;
-        int64_t i; int64_t row = 0, col = 0; bool active;
+// XCD-aware persistent tile walk: workgroup b runs on XCD b%8 -> each XCD sweeps one contiguous band of tiles.
+struct TileWalk {
+    int64_t chunk, tt; int nslot, xcd;
+    __device__ __forceinline__ TileWalk(int64_t count) {
+        xcd = blockIdx.x & 7; nslot = gridDim.x >> 3; chunk = (count + 7) / 8; tt = blockIdx.x >> 3;
+    }
+    __device__ __forceinline__ bool next(int64_t count, int64_t& local) {
+        if (tt >= chunk) return false;
+        local = (int64_t)xcd * chunk + tt;
+        tt += nslot;
+        return local < count;
+    }
+};
+
+// ---- pass 1: per-ray set-up + level crossings (build_ray, losreader.py:772-835) ------------------------------------
+// Optional outputs (both may be on): the per-level batch maximum of the ray length + flags (what delay.py:283,306-311
+// reduce over the slice) and the workspace record for pass 2.
+// SLOW = false: the light-fp64 path, skips (but counts) the rays the static classification rejects;
+// SLOW = true : generic geodesy, processes ONLY those rays, exits at once when there are none.
+template <typename T2, bool SLOW>
+__global__ __launch_bounds__(BLOCK) void crossings_kernel(CubeView<T2> c, RayParams P) {
+    if (SLOW && *P.nslow == 0) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const RaySmem m = carve_smem(smem_raw, c.ny, c.nx, c.nz);
+    const int K = fill_tables(c, m, P.ht, P.zref);
+    const int tid = threadIdx.x;
+    const bool reduce = P.maxlen_bits != nullptr;
+    if (reduce) for (int k = tid; k < K; k += BLOCK) m.mx[k] = 0ULL;
+    __syncthreads();
+    int my_flags = 0;
+    TileWalk walk(P.tile_count);
+    int64_t lt;
+    while (walk.next(P.tile_count, lt)) {
+        const int64_t t = P.tile_begin + lt;
+        int64_t i, row = 0, col = 0; bool active;
         if (P.origin_mode == 0) {
             const int64_t ty = t / P.tiles_x, tx = t - ty * P.tiles_x;
             row = ty * TILE + (tid >> 4); col = tx * TILE + (tid & 15);
@@ -330,77 +384,156 @@ __global__ __launch_bounds__(BLOCK) void ray_kernel(CubeView<T2> c, RayParams P)
             if (P.los_mode == 0) { lx = P.los[3 * i]; ly = P.los[3 * i + 1]; lz = P.los[3 * i + 2]; }
             else if (P.los_mode == 1) inc_hd_to_ecef(P.inc[i], P.hd[i], lat, lon, lx, ly, lz);
             else if (P.los_mode == 2) inc_hd_to_ecef(P.inc0, P.hd0, lat, lon, lx, ly, lz);
-            else {   // zenith (losreader.py:302-316)
-                double sla, cla, slo, clo;
-                sincos(lat * DEG_TO_RAD, &sla, &cla); sincos(lon * DEG_TO_RAD, &slo, &clo);
-                lx = cla * clo; ly = cla * slo; lz = sla;
-            }
+            else { lx = base.c0 * base.cl0; ly = base.c0 * base.sl0; lz = base.s0; }   // zenith (losreader.py:302-316)
         }
         // |l| (1 for unit look vectors): ray length between two crossings = (t_hi - t_lo) * |l|   (losreader.py:821)
         const double nl2 = fma(lx, lx, fma(ly, ly, lz * lz));
         const double nl = nl2 * rsq_nr<2>(nl2);
+        // Static classification: may the light geodesy be used along the WHOLE ray?  (cos(lat) stays > 0.01 and the ray
+        // stays within ~0.1 rad of its origin.)  t_max <= (zref-ht)/cos(inc) because the local zenith angle of a
+        // straight ray decreases with height.
+        const double cosi = (lx * base.c0 * base.cl0 + ly * base.c0 * base.sl0 + lz * base.s0) / nl;
+        const double gam = (P.zref - P.ht) / (cosi * 6.3e6);                       // bound on the angular travel
+        const bool fast_ok = !active || ((cosi > 0.05) && (base.c0 > gam + 0.02) && (gam < 0.09 * (base.c0 - gam)));
+        const int64_t slot = lt * BLOCK + tid;
+        if (!SLOW) {
+            const unsigned long long slow_mask = __ballot(!fast_ok);
+            if (slow_mask && (tid & 63) == 0) atomicAdd(P.nslow, (int)__popcll(slow_mask));
+        }
+        const bool mine = SLOW ? !fast_ok : fast_ok;      // lanes this instantiation is responsible for
+        if (SLOW && !__any(mine)) continue;               // (wave-uniform) nothing to mop up in this wave
+        if (P.ws && mine) {
+            double* w = P.ws + slot;
+            w[(int64_t)(WS_ORIGIN + 0) * P.nslots] = ox; w[(int64_t)(WS_ORIGIN + 1) * P.nslots] = oy; w[(int64_t)(WS_ORIGIN + 2) * P.nslots] = oz;
+            w[(int64_t)(WS_LOS + 0) * P.nslots] = lx; w[(int64_t)(WS_LOS + 1) * P.nslots] = ly; w[(int64_t)(WS_LOS + 2) * P.nslots] = lz;
+            w[(int64_t)WS_LAT0 * P.nslots] = lat; w[(int64_t)WS_LON0 * P.nslots] = lon;
+            w[(int64_t)WS_S0 * P.nslots] = base.s0; w[(int64_t)WS_C0 * P.nslots] = base.c0;
+            w[(int64_t)WS_SL0 * P.nslots] = base.sl0; w[(int64_t)WS_CL0 * P.nslots] = base.cl0;
+            w[(int64_t)WS_FAST * P.nslots] = fast_ok ? 1.0 : 0.0;
+        }
         double t_hi = 0.0, inv_cosf = 1.0;
-        double acc_w = 0.0, acc_h = 0.0;
-        double vw_top = 0.0, vh_top = 0.0;    // sample values at the top of the previous segment (= bottom of this one)
 #pragma unroll 1
         for (int k = 0; k < K; ++k) {
-            const double lo = s_lo[k], hi = s_hi[k];
+            const double lo = m.lo[k], hi = m.hi[k];
             // first interval: cos_factor is None -> 10 iterations with factor 1 for both ends (losreader.py:812-825);
             // later intervals reuse the previous top as their bottom (losreader.py:811-812)
-            const double t_lo = (k == 0) ? toa_newton_t(ox, oy, oz, lx, ly, lz, lo, 10, 1.0) : t_hi;
-            t_hi = toa_newton_t(ox, oy, oz, lx, ly, lz, hi, k == 0 ? 10 : 3, inv_cosf);
-            const double dt = t_hi - t_lo;
-            const double L = dt * nl;
+            double t_lo = t_hi;
+            if (k == 0) t_lo = toa_newton_t<SLOW>(ox, oy, oz, lx, ly, lz, lo, 10, 1.0);
+            t_hi = toa_newton_t<SLOW>(ox, oy, oz, lx, ly, lz, hi, k == 0 ? 10 : 3, inv_cosf);
+            const double L = (t_hi - t_lo) * nl;
             if (k == 0) inv_cosf = L / (hi - lo);                                       // 1/cos_factor, losreader.py:824-825
-            if (MODE == 0) {
+            if (P.ws && mine) {
+                if (k == 0) P.ws[(int64_t)WS_T * P.nslots + slot] = t_lo;
+                P.ws[(int64_t)(WS_T + k + 1) * P.nslots + slot] = t_hi;
+            }
+            if (reduce) {
                 // NaN poisons the max exactly as ndarray.max does (delay.py:283): tracked via flags
-                if (active) my_flags |= (L != L) ? 1 : 2;
-                double m = (active && L == L) ? L : 0.0;
-                m = wave_max(m);
-                if ((tid & 63) == 0) atomicMax(&s_max[k], (unsigned long long)__double_as_longlong(m));
-                if (k == 0 && active) {          // first sample of the ray (fraction 0)
-                    const double h0 = height_fast(fma(t_lo, lx, ox), fma(t_lo, ly, oy), fma(t_lo, lz, oz));
+                const bool cnt = active && mine;
+                if (cnt) my_flags |= (L != L) ? 1 : 2;
+                const double mx = wave_max_lane63((cnt && L == L) ? L : 0.0);
+                if ((tid & 63) == 63) atomicMax(&m.mx[k], (unsigned long long)__double_as_longlong(mx));
+                if (k == 0 && cnt) {             // first sample of the ray (fraction 0)
+                    const double h0 = height_sel<SLOW>(fma(t_lo, lx, ox), fma(t_lo, ly, oy), fma(t_lo, lz, oz));
                     if (!(h0 < c.z_lo)) my_flags |= 4;
                 }
-                if (k == K - 1 && active) {      // last sample of the ray (fraction 1)
-                    const double h1 = height_fast(fma(t_hi, lx, ox), fma(t_hi, ly, oy), fma(t_hi, lz, oz));
+                if (k == K - 1 && cnt) {         // last sample of the ray (fraction 1)
+                    const double h1 = height_sel<SLOW>(fma(t_hi, lx, ox), fma(t_hi, ly, oy), fma(t_hi, lz, oz));
                     if (!(h1 > c.z_hi)) my_flags |= 8;
-                }
-            } else {
-                const int np = s_np[k];
-                const double nm1 = (double)np - 1.0;
-                const double step = 1.0 / nm1;                       // np.linspace(0,1,np) (delay.py:287)
-                const double segw = (L * 1.0e-6) * step;             // delay.py:315: L*1e-6/(np-1)
-                const int kz = s_kz[k];
-                // j = 0 of this segment is the SAME point as j = np-1 of the previous one (low_xyz is high_xyz,
-                // losreader.py:811-812), so its interpolated value is reused instead of recomputed; the reference
-                // evaluates it twice and gets the same number both times.  Order of accumulation is unchanged.
-                if (k > 0) { acc_w = fma(0.5 * segw, vw_top, acc_w); acc_h = fma(0.5 * segw, vh_top, acc_h); }   // j = 0, reused
-#pragma unroll 1
-                for (int j = (k == 0 ? 0 : 1); j < np; ++j) {
-                    const double f = (j == np - 1) ? 1.0 : (double)j * step;
-                    const double ts = fma(f, dt, t_lo);                                   // low + f*(high-low), delay.py:292
-                    double plon, plat, ph;
-                    ecef2lla_fast(base, fma(ts, lx, ox), fma(ts, ly, oy), fma(ts, lz, oz), plon, plat, ph);   // delay.py:295
-                    if (clamp_lo && k == 0 && j == 0) ph = c.z_lo;                       // delay.py:306-307
-                    if (clamp_hi && k == K - 1 && j == np - 1) ph = c.z_hi;              // delay.py:310-311
-                    double vw, vh;
-                    sample_cube(c, s_y, plat, plon, ph, kz, vw, vh);                      // delay.py:298,319
-                    const double wt = ((j == 0) | (j == np - 1)) ? 0.5 * segw : segw;     // delay.py:314-315
-                    acc_w = fma(wt, vw, acc_w); acc_h = fma(wt, vh, acc_h);               // delay.py:323
-                    vw_top = vw; vh_top = vh;                                             // after the loop: value at j = np-1
                 }
             }
         }
-        if (MODE == 1 && active) { P.wet[i] = acc_w; P.hyd[i] = acc_h; }
     }
-    if (MODE == 0) {
+    if (reduce) {
         __syncthreads();
-        for (int k = tid; k < K; k += BLOCK) atomicMax(&P.maxlen_bits[k], s_max[k]);
-        // OR-reduce flags: wave ballot then one atomic per wave
+        for (int k = tid; k < K; k += BLOCK) atomicMax(&P.maxlen_bits[k], m.mx[k]);
         int f = my_flags;
         for (int off = 32; off > 0; off >>= 1) f |= __shfl_xor(f, off, 64);
         if ((tid & 63) == 0 && f) atomicOr(P.flags, f);
+    }
+}
+
+// ---- pass 2: trapezoid integration of both fields along every ray (delay.py:285-323) -------------------------------
+// SLOW as in crossings_kernel: <false> integrates the classified-fast rays with the light geodesy, <true> the rest
+// with the generic one (and returns immediately when there are none).
+template <typename T2, bool SLOW>
+__global__ __launch_bounds__(BLOCK) void march_kernel(CubeView<T2> c, RayParams P) {
+    if (SLOW && *P.nslow == 0) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const RaySmem m = carve_smem(smem_raw, c.ny, c.nx, c.nz);
+    const int K = fill_tables(c, m, P.ht, P.zref);
+    const int tid = threadIdx.x;
+    for (int k = tid; k < K; k += BLOCK) {
+        int np;
+        if (P.nparts_override) np = P.nparts_override[k];
+        else np = (int)ceil(__longlong_as_double((long long)P.maxlen_bits[k]) / P.max_seg) + 1;   // delay.py:283
+        m.np[k] = np;
+    }
+    __syncthreads();
+    const int flags_in = *P.flags;
+    const bool clamp_lo = !(flags_in & 4);   // ALL first samples below zmin  (delay.py:306-307)
+    const bool clamp_hi = !(flags_in & 8);   // ALL last samples above zmax   (delay.py:310-311)
+    TileWalk walk(P.tile_count);
+    int64_t lt;
+    while (walk.next(P.tile_count, lt)) {
+        const int64_t t = P.tile_begin + lt;
+        int64_t i; bool active;
+        if (P.origin_mode == 0) {
+            const int64_t ty = t / P.tiles_x, tx = t - ty * P.tiles_x;
+            const int64_t row = ty * TILE + (tid >> 4), col = tx * TILE + (tid & 15);
+            active = row < P.ny && col < P.nx;
+            i = row * P.nx + col;
+        } else {
+            i = t * BLOCK + tid;
+            active = i < P.n;
+        }
+        const double* w = P.ws + (lt * BLOCK + tid);
+        const int64_t ns = P.nslots;
+        const double ox = w[(int64_t)(WS_ORIGIN + 0) * ns], oy = w[(int64_t)(WS_ORIGIN + 1) * ns], oz = w[(int64_t)(WS_ORIGIN + 2) * ns];
+        const double lx = w[(int64_t)(WS_LOS + 0) * ns], ly = w[(int64_t)(WS_LOS + 1) * ns], lz = w[(int64_t)(WS_LOS + 2) * ns];
+        RayBase base;
+        base.lat0 = w[(int64_t)WS_LAT0 * ns]; base.lon0 = w[(int64_t)WS_LON0 * ns];
+        base.s0 = w[(int64_t)WS_S0 * ns]; base.c0 = w[(int64_t)WS_C0 * ns];
+        base.sl0 = w[(int64_t)WS_SL0 * ns]; base.cl0 = w[(int64_t)WS_CL0 * ns];
+        const bool fast_ok = !active || w[(int64_t)WS_FAST * ns] != 0.0;
+        const bool mine = SLOW ? !fast_ok : fast_ok;
+        if (SLOW && !__any(mine)) continue;
+        const double nl2 = fma(lx, lx, fma(ly, ly, lz * lz));
+        const double nl = nl2 * rsq_nr<2>(nl2);
+        double acc_w = 0.0, acc_h = 0.0;
+        double vw_top = 0.0, vh_top = 0.0;    // sample values at the top of the previous segment (= bottom of this one)
+        double t_hi = w[(int64_t)WS_T * ns];
+        double t_next = w[(int64_t)(WS_T + 1) * ns];             // crossings are streamed one level ahead of their use
+#pragma unroll 1
+        for (int k = 0; k < K; ++k) {
+            const double t_lo = t_hi;
+            t_hi = t_next;
+            if (k + 2 <= K) t_next = w[(int64_t)(WS_T + k + 2) * ns];
+            const double dt = t_hi - t_lo;
+            const int np = m.np[k];
+            const double step = 1.0 / ((double)np - 1.0);        // np.linspace(0,1,np) (delay.py:287)
+            const double segw = (dt * nl * 1.0e-6) * step;       // delay.py:315: L*1e-6/(np-1), L = |high-low| (losreader.py:821)
+            const int kz = m.kz[k];
+            // j = 0 of this segment is the SAME point as j = np-1 of the previous one (low_xyz is high_xyz,
+            // losreader.py:811-812): its interpolated value is reused instead of recomputed (the reference evaluates
+            // it twice and gets the same number both times).  The order of accumulation is unchanged.
+            if (k > 0) { acc_w = fma(0.5 * segw, vw_top, acc_w); acc_h = fma(0.5 * segw, vh_top, acc_h); }
+#pragma unroll 1
+            for (int j = (k == 0 ? 0 : 1); j < np; ++j) {
+                const double f = (j == np - 1) ? 1.0 : (double)j * step;
+                const double ts = fma(f, dt, t_lo);                                   // low + f*(high-low), delay.py:292
+                double plon, plat, ph;
+                if (SLOW) ecef2lla(fma(ts, lx, ox), fma(ts, ly, oy), fma(ts, lz, oz), plon, plat, ph);
+                else ecef2lla_near(base, fma(ts, lx, ox), fma(ts, ly, oy), fma(ts, lz, oz), plon, plat, ph);   // delay.py:295
+                if (clamp_lo && k == 0 && j == 0) ph = c.z_lo;                       // delay.py:306-307
+                if (clamp_hi && k == K - 1 && j == np - 1) ph = c.z_hi;              // delay.py:310-311
+                double vw, vh;
+                sample_cube(c, m.tab, plat, plon, ph, kz, vw, vh);                    // delay.py:298,319
+                const double wt = ((j == 0) | (j == np - 1)) ? 0.5 * segw : segw;     // delay.py:314-315
+                acc_w = fma(wt, vw, acc_w); acc_h = fma(wt, vh, acc_h);               // delay.py:323
+                vw_top = vw; vh_top = vh;                                             // after the loop: value at j = np-1
+            }
+        }
+        if (active && mine) { P.wet[i] = acc_w; P.hyd[i] = acc_h; }
     }
 }
 

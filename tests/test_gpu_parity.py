@@ -159,12 +159,13 @@ def test_g5b_shards_need_global_nparts(R, golden, cubes):
     assert np.abs(hyd - g['hydro'][0][:, :32]).max() > 1e-6
 
 
-@pytest.mark.parametrize('region', ['arctic', 'equator_east', 'south', 'dateline'])
+@pytest.mark.parametrize('region', ['arctic', 'equator_east', 'south', 'dateline', 'polar'])
 def test_raytrace_domain_sweep(R, region):
     """The light-fp64 geodesy (delta lat/lon, rsq/rcp + NR, exact-height Newton) across latitudes, hemispheres,
     incidence 15..60 deg and all headings, against the oracle on the same inputs."""
     box = {'arctic': (68.0, 76.0, 10.0, 40.0), 'equator_east': (-4.0, 4.0, 95.0, 105.0),
-           'south': (-48.0, -40.0, -75.0, -63.0), 'dateline': (10.0, 18.0, 168.0, 179.9)}[region]
+           'south': (-48.0, -40.0, -75.0, -63.0), 'dateline': (10.0, 18.0, 168.0, 179.9),
+           'polar': (82.0, 89.9, -60.0, 60.0)}[region]     # polar: most rays fail the static classification -> generic kernels
     c = O.synthetic_cube(40, 44, 36, seed=7, y0=box[0], y1=box[1], x0=box[2], x1=box[3])
     cube = R.Cube(c['ys'], c['xs'], c['zs'], c['wet'], c['hydro'], order='zyx')
     ip = list(O.getInterpolators(c['xs'], c['ys'], c['zs'], c['wet'], c['hydro']))
@@ -172,6 +173,8 @@ def test_raytrace_domain_sweep(R, region):
     ny, nx = 20, 24
     ymid, xmid = 0.5 * (box[0] + box[1]), 0.5 * (box[2] + box[3])
     ypts = np.linspace(ymid + 1.0, ymid - 1.0, ny); xpts = np.linspace(xmid - 1.2, xmid + 1.2, nx)
+    if region == 'polar':
+        ypts = np.linspace(89.2, 84.0, ny); xpts = np.linspace(-20.0, 20.0, nx)
     inc = rng.uniform(15, 60, (ny, nx)); hd = rng.uniform(-180, 180, (ny, nx))
     zref = c['zs'].max() - 1
     for ht in (0.0, 1500.0):
