@@ -816,7 +816,7 @@ static int stage_rays(rdr_ctx* c, const rdr_rays* r, RayParams& P) {
 }
 
 static size_t ray_smem(const rdr_cube* q) {
-    return (size_t)(q->ny + q->nx + q->nz) * 8 * 2 + (size_t)q->nz * 8 * 3 + (size_t)q->nz * 4 * 2 + 16;
+    return (size_t)(q->ny + q->nx + q->nz) * 8 * 3 + (size_t)q->nz * 8 * 3 + (size_t)q->nz * 4 * 2 + 16;
 }
 
 static int ray_grid(rdr_ctx* c, int64_t ntiles) {

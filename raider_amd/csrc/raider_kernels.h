@@ -124,42 +124,45 @@ __device__ __forceinline__ void trilinear(const CubeView<T2>& c, const double* s
 }
 
 // ---- ray-kernel sampler ----------------------------------------------------------------------------------------
-// Same scipy semantics as trilinear<> (interval g[i] <= v < g[i+1], last cell closed; outside / NaN -> NaN) with a
-// branch-light cell search: on (nearly) uniform axes the linear guess is at most one cell off, so a single
-// compare-and-step in each direction is exact; along z the model interval of the segment is the guess.  A lane whose
-// guess is further off (possible only for non-converged Newton crossings in sub-metre levels) re-does a bisection.
-__device__ __forceinline__ int bisect_cell(const double* g, int n, double v) {
+// Same scipy semantics as trilinear<> (interval g[i] <= v < g[i+1], last cell closed; outside / NaN -> NaN).
+// Cell search = ONE LDS round trip per axis: the axis table is stored as (g[i], 1/(g[i+1]-g[i])) pairs, a guess i0
+// is made (linear guess on (nearly) uniform axes, the segment's model interval along z), the three entries
+// i0-1, i0, i0+1 are fetched together and the right one is selected in registers.  A lane whose guess is more
+// than one cell off (non-uniform axis, non-converged crossing in sub-metre levels, < 4-node axes) bisects instead.
+__device__ __forceinline__ int bisect_cell2(const double2* e, int n, double v) {
     int lo = 0, hi = n;   // first index with v < g[idx]
     while (lo < hi) {
         const int mid = (lo + hi) >> 1;
-        if (v < g[mid]) hi = mid; else lo = mid + 1;
+        if (v < e[mid].x) hi = mid; else lo = mid + 1;
     }
     return min(max(lo - 1, 0), n - 2);
 }
 
-__device__ __forceinline__ int step_cell(const double* g, int n, double v, int guess) {
-    int i = min(max(guess, 0), n - 2);
-    i -= (int)((v < g[i]) & (i > 0));
-    i += (int)((v >= g[i + 1]) & (i < n - 2));
-    const bool ok = ((v >= g[i]) | (i == 0)) & ((v < g[i + 1]) | (i == n - 2));
-    if (!ok) i = bisect_cell(g, n, v);
-    return i;
+__device__ __forceinline__ void window_cell(const double2* e, int n, double v, int guess, bool trust, int& i, double& t) {
+    const int i0 = min(max(guess, 1), n - 3);
+    const double2 em = e[i0 - 1], e0 = e[i0], e1 = e[i0 + 1];
+    const bool dn = v < e0.x, up = v >= e1.x;
+    i = i0 - (int)dn + (int)up;
+    const double g = dn ? em.x : (up ? e1.x : e0.x);
+    const double r = dn ? em.y : (up ? e1.y : e0.y);
+    t = (v - g) * r;
+    if (!trust || !(t >= 0.0) || !(t <= 1.0)) {      // rare: exact search
+        i = bisect_cell2(e, n, v);
+        t = (v - e[i].x) * e[i].y;
+    }
 }
 
-// tab = [ys | xs | zs | 1/dy | 1/dx | 1/dz] in LDS.
+// tab2 = (g, 1/dg) pairs of [ys | xs | zs] in LDS.
 template <typename T2>
-__device__ __forceinline__ void sample_cube(const CubeView<T2>& c, const double* tab, double y, double x, double z, int kz,
+__device__ __forceinline__ void sample_cube(const CubeView<T2>& c, const double2* tab2, double y, double x, double z, int kz,
                                             double& wet, double& hyd) {
     const bool inside = (y >= c.y_lo) && (y <= c.y_hi) && (x >= c.x_lo) && (x <= c.x_hi) && (z >= c.z_lo) && (z <= c.z_hi);
     if (!inside) { wet = qnan(); hyd = qnan(); return; }
-    const double* sy = tab; const double* sx = tab + c.ny; const double* sz = sx + c.nx;
-    const int na = c.ny + c.nx + c.nz;
-    const int iy = c.uni_y ? step_cell(sy, c.ny, y, (int)((y - c.y_lo) * c.inv_dy)) : bisect_cell(sy, c.ny, y);
-    const int ix = c.uni_x ? step_cell(sx, c.nx, x, (int)((x - c.x_lo) * c.inv_dx)) : bisect_cell(sx, c.nx, x);
-    const int iz = step_cell(sz, c.nz, z, kz);
-    const double ty = (y - sy[iy]) * sy[na + iy];
-    const double tx = (x - sx[ix]) * sx[na + ix];
-    const double tz = (z - sz[iz]) * sz[na + iz];
+    const double2* ey = tab2; const double2* ex = tab2 + c.ny; const double2* ez = ex + c.nx;
+    int iy, ix, iz; double ty, tx, tz;
+    window_cell(ey, c.ny, y, (int)((y - c.y_lo) * c.inv_dy), c.uni_y && c.ny >= 4, iy, ty);
+    window_cell(ex, c.nx, x, (int)((x - c.x_lo) * c.inv_dx), c.uni_x && c.nx >= 4, ix, tx);
+    window_cell(ez, c.nz, z, kz, c.nz >= 4, iz, tz);
     const T2* p00 = c.v + ((int64_t)iy * c.nx + ix) * c.nz + iz;
     const T2* p01 = p00 + c.nz;
     const T2* p10 = p00 + (int64_t)c.nx * c.nz;
@@ -290,7 +293,8 @@ __device__ __forceinline__ double wave_max_lane63(double v) {
 
 // Shared LDS layout of the two ray kernels.
 struct RaySmem {
-    double* tab;            // [ys | xs | zs | 1/dy | 1/dx | 1/dz]
+    double* tab;            // [ys | xs | zs]
+    double2* tab2;          // the same axes as (g[i], 1/(g[i+1]-g[i])) pairs (pass 2 cell search)
     double* lo; double* hi; // level table
     unsigned long long* mx; // per-level block max (pass 1)
     int* kz; int* np; int* K;
@@ -298,8 +302,9 @@ struct RaySmem {
 __device__ __forceinline__ RaySmem carve_smem(unsigned char* raw, int ny, int nx, int nz) {
     RaySmem m;
     const int na = ny + nx + nz;
-    m.tab = reinterpret_cast<double*>(raw);
-    m.lo = m.tab + 2 * na;
+    m.tab2 = reinterpret_cast<double2*>(raw);                 // 16-byte aligned for ds_read_b128
+    m.tab = reinterpret_cast<double*>(m.tab2 + na);
+    m.lo = m.tab + na;
     m.hi = m.lo + nz;
     m.mx = reinterpret_cast<unsigned long long*>(m.hi + nz);
     m.kz = reinterpret_cast<int*>(m.mx + nz);
@@ -316,7 +321,8 @@ __device__ __forceinline__ int fill_tables(const CubeView<T2>& c, const RaySmem&
     __syncthreads();
     for (int i = tid; i < na; i += BLOCK) {
         const bool last = (i == c.ny - 1) || (i == c.ny + c.nx - 1) || (i == na - 1);
-        m.tab[na + i] = last ? 0.0 : 1.0 / (m.tab[i + 1] - m.tab[i]);
+        double2 e; e.x = m.tab[i]; e.y = last ? 0.0 : 1.0 / (m.tab[i + 1] - m.tab[i]);
+        m.tab2[i] = e;
     }
     if (tid == 0) *m.K = build_levels(m.tab + c.ny + c.nx, c.nz, ht, zref, m.lo, m.hi, m.kz);
     __syncthreads();
@@ -512,6 +518,7 @@ __global__ __launch_bounds__(BLOCK) void march_kernel(CubeView<T2> c, RayParams 
             const int np = m.np[k];
             const double step = 1.0 / ((double)np - 1.0);        // np.linspace(0,1,np) (delay.py:287)
             const double segw = (dt * nl * 1.0e-6) * step;       // delay.py:315: L*1e-6/(np-1), L = |high-low| (losreader.py:821)
+            const double dts = dt * step;                        // sample spacing in t: low + (j*step)*(high-low), delay.py:292
             const int kz = m.kz[k];
             // j = 0 of this segment is the SAME point as j = np-1 of the previous one (low_xyz is high_xyz,
             // losreader.py:811-812): its interpolated value is reused instead of recomputed (the reference evaluates
@@ -519,15 +526,17 @@ __global__ __launch_bounds__(BLOCK) void march_kernel(CubeView<T2> c, RayParams 
             if (k > 0) { acc_w = fma(0.5 * segw, vw_top, acc_w); acc_h = fma(0.5 * segw, vh_top, acc_h); }
 #pragma unroll 1
             for (int j = (k == 0 ? 0 : 1); j < np; ++j) {
-                const double f = (j == np - 1) ? 1.0 : (double)j * step;
-                const double ts = fma(f, dt, t_lo);                                   // low + f*(high-low), delay.py:292
+                const double ts = fma((double)j, dts, t_lo);
                 double plon, plat, ph;
                 if (SLOW) ecef2lla(fma(ts, lx, ox), fma(ts, ly, oy), fma(ts, lz, oz), plon, plat, ph);
                 else ecef2lla_near(base, fma(ts, lx, ox), fma(ts, ly, oy), fma(ts, lz, oz), plon, plat, ph);   // delay.py:295
-                if (clamp_lo && k == 0 && j == 0) ph = c.z_lo;                       // delay.py:306-307
-                if (clamp_hi && k == K - 1 && j == np - 1) ph = c.z_hi;              // delay.py:310-311
+                // all-pixels z-clamp of the very first / very last sample (delay.py:306-311): when it applies every
+                // pixel is below (above) the cube, so "set to zmin" == max(ph, zmin); the bounds are wave-uniform
+                const double zfloor = (clamp_lo && k == 0 && j == 0) ? c.z_lo : -__builtin_huge_val();
+                const double zceil = (clamp_hi && k == K - 1 && j == np - 1) ? c.z_hi : __builtin_huge_val();
+                ph = fmin(fmax(ph, zfloor), zceil);
                 double vw, vh;
-                sample_cube(c, m.tab, plat, plon, ph, kz, vw, vh);                    // delay.py:298,319
+                sample_cube(c, m.tab2, plat, plon, ph, kz, vw, vh);                   // delay.py:298,319
                 const double wt = ((j == 0) | (j == np - 1)) ? 0.5 * segw : segw;     // delay.py:314-315
                 acc_w = fma(wt, vw, acc_w); acc_h = fma(wt, vh, acc_h);               // delay.py:323
                 vw_top = vw; vh_top = vh;                                             // after the loop: value at j = np-1
