@@ -1,17 +1,18 @@
 // Device-only "light fp64" geodesy for the ray kernels (gfx950).
 //
-// Same FUNCTIONS as geodesy.h (PROJ `cart` inverse: single-pass Bowring latitude, h = p/cos(phi) - N,
-// lon = atan2(y,x)), evaluated with cheaper instruction sequences:
-//   * 1/sqrt and 1/x come from v_rsq_f64 / v_rcp_f64 + Newton-Raphson steps instead of the correctly
-//     rounded sqrt()/div expansions (each ~4x the instructions); two NR steps leave <= ~1 ulp, which is
-//     the same rounding noise the CPU reference has (|dh| ~ 1e-9 m on 6.4e6 m coordinates);
-//   * latitude / longitude of a ray sample are computed RELATIVE to the ray origin (whose geodetic
-//     coordinates are the kernel's exact inputs): sin(phi-phi0) and sin(lam-lam0) come from 2 FMAs each
-//     and the angle from a 5-term asin series (|angle| < 0.05 rad, i.e. < 300 km from the origin; larger
-//     angles take the generic atan2 path).  No atan/atan2 per sample, and less cancellation than
-//     re-deriving a 6-digit longitude from scratch.
-// Accuracy is pinned by tests/test_gpu_parity.py (rdr_ecef2lla / rdr_top_of_atmosphere / ray tracing
-// against the oracle: heights to 2e-8 m, angles to 1e-12 deg, delays to 1e-9 m).
+// Same quantities as geodesy.h (PROJ `cart` inverse: single-pass Bowring latitude, ellipsoidal height, longitude),
+// evaluated with cheaper instruction sequences:
+//   * 1/sqrt comes from v_rsq_f64 + ONE Newton-Raphson step (4e-15 relative; the seed alone is 2^-24) instead of the
+//     correctly rounded sqrt()/div expansions (each ~4x the instructions);
+//   * the height uses the support-function identity h = p cos(phi) + z sin(phi) - a sqrt(1 - es sin^2(phi)): exact
+//     for the exact latitude, second-order in the latitude error, no division; sqrt(1-u), u <= es, is a 6-term
+//     polynomial;
+//   * latitude / longitude of a ray sample are computed RELATIVE to the ray origin (whose geodetic coordinates are
+//     the kernel's exact inputs): sin(phi-phi0) and sin(lam-lam0) come from 2 FMAs each and the angle from an odd
+//     asin series (valid to ~0.13 rad; rays that could travel further are classified "slow" up front and handled by
+//     the generic-geodesy kernels).  No atan/atan2 per sample.
+// Accuracy is pinned by tests/test_gpu_parity.py (ray-traced delays against the CPU restatement of the reference:
+// 1e-9 m across latitudes, hemispheres, the dateline and a polar scene).
 #pragma once
 #include "geodesy.h"
 
