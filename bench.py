@@ -36,6 +36,7 @@ def main():
     ap.add_argument('--rows', type=int, default=4000)
     ap.add_argument('--cols', type=int, default=4000)
     ap.add_argument('--cube', type=str, default='300x300x80')
+    ap.add_argument('--backend', type=str, default='nccl', help='torch.distributed backend for N>1 (nccl = RCCL; gloo only for single-GPU dry runs of the N>1 path)')
     ap.add_argument('--cpu-sample', type=int, default=640, help='edge of the square ray block timed on the CPU oracle (0 = skip)')
     args = ap.parse_args()
 
@@ -53,14 +54,19 @@ def main():
             raise SystemExit('launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (no CPU fallback)')
+    local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
+    coll_dev = dev if args.backend == 'nccl' else None      # where the collectives' tensors live
 
     ctx = R.Context(local)
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)     # library kernels run on torch's current stream
+    # (raider_amd launches on torch's current stream whenever it is handed device tensors)
 
     # ---- weather cube: generated on rank 0, broadcast once over RCCL/xGMI, packed on device -----------
     ny, nx, nz = (int(v) for v in args.cube.split('x'))
@@ -77,7 +83,11 @@ def main():
     if world > 1:
         torch.cuda.synchronize(); dist.barrier()
         t0 = time.perf_counter()
-        dist.broadcast(axes, 0); dist.broadcast(wet, 0); dist.broadcast(hyd, 0)
+        if coll_dev is None:      # gloo dry run: stage through the host
+            for t_ in (axes, wet, hyd):
+                h_ = t_.cpu(); dist.broadcast(h_, 0); t_.copy_(h_)
+        else:
+            dist.broadcast(axes, 0); dist.broadcast(wet, 0); dist.broadcast(hyd, 0)
         torch.cuda.synchronize()
         t_bcast = time.perf_counter() - t0
     ax = axes.cpu().numpy()
@@ -103,7 +113,7 @@ def main():
         if world == 1:
             cube.raytrace(rays, ht, zref, out=(out_w, out_h), want_nparts=False)       # fully asynchronous
             return None
-        _, _, nparts = D.raytrace_slab(cube, rays, ht, zref, out=(out_w, out_h), device=dev)    # pass 1 -> RCCL MAX all-reduce (K+4 doubles) -> pass 2
+        _, _, nparts = D.raytrace_slab(cube, rays, ht, zref, out=(out_w, out_h), device=coll_dev)    # pass 1 -> RCCL MAX all-reduce (K+4 doubles) -> pass 2
         return nparts
 
     # nParts / S for the roofline formula (one synchronous untimed call)
@@ -131,7 +141,7 @@ def main():
     n_march, ms_march = ctx.profile_get(1)
     ctx.set_profiling(False)
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=coll_dev if coll_dev is not None else 'cpu')
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 

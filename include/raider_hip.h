@@ -84,7 +84,8 @@ int rdr_create(int device, rdr_ctx** out);
 void rdr_destroy(rdr_ctx* ctx);
 /* message of the last failure on this thread (ctx may be NULL) */
 const char* rdr_last_error(rdr_ctx* ctx);
-/* adopt an external hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = ctx's own */
+/* Launch on an external hipStream_t (e.g. torch.cuda.current_stream().cuda_stream).  NULL is HIP's default stream;
+ * (void*)-1 goes back to the ctx's private stream.  RDR_DEVICE arrays are only ordered against work on THIS stream. */
 int rdr_set_stream(rdr_ctx* ctx, void* hip_stream);
 int rdr_synchronize(rdr_ctx* ctx);
 int rdr_device_info(rdr_ctx* ctx, char* name, int name_len, int* compute_units, int64_t* total_mem);

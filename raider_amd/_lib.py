@@ -83,6 +83,30 @@ SYMBOLS = [
 ]
 
 
+def _preload_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so (SONAME libamdhip64.so.7, the same as /opt/rocm's).  Two HIP
+    runtimes in one process do not work ("No HIP GPUs are available" from whichever initialises second), and which
+    one libraider_hip.so binds to would depend on import order.  So when torch is installed but not imported yet,
+    load ITS copy first: our NEEDED libamdhip64.so.7 then resolves to it, and a later `import torch` finds the same
+    file already mapped.  RAIDER_HIP_RUNTIME=system keeps the system runtime, RAIDER_HIP_RUNTIME=/path/lib.so forces one."""
+    import importlib.util
+    import sys
+    choice = os.environ.get('RAIDER_HIP_RUNTIME', '')
+    if choice == 'system' or 'torch' in sys.modules:
+        return
+    if choice:
+        C.CDLL(choice, mode=C.RTLD_GLOBAL)
+        return
+    try:
+        spec = importlib.util.find_spec('torch')
+    except (ImportError, ValueError):
+        spec = None
+    if spec and spec.submodule_search_locations:
+        cand = Path(list(spec.submodule_search_locations)[0]) / 'lib' / 'libamdhip64.so'
+        if cand.exists():
+            C.CDLL(str(cand), mode=C.RTLD_GLOBAL)
+
+
 def load():
     """dlopen the HIP library (does not need a GPU) and declare every prototype."""
     global _lib
@@ -94,6 +118,7 @@ def load():
                 f'raider_amd: HIP library {LIB_PATH} is missing - build it with '
                 f'`python -c "import __graft_entry__ as g; g.build()"` (hipcc --offload-arch=gfx950). '
                 'There is no CPU fallback.')
+        _preload_hip_runtime()
         lib = C.CDLL(str(LIB_PATH))
         for name, res, args in SYMBOLS:
             fn = getattr(lib, name)      # AttributeError if the .so does not export a declared symbol
@@ -147,7 +172,14 @@ class Context:
         return cls._default
 
     def set_stream(self, stream_handle):
-        check(self.lib.rdr_set_stream(self.handle, C.c_void_p(stream_handle or 0)), self.handle)
+        """Launch on an external HIP stream (0 / None = HIP's default stream, -1 = the context's private stream)."""
+        h = -1 if stream_handle == -1 else (stream_handle or 0)
+        check(self.lib.rdr_set_stream(self.handle, C.c_void_p(h)), self.handle)
+
+    def adopt_torch_stream(self, tensor):
+        """Order this context's kernels with torch work on `tensor`'s device: launch on torch's current stream."""
+        import torch
+        self.set_stream(torch.cuda.current_stream(tensor.device).cuda_stream)
 
     def synchronize(self):
         check(self.lib.rdr_synchronize(self.handle), self.handle)

@@ -449,7 +449,10 @@ void rdr_destroy(rdr_ctx* c) {
 
 int rdr_set_stream(rdr_ctx* c, void* s) {
     if (!c) return fail(nullptr, RDR_ERR_INVALID, "ctx is NULL");
-    c->stream = s ? (hipStream_t)s : c->own_stream;
+    // NULL is HIP's legacy default stream (what torch.cuda.current_stream().cuda_stream is unless the caller
+    // switched streams); (void*)-1 restores the ctx's private stream
+    if (s == (void*)(intptr_t)-1) c->stream = c->own_stream;
+    else c->stream = (hipStream_t)s;
     return RDR_OK;
 }
 
@@ -585,7 +588,9 @@ int rdr_cube_create(rdr_ctx* c, const double* ys, int64_t ny, const double* xs, 
                            (double2*)q->d_vals, ny, nx, nz, sy, sx, sz, fy, fx, fz);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { rdr_cube_destroy(q); return fail(c, RDR_ERR_HIP, hipGetErrorString(e)); }
-    if (loc == RDR_HOST) { e = hipStreamSynchronize(c->stream); if (e != hipSuccess) { rdr_cube_destroy(q); return fail(c, RDR_ERR_HIP, hipGetErrorString(e)); } }
+    // one-time: the cube must be complete before it is used from any other stream (and the staging slots reused)
+    e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { rdr_cube_destroy(q); return fail(c, RDR_ERR_HIP, hipGetErrorString(e)); }
     *out = q;
     return RDR_OK;
 }
@@ -634,6 +639,7 @@ int rdr_cube_blend(rdr_ctx* c, const rdr_cube* a, double w1, const rdr_cube* b, 
                                (const double2*)b->d_vals, w2, (double2*)q->d_vals, total);
     }
     hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) { rdr_cube_destroy(q); return fail(c, RDR_ERR_HIP, hipGetErrorString(e)); }
     *out = q;
     return RDR_OK;

@@ -43,6 +43,7 @@ class Cube:
             dt = L.RDR_F32 if wet.dtype == torch.float32 else L.RDR_F64
             shape = tuple(wet.shape)
             assert wet.is_contiguous() and hydro.is_contiguous()
+            self.ctx.adopt_torch_stream(wet)
         ny, nx, nz = ys.size, xs.size, zs.size
         if order == 'yxz':
             want = (ny, nx, nz)
@@ -94,6 +95,7 @@ class Cube:
         """scipy RGI __call__ on both fields; pts[...,3] = (y,x,z).  Returns (wet, hydro) f64."""
         if _is_dev(pts):
             import torch
+            self.ctx.adopt_torch_stream(pts)
             n = pts.numel() // 3
             wet = torch.empty(pts.shape[:-1], dtype=torch.float64, device=pts.device)
             hyd = torch.empty_like(wet)
@@ -112,6 +114,7 @@ class Cube:
         """_build_cube (delay.py:196-216): (wet, hydro) of shape (nz, ny, nx)."""
         if _is_dev(xpts):
             import torch
+            self.ctx.adopt_torch_stream(xpts)
             nx, ny, nz = xpts.numel(), ypts.numel(), zpts.numel()
             wet, hyd = out if out is not None else (torch.empty((nz, ny, nx), dtype=torch.float64, device=xpts.device),
                                                     torch.empty((nz, ny, nx), dtype=torch.float64, device=xpts.device))
@@ -134,6 +137,7 @@ class Cube:
         return lo[:K.value].copy(), hi[:K.value].copy(), kz[:K.value].copy()
 
     def ray_prepass(self, rays, ht, zref):
+        rays.adopt_stream(self.ctx)
         K = len(self.ray_levels(ht, zref)[0])
         maxlen = np.zeros(K)
         flags = C.c_int32()
@@ -142,6 +146,7 @@ class Cube:
         return maxlen, flags.value
 
     def ray_march(self, rays, ht, zref, nparts, flags, out=None):
+        rays.adopt_stream(self.ctx)
         nparts = np.ascontiguousarray(nparts, dtype=np.int32)
         wet, hyd = out if out is not None else rays.empty_outputs()
         check(self.ctx.lib.rdr_ray_march(self.ctx.handle, self.handle, C.byref(rays.struct), float(ht), float(zref), ptr(nparts),
@@ -151,6 +156,7 @@ class Cube:
     def raytrace(self, rays, ht, zref, max_seg=1000.0, out=None, want_nparts=True):
         """One slice of _build_cube_ray (delay.py:256-323).  Returns (wet, hydro, nparts, flags);
         nparts/flags are None when want_nparts is False (fully asynchronous for device arrays)."""
+        rays.adopt_stream(self.ctx)
         wet, hyd = out if out is not None else rays.empty_outputs()
         if want_nparts:
             K = len(self.ray_levels(ht, zref)[0])
@@ -181,12 +187,14 @@ class Rays:
         self._keep = []
         self.shape = ()
         self._torch_device = None
+        self._keep_tensor = None
 
     def _set(self, field, arr):
         if arr is None:
             return
         if _is_dev(arr):
             self._torch_device = arr.device
+            self._keep_tensor = arr
             assert arr.is_contiguous()
             self._keep.append(arr)
             setattr(self.struct, field, arr.data_ptr())
@@ -256,6 +264,14 @@ class Rays:
             raise ValueError('a ray batch needs look vectors, inc/heading, or zenith=True')
         self.struct.loc = L.RDR_DEVICE if self._torch_device is not None else L.RDR_HOST
 
+    def adopt_stream(self, ctx):
+        """Device-resident batches run on torch's current stream (so they are ordered with the producer / consumer of
+        the tensors); host batches run on the context's private stream."""
+        if self._keep_tensor is not None:
+            ctx.adopt_torch_stream(self._keep_tensor)
+        else:
+            ctx.set_stream(-1)
+
     def empty_outputs(self):
         if self._torch_device is not None:
             import torch
@@ -265,6 +281,7 @@ class Rays:
 
     def look_vectors(self, ctx=None):
         ctx = ctx or Context.default()
+        self.adopt_stream(ctx)
         if self._torch_device is not None:
             import torch
             out = torch.empty(self.shape + (3,), dtype=torch.float64, device=self._torch_device)

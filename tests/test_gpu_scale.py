@@ -1,0 +1,256 @@
+"""GPU: BASELINE-sized workloads through size-independent properties + spot checks against the oracle, and the edge
+cases of the ray tracer (ragged tiles, tiny / non-uniform / descending axes, f64 cubes, origin & LOS modes, empty
+batches, NaN rays, workspace chunking)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import raider_oracle as O
+
+TIGHT = 1e-9
+
+
+@pytest.fixture(scope='module')
+def R():
+    import raider_amd
+    return raider_amd
+
+
+@pytest.fixture(scope='module')
+def era5():
+    return O.synthetic_cube(300, 300, 80, seed=0)
+
+
+def _scene(rows, cols):
+    xpts = np.linspace(-119.5, -115.5, cols)
+    ypts = np.linspace(34.5, 31.5, rows)
+    inc_cols = 30.0 + 16.0 * (np.arange(cols) / float(cols))
+    return xpts, ypts, inc_cols
+
+
+def _oracle_block(cube, xp, yp, inc_block, hd, zref, nparts, ht=0.0):
+    ip = list(O.getInterpolators(cube['xs'], cube['ys'], cube['zs'], cube['wet'], cube['hydro']))
+    look = lambda ht_, llh, xyz, yy: O.look_vectors_from_inc_hd(inc_block, np.full(yy.shape, hd), llh[1], llh[0], llh[2])
+    w, h = O.build_cube_ray(xp, yp, np.array([ht]), look, ip, MAX_TROPO_HEIGHT=zref, nParts_override=[nparts])
+    return w[0], h[0]
+
+
+def test_config3_full_size_properties(R, era5):
+    """configs[2]: 4000x4000 rays through the 300x300x80 cube.  (a) random blocks against the oracle driven with the
+    whole-slice partition; (b) chunked workspace == single-chunk workspace bit for bit; (c) exact linearity in the cube
+    (doubling f32 refractivities doubles every delay bit for bit); (d) two half scenes driven with the all-reduced
+    partition == the whole scene bit for bit."""
+    import torch
+    dev = torch.device('cuda')
+    ctx = R.Context.default()
+    rows = cols = 4000
+    xpts, ypts, inc_cols = _scene(rows, cols)
+    hd = -167.9
+    zref = float(era5['zs'].max() - 1)
+    cube = R.Cube(era5['ys'], era5['xs'], era5['zs'], era5['wet'], era5['hydro'], order='zyx')
+    xt, yt = torch.from_numpy(xpts).to(dev), torch.from_numpy(ypts).to(dev)
+    inc = torch.from_numpy(np.ascontiguousarray(np.broadcast_to(inc_cols, (rows, cols)))).to(dev)
+    hdt = torch.full((rows, cols), hd, dtype=torch.float64, device=dev)
+    rays = R.Rays.grid(xt, yt, inc=inc, hd=hdt)
+    wet, hyd, nparts, flags = cube.raytrace(rays, 0.0, zref)
+    torch.cuda.synchronize()
+    assert int(nparts.sum()) == 178 and len(nparts) == 76
+    wn, hn = wet.cpu().numpy(), hyd.cpu().numpy()
+    assert np.isfinite(wn).all() and np.isfinite(hn).all()
+    # (a) four 20x20 blocks (corners + interior)
+    for r0, c0 in ((0, 0), (rows - 20, cols - 20), (1234, 2777), (3000, 16)):
+        ow, oh = _oracle_block(era5, xpts[c0:c0 + 20], ypts[r0:r0 + 20], np.broadcast_to(inc_cols[c0:c0 + 20], (20, 20)), hd, zref, nparts)
+        np.testing.assert_allclose(wn[r0:r0 + 20, c0:c0 + 20], ow, rtol=0, atol=TIGHT)
+        np.testing.assert_allclose(hn[r0:r0 + 20, c0:c0 + 20], oh, rtol=0, atol=TIGHT)
+    # (b) chunked integration (1 GiB workspace -> 11 chunks)
+    ctx.set_workspace_limit(1 << 30)
+    try:
+        w2, h2, np2, _ = cube.raytrace(rays, 0.0, zref)
+        assert np.array_equal(np2, nparts)
+        assert torch.equal(w2, wet) and torch.equal(h2, hyd)
+    finally:
+        ctx.set_workspace_limit(48 << 30)
+    # (c) linearity
+    cube2 = R.Cube(era5['ys'], era5['xs'], era5['zs'], 2 * era5['wet'], 2 * era5['hydro'], order='zyx')
+    w3, h3, _, _ = cube2.raytrace(rays, 0.0, zref)
+    assert torch.equal(w3, 2 * wet) and torch.equal(h3, 2 * hyd)
+    # (d) halves with the all-reduced partition (what raider_amd.distributed does across ranks)
+    tops, parts = [], []
+    for sl in (slice(0, 2000), slice(2000, 4000)):
+        rr = R.Rays.grid(xt, yt[sl].contiguous(), inc=inc[sl].contiguous(), hd=hdt[sl].contiguous())
+        ml, fl = cube.ray_prepass(rr, 0.0, zref)
+        tops.append((rr, ml, fl))
+    gmax = np.maximum(tops[0][1], tops[1][1]); gfl = tops[0][2] | tops[1][2]
+    gnp = R.nparts_from_maxlen(gmax)
+    assert np.array_equal(gnp, nparts)
+    for (rr, _, _), sl in zip(tops, (slice(0, 2000), slice(2000, 4000))):
+        wh, hh = cube.ray_march(rr, 0.0, zref, gnp, gfl)
+        assert torch.equal(wh, wet[sl]) and torch.equal(hh, hyd[sl])
+
+
+def test_zenith_constant_refractivity_is_path_length(R, era5):
+    """N == 1, zenith look vectors: delay*1e6 == zref - ht (the ray runs along the ellipsoid normal)."""
+    ones = np.ones_like(era5['wet'])
+    cube = R.Cube(era5['ys'], era5['xs'], era5['zs'], ones, ones, order='zyx')
+    xpts, ypts, _ = _scene(1000, 1000)
+    zref = 30000.0
+    for ht in (0.0, 1234.5):
+        wet, hyd, _, _ = cube.raytrace(R.Rays.grid(xpts, ypts, zenith=True), ht, zref)
+        np.testing.assert_allclose(wet * 1e6, zref - ht, rtol=0, atol=2e-4)
+        assert np.array_equal(wet, hyd)
+
+
+def test_config2_conventional_1000(R, era5):
+    """configs[1]: 1000x1000 ZTD gather on the f64 totals cube, then /cos(inc); sample rows against the oracle."""
+    tot = R.Cube(era5['ys'], era5['xs'], era5['zs'], era5['wet_total'], era5['hydro_total'], order='zyx')
+    xpts, ypts, _ = _scene(1000, 1000)
+    zpts = np.array([0.0, 150.0, 2999.0])
+    wet, hyd = tot.build_cube(xpts, ypts, zpts)
+    it = list(O.getInterpolators(era5['xs'], era5['ys'], era5['zs'], era5['wet_total'], era5['hydro_total']))
+    for r in (0, 499, 999):
+        ow, oh = O.build_cube(xpts, ypts[r:r + 1], zpts, it)
+        np.testing.assert_allclose(wet[:, r:r + 1], ow, rtol=0, atol=1e-14)
+        np.testing.assert_allclose(hyd[:, r:r + 1], oh, rtol=0, atol=1e-14)
+    from raider_amd.losreader import Conventional
+    conv = Conventional(inc=np.full((1000, 1000), 39.0), heading=np.full((1000, 1000), -167.9))
+    conv.setPoints(np.zeros((1000, 1000)), np.zeros((1000, 1000)), np.zeros((1000, 1000)))
+    np.testing.assert_allclose(conv(hyd[0]), hyd[0] / np.cos(np.radians(39.0)), rtol=1e-15)
+
+
+def test_config5_blend_and_stations(R):
+    """configs[4]-like: HRRR-sized 1000x1000x50 f32 cubes, two-epoch blend, 5 M station points (sampled check):
+    gather(blend) == the oracle RGI on the f32-blended cube; and == w1*gather(a)+w2*gather(b) to f32 rounding."""
+    rng = np.random.default_rng(3)
+    ys = np.linspace(30, 45, 1000); xs = np.linspace(-125, -100, 1000); zs = np.round(-100 + 26100 * np.linspace(0, 1, 50) ** 2, 3)
+    base = 300 * np.exp(-zs / 8000)[:, None, None]
+    e = [(base * (1 + 0.05 * rng.standard_normal((50, 1000, 1000)))).astype(np.float32) for _ in range(4)]
+    a = R.Cube(ys, xs, zs, e[0], e[1], order='zyx'); b = R.Cube(ys, xs, zs, e[2], e[3], order='zyx')
+    w1, w2 = O.time_weights(2700.0, 0.0, 3600.0)
+    m = a.blend(w1, b, w2)
+    n = 5_000_000
+    pts = np.stack([rng.uniform(30.5, 44.5, n), rng.uniform(-124, -101, n), rng.uniform(0, 4000, n)], -1)
+    gw, gh = m.interp(pts)
+    assert np.isfinite(gw).all()
+    idx = rng.choice(n, 20000, replace=False)
+    bw = O.blend_cubes(w1, e[0], w2, e[2]); bh = O.blend_cubes(w1, e[1], w2, e[3])
+    iw, ih = O.getInterpolators(xs, ys, zs, bw, bh)
+    np.testing.assert_allclose(gw[idx], iw(pts[idx]), rtol=0, atol=1e-11)
+    np.testing.assert_allclose(gh[idx], ih(pts[idx]), rtol=0, atol=1e-11)
+    aw, _ = a.interp(pts[idx]); cw, _ = b.interp(pts[idx])
+    np.testing.assert_allclose(gw[idx], w1 * aw + w2 * cw, rtol=3e-7)
+
+
+# ---- edge cases -----------------------------------------------------------------------------------------------
+def _small_cube(ny=9, nx=11, nz=12, seed=2, **kw):
+    return O.synthetic_cube(ny, nx, nz, seed=seed, y0=31.0, y1=35.0, x0=-120.0, x1=-115.0, **kw)
+
+
+def _check_against_oracle(R, c, xpts, ypts, inc, hd, ht, zref, cube=None, max_seg=1000.0):
+    cube = cube or R.Cube(c['ys'], c['xs'], c['zs'], c['wet'], c['hydro'], order='zyx')
+    ip = list(O.getInterpolators(c['xs'], c['ys'], c['zs'], c['wet'], c['hydro']))
+    incb = np.broadcast_to(np.asarray(inc, float), (len(ypts), len(xpts)))
+    look = lambda ht_, llh, xyz, yy: O.look_vectors_from_inc_hd(incb, np.full(yy.shape, hd), llh[1], llh[0], llh[2])
+    (ow, oh), onp = O.build_cube_ray(xpts, ypts, np.array([ht]), look, ip, MAX_SEGMENT_LENGTH=max_seg, MAX_TROPO_HEIGHT=zref, return_nparts=True)
+    wet, hyd, nparts, _ = cube.raytrace(R.Rays.grid(xpts, ypts, inc=incb.copy(), hd=hd), ht, zref, max_seg=max_seg)
+    assert np.array_equal(nparts, onp[0])
+    np.testing.assert_allclose(wet, ow[0], rtol=0, atol=TIGHT, equal_nan=True)
+    np.testing.assert_allclose(hyd, oh[0], rtol=0, atol=TIGHT, equal_nan=True)
+    return wet, hyd
+
+
+@pytest.mark.parametrize('shape', [(1, 1), (1, 37), (17, 1), (16, 16), (33, 47)])
+def test_ragged_scene_shapes(R, shape):
+    c = _small_cube()
+    ny, nx = shape
+    _check_against_oracle(R, c, np.linspace(-118.5, -116.5, nx), np.linspace(33.9, 32.1, ny), 35.0, -167.9, 10.0, c['zs'].max() - 1)
+
+
+def test_tiny_and_nonuniform_axes(R):
+    """3-node axes (window search falls back to bisection), non-uniform x/y axes (bisection path), descending y."""
+    c = _small_cube(ny=3, nx=3, nz=3)
+    _check_against_oracle(R, c, np.linspace(-118.5, -116.5, 5), np.linspace(33.9, 32.1, 4), 30.0, -12.1, 0.0, c['zs'].max() - 1)
+    c = _small_cube()
+    rng = np.random.default_rng(0)
+    c['xs'] = np.sort(-120 + 5 * rng.uniform(0, 1, 11)); c['xs'][0] = -120; c['xs'][-1] = -115
+    c['ys'] = np.sort(31 + 4 * rng.uniform(0, 1, 9)); c['ys'][0] = 31; c['ys'][-1] = 35
+    _check_against_oracle(R, c, np.linspace(-118.5, -116.5, 9), np.linspace(33.9, 32.1, 8), 40.0, -167.9, 0.0, c['zs'].max() - 1)
+    # descending y axis in the file (scipy flips; so does the device pack kernel)
+    d = dict(c); d['ys'] = c['ys'][::-1].copy(); d['wet'] = c['wet'][:, ::-1].copy(); d['hydro'] = c['hydro'][:, ::-1].copy()
+    w1, h1 = _check_against_oracle(R, d, np.linspace(-118.5, -116.5, 9), np.linspace(33.9, 32.1, 8), 40.0, -167.9, 0.0, c['zs'].max() - 1)
+    w0, h0 = _check_against_oracle(R, c, np.linspace(-118.5, -116.5, 9), np.linspace(33.9, 32.1, 8), 40.0, -167.9, 0.0, c['zs'].max() - 1)
+    assert np.array_equal(w0, w1) and np.array_equal(h0, h1)
+
+
+def test_f64_cube_and_other_maxseg(R):
+    c = _small_cube(nz=30)
+    c64 = dict(c); c64['wet'] = c['wet'].astype(np.float64) * 1.000000123; c64['hydro'] = c['hydro'].astype(np.float64) * 0.999999877
+    _check_against_oracle(R, c64, np.linspace(-118.5, -116.5, 13), np.linspace(33.9, 32.1, 10), 25.0, 12.0, 300.0, 26000.0, max_seg=250.0)
+    _check_against_oracle(R, c64, np.linspace(-118.5, -116.5, 13), np.linspace(33.9, 32.1, 10), 50.0, 170.0, -50.0, 9000.0, max_seg=3000.0)
+
+
+def test_origin_and_los_modes_agree(R):
+    """GRID / LLH / XYZ origins and vector / per-ray inc-heading / scalar inc-heading look vectors: same rays, same bits."""
+    c = _small_cube(nz=20)
+    cube = R.Cube(c['ys'], c['xs'], c['zs'], c['wet'], c['hydro'], order='zyx')
+    xp = np.linspace(-118.5, -116.5, 19); yp = np.linspace(33.9, 32.1, 14)
+    xx, yy = np.meshgrid(xp, yp)
+    ht, zref = 120.0, c['zs'].max() - 1
+    ref = cube.raytrace(R.Rays.grid(xp, yp, inc=37.0, hd=-167.9), ht, zref)
+    los = R.Rays.grid(xp, yp, inc=37.0, hd=-167.9).look_vectors()
+    np.testing.assert_allclose(los, O.look_vectors_from_inc_hd(np.full(yy.shape, 37.0), np.full(yy.shape, -167.9), yy, xx, ht), rtol=0, atol=1e-15)
+    xyz = np.stack(O.lla2ecef(yy, xx, np.full(yy.shape, ht)), -1)
+    variants = [
+        R.Rays.grid(xp, yp, inc=np.full(yy.shape, 37.0), hd=np.full(yy.shape, -167.9)),
+        R.Rays.grid(xp, yp, los=los),
+        R.Rays.points(lat=yy.copy(), lon=xx.copy(), inc=37.0, hd=-167.9),
+        R.Rays.points(lat=yy.copy(), lon=xx.copy(), los=los),
+    ]
+    for rays in variants:
+        w, h, npx, _ = cube.raytrace(rays, ht, zref)
+        assert np.array_equal(npx, ref[2])
+        np.testing.assert_allclose(w, ref[0], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(h, ref[1], rtol=0, atol=1e-12)
+    # ECEF origins (1 ulp away from the device's own lla2ecef) with explicit look vectors
+    w, h, npx, _ = cube.raytrace(R.Rays.points(xyz=xyz, los=los), ht, zref)
+    np.testing.assert_allclose(w, ref[0], rtol=0, atol=1e-11)
+    np.testing.assert_allclose(h, ref[1], rtol=0, atol=1e-11)
+
+
+def test_empty_and_nan_batches(R):
+    c = _small_cube()
+    cube = R.Cube(c['ys'], c['xs'], c['zs'], c['wet'], c['hydro'], order='zyx')
+    zref = c['zs'].max() - 1
+    w, h, _, _ = cube.raytrace(R.Rays.points(lat=np.zeros(0), lon=np.zeros(0), inc=30.0, hd=0.0), 0.0, zref)
+    assert w.shape == (0,) and h.shape == (0,)
+    gw, gh = cube.interp(np.zeros((0, 3)))
+    assert gw.shape == (0,)
+    xp = np.linspace(-118.5, -116.5, 8); yp = np.linspace(33.9, 32.1, 6)
+    los = R.Rays.grid(xp, yp, inc=30.0, hd=0.0).look_vectors()
+    los[2, 3] = np.nan                                     # ONE failed geo2rdr pixel: the reference's nParts is undefined
+    with pytest.raises(ValueError):
+        cube.raytrace(R.Rays.grid(xp, yp, los=los), 0.0, zref)
+    # ...but the explicit-partition path still integrates every other ray and leaves NaN in that pixel
+    good = R.Rays.grid(xp, yp, inc=30.0, hd=0.0)
+    ml, fl = cube.ray_prepass(good, 0.0, zref)
+    w, h = cube.ray_march(R.Rays.grid(xp, yp, los=los), 0.0, zref, R.nparts_from_maxlen(ml), fl)
+    assert np.isnan(w[2, 3]) and np.isnan(h[2, 3]) and np.isfinite(np.delete(w.ravel(), 2 * 8 + 3)).all()
+    ref = cube.raytrace(good, 0.0, zref)
+    mask = np.ones(w.shape, bool); mask[2, 3] = False
+    np.testing.assert_allclose(w[mask], ref[0][mask], rtol=0, atol=1e-12)
+
+
+def test_bottom_clamp_quirk(R):
+    """ht == min(model_zs): the first sample sits on the cube floor +- 1e-9 m; when EVERY pixel's sample is below it the
+    reference clamps them to zmin (delay.py:306-307), otherwise the pixels below get NaN.  Which one happens is decided
+    by round-off in the reference too; here: the kernel's own flag decides, and results are finite or NaN accordingly."""
+    c = _small_cube()
+    cube = R.Cube(c['ys'], c['xs'], c['zs'], c['wet'], c['hydro'], order='zyx')
+    xp = np.linspace(-118.5, -116.5, 8); yp = np.linspace(33.9, 32.1, 6)
+    rays = R.Rays.grid(xp, yp, inc=30.0, hd=0.0)
+    zmin = float(c['zs'].min())
+    ml, fl = cube.ray_prepass(rays, zmin, c['zs'].max() - 1)
+    w, h = cube.ray_march(rays, zmin, c['zs'].max() - 1, R.nparts_from_maxlen(ml), fl & ~4)      # force "all below" -> clamp
+    assert np.isfinite(w).all()
+    ref = cube.raytrace(R.Rays.grid(xp, yp, inc=30.0, hd=0.0), zmin + 1e-3, c['zs'].max() - 1)
+    np.testing.assert_allclose(h, ref[1], rtol=0, atol=1e-6)
