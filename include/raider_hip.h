@@ -116,6 +116,16 @@ void rdr_cube_destroy(rdr_cube* cube);
 int rdr_cube_shape(const rdr_cube* cube, int64_t* ny, int64_t* nx, int64_t* nz, int* dtype);
 /* ascending copies of the axes as the interpolator's `.grid` exposes them (delay.py:239) */
 int rdr_cube_axes(const rdr_cube* cube, double* ys, double* xs, double* zs);
+/* Projected weather models (HRRR Lambert conformal conic, models/hrrr.py:248-259): tell the cube that its x/y axes are
+ * projected metres.  Every entry point that takes GEODETIC query coordinates (rdr_build_cube's xpts/ypts = lon/lat,
+ * the ray tracer's samples) then applies geodetic -> model CRS on the device - the pyproj step of delay.py:207-209,253,295.
+ * kind RDR_PROJ_LCC, params = {a, es, lat_1, lat_2, lat_0, lon_0, x_0, y_0} (m, -, deg, deg, deg, deg, m, m); es = 0 for
+ * HRRR's sphere (a = 6371229).  rdr_interp3 keeps taking points already in cube coordinates (scipy semantics). */
+#define RDR_PROJ_LONLAT 0
+#define RDR_PROJ_LCC 1
+int rdr_cube_set_projection(rdr_cube* cube, int kind, const double* params, int nparams);
+/* transformPoints (delay.py:404-436) for EPSG:4326 -> the cube's CRS: (lat, lon) deg -> (y, x) model coordinates */
+int rdr_project_points(rdr_ctx* ctx, const rdr_cube* cube, const double* lat, const double* lon, int64_t n, double* y, double* x, int loc);
 /* temporal blend, cli/raider.py:817-819: out = w1*a + w2*b (f32 cubes blend in f32, f64 in f64) */
 int rdr_cube_blend(rdr_ctx* ctx, const rdr_cube* a, double w1, const rdr_cube* b, double w2, rdr_cube** out);
 /* copy the (blended) fields back, (y,x,z) C-order, dtype of the cube */

@@ -159,6 +159,32 @@ def look_vectors_from_inc_hd(inc, hd, lat, lon, ht):
     return enu2ecef(enu[..., 0], enu[..., 1], enu[..., 2], lat, lon, ht)
 
 
+def lcc_forward(lat, lon, lat_1, lat_2, lat_0, lon_0, x_0=0.0, y_0=0.0, a=6371229.0, es=0.0):
+    """Geodetic -> Lambert conformal conic, what pyproj does for a projected model CRS (HRRR: models/hrrr.py:248-259;
+    call sites delay.py:207-209,253,295).  Restates PROJ's published `lcc` (Snyder 15-1..15-4); PARITY WITH PROJ ITSELF
+    IS UNPINNED (pyproj is not installed here).  Returns (x, y)."""
+    e = np.sqrt(es)
+
+    def tsfn(phi):
+        s_ = np.sin(phi)
+        t_ = np.tan(0.5 * (np.pi / 2 - phi))
+        return t_ / ((1 - e * s_) / (1 + e * s_)) ** (0.5 * e) if e != 0 else t_
+
+    def msfn(phi):
+        return np.cos(phi) / np.sqrt(1 - es * np.sin(phi) ** 2)
+    p1, p2, p0 = np.radians(lat_1), np.radians(lat_2), np.radians(lat_0)
+    if abs(p1 - p2) >= 1e-10:
+        n = np.log(msfn(p1) / msfn(p2)) / np.log(tsfn(p1) / tsfn(p2))
+    else:
+        n = np.sin(p1)
+    F = msfn(p1) * tsfn(p1) ** (-n) / n
+    rho0 = a * F * tsfn(p0) ** n
+    dlam = np.radians(np.asarray(lon, dtype=np.float64)) - np.radians(lon_0)
+    dlam = np.where(dlam > np.pi, dlam - 2 * np.pi, np.where(dlam < -np.pi, dlam + 2 * np.pi, dlam))
+    rho = a * F * tsfn(np.radians(np.asarray(lat, dtype=np.float64))) ** n
+    return x_0 + rho * np.sin(n * dlam), y_0 + rho0 - rho * np.cos(n * dlam)
+
+
 # ----------------------------------------------------------------------------------------------
 # scipy RegularGridInterpolator (linear, bounds_error=False, fill_value=nan) restated
 #   call sites: delayFcns.py:55-56, delay.py:214,319,120-121
@@ -293,11 +319,15 @@ def nparts_from_lengths(ray_lengths, MAX_SEGMENT_LENGTH=1000.0):
 # ----------------------------------------------------------------------------------------------
 # cube builders
 # ----------------------------------------------------------------------------------------------
-def build_cube(xpts, ypts, zpts, interpolators):
-    """delay.py:196-216 for model_crs == pts_crs (EPSG:4326 cube)."""
+def build_cube(xpts, ypts, zpts, interpolators, model_proj=None):
+    """delay.py:196-216.  model_proj=None: model_crs == pts_crs (EPSG:4326 cube); else a dict of lcc_forward keyword
+    arguments = the `transformPoints(yy, xx, ht, pts_crs, model_crs)` branch (delay.py:207-209) for an LCC model."""
     xx, yy = np.meshgrid(xpts, ypts)
     zpts = np.asarray(zpts)
     out = [np.zeros((zpts.size, len(ypts), len(xpts))) for _ in interpolators]
+    if model_proj is not None:
+        px, py = lcc_forward(yy, xx, **model_proj)
+        xx, yy = px, py
     for ii, ht in enumerate(zpts):
         pts = np.stack([yy, xx, np.full(yy.shape, ht)], axis=-1)
         for mm, intp in enumerate(interpolators):
@@ -305,8 +335,8 @@ def build_cube(xpts, ypts, zpts, interpolators):
     return out
 
 
-def integrate_slice(model_zs, ray_lengths, low_xyzs, high_xyzs, nParts, interpolators, outSubs):
-    """delay.py:285-323: the sample loop for one slice (EPSG:4326 model cube)."""
+def integrate_slice(model_zs, ray_lengths, low_xyzs, high_xyzs, nParts, interpolators, outSubs, model_proj=None):
+    """delay.py:285-323: the sample loop for one slice (EPSG:4326 model cube, or an LCC one via model_proj)."""
     zmin = np.array(model_zs).min()
     zmax = np.array(model_zs).max()
     for zz, nparts in enumerate(nParts):
@@ -314,6 +344,8 @@ def integrate_slice(model_zs, ray_lengths, low_xyzs, high_xyzs, nParts, interpol
         for findex, ff in enumerate(fracs):
             pts_xyz = low_xyzs[zz] + ff * (high_xyzs[zz] - low_xyzs[zz])
             lon, lat, h = ecef2lla(pts_xyz[..., 0], pts_xyz[..., 1], pts_xyz[..., 2])
+            if model_proj is not None:      # ecef_to_model = ECEF -> geodetic -> model CRS (delay.py:253,295)
+                lon, lat = lcc_forward(lat, lon, **model_proj)
             pts = np.stack((lat, lon, h), axis=-1)
             if (pts[..., -1] < zmin).all():
                 pts[..., -1] = zmin
@@ -327,7 +359,7 @@ def integrate_slice(model_zs, ray_lengths, low_xyzs, high_xyzs, nParts, interpol
 
 
 def build_cube_ray(xpts, ypts, zpts, look_fn, interpolators, MAX_SEGMENT_LENGTH=1000.0,
-                   MAX_TROPO_HEIGHT=_ZREF, nParts_override=None, return_nparts=False):
+                   MAX_TROPO_HEIGHT=_ZREF, nParts_override=None, return_nparts=False, model_proj=None):
     """delay.py:219-326 for an EPSG:4326 cube and EPSG:4326 query grid.
 
     `look_fn(ht, llh, xyz, yy) -> (ny,nx,3)` plays `los.getLookVectors` (delay.py:270).
@@ -354,7 +386,7 @@ def build_cube_ray(xpts, ypts, zpts, look_fn, interpolators, MAX_SEGMENT_LENGTH=
         else:
             nParts = nparts_from_lengths(ray_lengths, MAX_SEGMENT_LENGTH)
         all_nparts.append(nParts)
-        integrate_slice(model_zs, ray_lengths, low_xyzs, high_xyzs, nParts, interpolators, outSubs)
+        integrate_slice(model_zs, ray_lengths, low_xyzs, high_xyzs, nParts, interpolators, outSubs, model_proj)
     if return_nparts:
         return outputArrs, all_nparts
     return outputArrs

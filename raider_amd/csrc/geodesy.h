@@ -110,4 +110,56 @@ RDR_HD void inc_hd_to_ecef(double inc_deg, double hd_deg, double lat_deg, double
     v = slo * t + clo * east;
 }
 
+// ---- Lambert conformal conic (PROJ `lcc`, Snyder 15-1..15-4 / 14-1..14-4 for the sphere) ---------------------------
+// Replaces pyproj's geodetic -> model-CRS step for projected weather models (HRRR: models/hrrr.py:248-259;
+// call sites delay.py:207-209,253,295).  Host code derives n, a*F and rho0 once (lcc_setup); the device evaluates
+// rho = a F t(phi)^n, theta = n (lam - lam0), x = x0 + rho sin(theta), y = y0 + rho0 - rho cos(theta).
+struct LccParams {
+    int kind;                 // 0 = cube is on lon/lat (no projection), 1 = LCC
+    double n, aF, rho0;       // cone constant, a*F, radius of the origin parallel
+    double lam0, x0, y0;      // central meridian (rad), false easting / northing (m)
+    double e;                 // first eccentricity (0 for a sphere)
+};
+
+inline double lcc_tsfn(double phi, double e) {       // PROJ pj_tsfn
+    const double s = sin(phi);
+    double t = tan(0.5 * (1.5707963267948966 - phi));
+    if (e != 0.0) t /= pow((1.0 - e * s) / (1.0 + e * s), 0.5 * e);
+    return t;
+}
+
+inline LccParams lcc_setup(double a, double es, double lat1_deg, double lat2_deg, double lat0_deg, double lon0_deg, double x0, double y0) {
+    LccParams L;
+    L.kind = 1; L.e = sqrt(es); L.x0 = x0; L.y0 = y0; L.lam0 = lon0_deg * DEG_TO_RAD;
+    const double p1 = lat1_deg * DEG_TO_RAD, p2 = lat2_deg * DEG_TO_RAD, p0 = lat0_deg * DEG_TO_RAD;
+    const double m1 = cos(p1) / sqrt(1.0 - es * sin(p1) * sin(p1));
+    const double t1 = lcc_tsfn(p1, L.e);
+    if (fabs(p1 - p2) >= 1e-10) {
+        const double m2 = cos(p2) / sqrt(1.0 - es * sin(p2) * sin(p2));
+        L.n = log(m1 / m2) / log(t1 / lcc_tsfn(p2, L.e));
+    } else {
+        L.n = sin(p1);
+    }
+    const double F = m1 * pow(t1, -L.n) / L.n;
+    L.aF = a * F;
+    L.rho0 = (fabs(fabs(p0) - 1.5707963267948966) < 1e-10) ? 0.0 : L.aF * pow(lcc_tsfn(p0, L.e), L.n);
+    return L;
+}
+
+RDR_HD void lcc_forward(const LccParams& L, double lat_deg, double lon_deg, double& x, double& y) {
+    const double phi = lat_deg * DEG_TO_RAD;
+    double dlam = lon_deg * DEG_TO_RAD - L.lam0;
+    // PROJ reduces lam - lam0 to (-pi, pi]
+    if (dlam > 3.141592653589793) dlam -= 6.283185307179586;
+    else if (dlam < -3.141592653589793) dlam += 6.283185307179586;
+    const double s = sin(phi);
+    double t = tan(0.5 * (1.5707963267948966 - phi));
+    if (L.e != 0.0) t /= pow((1.0 - L.e * s) / (1.0 + L.e * s), 0.5 * L.e);
+    const double rho = L.aF * pow(t, L.n);
+    double st, ct;
+    sincos(L.n * dlam, &st, &ct);
+    x = L.x0 + rho * st;
+    y = L.y0 + L.rho0 - rho * ct;
+}
+
 }  // namespace rdr

@@ -58,6 +58,7 @@ struct rdr_cube {
     std::vector<double> ys, xs, zs;
     int uni[3] = {0, 0, 0};
     double inv_d[3] = {0, 0, 0};
+    LccParams proj = {0, 0, 0, 0, 0, 0, 0, 0};   // kind 0: the cube axes are lon/lat degrees
 };
 
 static int fail(rdr_ctx* ctx, int code, const std::string& msg) {
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(256) void interp_points_kernel(CubeView<T2> c, cons
 
 // _build_cube (delay.py:196-216): points generated on the fly from (xpts, ypts, zpts)
 template <typename T2>
-__global__ __launch_bounds__(256) void build_cube_kernel(CubeView<T2> c, const double* __restrict__ xpts, int64_t nx,
+__global__ __launch_bounds__(256) void build_cube_kernel(CubeView<T2> c, LccParams proj, const double* __restrict__ xpts, int64_t nx,
                                                          const double* __restrict__ ypts, int64_t ny,
                                                          const double* __restrict__ zpts, int64_t nz,
                                                          double* __restrict__ wet, double* __restrict__ hyd) {
@@ -202,8 +203,9 @@ __global__ __launch_bounds__(256) void build_cube_kernel(CubeView<T2> c, const d
     const int64_t n = nx * ny * nz;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t ix = i % nx, r = i / nx, iy = r % ny, iz = r / ny;
-        double w, h;
-        trilinear(c, s_y, s_x, s_z, ypts[iy], xpts[ix], zpts[iz], -1, w, h);
+        double w, h, qy = ypts[iy], qx = xpts[ix];
+        if (proj.kind == 1) { double px_, py_; lcc_forward(proj, qy, qx, px_, py_); qx = px_; qy = py_; }   // transformPoints, delay.py:207-209
+        trilinear(c, s_y, s_x, s_z, qy, qx, zpts[iz], -1, w, h);
         wet[i] = w; hyd[i] = h;
     }
 }
@@ -212,6 +214,14 @@ __global__ void project_kernel(double* wet, double* hyd, const double* __restric
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const double up = cos(inc[i] * DEG_TO_RAD);   // inc_hd_to_enu(...)[..., -1] = cosd(inc)
         wet[i] = wet[i] / up; hyd[i] = hyd[i] / up;
+    }
+}
+
+__global__ void lcc_kernel(LccParams proj, const double* __restrict__ lat, const double* __restrict__ lon, int64_t n,
+                           double* __restrict__ y, double* __restrict__ x) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        double px, py; lcc_forward(proj, lat[i], lon[i], px, py);
+        x[i] = px; y[i] = py;
     }
 }
 
@@ -617,6 +627,41 @@ int rdr_cube_axes(const rdr_cube* q, double* ys, double* xs, double* zs) {
     return RDR_OK;
 }
 
+int rdr_cube_set_projection(rdr_cube* q, int kind, const double* p, int np) {
+    if (!q) return fail(nullptr, RDR_ERR_INVALID, "cube is NULL");
+    if (kind == RDR_PROJ_LONLAT) { q->proj = LccParams{0, 0, 0, 0, 0, 0, 0, 0}; return RDR_OK; }
+    if (kind != RDR_PROJ_LCC || !p || np < 8) return fail(q->ctx, RDR_ERR_INVALID, "rdr_cube_set_projection: LCC needs 8 parameters (a, es, lat_1, lat_2, lat_0, lon_0, x_0, y_0)");
+    if (!(p[0] > 0) || p[1] < 0 || p[1] >= 1 || std::fabs(p[2]) >= 90 || std::fabs(p[3]) >= 90 || std::fabs(p[2] + p[3]) < 1e-10)
+        return fail(q->ctx, RDR_ERR_INVALID, "rdr_cube_set_projection: invalid LCC parameters");
+    q->proj = lcc_setup(p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7]);
+    return RDR_OK;
+}
+
+int rdr_project_points(rdr_ctx* c, const rdr_cube* q, const double* lat, const double* lon, int64_t n, double* y, double* x, int loc) {
+    if (!c || !q || !lat || !lon || !y || !x) return fail(c, RDR_ERR_INVALID, "rdr_project_points: NULL argument");
+    if (n == 0) return RDR_OK;
+    HIPCHECK(c, hipSetDevice(c->device));
+    if (q->proj.kind == 0) {     // lon/lat cube: identity
+        const hipMemcpyKind k = loc == RDR_HOST ? hipMemcpyHostToHost : hipMemcpyDeviceToDevice;
+        HIPCHECK(c, hipMemcpyAsync(y, lat, (size_t)n * 8, k, c->stream));
+        HIPCHECK(c, hipMemcpyAsync(x, lon, (size_t)n * 8, k, c->stream));
+        if (loc == RDR_HOST) HIPCHECK(c, hipStreamSynchronize(c->stream));
+        return RDR_OK;
+    }
+    const void *a, *b; void *oy, *ox;
+    int rc = stage_in(c, SLOT_IN0, lat, (size_t)n * 8, loc, &a); if (rc) return rc;
+    rc = stage_in(c, SLOT_IN1, lon, (size_t)n * 8, loc, &b); if (rc) return rc;
+    rc = stage_out(c, SLOT_OUT0, y, (size_t)n * 8, loc, &oy); if (rc) return rc;
+    rc = stage_out(c, SLOT_OUT1, x, (size_t)n * 8, loc, &ox); if (rc) return rc;
+    hipLaunchKernelGGL(lcc_kernel, dim3(grid_for(n, 256, c->num_cus * 8)), dim3(256), 0, c->stream, q->proj, (const double*)a, (const double*)b, n,
+                       (double*)oy, (double*)ox);
+    HIPCHECK(c, hipGetLastError());
+    rc = finish_out(c, y, oy, (size_t)n * 8, loc); if (rc) return rc;
+    rc = finish_out(c, x, ox, (size_t)n * 8, loc); if (rc) return rc;
+    if (loc == RDR_HOST) HIPCHECK(c, hipStreamSynchronize(c->stream));
+    return RDR_OK;
+}
+
 int rdr_cube_blend(rdr_ctx* c, const rdr_cube* a, double w1, const rdr_cube* b, double w2, rdr_cube** out) {
     if (!c || !a || !b || !out) return fail(c, RDR_ERR_INVALID, "rdr_cube_blend: NULL argument");
     if (a->ny != b->ny || a->nx != b->nx || a->nz != b->nz || a->dtype != b->dtype || a->ys != b->ys || a->xs != b->xs || a->zs != b->zs)
@@ -624,7 +669,7 @@ int rdr_cube_blend(rdr_ctx* c, const rdr_cube* a, double w1, const rdr_cube* b, 
     HIPCHECK(c, hipSetDevice(c->device));
     rdr_cube* q = new rdr_cube();
     q->ctx = c; q->ny = a->ny; q->nx = a->nx; q->nz = a->nz; q->dtype = a->dtype;
-    q->ys = a->ys; q->xs = a->xs; q->zs = a->zs;
+    q->ys = a->ys; q->xs = a->xs; q->zs = a->zs; q->proj = a->proj;
     int rc = cube_alloc(c, q);
     if (rc) { rdr_cube_destroy(q); return rc; }
     const int64_t total = a->ny * a->nx * a->nz;
@@ -707,10 +752,10 @@ int rdr_build_cube(rdr_ctx* c, const rdr_cube* q, const double* xpts, int64_t nx
     {
         KTimer t(c, 2);
         if (q->dtype == RDR_F32)
-            hipLaunchKernelGGL((build_cube_kernel<float2>), dim3(g), dim3(256), axes_smem(q), c->stream, make_view<float2>(q),
+            hipLaunchKernelGGL((build_cube_kernel<float2>), dim3(g), dim3(256), axes_smem(q), c->stream, make_view<float2>(q), q->proj,
                                (const double*)dx, nx, (const double*)dy, ny, (const double*)dz, nz, (double*)dw, (double*)dh);
         else
-            hipLaunchKernelGGL((build_cube_kernel<double2>), dim3(g), dim3(256), axes_smem(q), c->stream, make_view<double2>(q),
+            hipLaunchKernelGGL((build_cube_kernel<double2>), dim3(g), dim3(256), axes_smem(q), c->stream, make_view<double2>(q), q->proj,
                                (const double*)dx, nx, (const double*)dy, ny, (const double*)dz, nz, (double*)dw, (double*)dh);
     }
     HIPCHECK(c, hipGetLastError());
@@ -817,7 +862,7 @@ static int stage_rays(rdr_ctx* c, const rdr_rays* r, RayParams& P) {
         P.ntiles = (r->n + BLOCK - 1) / BLOCK;
     }
     P.maxlen_bits = c->d_maxlen; P.flags = c->d_flags;
-    P.ws = nullptr; P.nslots = 0; P.tile_begin = 0; P.tile_count = P.ntiles; P.nslow = c->d_nslow;
+    P.ws = nullptr; P.nslots = 0; P.tile_begin = 0; P.tile_count = P.ntiles; P.nslow = c->d_nslow; P.projected = 0;
     return RDR_OK;
 }
 
@@ -892,19 +937,19 @@ static int launch_crossings(rdr_ctx* c, const rdr_cube* q, RayParams P, int64_t 
 }
 
 static int launch_march(rdr_ctx* c, const rdr_cube* q, RayParams P, int64_t tb, int64_t tc) {
-    P.tile_begin = tb; P.tile_count = tc; P.nslots = tc * BLOCK;
+    P.tile_begin = tb; P.tile_count = tc; P.nslots = tc * BLOCK; P.projected = q->proj.kind != 0;
     const int g = ray_grid(c, tc);
     {
         KTimer t(c, 1);
         if (q->dtype == RDR_F32)
-            hipLaunchKernelGGL((march_kernel<float2, false>), dim3(g), dim3(BLOCK), ray_smem(q), c->stream, make_view<float2>(q), P);
+            hipLaunchKernelGGL((march_kernel<float2, false>), dim3(g), dim3(BLOCK), ray_smem(q), c->stream, make_view<float2>(q), P, q->proj);
         else
-            hipLaunchKernelGGL((march_kernel<double2, false>), dim3(g), dim3(BLOCK), ray_smem(q), c->stream, make_view<double2>(q), P);
+            hipLaunchKernelGGL((march_kernel<double2, false>), dim3(g), dim3(BLOCK), ray_smem(q), c->stream, make_view<double2>(q), P, q->proj);
     }
     if (q->dtype == RDR_F32)
-        hipLaunchKernelGGL((march_kernel<float2, true>), dim3(g), dim3(BLOCK), ray_smem(q), c->stream, make_view<float2>(q), P);
+        hipLaunchKernelGGL((march_kernel<float2, true>), dim3(g), dim3(BLOCK), ray_smem(q), c->stream, make_view<float2>(q), P, q->proj);
     else
-        hipLaunchKernelGGL((march_kernel<double2, true>), dim3(g), dim3(BLOCK), ray_smem(q), c->stream, make_view<double2>(q), P);
+        hipLaunchKernelGGL((march_kernel<double2, true>), dim3(g), dim3(BLOCK), ray_smem(q), c->stream, make_view<double2>(q), P, q->proj);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(c, RDR_ERR_HIP, std::string("march_kernel launch: ") + hipGetErrorString(e));
     return RDR_OK;

@@ -243,6 +243,7 @@ struct RayParams {
     int* flags;                        // RDR_FLAG_* bits (OR-reduced)
     const int* nparts_override;        // [K] or nullptr -> ceil(maxlen/max_seg)+1
     int* nslow;                        // number of rays the static classification sent to the generic (slow) kernels
+    int projected;                     // the cube is on a projected grid: every ray is integrated by the generic kernel
     // pass 1 -> pass 2 workspace (this launch covers tiles [tile_begin, tile_begin + tile_count))
     double* ws; int64_t nslots;
     int64_t tile_begin, tile_count;
@@ -462,8 +463,8 @@ __global__ __launch_bounds__(BLOCK) void crossings_kernel(CubeView<T2> c, RayPar
 // SLOW as in crossings_kernel: <false> integrates the classified-fast rays with the light geodesy, <true> the rest
 // with the generic one (and returns immediately when there are none).
 template <typename T2, bool SLOW>
-__global__ __launch_bounds__(BLOCK) void march_kernel(CubeView<T2> c, RayParams P) {
-    if (SLOW && *P.nslow == 0) return;
+__global__ __launch_bounds__(BLOCK) void march_kernel(CubeView<T2> c, RayParams P, LccParams proj) {
+    if (SLOW && *P.nslow == 0 && !P.projected) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const RaySmem m = carve_smem(smem_raw, c.ny, c.nx, c.nz);
     const int K = fill_tables(c, m, P.ht, P.zref);
@@ -500,7 +501,7 @@ __global__ __launch_bounds__(BLOCK) void march_kernel(CubeView<T2> c, RayParams 
         base.lat0 = w[(int64_t)WS_LAT0 * ns]; base.lon0 = w[(int64_t)WS_LON0 * ns];
         base.s0 = w[(int64_t)WS_S0 * ns]; base.c0 = w[(int64_t)WS_C0 * ns];
         base.sl0 = w[(int64_t)WS_SL0 * ns]; base.cl0 = w[(int64_t)WS_CL0 * ns];
-        const bool fast_ok = !active || w[(int64_t)WS_FAST * ns] != 0.0;
+        const bool fast_ok = !active || (w[(int64_t)WS_FAST * ns] != 0.0 && !P.projected);
         const bool mine = SLOW ? !fast_ok : fast_ok;
         if (SLOW && !__any(mine)) continue;
         const double nl2 = fma(lx, lx, fma(ly, ly, lz * lz));
@@ -528,8 +529,10 @@ __global__ __launch_bounds__(BLOCK) void march_kernel(CubeView<T2> c, RayParams 
             for (int j = (k == 0 ? 0 : 1); j < np; ++j) {
                 const double ts = fma((double)j, dts, t_lo);
                 double plon, plat, ph;
-                if (SLOW) ecef2lla(fma(ts, lx, ox), fma(ts, ly, oy), fma(ts, lz, oz), plon, plat, ph);
-                else ecef2lla_near(base, fma(ts, lx, ox), fma(ts, ly, oy), fma(ts, lz, oz), plon, plat, ph);   // delay.py:295
+                if (SLOW) {
+                    ecef2lla(fma(ts, lx, ox), fma(ts, ly, oy), fma(ts, lz, oz), plon, plat, ph);
+                    if (proj.kind == 1) { double px_, py_; lcc_forward(proj, plat, plon, px_, py_); plon = px_; plat = py_; }   // ecef_to_model, delay.py:253,295
+                } else ecef2lla_near(base, fma(ts, lx, ox), fma(ts, ly, oy), fma(ts, lz, oz), plon, plat, ph);   // delay.py:295
                 // all-pixels z-clamp of the very first / very last sample (delay.py:306-311): when it applies every
                 // pixel is below (above) the cube, so "set to zmin" == max(ph, zmin); the bounds are wave-uniform
                 const double zfloor = (clamp_lo && k == 0 && j == 0) ? c.z_lo : -__builtin_huge_val();

@@ -57,6 +57,56 @@ def _is_4326(crs):
     return _epsg(crs) == 4326
 
 
+def _lcc_params(crs):
+    """Lambert-conformal-conic parameters of a model CRS, or None.  Accepts a dict ({'proj': 'lcc', 'lat_1': ...}),
+    a PROJ string ('+proj=lcc +lat_1=... +a=... +b=...', models/hrrr.py:255-259), or a pyproj CRS."""
+    d = None
+    if isinstance(crs, dict):
+        d = dict(crs)
+    elif isinstance(crs, str) and '+proj=' in crs:
+        d = {}
+        for tok in crs.split():
+            if tok.startswith('+') and '=' in tok:
+                k, v = tok[1:].split('=', 1)
+                try:
+                    d[k] = float(v)
+                except ValueError:
+                    d[k] = v
+    elif pyproj is not None and hasattr(crs, 'to_dict'):
+        try:
+            d = crs.to_dict()
+        except Exception:
+            d = None
+    if not d or d.get('proj') != 'lcc':
+        return None
+    a = float(d.get('a', d.get('R', 6378137.0)))
+    if 'b' in d:
+        b = float(d['b']); es = 1.0 - (b * b) / (a * a)
+    elif 'rf' in d:
+        f = 1.0 / float(d['rf']); es = 2 * f - f * f
+    elif 'es' in d:
+        es = float(d['es'])
+    elif 'R' in d or 'a' in d:
+        es = 0.0 if 'R' in d or 'ellps' not in d else 0.0066943799901413165
+    else:
+        es = 0.0066943799901413165     # WGS84 default ellipsoid
+    lat_1 = float(d.get('lat_1', d.get('lat_0', 0.0)))
+    return dict(lat_1=lat_1, lat_2=float(d.get('lat_2', lat_1)), lat_0=float(d.get('lat_0', 0.0)), lon_0=float(d.get('lon_0', 0.0)),
+                x_0=float(d.get('x_0', 0.0)), y_0=float(d.get('y_0', 0.0)), a=a, es=max(es, 0.0))
+
+
+def _apply_model_crs(cube, model_crs):
+    """Make the device cube aware of a projected model CRS; returns True when queries must stay geodetic."""
+    if _is_4326(model_crs):
+        return False
+    lcc = _lcc_params(model_crs)
+    if lcc is None:
+        return False
+    if cube.projection is None or {k: cube.projection.get(k) for k in lcc} != lcc:
+        cube.set_projection_lcc(**lcc)
+    return True
+
+
 # ------------------------------------------------------------------------------------------------
 # small containers (the AOI / Dataset providers themselves are outside the hot path, SURVEY.md §2 row 9)
 # ------------------------------------------------------------------------------------------------
@@ -176,8 +226,14 @@ def tropo_delay(datetime, weather_model_file, aoi, los, height_levels=None, out_
     # CRS of the weather model (delay.py:66-73)
     wm_proj = None
     try:
-        wkt = var['proj'].attrs['crs_wkt']
-        wm_proj = pyproj.CRS.from_wkt(wkt) if pyproj is not None else (4326 if ('WGS 84' in wkt and 'PROJCRS' not in wkt) or wkt.endswith('4326') else wkt)
+        pj = var['proj']
+        if isinstance(pj, (str, dict, int)):                       # mapping input: CRS given directly (EPSG / PROJ string / dict)
+            wkt = None
+            wm_proj = pj
+        else:
+            wkt = pj.attrs['crs_wkt']
+        if wkt is not None:
+            wm_proj = pyproj.CRS.from_wkt(wkt) if pyproj is not None else (4326 if ('WGS 84' in wkt and 'PROJCRS' not in wkt) or wkt.endswith('4326') else wkt)
     except (KeyError, AttributeError, TypeError):
         logger.warning("WARNING: I can't find a CRS in the weather model file, so I will assume you are using WGS84")
         wm_proj = 4326
@@ -253,8 +309,11 @@ def _build_cube(xpts, ypts, zpts, model_crs, pts_crs, interpolators):
     """delay.py:196-216: zenith / projected cube, one trilinear gather of both fields per node."""
     cube, fields = _cube_of(interpolators)
     zpts = np.asarray(zpts)
-    if _same_crs(model_crs, pts_crs):
+    if _same_crs(model_crs, pts_crs) and cube.projection is None:
         res = cube.build_cube(xpts, ypts, zpts)            # points generated on the fly in the kernel
+        return [res[f] for f in fields]
+    if _is_4326(pts_crs) and _apply_model_crs(cube, model_crs):
+        res = cube.build_cube(xpts, ypts, zpts)            # lon/lat nodes projected to the model's LCC grid on the device
         return [res[f] for f in fields]
     xx, yy = np.meshgrid(xpts, ypts)
     outputArrs = [np.zeros((zpts.size, len(ypts), len(xpts))) for _ in interpolators]
@@ -271,10 +330,10 @@ def _build_cube_ray(xpts, ypts, zpts, los, model_crs, pts_crs, interpolators, ou
     """delay.py:219-326: ray-traced cube.  One fused GPU pass pair per height slice:
     pass 1 = build_ray's per-level ray lengths reduced to the slice maximum (-> nParts, delay.py:283),
     pass 2 = Newton level intersections + ECEF->geodetic + trilinear gather + trapezoid, per ray."""
-    if not _is_4326(model_crs):
-        raise NotImplementedError('ray tracing through projected (e.g. HRRR Lambert) cubes is not built yet '
-                                  '(SURVEY.md §8f); the weather cube must be on an EPSG:4326 lat/lon grid')
     cube, fields = _cube_of(interpolators)
+    if not _is_4326(model_crs) and not _apply_model_crs(cube, model_crs):
+        raise NotImplementedError('ray tracing needs the weather cube on an EPSG:4326 lat/lon grid or on a Lambert-conformal-'
+                                  f'conic grid (HRRR); got {model_crs!r}')
     xpts = np.asarray(xpts, dtype=np.float64)
     ypts = np.asarray(ypts, dtype=np.float64)
     zpts = np.asarray(zpts)

@@ -64,6 +64,7 @@ class Cube:
         gy, gx, gz = np.empty(ny), np.empty(nx), np.empty(nz)
         check(self.ctx.lib.rdr_cube_axes(h, ptr(gy), ptr(gx), ptr(gz)))
         self.grid = (gy, gx, gz)       # ascending, as scipy exposes `.grid` (delay.py:239)
+        self.projection = None
 
     @classmethod
     def _from_handle(cls, ctx, h):
@@ -76,13 +77,32 @@ class Cube:
         gy, gx, gz = np.empty(ny.value), np.empty(nx.value), np.empty(nz.value)
         check(ctx.lib.rdr_cube_axes(h, ptr(gy), ptr(gx), ptr(gz)))
         self.grid = (gy, gx, gz)
+        self.projection = None
         return self
+
+    def set_projection_lcc(self, lat_1, lat_2, lat_0, lon_0, x_0=0.0, y_0=0.0, a=6371229.0, es=0.0):
+        """The cube's x/y axes are Lambert-conformal-conic metres (HRRR: models/hrrr.py:248-259, sphere a=6371229).
+        build_cube / ray tracing then take geodetic lon/lat queries and project them on the device."""
+        p = np.array([a, es, lat_1, lat_2, lat_0, lon_0, x_0, y_0], dtype=np.float64)
+        check(self.ctx.lib.rdr_cube_set_projection(self.handle, 1, ptr(p), p.size), self.ctx.handle)
+        self.projection = dict(proj='lcc', lat_1=lat_1, lat_2=lat_2, lat_0=lat_0, lon_0=lon_0, x_0=x_0, y_0=y_0, a=a, es=es)
+        return self
+
+    def project(self, lats, lons):
+        """EPSG:4326 (lat, lon) -> the cube's (y, x) coordinates (identity for lon/lat cubes)."""
+        lats, lons = np.broadcast_arrays(np.asarray(lats, dtype=np.float64), np.asarray(lons, dtype=np.float64))
+        la, lo = f64(lats).ravel(), f64(lons).ravel()
+        y, x = np.empty(la.size), np.empty(la.size)
+        check(self.ctx.lib.rdr_project_points(self.ctx.handle, self.handle, ptr(la), ptr(lo), la.size, ptr(y), ptr(x), L.RDR_HOST), self.ctx.handle)
+        return y.reshape(lats.shape), x.reshape(lats.shape)
 
     def blend(self, w1, other, w2):
         """cli/raider.py:817-819: w1*self + w2*other on the device."""
         h = C.c_void_p()
         check(self.ctx.lib.rdr_cube_blend(self.ctx.handle, self.handle, float(w1), other.handle, float(w2), C.byref(h)), self.ctx.handle)
-        return Cube._from_handle(self.ctx, h)
+        out = Cube._from_handle(self.ctx, h)
+        out.projection = self.projection       # the C side copies the projection too
+        return out
 
     def read(self):
         wet = np.empty(self.shape, dtype=self.dtype)

@@ -254,3 +254,46 @@ def test_bottom_clamp_quirk(R):
     assert np.isfinite(w).all()
     ref = cube.raytrace(R.Rays.grid(xp, yp, inc=30.0, hd=0.0), zmin + 1e-3, c['zs'].max() - 1)
     np.testing.assert_allclose(h, ref[1], rtol=0, atol=1e-6)
+
+
+def test_hrrr_lambert_cube(R):
+    """Projected model CRS (HRRR spherical LCC, models/hrrr.py:248-259): lon/lat query nodes and ray samples are
+    projected to the model's x/y metres on the device (pyproj's step in delay.py:207-209,253,295).  Checked against the
+    oracle's restatement of the PROJ formulas (parity with PROJ itself is unpinned) and against closed-form properties."""
+    from raider_amd.delay import _build_cube, _build_cube_ray
+    from raider_amd.delayFcns import interpolators_from_cube
+    from raider_amd.losreader import Raytracing
+    hrrr = dict(lat_1=38.5, lat_2=38.5, lat_0=38.5, lon_0=262.5, x_0=0.0, y_0=0.0, a=6371229.0, es=0.0)
+    # origin of the projection maps to (0,0); scale is true on the standard parallel
+    x0, y0 = O.lcc_forward(38.5, 262.5, **hrrr)
+    assert abs(x0) < 1e-6 and abs(y0) < 1e-6
+    xe, _ = O.lcc_forward(38.5, 262.5 + 1e-4, **hrrr)
+    assert abs(xe - 6371229.0 * np.cos(np.radians(38.5)) * np.radians(1e-4)) < 1e-6
+    # 3-km HRRR-like grid
+    ny, nx, nz = 120, 140, 30
+    ys = -180e3 + 3000.0 * np.arange(ny); xs = -900e3 + 3000.0 * np.arange(nx)
+    zs = np.round(-100 + 26100 * np.linspace(0, 1, nz) ** 2, 3)
+    rng = np.random.default_rng(9)
+    z3 = zs[:, None, None]
+    wet = (60 * np.exp(-z3 / 2000) * (1 + 0.1 * rng.standard_normal((ny, nx))[None])).astype(np.float32)
+    hyd = (270 * np.exp(-z3 / 8000) * (1 + 0.01 * rng.standard_normal((ny, nx))[None])).astype(np.float32)
+    cube = R.Cube(ys, xs, zs, wet, hyd, order='zyx')
+    cube.set_projection_lcc(**hrrr)
+    lat = np.linspace(38.4, 37.6, 21); lon = np.linspace(-106.5, -104.9, 25)      # negative longitudes vs lon_0 = 262.5
+    py, px = cube.project(*np.meshgrid(lat, lon, indexing='ij'))
+    ox, oy = O.lcc_forward(*np.meshgrid(lat, lon, indexing='ij'), **hrrr)
+    np.testing.assert_allclose(px, ox, rtol=0, atol=1e-6); np.testing.assert_allclose(py, oy, rtol=0, atol=1e-6)
+    assert xs[0] < px.min() and px.max() < xs[-1] and ys[0] < py.min() and py.max() < ys[-1]
+    ifw, ifh = interpolators_from_cube(cube)
+    ip = list(O.getInterpolators(xs, ys, zs, wet, hyd))
+    proj_str = '+proj=lcc +lat_1=38.5 +lat_2=38.5 +lat_0=38.5 +lon_0=262.5 +x_0=0 +y_0=0 +a=6371229 +b=6371229 +units=m +no_defs'
+    zpts = np.array([0.0, 1500.0])
+    gw, gh = _build_cube(lon, lat, zpts, proj_str, 4326, [ifw, ifh])
+    ow, oh = O.build_cube(lon, lat, zpts, ip, model_proj=hrrr)
+    np.testing.assert_allclose(gw, ow, rtol=0, atol=1e-9); np.testing.assert_allclose(gh, oh, rtol=0, atol=1e-9)
+    look = lambda ht, llh, xyz, yy: O.look_vectors_from_inc_hd(np.full(yy.shape, 36.0), np.full(yy.shape, -167.9), llh[1], llh[0], llh[2])
+    zref = float(zs.max() - 1)
+    (rw, rh), onp = O.build_cube_ray(lon, lat, zpts, look, ip, MAX_TROPO_HEIGHT=zref, return_nparts=True, model_proj=hrrr)
+    w, h = _build_cube_ray(lon, lat, zpts, Raytracing(inc=36.0, heading=-167.9), proj_str, 4326, [ifw, ifh], MAX_TROPO_HEIGHT=zref)
+    assert np.isfinite(rw).all()
+    np.testing.assert_allclose(w, rw, rtol=0, atol=TIGHT); np.testing.assert_allclose(h, rh, rtol=0, atol=TIGHT)
