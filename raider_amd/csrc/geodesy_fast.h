@@ -92,6 +92,28 @@ __device__ __forceinline__ double height_fast_nocheck(double x, double y, double
     return geo_fast<false>(x, y, z).h;
 }
 
+// Cheap ellipsoidal height for the NON-FINAL Newton iterations of a level crossing: radial height above the ellipse at
+// the geocentric latitude psi, times cos(delta), delta = f sin(2 psi) being the angle between the radial and the normal:
+//     h ~ (r - a / sqrt(1 + e'^2 sin^2 psi)) * (1 - 2 f^2 sin^2 psi cos^2 psi)
+// 22 fp64 instructions (one v_rsq_f64) against 47; error 2e-5 m at the surface, 3e-4 m at 20 km, 1.4e-3 m at 45 km.
+// The crossing iteration contracts by |1 - cos(inc_h)/cos(inc_0)| <= 0.005 (0.02 at 60 deg) per step, so an error eps
+// in an early iterate reaches the final one as <= 0.005^k eps: the final iterate (evaluated with the accurate height)
+// moves by < 1e-5 m, the delays by < 1e-10 m.
+__device__ __forceinline__ double height_cheap(double x, double y, double z) {
+    const double r2 = fma(x, x, fma(y, y, z * z));
+    const double rr = rsq_nr<1>(r2);
+    const double s = z * rr;
+    const double s2 = s * s;
+    const double u = WGS84_E2S * s2;
+    double q = fma(u, 35.0 / 128.0, -5.0 / 16.0);      // (1+u)^(-1/2), u <= 0.0068
+    q = fma(u, q, 3.0 / 8.0);
+    q = fma(u, q, -0.5);
+    q = fma(u, q, 1.0);
+    const double d = fma(-WGS84_A, q, r2 * rr);
+    const double corr = fma(-2.0 * WGS84_F * WGS84_F * s2, 1.0 - s2, 1.0);
+    return d * corr;
+}
+
 // asin(s): odd series through s^11; truncation < 3e-17 rad for |s| <= 0.05, 4e-12 rad (2.5e-5 m) at |s| = 0.13
 __device__ __forceinline__ double asin_small(double s) {
     const double s2 = s * s;
