@@ -9,8 +9,8 @@
 //     polynomial;
 //   * latitude / longitude of a ray sample are computed RELATIVE to the ray origin (whose geodetic coordinates are
 //     the kernel's exact inputs): sin(phi-phi0) and sin(lam-lam0) come from 2 FMAs each and the angle from an odd
-//     asin series (valid to ~0.13 rad; rays that could travel further are classified "slow" up front and handled by
-//     the generic-geodesy kernels).  No atan/atan2 per sample.
+//     asin series (rays that could travel more than 0.03 rad, or come within 2 deg of the +-180 meridian, are
+//     classified "slow" up front and handled by the generic-geodesy kernels).  No atan/atan2 per sample.
 // Accuracy is pinned by tests/test_gpu_parity.py (ray-traced delays against the CPU restatement of the reference:
 // 1e-9 m across latitudes, hemispheres, the dateline and a polar scene).
 #pragma once
@@ -114,12 +114,12 @@ __device__ __forceinline__ double height_cheap(double x, double y, double z) {
     return d * corr;
 }
 
-// asin(s): odd series through s^11; truncation < 3e-17 rad for |s| <= 0.05, 4e-12 rad (2.5e-5 m) at |s| = 0.13
+// asin(s) for the small angles between a ray sample and the ray origin: odd series through s^7.  The static
+// classification admits only rays whose angular travel stays below 0.03 rad (190 km), where the truncation is
+// < 2e-13 rad (1e-6 m on the ground).
 __device__ __forceinline__ double asin_small(double s) {
     const double s2 = s * s;
-    double q = fma(s2, 63.0 / 2816.0, 35.0 / 1152.0);
-    q = fma(s2, q, 5.0 / 112.0);
-    q = fma(s2, q, 3.0 / 40.0);
+    double q = fma(s2, 5.0 / 112.0, 3.0 / 40.0);
     q = fma(s2, q, 1.0 / 6.0);
     return fma(s * s2, q, s);
 }
@@ -139,7 +139,7 @@ __device__ __forceinline__ RayBase make_base(double lat_deg, double lon_deg) {
     return b;
 }
 
-// ECEF -> (lon deg, lat deg, h) of a point within ~0.13 rad of the ray origin (guaranteed by the per-ray static
+// ECEF -> (lon deg, lat deg, h) of a point within 0.03 rad of the ray origin (guaranteed by the per-ray static
 // classification in crossings_kernel; rays that fail it never come here).
 __device__ __forceinline__ void ecef2lla_near(const RayBase& b, double x, double y, double z,
                                               double& lon_deg, double& lat_deg, double& h) {
@@ -147,10 +147,7 @@ __device__ __forceinline__ void ecef2lla_near(const RayBase& b, double x, double
     const double sd = fma(g.sphi, b.c0, -g.cphi * b.s0);             // sin(phi - phi0)
     const double sl = fma(b.cl0, y, -b.sl0 * x) * g.rp;              // sin(lam - lam0)
     lat_deg = fma(asin_small(sd), RAD_TO_DEG, b.lat0);
-    double lon = fma(asin_small(sl), RAD_TO_DEG, b.lon0);
-    if (lon > 180.0) lon -= 360.0;                                    // PROJ returns lam in (-180, 180]
-    else if (lon < -180.0) lon += 360.0;
-    lon_deg = lon;
+    lon_deg = fma(asin_small(sl), RAD_TO_DEG, b.lon0);                // no +-180 wrap: such rays are classified slow
     h = g.h;
 }
 

@@ -405,11 +405,13 @@ __global__ __launch_bounds__(BLOCK) void crossings_kernel(CubeView<T2> c, RayPar
         const double nl2 = fma(lx, lx, fma(ly, ly, lz * lz));
         const double nl = nl2 * rsq_nr<2>(nl2);
         // Static classification: may the light geodesy be used along the WHOLE ray?  (cos(lat) stays > 0.01 and the ray
-        // stays within ~0.1 rad of its origin.)  t_max <= (zref-ht)/cos(inc) because the local zenith angle of a
+        // stays within 0.03 rad of its origin in latitude and longitude.)  t_max <= (zref-ht)/cos(inc) because the local zenith angle of a
         // straight ray decreases with height.
         const double cosi = (lx * base.c0 * base.cl0 + ly * base.c0 * base.sl0 + lz * base.s0) / nl;
         const double gam = (P.zref - P.ht) / (cosi * 6.3e6);                       // bound on the angular travel
-        const bool fast_ok = !active || ((cosi > 0.05) && (base.c0 > gam + 0.02) && (gam < 0.09 * (base.c0 - gam)));
+        // ... and never crosses the +-180 meridian (the light path does not wrap longitudes): |lon0| + travel < 180 deg
+        const bool fast_ok = !active || ((cosi > 0.05) && (base.c0 > gam + 0.02) && (gam < 0.03 * (base.c0 - gam)) &&
+                                         (fabs(lon) + 2.0 < 180.0));
         const int64_t slot = lt * BLOCK + tid;
         if (!SLOW) {
             const unsigned long long slow_mask = __ballot(!fast_ok);
