@@ -36,6 +36,7 @@ def main():
     ap.add_argument('--rows', type=int, default=4000)
     ap.add_argument('--cols', type=int, default=4000)
     ap.add_argument('--cube', type=str, default='300x300x80')
+    ap.add_argument('--cube-f64', action='store_true', help='experiment: upload the f32 refractivities as f64 (no cvt in the gather)')
     ap.add_argument('--backend', type=str, default='nccl', help='torch.distributed backend for N>1 (nccl = RCCL; gloo only for single-GPU dry runs of the N>1 path)')
     ap.add_argument('--cpu-sample', type=int, default=640, help='edge of the square ray block timed on the CPU oracle (0 = skip)')
     args = ap.parse_args()
@@ -92,6 +93,8 @@ def main():
         t_bcast = time.perf_counter() - t0
     ax = axes.cpu().numpy()
     ys, xs, zs = ax[:ny], ax[ny:ny + nx], ax[ny + nx:]
+    if args.cube_f64:
+        wet, hyd = wet.double(), hyd.double()
     cube = R.Cube(ys, xs, zs, wet, hyd, order='zyx', ctx=ctx)
     zref = float(zs.max() - 1.0)                                 # delay.py:78,86-87
     ht = 0.0

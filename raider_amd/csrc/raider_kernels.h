@@ -152,6 +152,20 @@ __device__ __forceinline__ void window_cell(const double2* e, int n, double v, i
     }
 }
 
+// (nearly) uniform x / y axes: the linear guess is right unless the point sits within round-off of a node (or the
+// axis deviates from uniform): read the guessed cell and the next node, verify, else search exactly.
+__device__ __forceinline__ void guess_cell(const double2* e, int n, double v, int guess, bool trust, int& i, double& t) {
+    i = min(max(guess, 0), n - 2);
+    const double2 e0 = e[i];
+    const double g1 = e[i + 1].x;
+    t = (v - e0.x) * e0.y;
+    const bool ok = trust & (v >= e0.x) & ((v < g1) | (i == n - 2));
+    if (!ok) {                                        // rare: exact search
+        i = bisect_cell2(e, n, v);
+        t = (v - e[i].x) * e[i].y;
+    }
+}
+
 // tab2 = (g, 1/dg) pairs of [ys | xs | zs] in LDS.
 template <typename T2>
 __device__ __forceinline__ void sample_cube(const CubeView<T2>& c, const double2* tab2, double y, double x, double z, int kz,
@@ -160,8 +174,8 @@ __device__ __forceinline__ void sample_cube(const CubeView<T2>& c, const double2
     if (!inside) { wet = qnan(); hyd = qnan(); return; }
     const double2* ey = tab2; const double2* ex = tab2 + c.ny; const double2* ez = ex + c.nx;
     int iy, ix, iz; double ty, tx, tz;
-    window_cell(ey, c.ny, y, (int)((y - c.y_lo) * c.inv_dy), c.uni_y && c.ny >= 4, iy, ty);
-    window_cell(ex, c.nx, x, (int)((x - c.x_lo) * c.inv_dx), c.uni_x && c.nx >= 4, ix, tx);
+    guess_cell(ey, c.ny, y, (int)((y - c.y_lo) * c.inv_dy), c.uni_y, iy, ty);
+    guess_cell(ex, c.nx, x, (int)((x - c.x_lo) * c.inv_dx), c.uni_x, ix, tx);
     window_cell(ez, c.nz, z, kz, c.nz >= 4, iz, tz);
     const T2* p00 = c.v + ((int64_t)iy * c.nx + ix) * c.nz + iz;
     const T2* p01 = p00 + c.nz;
