@@ -26,6 +26,10 @@ REPO = Path(__file__).resolve().parent
 sys.path.insert(0, str(REPO))
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+# HBM bytes per march_kernel launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate runs,
+# FETCH_SIZE x2 per the gfx950 correction, verified on a 1 GiB calibration copy): profiles/r01_v5_hbm_traffic_pmc.txt.
+# Only valid for the default workload; any other shape reports null.
+PMC_TRAFFIC_BYTES = {(4000, 4000, '300x300x80'): 11.655e9 + 0.256e9}
 
 
 def main():
@@ -170,7 +174,8 @@ def main():
                        'parallelism': f'rows sharded x{world}, cube broadcast over RCCL ({t_bcast*1e3:.1f} ms), MAX all-reduce of {K} doubles per step' if world > 1 else 'single GPU',
                        'mean_hydro_m': mean_h, 'mean_wet_m': mean_w, 'nan_fraction': nan_frac},
             'roofline': {'bound': 'hbm', 'kernel': 'march_kernel<float2,false>', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': PMC_TRAFFIC_BYTES.get((rows, cols, args.cube)) if world == 1 else None,
+                         'traffic_unit': 'bytes per march_kernel launch (PMC, profiles/r01_v5_hbm_traffic_pmc.txt)',
                          'algorithmic_bytes_per_ray': bytes_per_ray, 'compulsory_bytes_per_ray': 64 + (ny * nx * nz * 8) / n_rays,
                          'march_ms_per_step': march_ms, 'crossings_ms_per_step': pre_ms, 'march_launches_timed': n_march,
                          'note': 'achieved = (64*S+64) B/ray (SURVEY 8d gather model, S = reference samples/ray) x rays / march_kernel time; '
