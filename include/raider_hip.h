@@ -179,6 +179,16 @@ int rdr_ecef2lla(rdr_ctx* ctx, const double* xyz, int64_t n, double* lon, double
 /* look vectors for a ray batch (any los_mode) -> los[n,3] */
 int rdr_look_vectors(rdr_ctx* ctx, const rdr_rays* rays, double ht, double* los);
 
+/* Look vectors from orbit state vectors: replaces the per-pixel isce3 geo2rdr + Orbit.interpolate loop of
+ * Raytracing.getLookVectors (losreader.py:219-255; zero-Doppler, threshold 1e-7, maxiter 30 at the call site).
+ * sv_t[nsv] seconds (strictly increasing, HOST), sv_pos/sv_vel [nsv,3] ECEF (HOST); xyz[n,3] targets, los[n,3] unit
+ * vectors target->sensor (NaN where the solve fails or leaves the orbit span); aztime / srange optional [n].
+ * isce3 itself is not available to this build: parity with it is UNPINNED (the algorithm is restated from its
+ * published description). */
+int rdr_orbit_look_vectors(rdr_ctx* ctx, const double* sv_t, const double* sv_pos, const double* sv_vel, int64_t nsv,
+                           const double* xyz, int64_t n, double threshold, int maxiter, double* los, double* aztime,
+                           double* srange, int loc);
+
 /* ---- the reference's two native extensions ----------------------------------------------------
  * RAiDER.interpolate.interpolate (tools/bindings/interpolate/src/module.cpp:26-294, interpolate.cpp):
  * N-D linear interpolation (ndim <= 8 on device), C-order values, interp_points[n,ndim].

@@ -317,6 +317,71 @@ def nparts_from_lengths(ray_lengths, MAX_SEGMENT_LENGTH=1000.0):
 
 
 # ----------------------------------------------------------------------------------------------
+# look vectors from orbit state vectors  (Raytracing.getLookVectors, losreader.py:219-255)
+#   The reference calls isce3 (geometry.geo2rdr with an empty Doppler LUT + Orbit.interpolate); isce3 is a third-party
+#   dependency that is neither installed here nor under /root/reference (environment.yml:25 `isce3>=0.15.0`).
+#   Restated from its published algorithm: zero-Doppler Newton on azimuth time with 4-point Hermite orbit
+#   interpolation.  PARITY WITH isce3 IS UNPINNED; only geometric properties are tested.
+# ----------------------------------------------------------------------------------------------
+def orbit_hermite(st, sp, sv, t):
+    """4-point Hermite interpolation of position and velocity at times t (array) from state vectors
+    st[n] (s), sp[n,3], sv[n,3]."""
+    t = np.atleast_1d(np.asarray(t, dtype=np.float64))
+    n = st.size
+    lo = np.searchsorted(st, t, side='right')
+    i0 = np.clip(lo - 2, 0, n - 4)
+    tt = np.stack([st[i0 + k] for k in range(4)], -1)            # (m, 4)
+    X = np.stack([sp[i0 + k] for k in range(4)], 1)               # (m, 4, 3)
+    V = np.stack([sv[i0 + k] for k in range(4)], 1)
+    f1 = t[:, None] - tt
+    pos = np.zeros((t.size, 3)); vel = np.zeros((t.size, 3))
+    for i in range(4):
+        others = [j for j in range(4) if j != i]
+        ssum = sum(1.0 / (tt[:, i] - tt[:, j]) for j in others)
+        f0 = 1.0 - 2.0 * (t - tt[:, i]) * ssum
+        h = np.ones(t.size)
+        for k in others:
+            h = h * (t - tt[:, k]) / (tt[:, i] - tt[:, k])
+        hdot = np.zeros(t.size)
+        for j in others:
+            p2 = np.ones(t.size)
+            for k in others:
+                if k != j:
+                    p2 = p2 * (t - tt[:, k]) / (tt[:, i] - tt[:, k])
+            hdot = hdot + p2 / (tt[:, i] - tt[:, j])
+        g1 = h + 2.0 * (t - tt[:, i]) * hdot
+        g0 = 2.0 * (f0 * hdot - h * ssum)
+        pos += (X[:, i] * f0[:, None] + V[:, i] * f1[:, i][:, None]) * (h * h)[:, None]
+        vel += (X[:, i] * g0[:, None] + V[:, i] * g1[:, None]) * h[:, None]
+    return pos, vel
+
+
+def orbit_look_vectors(st, sp, sv, xyz, threshold=1.0e-7, maxiter=30):
+    """Zero-Doppler geo2rdr per target + unit look vector target->sensor.  Returns (los[...,3], aztime, slant_range)."""
+    shp = xyz.shape[:-1]
+    T = np.asarray(xyz, dtype=np.float64).reshape(-1, 3)
+    t = np.full(T.shape[0], 0.5 * (st[0] + st[-1]))
+    done = np.zeros(T.shape[0], dtype=bool)
+    for _ in range(maxiter):
+        pos, vel = orbit_hermite(st, sp, sv, t)
+        d = T - pos
+        fn = np.sum(d * vel, -1)
+        fnp = -np.sum(vel * vel, -1)
+        step = np.where(done, 0.0, fn / fnp)
+        t = t - step
+        done |= np.abs(step) < threshold
+        if done.all():
+            break
+    pos, _ = orbit_hermite(st, sp, sv, np.where(np.isnan(t), st[0], t))
+    d = pos - T
+    rg = np.linalg.norm(d, axis=-1)
+    bad = ~done | (t < st[0]) | (t > st[-1]) | np.isnan(T).any(-1)
+    los = d / rg[:, None]
+    los[bad] = np.nan; rg = np.where(bad, np.nan, rg); t = np.where(bad, np.nan, t)
+    return los.reshape(shp + (3,)), t.reshape(shp), rg.reshape(shp)
+
+
+# ----------------------------------------------------------------------------------------------
 # cube builders
 # ----------------------------------------------------------------------------------------------
 def build_cube(xpts, ypts, zpts, interpolators, model_proj=None):

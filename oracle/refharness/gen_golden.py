@@ -17,6 +17,7 @@ The reference functions exercised (file:line under /root/reference/tools/RAiDER 
   (G7 time weights cli/raider.py:877-888: NOT generated - RAiDER.cli.raider imports h5py, absent here;
    the two-line formula is restated in the oracle and pinned by its mean-of-epochs property only)
   G8 tropo_delay point branch              delay.py:35-130
+  G9 read_ESA_Orbit_file, read_txt_file, get_sv, cut_times   losreader.py:429-518,319-371,617-634
 pyproj/xarray/rasterio are build-owned stubs (oracle/refharness/stubs): geodetic<->ECEF arithmetic
 is therefore the stub's restatement of PROJ `cart`, not PROJ itself ("parity unpinned" for that
 one conversion; everything downstream of it is the reference's own code).
@@ -368,7 +369,29 @@ def g8():
          wet_zen=wz, hydro_zen=hz, xpts_ray=xpts[::4], ypts_ray=ypts[::3], wet_ray=wr, hydro_ray=hr)
 
 
+# ---------------------------------------------------------------------------------------------- G9
+def g9():
+    """Orbit-file readers (losreader.py:429-518,319-371,617-634) on the reference's own fixtures
+    (test/orbit_files/*, copied as DATA to tests/golden/orbit_files/)."""
+    orb = ref_import.REF_ROOT / 'test' / 'orbit_files'
+    out = {}
+    for tag, fn, reader in (('eof', 'S1_orbit_example.EOF', rlos.read_ESA_Orbit_file), ('txt', 'S1_sv_file.txt', rlos.read_txt_file)):
+        svs = reader(str(orb / fn))
+        t0 = svs[0][0]
+        out[f'{tag}_t'] = np.array([(t - t0).total_seconds() for t in svs[0]])
+        out[f'{tag}_epoch'] = np.array(t0.isoformat())
+        out[f'{tag}_sv'] = np.stack(svs[1:], -1)
+    t_ref = dt.datetime(2018, 11, 12, 23, 0, 2)
+    svs = rlos.get_sv(str(orb / 'S1_sv_file.txt'), t_ref + dt.timedelta(seconds=40), 15)
+    out['cut_t'] = np.array([(t - t_ref).total_seconds() for t in svs[0]])
+    out['cut_sv'] = np.stack(svs[1:], -1)
+    times = rlos.read_txt_file(str(orb / 'S1_sv_file.txt'))[0]
+    out['cut_mask_5'] = rlos.cut_times(times, t_ref, pad=5)
+    out['cut_mask_15'] = rlos.cut_times(times, times[4], pad=15)
+    save('g9_orbit_readers', **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g8']   # g7: cli.raider needs h5py (absent)
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g8', 'g9']   # g7: cli.raider needs h5py (absent)
     for w in which:
         globals()[w]()

@@ -293,6 +293,80 @@ __global__ void build_ray_kernel(const double* __restrict__ xyz, const double* _
     }
 }
 
+// ---- look vectors from orbit state vectors ----------------------------------------------------------------------------
+// Replaces the per-pixel Python loop over isce3.geometry.geo2rdr + Orbit.interpolate of Raytracing.getLookVectors
+// (losreader.py:219-255).  isce3 is a third-party dependency that is not under /root/reference: this restates the published
+// algorithm as the call site uses it (empty Doppler LUT => zero-Doppler): Newton on azimuth time t for
+// f(t) = (T - S(t)) . V(t) = 0 with f'(t) ~ -|V|^2, S/V from 4-point Hermite interpolation of the state vectors,
+// threshold 1e-7 s, <= 30 iterations; los = (S(t) - T)/|S(t) - T|; failures -> NaN.  PARITY WITH isce3 IS UNPINNED.
+__device__ inline void orbit_hermite(const double* __restrict__ st, const double* __restrict__ sp, const double* __restrict__ sv,
+                                     int n, double t, double* pos, double* vel) {
+    // 4 state vectors bracketing t (two on each side where possible)
+    int lo = 0, hi = n;                      // first index with t < st[idx]
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (t < st[mid]) hi = mid; else lo = mid + 1; }
+    int i0 = min(max(lo - 2, 0), n - 4);
+    double tt[4], h[4], hdot[4], f0[4], f1[4], g0[4], g1[4];
+    for (int i = 0; i < 4; ++i) tt[i] = st[i0 + i];
+    for (int i = 0; i < 4; ++i) {
+        f1[i] = t - tt[i];
+        double sum = 0.0;
+        for (int j = 0; j < 4; ++j) if (j != i) sum += 1.0 / (tt[i] - tt[j]);
+        f0[i] = 1.0 - 2.0 * (t - tt[i]) * sum;
+        double prod = 1.0;
+        for (int k = 0; k < 4; ++k) if (k != i) prod *= (t - tt[k]) / (tt[i] - tt[k]);
+        h[i] = prod;
+        double s2 = 0.0;
+        for (int j = 0; j < 4; ++j) {
+            if (j == i) continue;
+            double p2 = 1.0;
+            for (int k = 0; k < 4; ++k) if (k != i && k != j) p2 *= (t - tt[k]) / (tt[i] - tt[k]);
+            s2 += p2 / (tt[i] - tt[j]);
+        }
+        hdot[i] = s2;
+        g1[i] = h[i] + 2.0 * (t - tt[i]) * hdot[i];
+        g0[i] = 2.0 * (f0[i] * hdot[i] - h[i] * sum);
+    }
+    for (int k = 0; k < 3; ++k) {
+        double sx = 0.0, sv_ = 0.0;
+        for (int i = 0; i < 4; ++i) {
+            const double x = sp[3 * (i0 + i) + k], v = sv[3 * (i0 + i) + k];
+            sx += (x * f0[i] + v * f1[i]) * h[i] * h[i];
+            sv_ += (x * g0[i] + v * g1[i]) * h[i];
+        }
+        pos[k] = sx; vel[k] = sv_;
+    }
+}
+
+__global__ void orbit_los_kernel(const double* __restrict__ st, const double* __restrict__ sp, const double* __restrict__ sv, int nsv,
+                                 const double* __restrict__ xyz, int64_t n, double threshold, int maxiter,
+                                 double* __restrict__ los, double* __restrict__ aztime, double* __restrict__ srange) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double tx = xyz[3 * i], ty = xyz[3 * i + 1], tz = xyz[3 * i + 2];
+        double t = 0.5 * (st[0] + st[nsv - 1]);          // start at the orbit mid time
+        double pos[3], vel[3];
+        bool ok = false;
+        for (int it = 0; it < maxiter; ++it) {
+            orbit_hermite(st, sp, sv, nsv, t, pos, vel);
+            const double dx = tx - pos[0], dy = ty - pos[1], dz = tz - pos[2];
+            const double fn = dx * vel[0] + dy * vel[1] + dz * vel[2];            // zero-Doppler condition
+            const double fnp = -(vel[0] * vel[0] + vel[1] * vel[1] + vel[2] * vel[2]);
+            const double step = fn / fnp;
+            t -= step;
+            if (fabs(step) < threshold) { ok = true; break; }
+        }
+        double l0 = qnan(), l1 = qnan(), l2 = qnan(), rg = qnan();
+        if (ok && t >= st[0] && t <= st[nsv - 1] && tx == tx && ty == ty && tz == tz) {
+            orbit_hermite(st, sp, sv, nsv, t, pos, vel);
+            const double dx = pos[0] - tx, dy = pos[1] - ty, dz = pos[2] - tz;
+            rg = sqrt(dx * dx + dy * dy + dz * dz);
+            l0 = dx / rg; l1 = dy / rg; l2 = dz / rg;                               // losreader.py:251-252
+        } else t = qnan();
+        los[3 * i] = l0; los[3 * i + 1] = l1; los[3 * i + 2] = l2;
+        if (aztime) aztime[i] = t;
+        if (srange) srange[i] = rg;
+    }
+}
+
 // ---- native extension kernels -------------------------------------------------------------------
 // interpolate.h:23-38 bisect_left: first index with x < a[i]
 __device__ __forceinline__ int upper_bound_idx(const double* a, int n, double x) {
@@ -1188,6 +1262,36 @@ int rdr_look_vectors(rdr_ctx* c, const rdr_rays* r, double ht, double* los) {
     HIPCHECK(c, hipGetLastError());
     rc = finish_out(c, los, o, (size_t)r->n * 24, r->loc); if (rc) return rc;
     if (r->loc == RDR_HOST) HIPCHECK(c, hipStreamSynchronize(c->stream));
+    return RDR_OK;
+}
+
+int rdr_orbit_look_vectors(rdr_ctx* c, const double* sv_t, const double* sv_pos, const double* sv_vel, int64_t nsv, const double* xyz,
+                           int64_t n, double threshold, int maxiter, double* los, double* aztime, double* srange, int loc) {
+    if (!c || !sv_t || !sv_pos || !sv_vel || !xyz || !los) return fail(c, RDR_ERR_INVALID, "rdr_orbit_look_vectors: NULL argument");
+    if (nsv < 4) return fail(c, RDR_ERR_INVALID, "state_to_los: At least 4 state vectors are required for orbit interpolation");
+    for (int64_t i = 1; i < nsv; ++i) if (!(sv_t[i] > sv_t[i - 1])) return fail(c, RDR_ERR_INVALID, "rdr_orbit_look_vectors: state-vector times must be strictly increasing");
+    if (n == 0) return RDR_OK;
+    HIPCHECK(c, hipSetDevice(c->device));
+    // the (small) state-vector table always comes from the host; targets / outputs follow `loc`
+    void* dtab;
+    int rc = ensure(c, SLOT_AUX, (size_t)nsv * 7 * 8, &dtab); if (rc) return rc;
+    double* dt_ = (double*)dtab; double* dp_ = dt_ + nsv; double* dv_ = dp_ + 3 * nsv;
+    HIPCHECK(c, hipMemcpyAsync(dt_, sv_t, (size_t)nsv * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(dp_, sv_pos, (size_t)nsv * 24, hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(dv_, sv_vel, (size_t)nsv * 24, hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    const void* dx; void *dl, *da = nullptr, *dr = nullptr;
+    rc = stage_in(c, SLOT_IN0, xyz, (size_t)n * 24, loc, &dx); if (rc) return rc;
+    rc = stage_out(c, SLOT_OUT0, los, (size_t)n * 24, loc, &dl); if (rc) return rc;
+    if (aztime) { rc = stage_out(c, SLOT_OUT1, aztime, (size_t)n * 8, loc, &da); if (rc) return rc; }
+    if (srange) { rc = stage_out(c, SLOT_OUT2, srange, (size_t)n * 8, loc, &dr); if (rc) return rc; }
+    hipLaunchKernelGGL(orbit_los_kernel, dim3(grid_for(n, 256, c->num_cus * 8)), dim3(256), 0, c->stream, dt_, dp_, dv_, (int)nsv,
+                       (const double*)dx, n, threshold, maxiter, (double*)dl, (double*)da, (double*)dr);
+    HIPCHECK(c, hipGetLastError());
+    rc = finish_out(c, los, dl, (size_t)n * 24, loc); if (rc) return rc;
+    if (aztime) { rc = finish_out(c, aztime, da, (size_t)n * 8, loc); if (rc) return rc; }
+    if (srange) { rc = finish_out(c, srange, dr, (size_t)n * 8, loc); if (rc) return rc; }
+    if (loc == RDR_HOST) HIPCHECK(c, hipStreamSynchronize(c->stream));
     return RDR_OK;
 }
 

@@ -346,7 +346,7 @@ def _build_cube_ray(xpts, ypts, zpts, los, model_crs, pts_crs, interpolators, ou
     for hh, ht in enumerate(zpts):
         logger.info(f'Processing slice {hh + 1} / {len(zpts)}: {ht}')
         if grid_is_ll and hasattr(los, 'ray_batch'):
-            rays = los.ray_batch(xpts, ypts)                               # look vectors made / read on the device
+            rays = los.ray_batch(xpts, ypts, ht)                           # look vectors made / read on the device
         else:
             xx, yy = np.meshgrid(xpts, ypts)
             if grid_is_ll:

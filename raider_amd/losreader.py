@@ -122,20 +122,18 @@ class Raytracing(LOS):
     Give EITHER `look_vectors` (ny,nx,3) ECEF unit vectors ground->sensor (what the reference's
     getLookVectors returns, delay.py:270; reused for every height slice) OR `inc`/`heading` (deg, scalars or
     (ny,nx) rasters) from which the kernels derive the vectors per pixel (inc_hd_to_enu + enu2ecef).
-    A statevector file (`filename=`) would need isce3's geo2rdr and raises ImportError like the reference
-    does when isce3 is missing (losreader.py:176-177)."""
+    With `filename=` (an orbit / state-vector file, as in the reference) the zero-Doppler geometry is solved per pixel
+    on the GPU (raider_amd.orbits.Orbit.look_vectors) - no isce3 needed; parity with isce3's geo2rdr is unpinned."""
 
     def __init__(self, filename=None, los_convention='isce', time=None, look_dir='right', pad=600,
                  look_vectors=None, inc=None, heading=None):
-        if filename is not None and look_vectors is None and inc is None:
-            raise ImportError('isce3 is required for orbit-based look vectors; raider_amd.Raytracing takes '
-                              'look_vectors= or inc=/heading= arrays instead')
         super().__init__()
         self._ray_trace = True
         self._file = filename
         self._time = time
         self._pad = pad
         self._convention = los_convention
+        self._orbit = None
         if self._convention.lower() != 'isce':
             raise NotImplementedError()
         if look_dir.lower() not in ('right', 'left'):
@@ -144,21 +142,46 @@ class Raytracing(LOS):
         self._lv = None if look_vectors is None else np.ascontiguousarray(look_vectors, dtype=np.float64)
         self._inc = inc
         self._hd = heading if heading is not None else (0.0 if inc is not None else None)
-        if self._lv is None and self._inc is None:
-            raise ValueError('Raytracing needs look_vectors= or inc=/heading=')
+        if self._lv is None and self._inc is None and self._file is None:
+            raise ValueError('Raytracing needs an orbit file, look_vectors= or inc=/heading=')
+        if self._file is not None and self._time is not None:
+            self._orbit = get_orbit(self._file, self._time, pad=pad)          # losreader.py:188-190
+
+    def setTime(self, time, pad=600):
+        """losreader.py:214-217 (called from checkArgs)."""
+        self._time = time
+        if self._file is not None:
+            self._orbit = get_orbit(self._file, self._time, pad=pad)
+
+    def getSensorDirection(self):
+        if self._orbit is None:
+            raise ValueError('The orbit has not been set')
+        return self._orbit.direction()
 
     def getLookDirection(self):
         return self._look_dir
 
-    def ray_batch(self, xpts, ypts):
+    def ray_batch(self, xpts, ypts, ht=None):
         """Engine fast path: a `Rays` batch whose look vectors are generated / read on the device."""
         from .engine import Rays
+        if self._lv is None and self._inc is None:
+            # orbit-based: zero-Doppler solve per pixel on the device (replaces the isce3 loop, losreader.py:230-254)
+            if self._orbit is None:
+                raise ValueError('The orbit has not been set (call setTime)')
+            from .utilFcns import lla2ecef
+            xx, yy = np.meshgrid(xpts, ypts)
+            xyz = np.stack(lla2ecef(yy, xx, np.full(yy.shape, float(ht))), axis=-1)
+            return Rays.grid(xpts, ypts, los=self._orbit.look_vectors(xyz))
         if self._lv is not None:
             return Rays.grid(xpts, ypts, los=self._lv)
         return Rays.grid(xpts, ypts, inc=self._inc, hd=self._hd)
 
     def getLookVectors(self, ht, llh, xyz, yy):
         """delay.py:270 protocol: (ny,nx,3) unit ECEF vectors."""
+        if self._lv is None and self._inc is None:
+            if self._orbit is None:
+                raise ValueError('The orbit has not been set (call setTime)')
+            return self._orbit.look_vectors(xyz)
         if self._lv is not None:
             if self._lv.shape != yy.shape + (3,):
                 raise ValueError(f'look_vectors have shape {self._lv.shape}, expected {yy.shape + (3,)}')
@@ -167,6 +190,12 @@ class Raytracing(LOS):
         hd = np.broadcast_to(np.asarray(self._hd, dtype=np.float64), yy.shape)
         enu = inc_hd_to_enu(inc, hd)
         return enu2ecef(enu[..., 0], enu[..., 1], enu[..., 2], llh[1], llh[0], llh[2])
+
+
+def get_orbit(orbit_file, ref_time, pad):
+    """losreader.py:736-769: state vectors within `pad` seconds of ref_time, unique and time-ordered."""
+    from .orbits import Orbit
+    return Orbit.from_file(orbit_file, ref_time, pad)
 
 
 def getZenithLookVecs(lats, lons, heights):

@@ -92,8 +92,11 @@ def test_los_protocol():
     assert z.is_Zenith() and not z.is_Projected() and not z.ray_trace()
     assert c.is_Projected() and not c.is_Zenith()
     assert r.ray_trace() and not r.is_Zenith() and not r.is_Projected()
-    with pytest.raises(ImportError):
-        Raytracing('orbit.EOF')                       # isce3-based path, as the reference without isce3
+    import datetime
+    with pytest.raises(ValueError):
+        Raytracing('no_such_orbit.EOF', time=datetime.datetime(2020, 1, 1))      # get_sv: cannot parse (losreader.py:362-366)
+    with pytest.raises(ValueError):
+        Raytracing()
     with pytest.raises(RuntimeError):
         Raytracing(inc=1.0, look_dir='up')
     with pytest.raises(NotImplementedError):
@@ -118,3 +121,58 @@ def test_synthetic_matches_oracle_recipe():
     a = synthetic_cube(20, 24, 12, seed=3); b = O.synthetic_cube(20, 24, 12, seed=3)
     for k in a:
         assert np.array_equal(a[k], b[k])
+
+
+def test_g9_orbit_readers(golden):
+    """File readers against the reference's own readers run on its own fixtures (tests/golden/orbit_files = DATA copies
+    of test/orbit_files/*; expected arrays from oracle/refharness/gen_golden.py g9)."""
+    import datetime as dt
+    from raider_amd import orbits
+    g = golden('g9_orbit_readers')
+    d = REPO / 'tests' / 'golden' / 'orbit_files'
+    for tag, fn, reader in (('eof', 'S1_orbit_example.EOF', orbits.read_ESA_Orbit_file), ('txt', 'S1_sv_file.txt', orbits.read_txt_file)):
+        svs = reader(str(d / fn))
+        assert svs[0][0].isoformat() == str(g[f'{tag}_epoch'])
+        assert np.array_equal([(t - svs[0][0]).total_seconds() for t in svs[0]], g[f'{tag}_t'])
+        assert np.array_equal(np.stack(svs[1:], -1), g[f'{tag}_sv'])
+    t_ref = dt.datetime(2018, 11, 12, 23, 0, 2)
+    svs = orbits.get_sv(str(d / 'S1_sv_file.txt'), t_ref + dt.timedelta(seconds=40), 15)
+    assert np.array_equal([(t - t_ref).total_seconds() for t in svs[0]], g['cut_t']) and np.array_equal(np.stack(svs[1:], -1), g['cut_sv'])
+    svs = orbits.get_sv(str(d / 'S1_orbit_example.EOF'), t_ref, 3 * 60)          # non-standard EOF name must not be filtered out
+    assert len(svs[0]) == 8
+    times = orbits.read_txt_file(str(d / 'S1_sv_file.txt'))[0]
+    assert np.array_equal(orbits.cut_times(times, t_ref, pad=5), g['cut_mask_5'])
+    assert np.array_equal(orbits.cut_times(times, times[4], pad=15), g['cut_mask_15'])
+    for bad in ('incorrect_file.txt', 'no_exist.txt'):                               # test_get_sv_3 / _4
+        with pytest.raises(ValueError):
+            orbits.get_sv(str(d / bad), t_ref, 3 * 60)
+    orb = orbits.Orbit.from_file(str(d / 'S1_sv_file.txt'), t_ref, 600)
+    assert orb.time.size == 8 and orb.direction() == 'desc' and np.all(np.diff(orb.time) == 10.0)
+    with pytest.raises(RuntimeError):
+        orbits.Orbit(list(times[:3]), np.zeros((3, 3)), np.zeros((3, 3)))
+
+
+def test_oracle_orbit_geometry():
+    """The oracle's zero-Doppler solve: (S - T) . V = 0 at the returned time, unit look vectors, Hermite reproduces the
+    state vectors at the nodes."""
+    import datetime as dt
+    from oracle import raider_oracle as O
+    from raider_amd import orbits
+    d = REPO / 'tests' / 'golden' / 'orbit_files'
+    orb = orbits.Orbit.from_file(str(d / 'S1_sv_file.txt'), dt.datetime(2018, 11, 12, 23, 0, 2), 600)
+    p, v = O.orbit_hermite(orb.time, orb.position, orb.velocity, orb.time[2:6])
+    np.testing.assert_allclose(p, orb.position[2:6], rtol=0, atol=1e-6); np.testing.assert_allclose(v, orb.velocity[2:6], rtol=0, atol=1e-9)
+    # ground targets ~ 250-450 km to the right of the (descending) track
+    mid, vmid = O.orbit_hermite(orb.time, orb.position, orb.velocity, [35.0])
+    lon_s, lat_s, _ = O.ecef2lla(mid[:, 0], mid[:, 1], mid[:, 2])
+    lat = lat_s[0] + np.linspace(-0.1, 0.1, 5)[:, None] + np.zeros((1, 6)); lon = lon_s[0] - np.linspace(2.5, 4.5, 6)[None, :] + np.zeros((5, 1))
+    xyz = np.stack(O.lla2ecef(lat, lon, np.zeros_like(lat)), -1)
+    los, az, rg = O.orbit_look_vectors(orb.time, orb.position, orb.velocity, xyz)
+    assert np.isfinite(los).all()
+    np.testing.assert_allclose(np.linalg.norm(los, axis=-1), 1.0, rtol=0, atol=1e-15)
+    S, V = O.orbit_hermite(orb.time, orb.position, orb.velocity, az.ravel())
+    dop = np.sum((S - xyz.reshape(-1, 3)) * V, -1) / (rg.ravel() * np.linalg.norm(V, axis=-1))
+    assert np.abs(dop).max() < 1e-9                               # cos of the squint angle
+    up = O.getZenithLookVecs(lat, lon, 0)
+    inc = np.degrees(np.arccos(np.sum(los * up, -1)))
+    assert inc.min() > 15 and inc.max() < 50
