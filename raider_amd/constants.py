@@ -1,13 +1,14 @@
-"""Hot-path constants (tools/RAiDER/constants.py:12-23)."""
+"""Numeric constants of the delay path (values of tools/RAiDER/constants.py:12-23)."""
 import numpy as np
 
-_ZMIN = np.float64(-100)     # minimum required height
-_ZREF = np.float64(26000)    # default maximum integration height
-_STEP = np.float64(15.0)     # legacy fixed integration step (makePoints)
-_g0 = np.float64(9.80665)
-_g1 = np.float64(9.80616)
+# heights (m)
+_ZMIN, _ZREF = np.float64(-100), np.float64(26000)     # lowest required model height; default top of the integration
+_STEP = np.float64(15.0)                               # fixed step of the legacy makePoints ray sampler
+_CUBE_SPACING_IN_M = float(2000)                       # default horizontal posting of output cubes
+
+# Earth
+R_EARTH_MAX_WGS84, R_EARTH_MIN_WGS84 = 6378137, 6356752
 _RE = np.float64(6371008.7714)
-R_EARTH_MAX_WGS84 = 6378137
-R_EARTH_MIN_WGS84 = 6356752
-_CUBE_SPACING_IN_M = float(2000)
-_THRESHOLD_SECONDS = 1 * 60
+_g0, _g1 = np.float64(9.80665), np.float64(9.80616)   # standard gravity; gravity at 45 deg latitude
+
+_THRESHOLD_SECONDS = 60                                 # temporal-interpolation tolerance

@@ -1,33 +1,25 @@
-"""scipy-like wrapper over the GPU `interpolate` (tools/RAiDER/interpolator.py:19-69)."""
+"""scipy-style callable over the GPU `interpolate` (counterpart of tools/RAiDER/interpolator.py:19-69).
+
+Edge rule = the native extension's, not scipy's: with a fill value, a query lying ON the last node of an axis is
+filled (interpolate.h:23-38,58-65); without one, queries outside the grid are linearly extrapolated."""
 import numpy as np
 
 from .interpolate import interpolate
 
 
 class RegularGridInterpolator:
-    """interpolator.py:19-69 - note the native edge rule (a query ON the last grid node is filled)."""
-
     def __init__(self, grid, values, fill_value=None, assume_sorted=False, max_threads=8):
-        self.grid = grid
-        self.values = values
-        self.fill_value = fill_value
-        self.assume_sorted = assume_sorted
-        self.max_threads = max_threads
+        self.grid, self.values = grid, values
+        self.fill_value, self.assume_sorted, self.max_threads = fill_value, assume_sorted, max_threads
 
     def __call__(self, points):
+        """points: an (..., ndim) array, or a tuple of equally shaped coordinate arrays (one per axis)."""
         if isinstance(points, tuple):
-            shape = points[0].shape
-            for arr in points:
-                assert arr.shape == shape, 'All dimensions must contain the same number of points!'
-            interp_points = np.stack(points, axis=-1)
-            in_shape = interp_points.shape
-            interp_points = interp_points.reshape(-1, in_shape[-1])
-        elif points.ndim > 2:
-            in_shape = points.shape
-            interp_points = points.reshape((int(np.prod(points.shape[:-1])),) + (points.shape[-1],))
-        else:
-            interp_points = points
-            in_shape = interp_points.shape
-        out = interpolate(self.grid, self.values, interp_points, fill_value=self.fill_value,
-                          assume_sorted=self.assume_sorted, max_threads=self.max_threads)
-        return out.reshape(in_shape[:-1])
+            shapes = {np.shape(p) for p in points}
+            assert len(shapes) == 1, 'All dimensions must contain the same number of points!'
+            points = np.stack(points, axis=-1)
+        points = np.asarray(points)
+        lead = points.shape[:-1]
+        flat = interpolate(self.grid, self.values, points.reshape(-1, points.shape[-1]), fill_value=self.fill_value,
+                           assume_sorted=self.assume_sorted, max_threads=self.max_threads)
+        return flat.reshape(lead)
