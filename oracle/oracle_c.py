@@ -1,0 +1,64 @@
+"""ctypes front end of oracle/oracle_c.c (TEST INFRASTRUCTURE: multi-core CPU restatement of the ray-traced path,
+used by tests/test_oracle_c.py and bench.py's cpu_baseline leg - never by the product)."""
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+from . import raider_oracle as O
+
+HERE = Path(__file__).resolve().parent
+SO = HERE / 'liboracle_c.so'
+_lib = None
+
+
+def build():
+    src = HERE / 'oracle_c.c'
+    if not SO.exists() or SO.stat().st_mtime < src.stat().st_mtime:
+        subprocess.run(['gcc', '-O3', '-fopenmp', '-shared', '-fPIC', '-ffp-contract=off', str(src), '-o', str(SO), '-lm'], check=True)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(str(SO))
+        _lib.orc_num_threads.restype = C.c_int
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def num_threads():
+    return lib().orc_num_threads()
+
+
+def build_cube_ray_slice(cube, xpts, ypts, ht, los, zref, max_seg=1000.0, nparts=None):
+    """One height slice of _build_cube_ray (delay.py:256-323) on meshgrid(xpts, ypts) with look vectors los (ny,nx,3).
+    cube: dict(xs, ys, zs, wet, hydro (z,y,x)).  Returns (wet, hydro, nparts)."""
+    L = lib()
+    xx, yy = np.meshgrid(np.asarray(xpts, float), np.asarray(ypts, float))
+    lat = np.ascontiguousarray(yy.ravel()); lon = np.ascontiguousarray(xx.ravel())
+    los = np.ascontiguousarray(np.asarray(los, dtype=np.float64).reshape(-1, 3))
+    n = lat.size
+    levels = O.ray_levels(cube['zs'], ht, zref)
+    K = len(levels)
+    lo = np.array([a for a, _ in levels]); hi = np.array([b for _, b in levels])
+    ys, xs, zs = (np.ascontiguousarray(cube[k], dtype=np.float64) for k in ('ys', 'xs', 'zs'))
+    wet = np.ascontiguousarray(np.asarray(cube['wet']).transpose(1, 2, 0)); hyd = np.ascontiguousarray(np.asarray(cube['hydro']).transpose(1, 2, 0))
+    dtype = 0 if wet.dtype == np.float32 else 1
+    if dtype == 1:
+        wet, hyd = wet.astype(np.float64), hyd.astype(np.float64)
+    maxlen = np.zeros(K); clamp = (C.c_int * 2)()
+    L.orc_prepass(_p(lat), _p(lon), _p(los), C.c_int64(n), C.c_double(ht), _p(lo), _p(hi), C.c_int(K), C.c_double(zs.min()), C.c_double(zs.max()),
+                  _p(maxlen), clamp)
+    if nparts is None:
+        nparts = np.ceil(maxlen / max_seg).astype(int) + 1
+    np32 = np.ascontiguousarray(nparts, dtype=np.int32)
+    ow, oh = np.empty(n), np.empty(n)
+    L.orc_march(_p(lat), _p(lon), _p(los), C.c_int64(n), C.c_double(ht), _p(lo), _p(hi), C.c_int(K), _p(np32), C.c_int(clamp[0]), C.c_int(clamp[1]),
+                _p(ys), C.c_int(ys.size), _p(xs), C.c_int(xs.size), _p(zs), C.c_int(zs.size), _p(wet), _p(hyd), C.c_int(dtype), _p(ow), _p(oh))
+    return ow.reshape(yy.shape), oh.reshape(yy.shape), np.asarray(nparts)
