@@ -51,13 +51,13 @@ static void lla2ecef(double lat, double lon, double h, double* x, double* y, dou
 
 /* PROJ cart.cpp geodetic(): returns lon, lat (deg), h */
 static void ecef2lla(double x, double y, double z, double* lon, double* lat, double* h) {
-    const double p = hypot(x, y);
+    const double p = sqrt(x * x + y * y);
     const double yt = z * A, xt = p * B;
-    const double nrm = hypot(yt, xt);
+    const double nrm = sqrt(yt * yt + xt * xt);
     const double c = nrm == 0 ? 1.0 : xt / nrm, s = nrm == 0 ? 0.0 : yt / nrm;
     const double yphi = z + E2S * B * s * s * s;
     const double xphi = p - ES * A * c * c * c;
-    const double nphi = hypot(yphi, xphi);
+    const double nphi = sqrt(yphi * yphi + xphi * xphi);
     double cphi = nphi == 0 ? 1.0 : xphi / nphi, sphi = nphi == 0 ? 0.0 : yphi / nphi;
     double phi;
     if (xphi <= 0) { phi = z >= 0 ? M_PI_2 : -M_PI_2; cphi = 0; sphi = z >= 0 ? 1.0 : -1.0; }
@@ -72,7 +72,21 @@ static void ecef2lla(double x, double y, double z, double* lon, double* lat, dou
     }
 }
 
-static double ecef_h(double x, double y, double z) { double a, b, h; ecef2lla(x, y, z, &a, &b, &h); return h; }
+/* height only (what the Newton iteration of getTopOfAtmosphere reads, losreader.py:729-731): same formulas as
+ * ecef2lla without the two arctangents; sqrt(x*x+y*y) instead of hypot (1 ulp) because glibc's hypot is ~10x slower */
+static double ecef_h(double x, double y, double z) {
+    const double p = sqrt(x * x + y * y);
+    const double yt = z * A, xt = p * B;
+    const double nrm = sqrt(yt * yt + xt * xt);
+    const double c = nrm == 0 ? 1.0 : xt / nrm, s = nrm == 0 ? 0.0 : yt / nrm;
+    const double yphi = z + E2S * B * s * s * s;
+    const double xphi = p - ES * A * c * c * c;
+    const double nphi = sqrt(yphi * yphi + xphi * xphi);
+    double cphi = nphi == 0 ? 1.0 : xphi / nphi, sphi = nphi == 0 ? 0.0 : yphi / nphi;
+    if (xphi <= 0) { cphi = 0; sphi = z >= 0 ? 1.0 : -1.0; }
+    if (cphi < 1e-6) return fabs(z) - hypot(A * A * cphi, B * B * sphi) / hypot(A * cphi, B * sphi);
+    return p / cphi - A / sqrt(1.0 - ES * sphi * sphi);
+}
 
 static void toa(const double* o, const double* l, double hgt, int iters, double factor, double* pos) {
     for (int k = 0; k < 3; ++k) pos[k] = o[k] + hgt * l[k];

@@ -32,6 +32,21 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+_cube_cache = {}
+
+
+def _yxz(cube):
+    """(y,x,z) C-order copies of the fields, cached per cube dict (the transposes are not part of the path)."""
+    key = id(cube['wet'])
+    if key not in _cube_cache:
+        _cube_cache.clear()
+        wet = np.ascontiguousarray(np.asarray(cube['wet']).transpose(1, 2, 0)); hyd = np.ascontiguousarray(np.asarray(cube['hydro']).transpose(1, 2, 0))
+        if wet.dtype != np.float32:
+            wet, hyd = wet.astype(np.float64), hyd.astype(np.float64)
+        _cube_cache[key] = (wet, hyd)
+    return _cube_cache[key]
+
+
 def num_threads():
     return lib().orc_num_threads()
 
@@ -48,10 +63,8 @@ def build_cube_ray_slice(cube, xpts, ypts, ht, los, zref, max_seg=1000.0, nparts
     K = len(levels)
     lo = np.array([a for a, _ in levels]); hi = np.array([b for _, b in levels])
     ys, xs, zs = (np.ascontiguousarray(cube[k], dtype=np.float64) for k in ('ys', 'xs', 'zs'))
-    wet = np.ascontiguousarray(np.asarray(cube['wet']).transpose(1, 2, 0)); hyd = np.ascontiguousarray(np.asarray(cube['hydro']).transpose(1, 2, 0))
+    wet, hyd = _yxz(cube)
     dtype = 0 if wet.dtype == np.float32 else 1
-    if dtype == 1:
-        wet, hyd = wet.astype(np.float64), hyd.astype(np.float64)
     maxlen = np.zeros(K); clamp = (C.c_int * 2)()
     L.orc_prepass(_p(lat), _p(lon), _p(los), C.c_int64(n), C.c_double(ht), _p(lo), _p(hi), C.c_int(K), C.c_double(zs.min()), C.c_double(zs.max()),
                   _p(maxlen), clamp)
