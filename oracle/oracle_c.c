@@ -32,6 +32,14 @@ static const double RF = 298.257223563;
 static const double D2R = 0.017453292519943296;
 static const double R2D = 57.295779513082321;
 
+void orc_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 int orc_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

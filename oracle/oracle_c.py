@@ -19,12 +19,34 @@ def build():
         subprocess.run(['gcc', '-O3', '-fopenmp', '-shared', '-fPIC', '-ffp-contract=off', str(src), '-o', str(SO), '-lm'], check=True)
 
 
+def usable_cpus():
+    """CPUs this process may really use: scheduler affinity, capped by a cgroup CPU quota when there is one."""
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    for path in ('/sys/fs/cgroup/cpu.max', '/sys/fs/cgroup/cpu/cpu.cfs_quota_us'):
+        try:
+            txt = open(path).read().split()
+            if path.endswith('cpu.max'):
+                if txt[0] != 'max':
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]))))
+            else:
+                q = int(txt[0]); per = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+        except (OSError, ValueError, IndexError):
+            pass
+    return n
+
+
 def lib():
     global _lib
     if _lib is None:
         build()
         _lib = C.CDLL(str(SO))
         _lib.orc_num_threads.restype = C.c_int
+        import os
+        if 'OMP_NUM_THREADS' not in os.environ:
+            _lib.orc_set_threads(C.c_int(usable_cpus()))
     return _lib
 
 
