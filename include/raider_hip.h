@@ -179,6 +179,18 @@ int rdr_ecef2lla(rdr_ctx* ctx, const double* xyz, int64_t n, double* lon, double
 /* look vectors for a ray batch (any los_mode) -> los[n,3] */
 int rdr_look_vectors(rdr_ctx* ctx, const rdr_rays* rays, double ht, double* los);
 
+/* Cube producer (models/weatherModel.py:235-262: _find_e -> _uniform_in_z -> _checkForNans -> wet/hydro refractivity ->
+ * _adjust_grid -> _getZTD): model-level columns zs3/p/t/hum [ny, nx, nlev] (heights ascending along the last axis,
+ * humidity_type 0 = specific humidity q, 1 = relative humidity %) are resampled to the uniform levels new_z[nz] and
+ * turned into the two device cubes the delay kernels read, without a NetCDF round trip:
+ *   *pointwise = (wet, hydro) refractivity, f32;   *total = (wet_total, hydro_total) zenith delays, f64.
+ * When zmin < new_z[0] an extra bottom level at zmin is added (the reference's padLower).  t_out/p_out/e_out (f32,
+ * [ny, nx, nz_out], all three or none) return the resampled state for parity checks.  k1,k2,k3: models/ecmwf.py:26-28. */
+int rdr_cubes_from_model_levels(rdr_ctx* ctx, const double* ys, int64_t ny, const double* xs, int64_t nx, const double* zs3,
+                                const double* p, const double* t, const double* hum, int humidity_type, int64_t nlev,
+                                const double* new_z, int64_t nz, double k1, double k2, double k3, double zmin, int loc,
+                                rdr_cube** pointwise, rdr_cube** total, float* t_out, float* p_out, float* e_out);
+
 /* Look vectors from orbit state vectors: replaces the per-pixel isce3 geo2rdr + Orbit.interpolate loop of
  * Raytracing.getLookVectors (losreader.py:219-255; zero-Doppler, threshold 1e-7, maxiter 30 at the call site).
  * sv_t[nsv] seconds (strictly increasing, HOST), sv_pos/sv_vel [nsv,3] ECEF (HOST); xyz[n,3] targets, los[n,3] unit

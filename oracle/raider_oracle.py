@@ -584,6 +584,84 @@ def makePoints(max_len, Rays_SP, Rays_SLV, stepSize):
 
 
 # ----------------------------------------------------------------------------------------------
+# cube producer  (models/weatherModel.py:235-262: what turns model-level (p, t, q|rh, z) columns into the four fields the
+# delay path reads).  Pinned by golden g10 (the reference's own WeatherModel run on synthetic columns).
+# ----------------------------------------------------------------------------------------------
+def find_svp(t):
+    """models/weatherModel.py:750-780 (saturation vapour pressure, Pa, returned as float32)."""
+    t = np.asarray(t)
+    t1, t2 = 273.15, 250.15
+    tref = t - t1
+    wgt = (t - t2) / (t1 - t2)
+    svpw = 6.1121 * np.exp((17.502 * tref) / (240.97 + tref))
+    svpi = 6.1121 * np.exp((22.587 * tref) / (273.86 + tref))
+    svp = svpi + (svpw - svpi) * wgt ** 2
+    svp = np.where(t > t1, svpw, svp)
+    svp = np.where(t < t2, svpi, svp)
+    return (svp * 100).astype(np.float32)
+
+
+def fillna_columns(a, fill_value=0.0):
+    """interpolator.py:110-130 `fillna3D` (pandas interpolate(axis=1, limit_direction='backward') along the last axis):
+    leading NaNs <- first valid value, interior NaN runs <- linear in the INDEX, trailing NaNs <- fill_value."""
+    a = np.asarray(a)
+    out = a.copy()
+    flat = out.reshape(-1, a.shape[-1])
+    idx = np.arange(a.shape[-1], dtype=np.float64)
+    for row in flat:
+        ok = ~np.isnan(row)
+        if not ok.any():
+            row[:] = fill_value
+            continue
+        last = np.nonzero(ok)[0][-1]
+        filled = np.interp(idx, idx[ok], row[ok].astype(np.float64))
+        row[:last + 1] = filled[:last + 1].astype(a.dtype)
+        row[last + 1:] = fill_value
+    return out
+
+
+def cube_from_model_levels(zs, p, t, hum, humidity_type, new_z, k1=0.776, k2=0.233, k3=3.75e3, zmin=_ZMIN,
+                           R_v=461.524, R_d=287.06):
+    """models/weatherModel.py:235-262 on arrays shaped (A, B, nlev) with per-column ascending heights `zs`:
+    _find_e (:332-353) -> _uniform_in_z (:603-629, native interpolate_along_axis with NaN fill, cast to f32) ->
+    _checkForNans (:631-635) -> refractivities (:355-361) -> _adjust_grid (:371-387, pad a level at zmin) -> _getZTD
+    (:389-403).  Returns dict(zs, t, p, e, wet, hydro (f32, (A,B,nz)), wet_total, hydro_total (f64))."""
+    svp = find_svp(t)
+    if humidity_type == 'q':
+        w = hum / (1 - hum)
+        e = w * R_v * (p - svp) / R_d
+    elif humidity_type == 'rh':
+        e = hum / 100 * svp
+    else:
+        raise RuntimeError('Not a valid humidity type')
+    new_z = np.asarray(new_z, dtype=np.float64)
+    new3 = np.broadcast_to(new_z, zs.shape[:2] + (new_z.size,))
+    tu = native_interpolate_along_axis(zs, t, new3, axis=2, fill_value=np.nan).astype(np.float32)
+    pu = native_interpolate_along_axis(zs, p, new3, axis=2, fill_value=np.nan).astype(np.float32)
+    eu = native_interpolate_along_axis(zs, e, new3, axis=2, fill_value=np.nan).astype(np.float32)
+    pf = fillna_columns(pu)
+    tf = fillna_columns(tu, fill_value=1e16)
+    ef = fillna_columns(eu)
+    wet = (np.float32(k2) * ef / tf + np.float32(k3) * ef / tf ** 2).astype(np.float32)
+    hydro = (np.float32(k1) * pf / tf).astype(np.float32)
+    out_z = new_z
+    if zmin < np.nanmin(new_z):                       # _adjust_grid: new lowest level at zmin holding each column's lowest value
+        out_z = np.insert(new_z, 0, zmin)
+        pad = lambda v: np.concatenate((v[:, :, :1], v), axis=2)
+        pf, tf, ef, wet, hydro = pad(pf), pad(tf), pad(ef), pad(wet), pad(hydro)
+
+    def ztd(f):
+        tot = np.zeros(f.shape)
+        for level in range(f.shape[2]):
+            y = f[..., level:]
+            d = np.diff(out_z[level:])
+            tot[..., level] = 1e-6 * (d * (y[..., 1:] + y[..., :-1]) / 2.0).sum(-1)
+        return tot
+    return dict(zs=out_z, t=tf, p=pf, e=ef, wet=wet, hydro=hydro, wet_total=ztd(wet), hydro_total=ztd(hydro),
+                t_u=tu, p_u=pu, e_u=eu, e_levels=e)
+
+
+# ----------------------------------------------------------------------------------------------
 # synthetic workloads (SURVEY.md §8(d)) - shared by tests and bench so GPU and CPU see the
 # same seeded inputs
 # ----------------------------------------------------------------------------------------------

@@ -17,6 +17,7 @@ The reference functions exercised (file:line under /root/reference/tools/RAiDER 
   (G7 time weights cli/raider.py:877-888: NOT generated - RAiDER.cli.raider imports h5py, absent here;
    the two-line formula is restated in the oracle and pinned by its mean-of-epochs property only)
   G8 tropo_delay point branch              delay.py:35-130
+  G10 cube producer (_find_e, _uniform_in_z, _checkForNans, refractivity, _adjust_grid, _getZTD)  models/weatherModel.py:235-262,332-403,603-629
   G9 read_ESA_Orbit_file, read_txt_file, get_sv, cut_times   losreader.py:429-518,319-371,617-634
 pyproj/xarray/rasterio are build-owned stubs (oracle/refharness/stubs): geodetic<->ECEF arithmetic
 is therefore the stub's restatement of PROJ `cart`, not PROJ itself ("parity unpinned" for that
@@ -391,7 +392,75 @@ def g9():
     save('g9_orbit_readers', **out)
 
 
+# ---------------------------------------------------------------------------------------------- G10
+def g10():
+    """The cube producer (models/weatherModel.py:235-262: _find_e -> _uniform_in_z -> _checkForNans -> refractivities ->
+    _adjust_grid -> _getZTD) run on synthetic model-level columns through the reference's own WeatherModel class."""
+    import warnings
+    warnings.filterwarnings('ignore')
+    from RAiDER.models.weatherModel import WeatherModel
+
+    class Model(WeatherModel):
+        def __init__(self, hum):
+            super().__init__()
+            self._k1, self._k2, self._k3 = 0.776, 0.233, 3.75e3           # models/ecmwf.py:26-28 (same for every provider)
+            self._humidityType = hum
+            self._Name = 'SYNTH'
+
+        def _fetch(self, *a):
+            pass
+
+        def load_weather(self, *a, **k):
+            pass
+
+    out = {}
+    rng = np.random.default_rng(10)
+    A, B, nl = 6, 7, 24
+    for tag, hum, newz in (('q', 'q', np.linspace(200.0, 30000.0, 16)),                 # lowest level above zmin -> padded (_adjust_grid)
+                           ('rh', 'rh', np.concatenate([[-100.0], np.linspace(50.0, 41000.0, 17)]))):   # starts AT zmin, tops above the columns
+        base = np.sort(rng.uniform(0.0, 1.0, (A, B, nl)), axis=2)
+        zs = -50.0 + 200.0 * rng.uniform(0, 1, (A, B, 1)) + 36000.0 * base ** 1.5     # per-column model-level heights (ascending)
+        t = 288.0 - 0.0062 * zs + rng.normal(0, 0.5, zs.shape)
+        t = np.maximum(t, 205.0)
+        p = 101325.0 * np.exp(-zs / 7800.0) * (1 + 0.002 * rng.normal(size=zs.shape))
+        m = Model(hum)
+        m._zs, m._t, m._p = zs.copy(), t.copy(), p.copy()
+        if hum == 'q':
+            m._q = 0.012 * np.exp(-zs / 2400.0) * (1 + 0.1 * rng.uniform(-1, 1, zs.shape))
+            out[f'{tag}_hum'] = m._q.copy()
+        else:
+            m._rh = np.clip(70.0 * np.exp(-zs / 9000.0) + 10 * rng.uniform(-1, 1, zs.shape), 1.0, 100.0)
+            out[f'{tag}_hum'] = m._rh.copy()
+        m._xs = np.arange(B) * 0.25 - 118.0
+        m._ys = np.arange(A) * 0.25 + 33.0
+        out[f'{tag}_zs'], out[f'{tag}_t'], out[f'{tag}_p'], out[f'{tag}_newz'] = zs, t, p, newz
+        m._find_e()
+        out[f'{tag}_e_levels'] = m._e.copy()
+        m._uniform_in_z(_zlevels=newz)
+        out[f'{tag}_t_u'], out[f'{tag}_p_u'], out[f'{tag}_e_u'] = m._t.copy(), m._p.copy(), m._e.copy()      # with NaNs
+        m._checkForNans()
+        out[f'{tag}_t_f'], out[f'{tag}_p_f'], out[f'{tag}_e_f'] = m._t.copy(), m._p.copy(), m._e.copy()
+        m._get_wet_refractivity()
+        m._get_hydro_refractivity()
+        m._adjust_grid()
+        m._getZTD()
+        out[f'{tag}_out_zs'] = np.asarray(m._zs, dtype=np.float64)
+        out[f'{tag}_wet'], out[f'{tag}_hydro'] = m._wet_refractivity, m._hydrostatic_refractivity
+        out[f'{tag}_wet_total'], out[f'{tag}_hydro_total'] = m._wet_ztd, m._hydrostatic_ztd
+        out[f'{tag}_t_out'], out[f'{tag}_p_out'], out[f'{tag}_e_out'] = m._t, m._p, m._e
+        print(' ', tag, 'zs', m._zs.shape, 'wet', m._wet_refractivity.dtype, m._wet_refractivity.shape, 'NaNs after interp', int(np.isnan(out[f'{tag}_t_u']).sum()))
+    # interpolator.fillna3D on its own, with interior NaN runs / leading / trailing / all-NaN columns (f32 like the model state)
+    from RAiDER.interpolator import fillna3D
+    holes = rng.normal(250.0, 20.0, (4, 5, 12)).astype(np.float32)
+    holes[0, 0, 3:6] = np.nan; holes[0, 1, :2] = np.nan; holes[0, 2, 9:] = np.nan; holes[0, 3, :] = np.nan
+    holes[1, 0, [1, 4, 5, 8]] = np.nan; holes[1, 1, [0, 2, 11]] = np.nan; holes[2, 2, 1:11] = np.nan
+    out['holes_in'] = holes.copy()
+    out['holes_fill0'] = fillna3D(holes.copy())
+    out['holes_fill1e16'] = fillna3D(holes.copy(), fill_value=1e16)
+    save('g10_cube_producer', **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g8', 'g9']   # g7: cli.raider needs h5py (absent)
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g8', 'g9', 'g10']   # g7: cli.raider needs h5py (absent)
     for w in which:
         globals()[w]()

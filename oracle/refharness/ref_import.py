@@ -41,4 +41,9 @@ def import_reference():
     sys.modules['RAiDER'] = pkg
     import RAiDER.cli.conf as conf  # noqa: E402
     conf.setLoggerPath(Path(tempfile.mkdtemp(prefix='raider_ref_log_')))
+    # RAiDER.models/__init__.py imports every provider (herbie, cdsapi, ...): seed a bare sub-package so that
+    # RAiDER.models.weatherModel alone can be imported (needs only the shapely import stub)
+    models = types.ModuleType('RAiDER.models')
+    models.__path__ = [str(REF_PKG / 'models')]
+    sys.modules['RAiDER.models'] = models
     return pkg

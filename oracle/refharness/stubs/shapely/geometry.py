@@ -1,0 +1,10 @@
+class _Box:
+    def __init__(self, *bounds):
+        self.bounds = bounds
+
+
+def box(*bounds):
+    return _Box(*bounds)
+
+
+Polygon = _Box

@@ -293,6 +293,147 @@ __global__ void build_ray_kernel(const double* __restrict__ xyz, const double* _
     }
 }
 
+// ---- cube producer ---------------------------------------------------------------------------------------------------
+// models/weatherModel.py:235-262 for one model-level column per wavefront (lanes = levels): _find_e (:332-353, find_svp
+// :750-780), _uniform_in_z (:603-629: native interpolate_1d with NaN fill, results cast to f32), _checkForNans (:631-635 =
+// interpolator.fillna3D :110-130: leading NaNs <- first valid value, interior runs linear in the index, trailing NaNs <- fill),
+// refractivities (:355-361, f32 arithmetic), _adjust_grid (:371-387: extra bottom level at zmin) and _getZTD (:389-403).
+// Output goes straight into the two device cubes the delay kernels read (interleaved (wet,hydro), (y,x,z)).
+__device__ __forceinline__ float svp_pa(double t) {
+    const double t1 = 273.15, t2 = 250.15;
+    const double tref = t - t1;
+    const double wgt = (t - t2) / (t1 - t2);
+    const double svpw = 6.1121 * exp((17.502 * tref) / (240.97 + tref));
+    const double svpi = 6.1121 * exp((22.587 * tref) / (273.86 + tref));
+    double svp = svpi + (svpw - svpi) * (wgt * wgt);
+    if (t > t1) svp = svpw;
+    if (t < t2) svp = svpi;
+    return (float)(svp * 100.0);
+}
+
+// interpolate_1d (interpolate.h:78-118) with fill NaN on an LDS-resident column
+__device__ __forceinline__ double interp_col(const double* xs, const double* ys, int n, double x) {
+    int left = 0, right = n;
+    while (right != left) { const int mid = (left + right) / 2; if (x < xs[mid]) right = mid; else left = mid + 1; }
+    if (right < 1 || right > n - 1) return qnan();
+    const double x0 = xs[right - 1], x1 = xs[right], y0 = ys[right - 1], y1 = ys[right];
+    double r;
+    {
+#pragma clang fp contract(off)
+        const double slope = (y1 - y0) / (x1 - x0);
+        r = y0 + slope * (x - x0);
+    }
+    return r;
+}
+
+// fillna3D on one column held in LDS (float col[n]); every lane fixes its own levels
+__device__ __forceinline__ void fillna_col(float* col, int n, float fill, int lane) {
+    int first = n, last = -1;
+    for (int j = lane; j < n; j += 64) if (col[j] == col[j]) { first = min(first, j); last = max(last, j); }
+    for (int off = 32; off > 0; off >>= 1) { first = min(first, __shfl_xor(first, off, 64)); last = max(last, __shfl_xor(last, off, 64)); }
+    float fixed[8];                                   // nz <= 512 -> <= 8 levels per lane
+    int cnt = 0;
+    for (int j = lane; j < n; j += 64, ++cnt) {
+        float v = col[j];
+        if (!(v == v)) {
+            if (last < 0 || j > last) v = fill;
+            else if (j < first) v = col[first];
+            else {                                    // interior run: np.interp on the index
+                int i = j - 1; while (!(col[i] == col[i])) --i;
+                int k = j + 1; while (!(col[k] == col[k])) ++k;
+                {
+#pragma clang fp contract(off)
+                    const double a = (double)col[i], b = (double)col[k]; const double slope = (b - a) / (double)(k - i); v = (float)(slope * (double)(j - i) + a);
+                }
+            }
+        }
+        fixed[cnt] = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+    cnt = 0;
+    for (int j = lane; j < n; j += 64, ++cnt) col[j] = fixed[cnt];
+    __builtin_amdgcn_wave_barrier();
+}
+
+struct ProducerParams {
+    const double* zs; const double* p; const double* t; const double* hum;   // [ncol, nlev]
+    int64_t ncol; int nlev; int hum_type;                                     // 0 = q, 1 = rh
+    const double* new_z; int nz; int pad;                                     // output levels (without the pad level)
+    float k1, k2, k3; double zmin, R_v, R_d;
+    float2* pw; double2* tot;                                                 // [ncol, nzo] interleaved (wet, hydro)
+    float* t_out; float* p_out; float* e_out;                                 // optional [ncol, nzo]
+};
+
+__global__ __launch_bounds__(256) void producer_kernel(ProducerParams P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int nzo = P.nz + P.pad;
+    // per-wave LDS: zs,p,t,e at model levels (f64) | t,p,e,wet,hyd at output levels (f32) | output level heights (f64)
+    double* wbase = reinterpret_cast<double*>(smem_raw) + (size_t)wave * (4 * P.nlev + nzo + (5 * nzo + 1) / 2 + 1);
+    double* c_z = wbase; double* c_p = c_z + P.nlev; double* c_t = c_p + P.nlev; double* c_e = c_t + P.nlev;
+    double* o_z = c_e + P.nlev;
+    float* o_t = reinterpret_cast<float*>(o_z + nzo); float* o_p = o_t + nzo; float* o_e = o_p + nzo; float* o_w = o_e + nzo; float* o_h = o_w + nzo;
+    for (int j = lane; j < nzo; j += 64) o_z[j] = (P.pad && j == 0) ? P.zmin : P.new_z[j - P.pad];
+    const int64_t wstride = (int64_t)gridDim.x * 4;
+    for (int64_t col = (int64_t)blockIdx.x * 4 + wave; col < P.ncol; col += wstride) {
+        __builtin_amdgcn_wave_barrier();
+        for (int k = lane; k < P.nlev; k += 64) {
+            const int64_t g = col * P.nlev + k;
+            const double t = P.t[g], p = P.p[g], h = P.hum[g];
+            const float svp = svp_pa(t);
+            double e;
+            {
+#pragma clang fp contract(off)
+                if (P.hum_type == 0) { const double w = h / (1.0 - h); e = w * P.R_v * (p - (double)svp) / P.R_d; }   // weatherModel.py:343-348
+                else e = h / 100.0 * (double)svp;                                                                      // :350-353
+            }
+            c_z[k] = P.zs[g]; c_p[k] = p; c_t[k] = t; c_e[k] = e;
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int j = lane; j < P.nz; j += 64) {
+            const double x = P.new_z[j];
+            o_t[j + P.pad] = (float)interp_col(c_z, c_t, P.nlev, x);
+            o_p[j + P.pad] = (float)interp_col(c_z, c_p, P.nlev, x);
+            o_e[j + P.pad] = (float)interp_col(c_z, c_e, P.nlev, x);
+        }
+        __builtin_amdgcn_wave_barrier();
+        fillna_col(o_p + P.pad, P.nz, 0.0f, lane);
+        fillna_col(o_t + P.pad, P.nz, 1e16f, lane);
+        fillna_col(o_e + P.pad, P.nz, 0.0f, lane);
+        for (int j = lane; j < P.nz; j += 64) {
+            const float t = o_t[j + P.pad], p = o_p[j + P.pad], e = o_e[j + P.pad];
+            float w, h;
+            {
+#pragma clang fp contract(off)
+                const float a = (P.k2 * e) / t; const float b = (P.k3 * e) / (t * t); w = a + b;                      // weatherModel.py:355-357
+                h = (P.k1 * p) / t;                                                                                    // :359-361
+            }
+            o_w[j + P.pad] = w; o_h[j + P.pad] = h;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (P.pad && lane == 0) { o_t[0] = o_t[1]; o_p[0] = o_p[1]; o_e[0] = o_e[1]; o_w[0] = o_w[1]; o_h[0] = o_h[1]; }   // utilFcns.padLower
+        __builtin_amdgcn_wave_barrier();
+        for (int j = lane; j < nzo; j += 64) {
+            const int64_t g = col * nzo + j;
+            float2 v; v.x = o_w[j]; v.y = o_h[j];
+            P.pw[g] = v;
+            if (P.t_out) { P.t_out[g] = o_t[j]; P.p_out[g] = o_p[j]; P.e_out[g] = o_e[j]; }
+            // _getZTD: 1e-6 * trapz(f[level:], zs[level:]); np.trapz = sum(d * (y[1:] + y[:-1]) / 2)
+            double sw = 0.0, sh = 0.0;
+            {
+#pragma clang fp contract(off)
+                for (int k = j; k < nzo - 1; ++k) {
+                    const double d = o_z[k + 1] - o_z[k];
+                    sw += d * (double)(o_w[k + 1] + o_w[k]) / 2.0;
+                    sh += d * (double)(o_h[k + 1] + o_h[k]) / 2.0;
+                }
+            }
+            double2 tt; tt.x = 1e-6 * sw; tt.y = 1e-6 * sh;
+            P.tot[g] = tt;
+        }
+    }
+}
+
 // ---- look vectors from orbit state vectors ----------------------------------------------------------------------------
 // Replaces the per-pixel Python loop over isce3.geometry.geo2rdr + Orbit.interpolate of Raytracing.getLookVectors
 // (losreader.py:219-255).  isce3 is a third-party dependency that is not under /root/reference: this restates the published
@@ -1262,6 +1403,70 @@ int rdr_look_vectors(rdr_ctx* c, const rdr_rays* r, double ht, double* los) {
     HIPCHECK(c, hipGetLastError());
     rc = finish_out(c, los, o, (size_t)r->n * 24, r->loc); if (rc) return rc;
     if (r->loc == RDR_HOST) HIPCHECK(c, hipStreamSynchronize(c->stream));
+    return RDR_OK;
+}
+
+int rdr_cubes_from_model_levels(rdr_ctx* c, const double* ys, int64_t ny, const double* xs, int64_t nx, const double* zs3, const double* p,
+                                const double* t, const double* hum, int humidity_type, int64_t nlev, const double* new_z, int64_t nz,
+                                double k1, double k2, double k3, double zmin, int loc, rdr_cube** pointwise, rdr_cube** total,
+                                float* t_out, float* p_out, float* e_out) {
+    if (!c || !ys || !xs || !zs3 || !p || !t || !hum || !new_z || !pointwise || !total) return fail(c, RDR_ERR_INVALID, "rdr_cubes_from_model_levels: NULL argument");
+    if (humidity_type != 0 && humidity_type != 1) return fail(c, RDR_ERR_INVALID, "Not a valid humidity type");
+    if (nlev < 2 || nlev > 1024 || nz < 2 || nz + 1 > MAX_LEVELS) return fail(c, RDR_ERR_INVALID, "rdr_cubes_from_model_levels: unsupported number of levels");
+    int fy, fx, fz;
+    if (axis_check(ys, ny, &fy) || axis_check(xs, nx, &fx) || axis_check(new_z, nz, &fz) || fy || fx || fz)
+        return fail(c, RDR_ERR_INVALID, "rdr_cubes_from_model_levels: x, y and the new z levels must be strictly ascending");
+    HIPCHECK(c, hipSetDevice(c->device));
+    double zlow = new_z[0];
+    const int pad = zmin < zlow ? 1 : 0;                              // _adjust_grid, weatherModel.py:376-378
+    const int64_t nzo = nz + pad, ncol = ny * nx;
+    rdr_cube* q[2] = {new rdr_cube(), new rdr_cube()};
+    for (int i = 0; i < 2; ++i) {
+        q[i]->ctx = c; q[i]->ny = ny; q[i]->nx = nx; q[i]->nz = nzo; q[i]->dtype = i == 0 ? RDR_F32 : RDR_F64;
+        q[i]->ys.assign(ys, ys + ny); q[i]->xs.assign(xs, xs + nx);
+        if (pad) q[i]->zs.push_back(zmin);
+        q[i]->zs.insert(q[i]->zs.end(), new_z, new_z + nz);
+        int rc = cube_alloc(c, q[i]);
+        if (rc) { rdr_cube_destroy(q[0]); rdr_cube_destroy(q[1]); return rc; }
+    }
+    auto bail = [&](int rc) { rdr_cube_destroy(q[0]); rdr_cube_destroy(q[1]); return rc; };
+    ProducerParams P;
+    const void* d;
+    const size_t nb = (size_t)ncol * nlev * 8;
+    int rc;
+    rc = stage_in(c, SLOT_IN0, zs3, nb, loc, &d); if (rc) return bail(rc); P.zs = (const double*)d;
+    rc = stage_in(c, SLOT_IN1, p, nb, loc, &d); if (rc) return bail(rc); P.p = (const double*)d;
+    rc = stage_in(c, SLOT_IN2, t, nb, loc, &d); if (rc) return bail(rc); P.t = (const double*)d;
+    rc = stage_in(c, SLOT_IN3, hum, nb, loc, &d); if (rc) return bail(rc); P.hum = (const double*)d;
+    void* dz;
+    rc = ensure(c, SLOT_AUX, (size_t)nz * 8, &dz); if (rc) return bail(rc);
+    if (hipMemcpyAsync(dz, new_z, (size_t)nz * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess)
+        return bail(fail(c, RDR_ERR_HIP, "rdr_cubes_from_model_levels: copy of the level table failed"));
+    P.new_z = (const double*)dz;
+    P.ncol = ncol; P.nlev = (int)nlev; P.hum_type = humidity_type; P.nz = (int)nz; P.pad = pad;
+    P.k1 = (float)k1; P.k2 = (float)k2; P.k3 = (float)k3; P.zmin = zmin; P.R_v = 461.524; P.R_d = 287.06;   // weatherModel.py:78-79
+    P.pw = (float2*)q[0]->d_vals; P.tot = (double2*)q[1]->d_vals;
+    void *dt_ = nullptr, *dp_ = nullptr, *de_ = nullptr;
+    const size_t ob = (size_t)ncol * nzo * 4;
+    if (t_out && p_out && e_out) {
+        rc = stage_out(c, SLOT_OUT0, t_out, ob, loc, &dt_); if (rc) return bail(rc);
+        rc = stage_out(c, SLOT_OUT1, p_out, ob, loc, &dp_); if (rc) return bail(rc);
+        rc = stage_out(c, SLOT_OUT2, e_out, ob, loc, &de_); if (rc) return bail(rc);
+    }
+    P.t_out = (float*)dt_; P.p_out = (float*)dp_; P.e_out = (float*)de_;
+    const size_t per_wave = ((size_t)4 * nlev + nzo + (5 * nzo + 1) / 2 + 1) * 8;
+    const int g = (int)std::max<int64_t>(1, std::min<int64_t>((ncol + 3) / 4, (int64_t)c->num_cus * 8));
+    {
+        KTimer tm(c, 3);
+        hipLaunchKernelGGL(producer_kernel, dim3(g), dim3(256), per_wave * 4, c->stream, P);
+    }
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && dt_) {
+        if (finish_out(c, t_out, dt_, ob, loc) || finish_out(c, p_out, dp_, ob, loc) || finish_out(c, e_out, de_, ob, loc)) return bail(RDR_ERR_HIP);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) return bail(fail(c, RDR_ERR_HIP, std::string("producer_kernel: ") + hipGetErrorString(e)));
+    *pointwise = q[0]; *total = q[1];
     return RDR_OK;
 }
 

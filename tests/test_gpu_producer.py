@@ -1,0 +1,112 @@
+"""GPU cube producer (rdr_cubes_from_model_levels) vs the reference's WeatherModel processing chain
+(models/weatherModel.py:235-262): golden g10 (made by the reference itself) and the NumPy oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+# t, p and hydro only go through IEEE +,-,*,/ in a fixed order -> bit-exact.  e (and wet, built on it) passes through exp():
+# the device libm and glibc may round the last bit differently, which shows up as <= 1 ulp of f32 after the cast.
+E_RTOL = 2.5e-7
+
+
+def _run(zs, p, t, hum, tag, newz, **kw):
+    from raider_amd.weather import cubes_from_model_levels
+    A, B, _ = zs.shape
+    xs = np.arange(B) * 0.25 - 118.0
+    ys = np.arange(A) * 0.25 + 33.0
+    return cubes_from_model_levels(xs, ys, zs, p, t, hum, tag, newz, return_state=True, **kw)
+
+
+@pytest.mark.parametrize('tag', ['q', 'rh'])
+def test_producer_matches_reference_golden(golden, tag):
+    g = golden('g10_cube_producer')
+    m = _run(g[f'{tag}_zs'], g[f'{tag}_p'], g[f'{tag}_t'], g[f'{tag}_hum'], tag, g[f'{tag}_newz'])
+    assert np.array_equal(m.zs, g[f'{tag}_out_zs'])
+    assert m.pointwise.dtype == np.float32 and m.total.dtype == np.float64
+    assert np.array_equal(m.t, g[f'{tag}_t_out'])
+    assert np.array_equal(m.p, g[f'{tag}_p_out'])
+    np.testing.assert_allclose(m.e, g[f'{tag}_e_out'], rtol=E_RTOL, atol=0)
+    wet, hyd = m.pointwise.read()
+    assert np.array_equal(hyd, g[f'{tag}_hydro'])
+    np.testing.assert_allclose(wet, g[f'{tag}_wet'], rtol=2 * E_RTOL, atol=0)
+    wt, ht = m.total.read()
+    np.testing.assert_allclose(ht, g[f'{tag}_hydro_total'], rtol=1e-13, atol=1e-18)
+    np.testing.assert_allclose(wt, g[f'{tag}_wet_total'], rtol=2 * E_RTOL, atol=1e-18)
+    assert (np.mean(m.e == g[f'{tag}_e_out'])) > 0.9            # and nearly all of e is bit-identical too
+
+
+def test_producer_vs_oracle_with_missing_data():
+    """NaN holes in the model columns (interior runs, whole columns) -> fillna3D semantics on the device"""
+    from oracle import raider_oracle as O
+    rng = np.random.default_rng(77)
+    A, B, nl = 9, 11, 37
+    base = np.sort(rng.uniform(0, 1, (A, B, nl)), axis=2)
+    zs = -80.0 + 300.0 * rng.uniform(0, 1, (A, B, 1)) + 42000.0 * base ** 1.4
+    t = np.maximum(289.0 - 0.0063 * zs + rng.normal(0, 0.4, zs.shape), 203.0)
+    p = 101000.0 * np.exp(-zs / 7700.0)
+    q = 0.011 * np.exp(-zs / 2500.0)
+    t[1, 2, 10:14] = np.nan                   # interior hole -> NaN in the resampled column around those heights
+    t[3, 3, :] = np.nan                       # dead column: t -> 1e16, p/e untouched
+    p[4, 5, 20:] = np.nan
+    newz = np.concatenate([np.arange(-100.0, 3000.0, 150.0), np.arange(3000.0, 44000.0, 1500.0)])
+    r = O.cube_from_model_levels(zs, p, t, q, 'q', newz)
+    m = _run(zs, p, t, q, 'q', newz)
+    assert np.array_equal(m.zs, r['zs'])
+    assert np.array_equal(m.t, r['t']) and np.array_equal(m.p, r['p'])
+    np.testing.assert_allclose(m.e, r['e'], rtol=E_RTOL, atol=0)
+    wet, hyd = m.pointwise.read()
+    assert np.array_equal(hyd, r['hydro'])
+    np.testing.assert_allclose(wet, r['wet'], rtol=2 * E_RTOL, atol=1e-30)
+    wt, ht = m.total.read()
+    np.testing.assert_allclose(ht, r['hydro_total'], rtol=1e-13, atol=1e-18)
+    np.testing.assert_allclose(wt, r['wet_total'], rtol=2 * E_RTOL, atol=1e-18)
+
+
+def test_producer_feeds_the_delay_path():
+    """producer cubes -> tropo_delay-style zenith cube and a ray-traced slice, without leaving the device"""
+    import torch
+    from oracle import raider_oracle as O
+    from raider_amd import Rays
+    from raider_amd.weather import cubes_from_model_levels, MODEL_LEVEL_HEIGHTS
+    rng = np.random.default_rng(5)
+    A, B, nl = 40, 48, 60
+    xs = -119.0 + 0.1 * np.arange(B)
+    ys = 32.0 + 0.1 * np.arange(A)
+    base = np.linspace(0, 1, nl)[None, None, :] ** 1.6
+    zs = -60.0 + 100.0 * rng.uniform(0, 1, (A, B, 1)) + 45000.0 * base
+    t = np.maximum(288.0 - 0.0065 * zs, 210.0)
+    p = 101325.0 * np.exp(-zs / 7600.0)
+    rh = np.clip(75.0 * np.exp(-zs / 8000.0), 1.0, 100.0)
+    dev = torch.device('cuda:0')
+    m = cubes_from_model_levels(xs, ys, *(torch.from_numpy(a).to(dev) for a in (zs, p, t, rh)), 'rh', MODEL_LEVEL_HEIGHTS)
+    r = O.cube_from_model_levels(zs, p, t, rh, 'rh', MODEL_LEVEL_HEIGHTS)
+    assert m.pointwise.shape == (A, B, MODEL_LEVEL_HEIGHTS.size)            # table starts at zmin: no pad
+    # zenith cube (delay._build_cube on the 'total' fields)
+    xq, yq, zq = xs[3:-3:2] + 0.013, ys[3:-3:2] + 0.021, np.array([0.0, 450.0, 2200.0, 9000.0])
+    wz, hz = m.total.build_cube(xq, yq, zq)
+    tot_ip = [O.RGI((ys, xs, r['zs']), r['wet_total']), O.RGI((ys, xs, r['zs']), r['hydro_total'])]
+    ow, oh = O.build_cube(xq, yq, zq, tot_ip)
+    np.testing.assert_allclose(hz, oh, rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(wz, ow, rtol=2 * E_RTOL, atol=1e-14)
+    assert 1.9 < hz[0].mean() < 2.6                                          # a sane hydrostatic ZTD in metres
+    # one ray-traced slice through the pointwise cube
+    xr, yr = xs[8:-8:3] + 0.01, ys[8:-8:3] + 0.02
+    zref = 38000.0
+    wr, hr, _, _ = m.pointwise.raytrace(Rays.grid(xr, yr, inc=35.0, hd=-12.0), 300.0, zref)
+    pw_ip = [O.RGI((ys, xs, r['zs']), r['wet']), O.RGI((ys, xs, r['zs']), r['hydro'])]
+    look = lambda ht_, llh, xyz, yy: O.look_vectors_from_inc_hd(np.full(yy.shape, 35.0), np.full(yy.shape, -12.0), llh[1], llh[0], llh[2])
+    ow2, oh2 = O.build_cube_ray(xr, yr, np.array([300.0]), look, pw_ip, MAX_TROPO_HEIGHT=zref)
+    np.testing.assert_allclose(hr, oh2[0], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(wr, ow2[0], rtol=0, atol=1e-6)
+
+
+def test_producer_errors():
+    from raider_amd.weather import cubes_from_model_levels
+    z = np.tile(np.linspace(0, 30000, 8), (3, 3, 1))
+    with pytest.raises(RuntimeError, match='Not a valid humidity type'):      # weatherModel.py:340-341
+        cubes_from_model_levels(np.arange(3.0), np.arange(3.0), z, z, z, z, 'dewpoint', np.linspace(0, 20000, 5))
+    with pytest.raises(ValueError):
+        cubes_from_model_levels(np.arange(4.0), np.arange(3.0), z, z, z, z, 'q', np.linspace(0, 20000, 5))
+    with pytest.raises(Exception, match='ascending'):
+        cubes_from_model_levels(np.arange(3.0), np.arange(3.0), z, z + 1, z + 200, z * 0, 'q', np.linspace(20000, 0, 5))

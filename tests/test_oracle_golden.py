@@ -221,3 +221,27 @@ def test_time_weights_and_blend():
     out = O.blend_cubes(0.5, a, 0.5, b)
     assert out.dtype == np.float32 and np.allclose(out, 2.5)   # mean of epochs (test_temporal_interpolate.py)
     assert O.blend_cubes(0.25, a.astype(np.float64), 0.75, b.astype(np.float64)).dtype == np.float64
+
+
+@pytest.mark.parametrize('tag', ['q', 'rh'])
+def test_g10_cube_producer(golden, tag):
+    """models/weatherModel.py:235-262 restated (oracle.cube_from_model_levels) vs the reference's own WeatherModel."""
+    g = golden('g10_cube_producer')
+    r = O.cube_from_model_levels(g[f'{tag}_zs'], g[f'{tag}_p'], g[f'{tag}_t'], g[f'{tag}_hum'], tag, g[f'{tag}_newz'])
+    np.testing.assert_allclose(r['e_levels'], g[f'{tag}_e_levels'], rtol=1e-15)
+    for k in ('t', 'p', 'e'):
+        assert np.array_equal(r[f'{k}_u'], g[f'{tag}_{k}_u'], equal_nan=True)          # after _uniform_in_z (with NaNs), f32
+        assert np.array_equal(r[k], g[f'{tag}_{k}_out'])                                 # after _checkForNans + _adjust_grid
+    assert np.array_equal(r['zs'], g[f'{tag}_out_zs'])
+    assert r['wet'].dtype == np.float32 and np.array_equal(r['wet'], g[f'{tag}_wet']) and np.array_equal(r['hydro'], g[f'{tag}_hydro'])
+    np.testing.assert_allclose(r['wet_total'], g[f'{tag}_wet_total'], rtol=1e-14, atol=1e-18)
+    np.testing.assert_allclose(r['hydro_total'], g[f'{tag}_hydro_total'], rtol=1e-14, atol=1e-18)
+    assert (tag == 'q') == (r['zs'].size == g[f'{tag}_newz'].size + 1)                   # q case is padded, rh case is not
+
+
+def test_g10_fillna3d(golden):
+    """interpolator.py:110-130 (pandas interpolate, limit_direction='backward') vs oracle.fillna_columns, incl. interior runs"""
+    g = golden('g10_cube_producer')
+    a = g['holes_in']
+    assert np.array_equal(O.fillna_columns(a, 0.0), g['holes_fill0'])
+    assert np.array_equal(O.fillna_columns(a, 1e16), g['holes_fill1e16'])
