@@ -70,6 +70,8 @@ def getInterpolators(wm_file, kind='pointwise', shared=False, ctx=None):
     """delayFcns.py:23-58.  `wm_file`: processed weather-model NetCDF path, an xarray.Dataset, or any mapping
     with x, y, z and wet/hydro (`kind != 'total'`) or wet_total/hydro_total (`kind == 'total'`) in file
     order (z, y, x).  `shared` is accepted and ignored (device memory is shared by construction)."""
+    if hasattr(wm_file, 'interpolators') and hasattr(wm_file, 'pointwise'):
+        return wm_file.interpolators('total' if kind == 'total' else 'pointwise')    # weather.ProcessedModel: already on the device
     var, get = _load_fields(wm_file)
     xs, ys, zs = get('x'), get('y'), get('z')
     wet = get('wet_total' if kind == 'total' else 'wet')

@@ -29,9 +29,29 @@ class ProcessedModel:
     """What WeatherModel.load leaves behind, GPU-resident: ``pointwise`` = (wet, hydro) refractivity cube (f32),
     ``total`` = (wet_total, hydro_total) zenith-delay cube (f64); ``t``, ``p``, ``e`` (f32, (y, x, z)) when asked for."""
 
-    def __init__(self, pointwise, total, zs, t=None, p=None, e=None):
+    def __init__(self, pointwise, total, zs, t=None, p=None, e=None, proj=4326):
         self.pointwise, self.total, self.zs = pointwise, total, zs
         self.t, self.p, self.e = t, p, e
+        self.proj = proj            # CRS of the x/y axes, as tropo_delay reads it off the model file (delay.py:66-73)
+
+    # mapping view with the processed file's variable names (weatherModel.py:685-693; fields in file order (z, y, x)), so an
+    # instance can be handed to tropo_delay / getInterpolators wherever they take a weather-model file
+    _KEYS = ('x', 'y', 'z', 'wet', 'hydro', 'wet_total', 'hydro_total', 'proj')
+
+    def keys(self):
+        return self._KEYS
+
+    def __contains__(self, k):
+        return k in self._KEYS
+
+    def __getitem__(self, k):
+        if k == 'x': return self.pointwise.grid[1]
+        if k == 'y': return self.pointwise.grid[0]
+        if k == 'z': return self.pointwise.grid[2]
+        if k == 'proj': return self.proj
+        if k in ('wet', 'hydro'): return np.ascontiguousarray(self.pointwise.read()[k == 'hydro'].transpose(2, 0, 1))
+        if k in ('wet_total', 'hydro_total'): return np.ascontiguousarray(self.total.read()[k == 'hydro_total'].transpose(2, 0, 1))
+        raise KeyError(k)
 
     def interpolators(self, kind='pointwise'):
         """getInterpolators(wm_file, kind) (delayFcns.py:23-58) without the file"""
