@@ -1131,7 +1131,7 @@ static bool wsig_match(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, double 
 
 // pass 1 over tiles [tb, tb+tc): optional reduction (P.maxlen_bits != null) and/or record store (P.ws != null)
 static int launch_crossings(rdr_ctx* c, const rdr_cube* q, RayParams P, int64_t tb, int64_t tc) {
-    P.tile_begin = tb; P.tile_count = tc; P.nslots = tc * BLOCK;
+    P.tile_begin = tb; P.tile_count = tc; P.nslots = tc * BLOCK; P.projected = q->proj.kind != 0;
     const int g = ray_grid(c, tc);
     HIPCHECK(c, hipMemsetAsync(c->d_nslow, 0, sizeof(int), c->stream));
     {

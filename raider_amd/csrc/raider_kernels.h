@@ -245,9 +245,15 @@ __device__ __forceinline__ double toa_newton_t(double ox, double oy, double oz, 
 
 // Workspace record handed from pass 1 (crossings_kernel) to pass 2 (march_kernel): one column per ray SLOT
 // (slot = local tile * 256 + thread), field-major so every field access is a perfectly coalesced 512 B per wave:
-//   ws[f * nslots + slot],  f = 0..2 origin ECEF | 3..5 look vector | 6 lat0 | 7 lon0 | 8..11 sin/cos lat0, sin/cos lon0
-//                           | 12 fast_ok | 13 .. 13+K  ray parameter t of the K+1 level crossings
-constexpr int WS_ORIGIN = 0, WS_LOS = 3, WS_LAT0 = 6, WS_LON0 = 7, WS_S0 = 8, WS_C0 = 9, WS_SL0 = 10, WS_CL0 = 11, WS_FAST = 12, WS_T = 13;
+//   ws[f * nslots + slot]
+//   f = 0        1.0: light ray (polynomial geodesy), 0.0: generic ray
+//   light ray:   1..6 h(u) | 7..12 lat(u) [deg] | 13..18 lon(u) [deg] monomial coefficients | 19  |l| / su  (metres per unit of u)
+//   generic ray: 1..3 origin ECEF | 4..6 look vector | 7 lat0 | 8 lon0 | 9..12 sin/cos lat0, sin/cos lon0
+//   f = 20 .. 20+K  ray parameter of the K+1 level crossings (u for a light ray, t for a generic one)
+constexpr int WS_FAST = 0, WS_POLY_H = 1, WS_POLY_LAT = 7, WS_POLY_LON = 13, WS_SCALE = 19;
+constexpr int WS_ORIGIN = 1, WS_LOS = 4, WS_LAT0 = 7, WS_LON0 = 8, WS_S0 = 9, WS_C0 = 10, WS_SL0 = 11, WS_CL0 = 12;
+constexpr int WS_T = 20;
+constexpr int WS_FIELDS_FIXED = WS_T + 1;     // + K
 
 struct RayParams {
     // geometry
@@ -372,7 +378,7 @@ struct TileWalk {
 // SLOW = false: the light-fp64 path, skips (but counts) the rays the static classification rejects;
 // SLOW = true : generic geodesy, processes ONLY those rays, exits at once when there are none.
 template <typename T2, bool SLOW>
-__global__ __launch_bounds__(BLOCK) void crossings_kernel(CubeView<T2> c, RayParams P) {
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) void crossings_kernel(CubeView<T2> c, RayParams P) {
     if (SLOW && *P.nslow == 0) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const RaySmem m = carve_smem(smem_raw, c.ny, c.nx, c.nz);
@@ -425,7 +431,7 @@ __global__ __launch_bounds__(BLOCK) void crossings_kernel(CubeView<T2> c, RayPar
         const double gam = (P.zref - P.ht) / (cosi * 6.3e6);                       // bound on the angular travel
         // ... and never crosses the +-180 meridian (the light path does not wrap longitudes): |lon0| + travel < 180 deg
         const bool fast_ok = !active || ((cosi > 0.05) && (base.c0 > gam + 0.02) && (gam < 0.03 * (base.c0 - gam)) &&
-                                         (fabs(lon) + 2.0 < 180.0));
+                                         (fabs(lon) + 2.0 < 180.0) && !P.projected);
         const int64_t slot = lt * BLOCK + tid;
         if (!SLOW) {
             const unsigned long long slow_mask = __ballot(!fast_ok);
@@ -433,43 +439,105 @@ __global__ __launch_bounds__(BLOCK) void crossings_kernel(CubeView<T2> c, RayPar
         }
         const bool mine = SLOW ? !fast_ok : fast_ok;      // lanes this instantiation is responsible for
         if (SLOW && !__any(mine)) continue;               // (wave-uniform) nothing to mop up in this wave
-        if (P.ws && mine) {
-            double* w = P.ws + slot;
-            w[(int64_t)(WS_ORIGIN + 0) * P.nslots] = ox; w[(int64_t)(WS_ORIGIN + 1) * P.nslots] = oy; w[(int64_t)(WS_ORIGIN + 2) * P.nslots] = oz;
-            w[(int64_t)(WS_LOS + 0) * P.nslots] = lx; w[(int64_t)(WS_LOS + 1) * P.nslots] = ly; w[(int64_t)(WS_LOS + 2) * P.nslots] = lz;
-            w[(int64_t)WS_LAT0 * P.nslots] = lat; w[(int64_t)WS_LON0 * P.nslots] = lon;
-            w[(int64_t)WS_S0 * P.nslots] = base.s0; w[(int64_t)WS_C0 * P.nslots] = base.c0;
-            w[(int64_t)WS_SL0 * P.nslots] = base.sl0; w[(int64_t)WS_CL0 * P.nslots] = base.cl0;
-            w[(int64_t)WS_FAST * P.nslots] = fast_ok ? 1.0 : 0.0;
-        }
-        double t_hi = 0.0, inv_cosf = 1.0;
-#pragma unroll 1
-        for (int k = 0; k < K; ++k) {
-            const double lo = m.lo[k], hi = m.hi[k];
-            // first interval: cos_factor is None -> 10 iterations with factor 1 for both ends (losreader.py:812-825);
-            // later intervals reuse the previous top as their bottom (losreader.py:811-812)
-            double t_lo = t_hi;
-            if (k == 0) t_lo = toa_newton_t<SLOW>(ox, oy, oz, lx, ly, lz, lo, 10, 1.0);
-            t_hi = toa_newton_t<SLOW>(ox, oy, oz, lx, ly, lz, hi, k == 0 ? 10 : 3, inv_cosf);
-            const double L = (t_hi - t_lo) * nl;
-            if (k == 0) inv_cosf = L / (hi - lo);                                       // 1/cos_factor, losreader.py:824-825
-            if (P.ws && mine) {
-                if (k == 0) P.ws[(int64_t)WS_T * P.nslots + slot] = t_lo;
-                P.ws[(int64_t)(WS_T + k + 1) * P.nslots + slot] = t_hi;
+        const bool cnt = active && mine;
+        double* const w = P.ws ? P.ws + slot : nullptr;
+        const int64_t ns = P.nslots;
+        if constexpr (SLOW) {
+            if (w && mine) {
+                w[(int64_t)WS_FAST * ns] = 0.0;
+                w[(int64_t)(WS_ORIGIN + 0) * ns] = ox; w[(int64_t)(WS_ORIGIN + 1) * ns] = oy; w[(int64_t)(WS_ORIGIN + 2) * ns] = oz;
+                w[(int64_t)(WS_LOS + 0) * ns] = lx; w[(int64_t)(WS_LOS + 1) * ns] = ly; w[(int64_t)(WS_LOS + 2) * ns] = lz;
+                w[(int64_t)WS_LAT0 * ns] = lat; w[(int64_t)WS_LON0 * ns] = lon;
+                w[(int64_t)WS_S0 * ns] = base.s0; w[(int64_t)WS_C0 * ns] = base.c0;
+                w[(int64_t)WS_SL0 * ns] = base.sl0; w[(int64_t)WS_CL0 * ns] = base.cl0;
             }
-            if (reduce) {
-                // NaN poisons the max exactly as ndarray.max does (delay.py:283): tracked via flags
-                const bool cnt = active && mine;
-                if (cnt) my_flags |= (L != L) ? 1 : 2;
-                const double mx = wave_max_lane63((cnt && L == L) ? L : 0.0);
-                if ((tid & 63) == 63) atomicMax(&m.mx[k], (unsigned long long)__double_as_longlong(mx));
-                if (k == 0 && cnt) {             // first sample of the ray (fraction 0)
-                    const double h0 = height_sel<SLOW>(fma(t_lo, lx, ox), fma(t_lo, ly, oy), fma(t_lo, lz, oz));
-                    if (!(h0 < c.z_lo)) my_flags |= 4;
+            double t_hi = 0.0, inv_cosf = 1.0;
+#pragma unroll 1
+            for (int k = 0; k < K; ++k) {
+                const double lo = m.lo[k], hi = m.hi[k];
+                // first interval: cos_factor is None -> 10 iterations with factor 1 for both ends (losreader.py:812-825);
+                // later intervals reuse the previous top as their bottom (losreader.py:811-812)
+                double t_lo = t_hi;
+                if (k == 0) t_lo = toa_newton_t<true>(ox, oy, oz, lx, ly, lz, lo, 10, 1.0);
+                t_hi = toa_newton_t<true>(ox, oy, oz, lx, ly, lz, hi, k == 0 ? 10 : 3, inv_cosf);
+                const double L = (t_hi - t_lo) * nl;
+                if (k == 0) inv_cosf = L / (hi - lo);                                       // 1/cos_factor, losreader.py:824-825
+                if (w && mine) {
+                    if (k == 0) w[(int64_t)WS_T * ns] = t_lo;
+                    w[(int64_t)(WS_T + k + 1) * ns] = t_hi;
                 }
-                if (k == K - 1 && cnt) {         // last sample of the ray (fraction 1)
-                    const double h1 = height_sel<SLOW>(fma(t_hi, lx, ox), fma(t_hi, ly, oy), fma(t_hi, lz, oz));
-                    if (!(h1 > c.z_hi)) my_flags |= 8;
+                if (reduce) {
+                    // NaN poisons the max exactly as ndarray.max does (delay.py:283): tracked via flags
+                    if (cnt) my_flags |= (L != L) ? 1 : 2;
+                    const double mx = wave_max_lane63((cnt && L == L) ? L : 0.0);
+                    if ((tid & 63) == 63) atomicMax(&m.mx[k], (unsigned long long)__double_as_longlong(mx));
+                    if (k == 0 && cnt) {             // first sample of the ray (fraction 0)
+                        const double h0 = ecef_height(fma(t_lo, lx, ox), fma(t_lo, ly, oy), fma(t_lo, lz, oz));
+                        if (!(h0 < c.z_lo)) my_flags |= 4;
+                    }
+                    if (k == K - 1 && cnt) {         // last sample of the ray (fraction 1)
+                        const double h1 = ecef_height(fma(t_hi, lx, ox), fma(t_hi, ly, oy), fma(t_hi, lz, oz));
+                        if (!(h1 > c.z_hi)) my_flags |= 8;
+                    }
+                }
+            }
+        } else {
+            // ---- light rays: fit h(u), lat(u), lon(u) once, then everything is polynomial arithmetic.
+            // Range of the ray parameter any Newton iterate / sample can take: iterates start at t0 = level height
+            // (>= ht) and move monotonically to the crossing, which lies in [0, (zref - ht)/cos(inc)].
+            const double t_a = fmin(0.0, P.ht) - 1.0;
+            const double t_b = fmax(P.zref, (P.zref - P.ht) / (cosi * nl)) + 1.0;
+            const double half = 0.5 * (t_b - t_a), mid = 0.5 * (t_b + t_a);
+            const double su = 1.0 / half, ou = -mid * su;
+            RayPoly q;
+            fit_ray_poly(base, ox, oy, oz, lx, ly, lz, mid, half, q);
+            const double scale = nl * half;                           // ray length per unit of u
+            if (w && mine) {
+                w[(int64_t)WS_FAST * ns] = 1.0;
+#pragma unroll
+                for (int n = 0; n < PN; ++n) {
+                    w[(int64_t)(WS_POLY_H + n) * ns] = q.h[n];
+                    w[(int64_t)(WS_POLY_LAT + n) * ns] = q.lat[n];
+                    w[(int64_t)(WS_POLY_LON + n) * ns] = q.lon[n];
+                }
+                w[(int64_t)WS_SCALE * ns] = scale;
+            }
+            // getTopOfAtmosphere carried on u: u0 = u(h); u += (h - H(u)) * su / factor   (losreader.py:724-731)
+            double u_hi = 0.0, gain = su, inv_cosf = 1.0;
+#pragma unroll 1
+            for (int k = 0; k < K; ++k) {
+                const double lo = m.lo[k], hi = m.hi[k];
+                double u_lo = u_hi;
+                if (k == 0) {
+                    u_lo = fma(lo, su, ou);
+#pragma unroll 1
+                    for (int it = 0; it < 10; ++it) u_lo = fma(lo - poly5(q.h, u_lo), su, u_lo);
+                }
+                u_hi = fma(hi, su, ou);
+                if (k == 0) {
+#pragma unroll 1
+                    for (int it = 0; it < 10; ++it) u_hi = fma(hi - poly5(q.h, u_hi), su, u_hi);
+                } else {
+#pragma unroll
+                    for (int it = 0; it < 3; ++it) u_hi = fma(hi - poly5(q.h, u_hi), gain, u_hi);
+                }
+                const double L = (u_hi - u_lo) * scale;
+                if (k == 0) { inv_cosf = L / (hi - lo); gain = su * inv_cosf; }               // 1/cos_factor, losreader.py:824-825
+                if (w && mine) {
+                    if (k == 0) w[(int64_t)WS_T * ns] = u_lo;
+                    w[(int64_t)(WS_T + k + 1) * ns] = u_hi;
+                }
+                if (reduce) {
+                    if (cnt) my_flags |= (L != L) ? 1 : 2;
+                    const double Lv = (cnt && L == L) ? L : 0.0;
+                    // most waves do not raise the workgroup's running maximum: one broadcast LDS read decides
+                    const double cur = __longlong_as_double((long long)m.mx[k]);
+                    if (__any(Lv > cur)) {
+                        const double mx = wave_max_lane63(Lv);
+                        if ((tid & 63) == 63) atomicMax(&m.mx[k], (unsigned long long)__double_as_longlong(mx));
+                    }
+                    if (k == 0 && cnt && !(poly5(q.h, u_lo) < c.z_lo)) my_flags |= 4;          // first sample of the ray
+                    if (k == K - 1 && cnt && !(poly5(q.h, u_hi) > c.z_hi)) my_flags |= 8;      // last sample of the ray
                 }
             }
         }
@@ -519,19 +587,28 @@ __global__ __launch_bounds__(BLOCK) void march_kernel(CubeView<T2> c, RayParams 
         }
         const double* w = P.ws + (lt * BLOCK + tid);
         const int64_t ns = P.nslots;
-        const double ox = w[(int64_t)(WS_ORIGIN + 0) * ns], oy = w[(int64_t)(WS_ORIGIN + 1) * ns], oz = w[(int64_t)(WS_ORIGIN + 2) * ns];
-        const double lx = w[(int64_t)(WS_LOS + 0) * ns], ly = w[(int64_t)(WS_LOS + 1) * ns], lz = w[(int64_t)(WS_LOS + 2) * ns];
-        RayBase base;
-        base.lat0 = w[(int64_t)WS_LAT0 * ns]; base.lon0 = w[(int64_t)WS_LON0 * ns];
-        base.s0 = w[(int64_t)WS_S0 * ns]; base.c0 = w[(int64_t)WS_C0 * ns];
-        base.sl0 = w[(int64_t)WS_SL0 * ns]; base.cl0 = w[(int64_t)WS_CL0 * ns];
-        const bool fast_ok = !active || (w[(int64_t)WS_FAST * ns] != 0.0 && !P.projected);
+        const bool fast_ok = !active || w[(int64_t)WS_FAST * ns] != 0.0;
         const bool mine = SLOW ? !fast_ok : fast_ok;
         if (SLOW && !__any(mine)) continue;
-        const double nl2 = fma(lx, lx, fma(ly, ly, lz * lz));
-        const double nl = nl2 * rsq_nr<2>(nl2);
         double acc_w = 0.0, acc_h = 0.0;
         double vw_top = 0.0, vh_top = 0.0;    // sample values at the top of the previous segment (= bottom of this one)
+        // generic rays: origin / look vector / origin frame; light rays: the three polynomials
+        double ox = 0, oy = 0, oz = 0, lx = 0, ly = 0, lz = 0, scale;
+        RayPoly q;
+        if constexpr (SLOW) {
+            ox = w[(int64_t)(WS_ORIGIN + 0) * ns]; oy = w[(int64_t)(WS_ORIGIN + 1) * ns]; oz = w[(int64_t)(WS_ORIGIN + 2) * ns];
+            lx = w[(int64_t)(WS_LOS + 0) * ns]; ly = w[(int64_t)(WS_LOS + 1) * ns]; lz = w[(int64_t)(WS_LOS + 2) * ns];
+            const double nl2 = fma(lx, lx, fma(ly, ly, lz * lz));
+            scale = nl2 * rsq_nr<2>(nl2);                          // |l|: ray length per unit of t
+        } else {
+#pragma unroll
+            for (int n = 0; n < PN; ++n) {
+                q.h[n] = w[(int64_t)(WS_POLY_H + n) * ns];
+                q.lat[n] = w[(int64_t)(WS_POLY_LAT + n) * ns];
+                q.lon[n] = w[(int64_t)(WS_POLY_LON + n) * ns];
+            }
+            scale = w[(int64_t)WS_SCALE * ns];                      // ray length per unit of u
+        }
         double t_hi = w[(int64_t)WS_T * ns];
         double t_next = w[(int64_t)(WS_T + 1) * ns];             // crossings are streamed one level ahead of their use
 #pragma unroll 1
@@ -542,8 +619,8 @@ __global__ __launch_bounds__(BLOCK) void march_kernel(CubeView<T2> c, RayParams 
             const double dt = t_hi - t_lo;
             const int np = m.np[k];
             const double step = 1.0 / ((double)np - 1.0);        // np.linspace(0,1,np) (delay.py:287)
-            const double segw = (dt * nl * 1.0e-6) * step;       // delay.py:315: L*1e-6/(np-1), L = |high-low| (losreader.py:821)
-            const double dts = dt * step;                        // sample spacing in t: low + (j*step)*(high-low), delay.py:292
+            const double segw = (dt * scale * 1.0e-6) * step;    // delay.py:315: L*1e-6/(np-1), L = |high-low| (losreader.py:821)
+            const double dts = dt * step;                        // sample spacing: low + (j*step)*(high-low), delay.py:292
             const int kz = m.kz[k];
             // j = 0 of this segment is the SAME point as j = np-1 of the previous one (low_xyz is high_xyz,
             // losreader.py:811-812): its interpolated value is reused instead of recomputed (the reference evaluates
@@ -553,10 +630,12 @@ __global__ __launch_bounds__(BLOCK) void march_kernel(CubeView<T2> c, RayParams 
             for (int j = (k == 0 ? 0 : 1); j < np; ++j) {
                 const double ts = fma((double)j, dts, t_lo);
                 double plon, plat, ph;
-                if (SLOW) {
+                if constexpr (SLOW) {
                     ecef2lla(fma(ts, lx, ox), fma(ts, ly, oy), fma(ts, lz, oz), plon, plat, ph);
                     if (proj.kind == 1) { double px_, py_; lcc_forward(proj, plat, plon, px_, py_); plon = px_; plat = py_; }   // ecef_to_model, delay.py:253,295
-                } else ecef2lla_near(base, fma(ts, lx, ox), fma(ts, ly, oy), fma(ts, lz, oz), plon, plat, ph);   // delay.py:295
+                } else {                                                              // delay.py:295 through the ray polynomials
+                    ph = poly5(q.h, ts); plat = poly5(q.lat, ts); plon = poly5(q.lon, ts);
+                }
                 // all-pixels z-clamp of the very first / very last sample (delay.py:306-311): when it applies every
                 // pixel is below (above) the cube, so "set to zmin" == max(ph, zmin); the bounds are wave-uniform
                 const double zfloor = (clamp_lo && k == 0 && j == 0) ? c.z_lo : -__builtin_huge_val();
