@@ -57,6 +57,7 @@ struct rdr_cube {
     double* d_axes = nullptr;   // ys | xs | zs ascending
     std::vector<double> ys, xs, zs;
     int uni[3] = {0, 0, 0};
+    int exact[2] = {0, 0};
     double inv_d[3] = {0, 0, 0};
     LccParams proj = {0, 0, 0, 0, 0, 0, 0, 0};   // kind 0: the cube axes are lon/lat degrees
 };
@@ -736,13 +737,14 @@ static int axis_check(const double* g, int64_t n, int* flip) {
     return 0;
 }
 
-static void axis_uniformity(const std::vector<double>& g, int* uni, double* inv_d) {
+static void axis_uniformity(const std::vector<double>& g, int* uni, double* inv_d, int* exact = nullptr) {
     const int64_t n = (int64_t)g.size();
     const double span = g[n - 1] - g[0];
     *inv_d = (double)(n - 1) / span;
     double worst = 0;
     for (int64_t i = 0; i < n; ++i) worst = std::max(worst, std::fabs((g[i] - g[0]) * (*inv_d) - (double)i));
     *uni = worst < 0.25 ? 1 : 0;   // guess lands within +-1 cell; fix-up loops make it exact
+    if (exact) *exact = worst < 1e-11 ? 1 : 0;   // uniform to round-off: cell index and weight from arithmetic alone (cell_xy)
 }
 
 template <typename T2>
@@ -756,6 +758,9 @@ static CubeView<T2> make_view(const rdr_cube* q) {
     v.z_lo = q->zs.front(); v.z_hi = q->zs.back();
     v.inv_dy = q->inv_d[0]; v.inv_dx = q->inv_d[1]; v.inv_dz = q->inv_d[2];
     v.uni_y = q->uni[0]; v.uni_x = q->uni[1]; v.uni_z = q->uni[2];
+    v.exact_y = q->exact[0]; v.exact_x = q->exact[1];
+    v.small = (q->ny * q->nx < (1 << 24)) && (q->nz < (1 << 24)) &&
+              ((uint64_t)q->ny * q->nx * q->nz * sizeof(T2) < (1ULL << 32));
     return v;
 }
 
@@ -771,8 +776,8 @@ static int cube_alloc(rdr_ctx* c, rdr_cube* q) {
     ax.insert(ax.end(), q->xs.begin(), q->xs.end());
     ax.insert(ax.end(), q->zs.begin(), q->zs.end());
     HIPCHECK(c, hipMemcpy(q->d_axes, ax.data(), ax.size() * sizeof(double), hipMemcpyHostToDevice));
-    axis_uniformity(q->ys, &q->uni[0], &q->inv_d[0]);
-    axis_uniformity(q->xs, &q->uni[1], &q->inv_d[1]);
+    axis_uniformity(q->ys, &q->uni[0], &q->inv_d[0], &q->exact[0]);
+    axis_uniformity(q->xs, &q->uni[1], &q->inv_d[1], &q->exact[1]);
     axis_uniformity(q->zs, &q->uni[2], &q->inv_d[2]);
     return RDR_OK;
 }
@@ -1082,7 +1087,7 @@ static int stage_rays(rdr_ctx* c, const rdr_rays* r, RayParams& P) {
 }
 
 static size_t ray_smem(const rdr_cube* q) {
-    return (size_t)(q->ny + q->nx + q->nz) * 8 * 3 + (size_t)q->nz * 8 * 3 + (size_t)q->nz * 4 * 2 + 16;
+    return ray_smem_bytes(q->ny, q->nx, q->nz);
 }
 
 static int ray_grid(rdr_ctx* c, int64_t ntiles) {

@@ -40,6 +40,8 @@ struct CubeView {
     double y_lo, y_hi, x_lo, x_hi, z_lo, z_hi;   // axis end points (bounds test)
     double inv_dy, inv_dx, inv_dz;               // (n-1)/(g[n-1]-g[0]) for the uniform-axis index guess
     int uni_y, uni_x, uni_z;                     // axis is (nearly) uniform: guess is within +-1 cell
+    int exact_y, exact_x;                        // axis is uniform to round-off: the cell follows from arithmetic alone
+    int small;                                   // ny*nx < 2^24, nz < 2^24 and the field fits 4 GB: 32-bit index arithmetic
 };
 
 __device__ __forceinline__ double qnan() { return __longlong_as_double(0x7ff8000000000000LL); }
@@ -138,6 +140,14 @@ __device__ __forceinline__ int bisect_cell2(const double2* e, int n, double v) {
     return min(max(lo - 1, 0), n - 2);
 }
 
+// Exact cell search (scipy find_indices semantics) - the rare path of the two fast searches below.  A coordinate outside
+// the axis (or NaN) gets a NaN weight, which makes the interpolated values NaN = scipy's fill_value (_rgi.py:437-442,585-592).
+__device__ __forceinline__ void cell_exact(const double2* e, int n, double v, int& i, double& t) {
+    if (!((v >= e[0].x) & (v <= e[n - 1].x))) { i = 0; t = qnan(); return; }
+    i = bisect_cell2(e, n, v);
+    t = (v - e[i].x) * e[i].y;
+}
+
 __device__ __forceinline__ void window_cell(const double2* e, int n, double v, int guess, bool trust, int& i, double& t) {
     const int i0 = min(max(guess, 1), n - 3);
     const double2 em = e[i0 - 1], e0 = e[i0], e1 = e[i0 + 1];
@@ -146,58 +156,93 @@ __device__ __forceinline__ void window_cell(const double2* e, int n, double v, i
     const double g = dn ? em.x : (up ? e1.x : e0.x);
     const double r = dn ? em.y : (up ? e1.y : e0.y);
     t = (v - g) * r;
-    if (!trust || !(t >= 0.0) || !(t <= 1.0)) {      // rare: exact search
-        i = bisect_cell2(e, n, v);
-        t = (v - e[i].x) * e[i].y;
-    }
+    if (!trust || !(t >= 0.0) || !(t <= 1.0)) cell_exact(e, n, v, i, t);      // rare
 }
 
-// (nearly) uniform x / y axes: the linear guess is right unless the point sits within round-off of a node (or the
-// axis deviates from uniform): read the guessed cell and the next node, verify, else search exactly.
-__device__ __forceinline__ void guess_cell(const double2* e, int n, double v, int guess, bool trust, int& i, double& t) {
-    i = min(max(guess, 0), n - 2);
-    const double2 e0 = e[i];
-    const double g1 = e[i + 1].x;
-    t = (v - e0.x) * e0.y;
-    const bool ok = trust & (v >= e0.x) & ((v < g1) | (i == n - 2));
-    if (!ok) {                                        // rare: exact search
-        i = bisect_cell2(e, n, v);
-        t = (v - e[i].x) * e[i].y;
+// x / y axes.  `exact` (axis uniform to round-off, the usual lat/lon grid): the cell index and the weight come from
+// (v - g0) * (n-1)/(g[n-1]-g0) alone - no table access; they differ from scipy's (v - g[i])/(g[i+1]-g[i]) by the axis's own
+// round-off (<= 1e-11 of a cell, checked on the host), which the continuous interpolant turns into <= 1e-12 relative.
+// Otherwise (nearly uniform axis): read the guessed cell and the next node from the LDS table and verify.
+// Anything else (last node, outside, NaN, irregular axis) takes the exact search.
+__device__ __forceinline__ void cell_xy(const double2* e, int n, double v, double g0, double inv_d, bool exact, bool trust, int& i, double& t) {
+    bool ok;
+    const double tf = (v - g0) * inv_d;
+    if (exact) {
+        const double fl = floor(tf);
+        i = (int)fl;
+        t = tf - fl;
+        ok = (tf >= 0.0) & (tf < (double)(n - 1));
+    } else {
+        i = min(max((int)tf, 0), n - 2);
+        const double2 e0 = e[i];
+        const double g1 = e[i + 1].x;
+        t = (v - e0.x) * e0.y;
+        ok = trust & (v >= e0.x) & (v < g1);
     }
+    if (!ok) cell_exact(e, n, v, i, t);                                         // rare
 }
 
+// One trilinear sample in two halves, so that several samples' gathers can be in flight together:
+//   sample_issue : cell search on the three axes, address, the four 16-byte (32-byte for f64 cubes) corner-pair loads
+//   sample_finish: weights, f32->f64 conversion, the 16 FMAs                    (weights/corner order: _rgi.py:490-498)
 // tab2 = (g, 1/dg) pairs of [ys | xs | zs] in LDS.
+template <typename T2>
+struct PendingSample {
+    T2 v[8];              // corners in (y,x,z) lexicographic order
+    double ty, tx, tz;
+};
+
+template <typename T2>
+__device__ __forceinline__ void sample_issue(const CubeView<T2>& c, const double2* tab2, double y, double x, double z, int kz,
+                                             PendingSample<T2>& s) {
+    const double2* ey = tab2; const double2* ex = tab2 + c.ny; const double2* ez = ex + c.nx;
+    int iy, ix, iz;
+    cell_xy(ey, c.ny, y, c.y_lo, c.inv_dy, c.exact_y, c.uni_y, iy, s.ty);
+    cell_xy(ex, c.nx, x, c.x_lo, c.inv_dx, c.exact_x, c.uni_x, ix, s.tx);
+    window_cell(ez, c.nz, z, kz, c.nz >= 4, iz, s.tz);
+    const T2 *p00, *p01, *p10, *p11;
+    if (c.small) {              // one 32-bit element offset against four uniform row bases
+        const unsigned off = (__umul24(__umul24((unsigned)iy, (unsigned)c.nx) + (unsigned)ix, (unsigned)c.nz) + (unsigned)iz) * (unsigned)sizeof(T2);
+        const char* b = reinterpret_cast<const char*>(c.v);
+        const size_t rowx = (size_t)c.nz * sizeof(T2), rowy = (size_t)c.nx * rowx;
+        p00 = reinterpret_cast<const T2*>(b + off);
+        p01 = reinterpret_cast<const T2*>(b + rowx + off);
+        p10 = reinterpret_cast<const T2*>(b + rowy + off);
+        p11 = reinterpret_cast<const T2*>(b + rowy + rowx + off);
+    } else {
+        p00 = c.v + ((int64_t)iy * c.nx + ix) * c.nz + iz;
+        p01 = p00 + c.nz;
+        p10 = p00 + (int64_t)c.nx * c.nz;
+        p11 = p10 + c.nz;
+    }
+    s.v[0] = p00[0]; s.v[1] = p00[1];
+    s.v[2] = p01[0]; s.v[3] = p01[1];
+    s.v[4] = p10[0]; s.v[5] = p10[1];
+    s.v[6] = p11[0]; s.v[7] = p11[1];
+}
+
+template <typename T2>
+__device__ __forceinline__ void sample_finish(const PendingSample<T2>& s, double& wet, double& hyd) {
+    const double wy0 = 1.0 - s.ty, wx0 = 1.0 - s.tx, wz0 = 1.0 - s.tz;
+    const double a00 = wy0 * wx0, a01 = wy0 * s.tx, a10 = s.ty * wx0, a11 = s.ty * s.tx;
+    double sw = 0.0, sh = 0.0, k;
+    k = a00 * wz0;  sw = fma((double)s.v[0].x, k, sw); sh = fma((double)s.v[0].y, k, sh);
+    k = a00 * s.tz; sw = fma((double)s.v[1].x, k, sw); sh = fma((double)s.v[1].y, k, sh);
+    k = a01 * wz0;  sw = fma((double)s.v[2].x, k, sw); sh = fma((double)s.v[2].y, k, sh);
+    k = a01 * s.tz; sw = fma((double)s.v[3].x, k, sw); sh = fma((double)s.v[3].y, k, sh);
+    k = a10 * wz0;  sw = fma((double)s.v[4].x, k, sw); sh = fma((double)s.v[4].y, k, sh);
+    k = a10 * s.tz; sw = fma((double)s.v[5].x, k, sw); sh = fma((double)s.v[5].y, k, sh);
+    k = a11 * wz0;  sw = fma((double)s.v[6].x, k, sw); sh = fma((double)s.v[6].y, k, sh);
+    k = a11 * s.tz; sw = fma((double)s.v[7].x, k, sw); sh = fma((double)s.v[7].y, k, sh);
+    wet = sw; hyd = sh;
+}
+
 template <typename T2>
 __device__ __forceinline__ void sample_cube(const CubeView<T2>& c, const double2* tab2, double y, double x, double z, int kz,
                                             double& wet, double& hyd) {
-    const bool inside = (y >= c.y_lo) && (y <= c.y_hi) && (x >= c.x_lo) && (x <= c.x_hi) && (z >= c.z_lo) && (z <= c.z_hi);
-    if (!inside) { wet = qnan(); hyd = qnan(); return; }
-    const double2* ey = tab2; const double2* ex = tab2 + c.ny; const double2* ez = ex + c.nx;
-    int iy, ix, iz; double ty, tx, tz;
-    guess_cell(ey, c.ny, y, (int)((y - c.y_lo) * c.inv_dy), c.uni_y, iy, ty);
-    guess_cell(ex, c.nx, x, (int)((x - c.x_lo) * c.inv_dx), c.uni_x, ix, tx);
-    window_cell(ez, c.nz, z, kz, c.nz >= 4, iz, tz);
-    const T2* p00 = c.v + ((int64_t)iy * c.nx + ix) * c.nz + iz;
-    const T2* p01 = p00 + c.nz;
-    const T2* p10 = p00 + (int64_t)c.nx * c.nz;
-    const T2* p11 = p10 + c.nz;
-    double w[8], h[8];
-    ld2(p00, w[0], h[0]); ld2(p00 + 1, w[1], h[1]);
-    ld2(p01, w[2], h[2]); ld2(p01 + 1, w[3], h[3]);
-    ld2(p10, w[4], h[4]); ld2(p10 + 1, w[5], h[5]);
-    ld2(p11, w[6], h[6]); ld2(p11 + 1, w[7], h[7]);
-    const double wy0 = 1.0 - ty, wx0 = 1.0 - tx, wz0 = 1.0 - tz;
-    const double a00 = wy0 * wx0, a01 = wy0 * tx, a10 = ty * wx0, a11 = ty * tx;
-    double sw = 0.0, sh = 0.0, k;      // weight = (wy*wx)*wz, corners in (y,x,z) lexicographic order (_rgi.py:490-498)
-    k = a00 * wz0; sw = fma(w[0], k, sw); sh = fma(h[0], k, sh);
-    k = a00 * tz;  sw = fma(w[1], k, sw); sh = fma(h[1], k, sh);
-    k = a01 * wz0; sw = fma(w[2], k, sw); sh = fma(h[2], k, sh);
-    k = a01 * tz;  sw = fma(w[3], k, sw); sh = fma(h[3], k, sh);
-    k = a10 * wz0; sw = fma(w[4], k, sw); sh = fma(h[4], k, sh);
-    k = a10 * tz;  sw = fma(w[5], k, sw); sh = fma(h[5], k, sh);
-    k = a11 * wz0; sw = fma(w[6], k, sw); sh = fma(h[6], k, sh);
-    k = a11 * tz;  sw = fma(w[7], k, sw); sh = fma(h[7], k, sh);
-    wet = sw; hyd = sh;
+    PendingSample<T2> s;
+    sample_issue(c, tab2, y, x, z, kz, s);
+    sample_finish(s, wet, hyd);
 }
 
 // getTopOfAtmosphere (losreader.py:706-733): pos = xyz + h*los; repeat: pos += los*((h - height(pos))/factor).
@@ -243,16 +288,29 @@ __device__ __forceinline__ double toa_newton_t(double ox, double oy, double oz, 
     return t;
 }
 
+// Top crossing of a model level on a light ray: getTopOfAtmosphere's 3 iterations (losreader.py:724-731,817-819) on the
+// normalised ray parameter u, with the height from the ray's polynomial.  gain = su / cos_factor.  Used by BOTH passes
+// (same instruction sequence -> identical crossings).
+__device__ __forceinline__ double level_top_u(const double* hpoly, double hi, double su, double ou, double gain) {
+    double u = fma(hi, su, ou);
+#pragma unroll
+    for (int it = 0; it < 3; ++it) u = fma(hi - poly5(hpoly, u), gain, u);
+    return u;
+}
+
 // Workspace record handed from pass 1 (crossings_kernel) to pass 2 (march_kernel): one column per ray SLOT
 // (slot = local tile * 256 + thread), field-major so every field access is a perfectly coalesced 512 B per wave:
 //   ws[f * nslots + slot]
 //   f = 0        1.0: light ray (polynomial geodesy), 0.0: generic ray
-//   light ray:   1..6 h(u) | 7..12 lat(u) [deg] | 13..18 lon(u) [deg] monomial coefficients | 19  |l| / su  (metres per unit of u)
+//   light ray:   1..6 h(u) | 7..12 lat(u) [deg] | 13..18 lon(u) [deg] monomial coefficients | 19 |l|/su (metres per unit of u)
+//                | 20 su | 21 ou (u = su t + ou) | 22 su/cos_factor | 23, 24 u at the bottom / top of the first level.
+//                Pass 2 re-derives the other level crossings from h(u) (21 FMAs per level) instead of streaming them.
 //   generic ray: 1..3 origin ECEF | 4..6 look vector | 7 lat0 | 8 lon0 | 9..12 sin/cos lat0, sin/cos lon0
-//   f = 20 .. 20+K  ray parameter of the K+1 level crossings (u for a light ray, t for a generic one)
-constexpr int WS_FAST = 0, WS_POLY_H = 1, WS_POLY_LAT = 7, WS_POLY_LON = 13, WS_SCALE = 19;
+//                | 25 .. 25+K  ray parameter t of the K+1 level crossings
+constexpr int WS_FAST = 0, WS_POLY_H = 1, WS_POLY_LAT = 7, WS_POLY_LON = 13, WS_SCALE = 19, WS_SU = 20, WS_OU = 21, WS_GAIN = 22,
+              WS_U0 = 23, WS_U1 = 24;
 constexpr int WS_ORIGIN = 1, WS_LOS = 4, WS_LAT0 = 7, WS_LON0 = 8, WS_S0 = 9, WS_C0 = 10, WS_SL0 = 11, WS_CL0 = 12;
-constexpr int WS_T = 20;
+constexpr int WS_T = 25;
 constexpr int WS_FIELDS_FIXED = WS_T + 1;     // + K
 
 struct RayParams {
@@ -325,9 +383,12 @@ struct RaySmem {
     double* tab;            // [ys | xs | zs]
     double2* tab2;          // the same axes as (g[i], 1/(g[i+1]-g[i])) pairs (pass 2 cell search)
     double* lo; double* hi; // level table
-    unsigned long long* mx; // per-level block max (pass 1)
+    unsigned long long* mxcol; // [nz][MXCOLS] per-level running maxima of the workgroup, one column per lane%MXCOLS (pass 1)
+    double* step;           // [nz] 1/(nParts-1) (pass 2)
+    double* hs;             // [nz] 0.5e-6/(nParts-1): half the trapezoid weight per unit of ray length (pass 2)
     int* kz; int* np; int* K;
 };
+constexpr int MXCOLS = 16;
 __device__ __forceinline__ RaySmem carve_smem(unsigned char* raw, int ny, int nx, int nz) {
     RaySmem m;
     const int na = ny + nx + nz;
@@ -335,11 +396,23 @@ __device__ __forceinline__ RaySmem carve_smem(unsigned char* raw, int ny, int nx
     m.tab = reinterpret_cast<double*>(m.tab2 + na);
     m.lo = m.tab + na;
     m.hi = m.lo + nz;
-    m.mx = reinterpret_cast<unsigned long long*>(m.hi + nz);
-    m.kz = reinterpret_cast<int*>(m.mx + nz);
+    m.mxcol = reinterpret_cast<unsigned long long*>(m.hi + nz);
+    m.step = reinterpret_cast<double*>(m.mxcol + (size_t)nz * MXCOLS);
+    m.hs = m.step + nz;
+    m.kz = reinterpret_cast<int*>(m.hs + nz);
     m.np = m.kz + nz;
     m.K = m.np + nz;
     return m;
+}
+
+// bytes carve_smem lays out (the launch's dynamic LDS size) - keep the two in step
+inline size_t ray_smem_bytes(int64_t ny, int64_t nx, int64_t nz) {
+    const size_t na = (size_t)(ny + nx + nz);
+    return na * 16 + na * 8                       // tab2, tab
+           + (size_t)nz * 8 * 2                   // lo, hi
+           + (size_t)nz * 8 * MXCOLS              // mxcol
+           + (size_t)nz * 8 * 2                   // step, hs
+           + (size_t)nz * 4 * 2 + 16;             // kz, np, K
 }
 
 template <typename T2>
@@ -378,15 +451,20 @@ struct TileWalk {
 // SLOW = false: the light-fp64 path, skips (but counts) the rays the static classification rejects;
 // SLOW = true : generic geodesy, processes ONLY those rays, exits at once when there are none.
 template <typename T2, bool SLOW>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) void crossings_kernel(CubeView<T2> c, RayParams P) {
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 : 4, SLOW ? 8 : 4))) void crossings_kernel(CubeView<T2> c, RayParams P) {
     if (SLOW && *P.nslow == 0) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const RaySmem m = carve_smem(smem_raw, c.ny, c.nx, c.nz);
     const int K = fill_tables(c, m, P.ht, P.zref);
     const int tid = threadIdx.x;
     const bool reduce = P.maxlen_bits != nullptr;
-    if (reduce) for (int k = tid; k < K; k += BLOCK) m.mx[k] = 0ULL;
+    if (reduce) for (int k = tid; k < K * MXCOLS; k += BLOCK) m.mxcol[k] = 0ULL;
     __syncthreads();
+    // per-level maximum of the ray length over the batch (delay.py:283): every lane folds its length into column lane%16 of
+    // the workgroup's LDS table with one ds_max_u64 (non-negative doubles order like their bit patterns); the columns are
+    // combined once, at the end of the kernel.  NaN lengths are left out here and reported through the flags, which is how
+    // ndarray.max's NaN poisoning is reproduced on the host side.
+    unsigned long long* const mxc = m.mxcol + (tid & (MXCOLS - 1));
     int my_flags = 0;
     TileWalk walk(P.tile_count);
     int64_t lt;
@@ -467,10 +545,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) v
                     w[(int64_t)(WS_T + k + 1) * ns] = t_hi;
                 }
                 if (reduce) {
-                    // NaN poisons the max exactly as ndarray.max does (delay.py:283): tracked via flags
                     if (cnt) my_flags |= (L != L) ? 1 : 2;
-                    const double mx = wave_max_lane63((cnt && L == L) ? L : 0.0);
-                    if ((tid & 63) == 63) atomicMax(&m.mx[k], (unsigned long long)__double_as_longlong(mx));
+                    atomicMax(&mxc[k * MXCOLS], (unsigned long long)__double_as_longlong((cnt && L > 0.0) ? L : 0.0));
                     if (k == 0 && cnt) {             // first sample of the ray (fraction 0)
                         const double h0 = ecef_height(fma(t_lo, lx, ox), fma(t_lo, ly, oy), fma(t_lo, lz, oz));
                         if (!(h0 < c.z_lo)) my_flags |= 4;
@@ -500,10 +576,11 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) v
                     w[(int64_t)(WS_POLY_LAT + n) * ns] = q.lat[n];
                     w[(int64_t)(WS_POLY_LON + n) * ns] = q.lon[n];
                 }
-                w[(int64_t)WS_SCALE * ns] = scale;
+                w[(int64_t)WS_SCALE * ns] = scale; w[(int64_t)WS_SU * ns] = su; w[(int64_t)WS_OU * ns] = ou;
             }
             // getTopOfAtmosphere carried on u: u0 = u(h); u += (h - H(u)) * su / factor   (losreader.py:724-731)
             double u_hi = 0.0, gain = su, inv_cosf = 1.0;
+            double sum_len = 0.0, min_len = __builtin_huge_val();      // NaN / finite bookkeeping for the flags
 #pragma unroll 1
             for (int k = 0; k < K; ++k) {
                 const double lo = m.lo[k], hi = m.hi[k];
@@ -517,34 +594,31 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) v
                 if (k == 0) {
 #pragma unroll 1
                     for (int it = 0; it < 10; ++it) u_hi = fma(hi - poly5(q.h, u_hi), su, u_hi);
-                } else {
-#pragma unroll
-                    for (int it = 0; it < 3; ++it) u_hi = fma(hi - poly5(q.h, u_hi), gain, u_hi);
-                }
+                } else u_hi = level_top_u(q.h, hi, su, ou, gain);
                 const double L = (u_hi - u_lo) * scale;
-                if (k == 0) { inv_cosf = L / (hi - lo); gain = su * inv_cosf; }               // 1/cos_factor, losreader.py:824-825
-                if (w && mine) {
-                    if (k == 0) w[(int64_t)WS_T * ns] = u_lo;
-                    w[(int64_t)(WS_T + k + 1) * ns] = u_hi;
+                if (k == 0) {
+                    inv_cosf = L / (hi - lo); gain = su * inv_cosf;                            // 1/cos_factor, losreader.py:824-825
+                    if (w && mine) { w[(int64_t)WS_GAIN * ns] = gain; w[(int64_t)WS_U0 * ns] = u_lo; w[(int64_t)WS_U1 * ns] = u_hi; }
+                    if (!reduce) break;                                                        // record complete; lengths not wanted
                 }
                 if (reduce) {
-                    if (cnt) my_flags |= (L != L) ? 1 : 2;
-                    const double Lv = (cnt && L == L) ? L : 0.0;
-                    // most waves do not raise the workgroup's running maximum: one broadcast LDS read decides
-                    const double cur = __longlong_as_double((long long)m.mx[k]);
-                    if (__any(Lv > cur)) {
-                        const double mx = wave_max_lane63(Lv);
-                        if ((tid & 63) == 63) atomicMax(&m.mx[k], (unsigned long long)__double_as_longlong(mx));
-                    }
+                    sum_len += L; min_len = fmin(min_len, L);
+                    atomicMax(&mxc[k * MXCOLS], (unsigned long long)__double_as_longlong((cnt && L > 0.0) ? L : 0.0));
                     if (k == 0 && cnt && !(poly5(q.h, u_lo) < c.z_lo)) my_flags |= 4;          // first sample of the ray
                     if (k == K - 1 && cnt && !(poly5(q.h, u_hi) > c.z_hi)) my_flags |= 8;      // last sample of the ray
                 }
             }
+            if (reduce && cnt && K > 0) my_flags |= ((sum_len != sum_len) ? 1 : 0) | ((min_len < __builtin_huge_val()) ? 2 : 0);
         }
     }
     if (reduce) {
         __syncthreads();
-        for (int k = tid; k < K; k += BLOCK) atomicMax(&P.maxlen_bits[k], m.mx[k]);
+        for (int k = tid; k < K; k += BLOCK) {
+            unsigned long long v = 0ULL;
+#pragma unroll
+            for (int cc = 0; cc < MXCOLS; ++cc) v = max(v, m.mxcol[k * MXCOLS + cc]);
+            atomicMax(&P.maxlen_bits[k], v);
+        }
         int f = my_flags;
         for (int off = 32; off > 0; off >>= 1) f |= __shfl_xor(f, off, 64);
         if ((tid & 63) == 0 && f) atomicOr(P.flags, f);
@@ -555,7 +629,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 // SLOW as in crossings_kernel: <false> integrates the classified-fast rays with the light geodesy, <true> the rest
 // with the generic one (and returns immediately when there are none).
 template <typename T2, bool SLOW>
-__global__ __launch_bounds__(BLOCK) void march_kernel(CubeView<T2> c, RayParams P, LccParams proj) {
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 : 3, SLOW ? 8 : 3))) void march_kernel(CubeView<T2> c, RayParams P, LccParams proj) {
     if (SLOW && *P.nslow == 0 && !P.projected) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const RaySmem m = carve_smem(smem_raw, c.ny, c.nx, c.nz);
@@ -566,11 +640,14 @@ __global__ __launch_bounds__(BLOCK) void march_kernel(CubeView<T2> c, RayParams 
         if (P.nparts_override) np = P.nparts_override[k];
         else np = (int)ceil(__longlong_as_double((long long)P.maxlen_bits[k]) / P.max_seg) + 1;   // delay.py:283
         m.np[k] = np;
+        m.step[k] = 1.0 / ((double)np - 1.0);                    // np.linspace(0,1,np) (delay.py:287)
+        m.hs[k] = 0.5e-6 * m.step[k];                            // delay.py:314-315: end points get half of L*1e-6/(np-1)
     }
     __syncthreads();
     const int flags_in = *P.flags;
     const bool clamp_lo = !(flags_in & 4);   // ALL first samples below zmin  (delay.py:306-307)
     const bool clamp_hi = !(flags_in & 8);   // ALL last samples above zmax   (delay.py:310-311)
+    const bool clamp_any = clamp_lo | clamp_hi;
     TileWalk walk(P.tile_count);
     int64_t lt;
     while (walk.next(P.tile_count, lt)) {
@@ -591,61 +668,125 @@ __global__ __launch_bounds__(BLOCK) void march_kernel(CubeView<T2> c, RayParams 
         const bool mine = SLOW ? !fast_ok : fast_ok;
         if (SLOW && !__any(mine)) continue;
         double acc_w = 0.0, acc_h = 0.0;
-        double vw_top = 0.0, vh_top = 0.0;    // sample values at the top of the previous segment (= bottom of this one)
-        // generic rays: origin / look vector / origin frame; light rays: the three polynomials
-        double ox = 0, oy = 0, oz = 0, lx = 0, ly = 0, lz = 0, scale;
-        RayPoly q;
-        if constexpr (SLOW) {
-            ox = w[(int64_t)(WS_ORIGIN + 0) * ns]; oy = w[(int64_t)(WS_ORIGIN + 1) * ns]; oz = w[(int64_t)(WS_ORIGIN + 2) * ns];
-            lx = w[(int64_t)(WS_LOS + 0) * ns]; ly = w[(int64_t)(WS_LOS + 1) * ns]; lz = w[(int64_t)(WS_LOS + 2) * ns];
-            const double nl2 = fma(lx, lx, fma(ly, ly, lz * lz));
-            scale = nl2 * rsq_nr<2>(nl2);                          // |l|: ray length per unit of t
-        } else {
+        if constexpr (!SLOW) {
+            // ---- light rays: one flat loop over the ray's distinct sample points, BATCH at a time -----------------------
+            // The sample schedule (level k, fraction j/(np-1)) is the same for every ray of the slice, so the iterator lives
+            // in scalar registers.  A sample shared by two segments (top of k = bottom of k+1, losreader.py:811-812) is
+            // evaluated once and carries both trapezoid end weights.  Each batch first issues the gathers of all its
+            // samples, then finishes them: BATCH x 4 loads are in flight per lane instead of 4.
+            constexpr int BATCH = sizeof(T2) == 8 ? 3 : 2;
+            RayPoly q;
 #pragma unroll
             for (int n = 0; n < PN; ++n) {
                 q.h[n] = w[(int64_t)(WS_POLY_H + n) * ns];
                 q.lat[n] = w[(int64_t)(WS_POLY_LAT + n) * ns];
                 q.lon[n] = w[(int64_t)(WS_POLY_LON + n) * ns];
             }
-            scale = w[(int64_t)WS_SCALE * ns];                      // ray length per unit of u
-        }
-        double t_hi = w[(int64_t)WS_T * ns];
-        double t_next = w[(int64_t)(WS_T + 1) * ns];             // crossings are streamed one level ahead of their use
-#pragma unroll 1
-        for (int k = 0; k < K; ++k) {
-            const double t_lo = t_hi;
-            t_hi = t_next;
-            if (k + 2 <= K) t_next = w[(int64_t)(WS_T + k + 2) * ns];
-            const double dt = t_hi - t_lo;
-            const int np = m.np[k];
-            const double step = 1.0 / ((double)np - 1.0);        // np.linspace(0,1,np) (delay.py:287)
-            const double segw = (dt * scale * 1.0e-6) * step;    // delay.py:315: L*1e-6/(np-1), L = |high-low| (losreader.py:821)
-            const double dts = dt * step;                        // sample spacing: low + (j*step)*(high-low), delay.py:292
-            const int kz = m.kz[k];
-            // j = 0 of this segment is the SAME point as j = np-1 of the previous one (low_xyz is high_xyz,
-            // losreader.py:811-812): its interpolated value is reused instead of recomputed (the reference evaluates
-            // it twice and gets the same number both times).  The order of accumulation is unchanged.
-            if (k > 0) { acc_w = fma(0.5 * segw, vw_top, acc_w); acc_h = fma(0.5 * segw, vh_top, acc_h); }
-#pragma unroll 1
-            for (int j = (k == 0 ? 0 : 1); j < np; ++j) {
-                const double ts = fma((double)j, dts, t_lo);
-                double plon, plat, ph;
-                if constexpr (SLOW) {
-                    ecef2lla(fma(ts, lx, ox), fma(ts, ly, oy), fma(ts, lz, oz), plon, plat, ph);
-                    if (proj.kind == 1) { double px_, py_; lcc_forward(proj, plat, plon, px_, py_); plon = px_; plat = py_; }   // ecef_to_model, delay.py:253,295
-                } else {                                                              // delay.py:295 through the ray polynomials
-                    ph = poly5(q.h, ts); plat = poly5(q.lat, ts); plon = poly5(q.lon, ts);
+            const double scale = w[(int64_t)WS_SCALE * ns];              // ray length per unit of u
+            // per-level lane state: u at the bottom of level k, du_k, du_{k+1}; uniform state: j, np_k, step_k, hs_k, hs_{k+1}.
+            // The level crossings are re-derived from h(u) as the loop reaches them (no global loads inside the loop besides
+            // the gathers, so the only memory waits are on a batch's own samples).
+            const double su = w[(int64_t)WS_SU * ns], ou = w[(int64_t)WS_OU * ns], gain = w[(int64_t)WS_GAIN * ns];
+            int k = 0, j = 0;
+            int np = __builtin_amdgcn_readfirstlane(m.np[0]);
+            int kz = __builtin_amdgcn_readfirstlane(m.kz[0]);
+            double step = m.step[0], hs = m.hs[0], hs1 = K > 1 ? m.hs[1] : 0.0;
+            double u_k = w[(int64_t)WS_U0 * ns];
+            double u_last = w[(int64_t)WS_U1 * ns];
+            double du = u_last - u_k, du1 = 0.0;
+            if (K > 1) { const double t2 = level_top_u(q.h, m.hi[1], su, ou, gain); du1 = t2 - u_last; u_last = t2; }
+            bool valid = true;
+            while (valid) {
+                PendingSample<T2> pend[BATCH];
+                double wgt[BATCH];
+                int n = 0;
+#pragma unroll
+                for (int b = 0; b < BATCH; ++b) {
+                    if (valid) {
+                        const double us = fma((double)j * step, du, u_k);           // low + frac * (high - low), delay.py:292
+                        double ph = poly5(q.h, us);
+                        const double plat = poly5(q.lat, us), plon = poly5(q.lon, us);   // delay.py:295 through the ray polynomials
+                        const bool last_j = j == np - 1;
+                        if (clamp_any) {   // all-pixels z-clamp of the very first / very last sample (delay.py:306-311)
+                            const double zfloor = (clamp_lo && k == 0 && j == 0) ? c.z_lo : -__builtin_huge_val();
+                            const double zceil = (clamp_hi && k == K - 1 && last_j) ? c.z_hi : __builtin_huge_val();
+                            ph = fmin(fmax(ph, zfloor), zceil);
+                        }
+                        sample_issue(c, m.tab2, plat, plon, ph, kz, pend[b]);          // delay.py:298,319
+                        // trapezoid weight per unit of u (delay.py:314-315), both segments for a shared sample
+                        double wv = (((j == 0) | last_j) ? hs : 2.0 * hs) * du;
+                        if (last_j && k + 1 < K) wv = fma(hs1, du1, wv);
+                        wgt[b] = wv;
+                        n = b + 1;
+                        ++j;
+                        while (valid && j >= np) {                                      // next level (its j = 0 is already done)
+                            ++k;
+                            if (k >= K) { valid = false; break; }
+                            j = 1;
+                            np = __builtin_amdgcn_readfirstlane(m.np[k]);
+                            kz = __builtin_amdgcn_readfirstlane(m.kz[k]);
+                            step = m.step[k]; hs = hs1;
+                            u_k += du; du = du1; du1 = 0.0; hs1 = 0.0;
+                            if (k + 1 < K) {
+                                const double t2 = level_top_u(q.h, m.hi[k + 1], su, ou, gain);
+                                du1 = t2 - u_last; u_last = t2; hs1 = m.hs[k + 1];
+                            }
+                        }
+                    }
                 }
-                // all-pixels z-clamp of the very first / very last sample (delay.py:306-311): when it applies every
-                // pixel is below (above) the cube, so "set to zmin" == max(ph, zmin); the bounds are wave-uniform
-                const double zfloor = (clamp_lo && k == 0 && j == 0) ? c.z_lo : -__builtin_huge_val();
-                const double zceil = (clamp_hi && k == K - 1 && j == np - 1) ? c.z_hi : __builtin_huge_val();
-                ph = fmin(fmax(ph, zfloor), zceil);
-                double vw, vh;
-                sample_cube(c, m.tab2, plat, plon, ph, kz, vw, vh);                   // delay.py:298,319
-                const double wt = ((j == 0) | (j == np - 1)) ? 0.5 * segw : segw;     // delay.py:314-315
-                acc_w = fma(wt, vw, acc_w); acc_h = fma(wt, vh, acc_h);               // delay.py:323
-                vw_top = vw; vh_top = vh;                                             // after the loop: value at j = np-1
+#pragma unroll
+                for (int b = 0; b < BATCH; ++b) {
+                    if (b < n) {
+                        double vw, vh;
+                        sample_finish(pend[b], vw, vh);
+                        acc_w = fma(wgt[b], vw, acc_w); acc_h = fma(wgt[b], vh, acc_h);    // delay.py:323
+                    }
+                }
+            }
+            acc_w *= scale; acc_h *= scale;
+        } else {
+            double vw_top = 0.0, vh_top = 0.0;    // sample values at the top of the previous segment (= bottom of this one)
+            // generic rays: origin / look vector / origin frame; light rays: the three polynomials
+            const double ox = w[(int64_t)(WS_ORIGIN + 0) * ns], oy = w[(int64_t)(WS_ORIGIN + 1) * ns], oz = w[(int64_t)(WS_ORIGIN + 2) * ns];
+            const double lx = w[(int64_t)(WS_LOS + 0) * ns], ly = w[(int64_t)(WS_LOS + 1) * ns], lz = w[(int64_t)(WS_LOS + 2) * ns];
+            const double nl2 = fma(lx, lx, fma(ly, ly, lz * lz));
+            const double scale = nl2 * rsq_nr<2>(nl2);                  // |l|: ray length per unit of t
+            double t_hi = w[(int64_t)WS_T * ns];
+            double t_next = w[(int64_t)(WS_T + 1) * ns];             // crossings are streamed one level ahead of their use
+    #pragma unroll 1
+            for (int k = 0; k < K; ++k) {
+                const double t_lo = t_hi;
+                t_hi = t_next;
+                if (k + 2 <= K) t_next = w[(int64_t)(WS_T + k + 2) * ns];
+                const double dt = t_hi - t_lo;
+                const int np = m.np[k];
+                const double step = m.step[k];
+                const double segw = (dt * scale * 1.0e-6) * step;    // delay.py:315: L*1e-6/(np-1), L = |high-low| (losreader.py:821)
+                const double dts = dt * step;                        // sample spacing: low + (j*step)*(high-low), delay.py:292
+                const int kz = m.kz[k];
+                // j = 0 of this segment is the SAME point as j = np-1 of the previous one (low_xyz is high_xyz,
+                // losreader.py:811-812): its interpolated value is reused instead of recomputed (the reference evaluates
+                // it twice and gets the same number both times).  The order of accumulation is unchanged.
+                if (k > 0) { acc_w = fma(0.5 * segw, vw_top, acc_w); acc_h = fma(0.5 * segw, vh_top, acc_h); }
+    #pragma unroll 1
+                for (int j = (k == 0 ? 0 : 1); j < np; ++j) {
+                    const double ts = fma((double)j, dts, t_lo);
+                    double plon, plat, ph;
+                    ecef2lla(fma(ts, lx, ox), fma(ts, ly, oy), fma(ts, lz, oz), plon, plat, ph);                     // delay.py:295
+                    if (proj.kind == 1) { double px_, py_; lcc_forward(proj, plat, plon, px_, py_); plon = px_; plat = py_; }   // ecef_to_model, delay.py:253
+                    // all-pixels z-clamp of the very first / very last sample (delay.py:306-311): when it applies every
+                    // pixel is below (above) the cube, so "set to zmin" == max(ph, zmin); the bounds are wave-uniform
+                    if (clamp_any) {
+                        const double zfloor = (clamp_lo && k == 0 && j == 0) ? c.z_lo : -__builtin_huge_val();
+                        const double zceil = (clamp_hi && k == K - 1 && j == np - 1) ? c.z_hi : __builtin_huge_val();
+                        ph = fmin(fmax(ph, zfloor), zceil);
+                    }
+                    double vw, vh;
+                    sample_cube(c, m.tab2, plat, plon, ph, kz, vw, vh);                   // delay.py:298,319
+                    const double wt = ((j == 0) | (j == np - 1)) ? 0.5 * segw : segw;     // delay.py:314-315
+                    acc_w = fma(wt, vw, acc_w); acc_h = fma(wt, vh, acc_h);               // delay.py:323
+                    vw_top = vw; vh_top = vh;                                             // after the loop: value at j = np-1
+                }
             }
         }
         if (active && mine) { P.wet[i] = acc_w; P.hyd[i] = acc_h; }
