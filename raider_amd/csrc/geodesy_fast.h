@@ -193,8 +193,13 @@ __device__ const double RAY_POLY_VINV[PN][PN] = {   // [node j][power n]
     {-0.1666666666666666667, 0.2357022603955158415, 2.666666666666666667, -3.771236166328253463, -2.666666666666666667, 3.771236166328253463},
     {0.04465819873852045108, -0.04623356941400984176, -0.7559830641437075688, 0.7826512591014083831, 1.333333333333333333, -1.380368240546777399}};
 
+// proj.kind == 1: the cube lives on a Lambert-conformal-conic grid (HRRR) - the "lat" / "lon" polynomials are then fitted to
+// the projected northing / easting of the node points (ecef_to_model, delay.py:253,295), which are just as smooth along a ray.
+template <bool LCC>
 __device__ __forceinline__ void fit_ray_poly(const RayBase& b, double ox, double oy, double oz, double lx, double ly, double lz,
-                                             double mid, double half, RayPoly& q) {
+                                             double mid, double half, const LccParams& proj, RayPoly& q) {
+    double x0 = b.lon0, y0 = b.lat0;
+    if (LCC) lcc_forward(proj, b.lat0, b.lon0, x0, y0);
 #pragma unroll
     for (int n = 0; n < PN; ++n) { q.h[n] = 0.0; q.lat[n] = 0.0; q.lon[n] = 0.0; }
 #pragma unroll 1
@@ -202,14 +207,19 @@ __device__ __forceinline__ void fit_ray_poly(const RayBase& b, double ox, double
         const double t = fma(half, RAY_POLY_NODES[j], mid);
         double dx, dy, h;
         ecef2lla_delta(b, fma(t, lx, ox), fma(t, ly, oy), fma(t, lz, oz), dx, dy, h);
+        if (LCC) {
+            double px, py;
+            lcc_forward(proj, b.lat0 + dy, b.lon0 + dx, px, py);
+            dx = px - x0; dy = py - y0;
+        }
 #pragma unroll
         for (int n = 0; n < PN; ++n) {
             const double v = RAY_POLY_VINV[j][n];
             q.h[n] = fma(v, h, q.h[n]); q.lat[n] = fma(v, dy, q.lat[n]); q.lon[n] = fma(v, dx, q.lon[n]);
         }
     }
-    q.lat[0] += b.lat0;
-    q.lon[0] += b.lon0;
+    q.lat[0] += y0;
+    q.lon[0] += x0;
 }
 
 }  // namespace rdr

@@ -1082,7 +1082,7 @@ static int stage_rays(rdr_ctx* c, const rdr_rays* r, RayParams& P) {
         P.ntiles = (r->n + BLOCK - 1) / BLOCK;
     }
     P.maxlen_bits = c->d_maxlen; P.flags = c->d_flags;
-    P.ws = nullptr; P.nslots = 0; P.tile_begin = 0; P.tile_count = P.ntiles; P.nslow = c->d_nslow; P.projected = 0;
+    P.ws = nullptr; P.nslots = 0; P.tile_begin = 0; P.tile_count = P.ntiles; P.nslow = c->d_nslow;
     return RDR_OK;
 }
 
@@ -1136,28 +1136,32 @@ static bool wsig_match(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, double 
 
 // pass 1 over tiles [tb, tb+tc): optional reduction (P.maxlen_bits != null) and/or record store (P.ws != null)
 static int launch_crossings(rdr_ctx* c, const rdr_cube* q, RayParams P, int64_t tb, int64_t tc) {
-    P.tile_begin = tb; P.tile_count = tc; P.nslots = tc * BLOCK; P.projected = q->proj.kind != 0;
+    P.tile_begin = tb; P.tile_count = tc; P.nslots = tc * BLOCK;
     const int g = ray_grid(c, tc);
     HIPCHECK(c, hipMemsetAsync(c->d_nslow, 0, sizeof(int), c->stream));
     {
         KTimer t(c, 0);
-        if (q->dtype == RDR_F32)
-            hipLaunchKernelGGL((crossings_kernel<float2, false>), dim3(g), dim3(BLOCK), ray_smem(q), c->stream, make_view<float2>(q), P);
-        else
-            hipLaunchKernelGGL((crossings_kernel<double2, false>), dim3(g), dim3(BLOCK), ray_smem(q), c->stream, make_view<double2>(q), P);
+        const bool lcc = q->proj.kind == 1;
+        if (q->dtype == RDR_F32) {
+            if (lcc) hipLaunchKernelGGL((crossings_kernel<float2, false, true>), dim3(g), dim3(BLOCK), ray_smem(q), c->stream, make_view<float2>(q), P, q->proj);
+            else hipLaunchKernelGGL((crossings_kernel<float2, false, false>), dim3(g), dim3(BLOCK), ray_smem(q), c->stream, make_view<float2>(q), P, q->proj);
+        } else {
+            if (lcc) hipLaunchKernelGGL((crossings_kernel<double2, false, true>), dim3(g), dim3(BLOCK), ray_smem(q), c->stream, make_view<double2>(q), P, q->proj);
+            else hipLaunchKernelGGL((crossings_kernel<double2, false, false>), dim3(g), dim3(BLOCK), ray_smem(q), c->stream, make_view<double2>(q), P, q->proj);
+        }
     }
     // generic-geodesy mop-up of the rays the classification rejected (returns at once when there are none)
     if (q->dtype == RDR_F32)
-        hipLaunchKernelGGL((crossings_kernel<float2, true>), dim3(g), dim3(BLOCK), ray_smem(q), c->stream, make_view<float2>(q), P);
+        hipLaunchKernelGGL((crossings_kernel<float2, true>), dim3(g), dim3(BLOCK), ray_smem(q), c->stream, make_view<float2>(q), P, q->proj);
     else
-        hipLaunchKernelGGL((crossings_kernel<double2, true>), dim3(g), dim3(BLOCK), ray_smem(q), c->stream, make_view<double2>(q), P);
+        hipLaunchKernelGGL((crossings_kernel<double2, true>), dim3(g), dim3(BLOCK), ray_smem(q), c->stream, make_view<double2>(q), P, q->proj);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(c, RDR_ERR_HIP, std::string("crossings_kernel launch: ") + hipGetErrorString(e));
     return RDR_OK;
 }
 
 static int launch_march(rdr_ctx* c, const rdr_cube* q, RayParams P, int64_t tb, int64_t tc) {
-    P.tile_begin = tb; P.tile_count = tc; P.nslots = tc * BLOCK; P.projected = q->proj.kind != 0;
+    P.tile_begin = tb; P.tile_count = tc; P.nslots = tc * BLOCK;
     const int g = ray_grid(c, tc);
     {
         KTimer t(c, 1);

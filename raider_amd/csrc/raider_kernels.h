@@ -329,7 +329,6 @@ struct RayParams {
     int* flags;                        // RDR_FLAG_* bits (OR-reduced)
     const int* nparts_override;        // [K] or nullptr -> ceil(maxlen/max_seg)+1
     int* nslow;                        // number of rays the static classification sent to the generic (slow) kernels
-    int projected;                     // the cube is on a projected grid: every ray is integrated by the generic kernel
     // pass 1 -> pass 2 workspace (this launch covers tiles [tile_begin, tile_begin + tile_count))
     double* ws; int64_t nslots;
     int64_t tile_begin, tile_count;
@@ -450,8 +449,10 @@ struct TileWalk {
 // reduce over the slice) and the workspace record for pass 2.
 // SLOW = false: the light-fp64 path, skips (but counts) the rays the static classification rejects;
 // SLOW = true : generic geodesy, processes ONLY those rays, exits at once when there are none.
-template <typename T2, bool SLOW>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 : 4, SLOW ? 8 : 4))) void crossings_kernel(CubeView<T2> c, RayParams P) {
+// LCC (light kernel only): the cube is on a Lambert-conformal-conic grid; a separate instantiation so that the projection's
+// pow/tan/sincos code does not weigh on the register allocation of the lon/lat one.
+template <typename T2, bool SLOW, bool LCC = false>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SLOW || LCC) ? 1 : 4, (SLOW || LCC) ? 8 : 4))) void crossings_kernel(CubeView<T2> c, RayParams P, LccParams proj) {
     if (SLOW && *P.nslow == 0) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const RaySmem m = carve_smem(smem_raw, c.ny, c.nx, c.nz);
@@ -509,7 +510,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
         const double gam = (P.zref - P.ht) / (cosi * 6.3e6);                       // bound on the angular travel
         // ... and never crosses the +-180 meridian (the light path does not wrap longitudes): |lon0| + travel < 180 deg
         const bool fast_ok = !active || ((cosi > 0.05) && (base.c0 > gam + 0.02) && (gam < 0.03 * (base.c0 - gam)) &&
-                                         (fabs(lon) + 2.0 < 180.0) && !P.projected);
+                                         (fabs(lon) + 2.0 < 180.0));
         const int64_t slot = lt * BLOCK + tid;
         if (!SLOW) {
             const unsigned long long slow_mask = __ballot(!fast_ok);
@@ -566,7 +567,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
             const double half = 0.5 * (t_b - t_a), mid = 0.5 * (t_b + t_a);
             const double su = 1.0 / half, ou = -mid * su;
             RayPoly q;
-            fit_ray_poly(base, ox, oy, oz, lx, ly, lz, mid, half, q);
+            fit_ray_poly<LCC>(base, ox, oy, oz, lx, ly, lz, mid, half, proj, q);
             const double scale = nl * half;                           // ray length per unit of u
             if (w && mine) {
                 w[(int64_t)WS_FAST * ns] = 1.0;
@@ -630,7 +631,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
 // with the generic one (and returns immediately when there are none).
 template <typename T2, bool SLOW>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 : 3, SLOW ? 8 : 3))) void march_kernel(CubeView<T2> c, RayParams P, LccParams proj) {
-    if (SLOW && *P.nslow == 0 && !P.projected) return;
+    if (SLOW && *P.nslow == 0) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const RaySmem m = carve_smem(smem_raw, c.ny, c.nx, c.nz);
     const int K = fill_tables(c, m, P.ht, P.zref);

@@ -32,3 +32,17 @@ def timed(fn, reps=5):
 print(json.dumps({'prepass_only(no workspace stores)': timed(lambda: cube.ray_prepass(rays, 0.0, zref)),
                   'raytrace': timed(lambda: cube.raytrace(rays, 0.0, zref, out=(ow, oh), want_nparts=False)),
                   'march_only(reusing records)': timed(lambda: cube.ray_march(rays, 0.0, zref, nparts, flags, out=(ow, oh)))}))
+
+# ---- the same scene through an HRRR-like Lambert-conformal-conic cube (projected model coordinates) ----------------
+if len(sys.argv) > 2 and sys.argv[2] == 'lcc':
+    hr = dict(lat_1=38.5, lat_2=38.5, lat_0=38.5, lon_0=262.5 - 360.0)
+    xs = np.linspace(-2.0e6, -1.0e6, 300); ys = np.linspace(-9.0e5, 1.0e5, 300)
+    cube2 = R.Cube(ys, xs, c['zs'], torch.from_numpy(c['wet']).to(dev), torch.from_numpy(c['hydro']).to(dev), order='zyx', ctx=ctx)
+    cube2.set_projection_lcc(**hr)
+    # lon/lat box well inside that grid
+    lon = np.linspace(-118.5, -112.5, cols); lat = np.linspace(31.5, 36.5, rows)
+    py, px = cube2.project(np.array([lat[0], lat[-1], lat[0], lat[-1]]), np.array([lon[0], lon[0], lon[-1], lon[-1]]))
+    print('corner x', px, 'y', py, 'grid x', xs[[0, -1]], 'y', ys[[0, -1]])
+    rays2 = R.Rays.grid(torch.from_numpy(lon).to(dev), torch.from_numpy(lat).to(dev), inc=36.0, hd=-167.9)
+    _, _, np2, fl2 = cube2.raytrace(rays2, 0.0, zref, out=(ow, oh))
+    print(json.dumps({'lcc raytrace': timed(lambda: cube2.raytrace(rays2, 0.0, zref, out=(ow, oh), want_nparts=False)), 'nan_fraction': float(torch.isnan(ow).double().mean())}))
