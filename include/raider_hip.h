@@ -54,6 +54,9 @@ extern "C" {
 #define RDR_FLAG_ANY_FINITE 2     /* some ray length is finite                                       */
 #define RDR_FLAG_FIRST_NOT_BELOW 4 /* some ray's first sample is NOT below min(model_zs)  (delay.py:306) */
 #define RDR_FLAG_LAST_NOT_ABOVE 8  /* some ray's last sample is NOT above max(model_zs)   (delay.py:310) */
+#define RDR_FLAG_DIVERGED 16      /* a level's maximum ray length asks for more than 65536 integration parts (or is not
+                                    * finite): the level crossings diverged, e.g. look vectors far from unit length.  The
+                                    * slice's outputs are NaN and synchronous calls return RDR_ERR_INVALID.               */
 
 typedef struct rdr_ctx rdr_ctx;
 typedef struct rdr_cube rdr_cube;

@@ -1032,7 +1032,10 @@ int rdr_ray_levels(const rdr_cube* q, double ht, double zref, int32_t* K, double
 
 int rdr_nparts(const double* maxlen, int32_t K, double max_seg, int32_t* nparts) {
     if (!maxlen || !nparts) return fail(nullptr, RDR_ERR_INVALID, "rdr_nparts: NULL argument");
-    for (int k = 0; k < K; ++k) nparts[k] = (int32_t)std::ceil(maxlen[k] / max_seg) + 1;   // delay.py:283
+    for (int k = 0; k < K; ++k) {
+        const double parts = std::ceil(maxlen[k] / max_seg) + 1;   // delay.py:283
+        nparts[k] = (parts >= 1 && parts <= 2147483647.0) ? (int32_t)parts : 2147483647;
+    }
     return RDR_OK;
 }
 
@@ -1198,6 +1201,7 @@ static int march_chunked(rdr_ctx* c, const rdr_cube* q, const RayParams& P0, int
 }
 
 static int flags_to_status(rdr_ctx* c, int flags) {
+    if (flags & RDR_FLAG_DIVERGED) return fail(c, RDR_ERR_INVALID, "ray lengths diverged: a model level asks for more than 65536 integration parts (are the look vectors unit vectors?)");
     if (!(flags & RDR_FLAG_ANY_FINITE)) return fail(c, RDR_ERR_ALL_NAN, "geo2rdr did not converge. Check orbit coverage");
     if (flags & RDR_FLAG_ANY_NAN) return fail(c, RDR_ERR_NAN_LENGTH, "some ray lengths are NaN: the number of integration parts (delay.py:283) is undefined");
     return RDR_OK;
@@ -1238,7 +1242,7 @@ int rdr_ray_march(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, double ht, d
     std::vector<double> lo, hi; std::vector<int> kz;
     const int K = levels_host(q->zs, ht, zref, lo, hi, kz);
     if (K == 0) return fail(c, RDR_ERR_NO_LEVELS, "no weather-model interval contributes to the ray integral (build_ray -> None)");
-    for (int k = 0; k < K; ++k) if (nparts[k] < 1 || nparts[k] > (1 << 24)) return fail(c, RDR_ERR_INVALID, "rdr_ray_march: nparts out of range");
+    for (int k = 0; k < K; ++k) if (nparts[k] < 1 || nparts[k] > MAX_NPARTS) return fail(c, RDR_ERR_INVALID, "rdr_ray_march: nparts out of range (1..65536)");
     if (r->n == 0) return RDR_OK;
     HIPCHECK(c, hipSetDevice(c->device));
     const bool reuse = wsig_match(c, q, r, ht, zref, K);

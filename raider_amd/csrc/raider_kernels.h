@@ -31,6 +31,7 @@ namespace rdr {
 constexpr int TILE = 16;         // 16x16 pixel tile per workgroup (GRID mode)
 constexpr int BLOCK = TILE * TILE;
 constexpr int MAX_LEVELS = 512;  // model intervals (ERA5 has 144)
+constexpr int MAX_NPARTS = 65536; // integration points per model interval (guards the sample loop against diverged ray lengths)
 
 template <typename T2>
 struct CubeView {
@@ -636,15 +637,26 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
     const RaySmem m = carve_smem(smem_raw, c.ny, c.nx, c.nz);
     const int K = fill_tables(c, m, P.ht, P.zref);
     const int tid = threadIdx.x;
+    if (tid == 0) m.K[1] = 0;
+    __syncthreads();
     for (int k = tid; k < K; k += BLOCK) {
         int np;
         if (P.nparts_override) np = P.nparts_override[k];
-        else np = (int)ceil(__longlong_as_double((long long)P.maxlen_bits[k]) / P.max_seg) + 1;   // delay.py:283
+        else {
+            const double parts = ceil(__longlong_as_double((long long)P.maxlen_bits[k]) / P.max_seg) + 1.0;   // delay.py:283
+            np = (parts >= 1.0 && parts <= (double)MAX_NPARTS) ? (int)parts : -1;
+        }
+        if (np < 1 || np > MAX_NPARTS) {      // diverged lengths (e.g. look vectors far from unit length): refuse to loop over them
+            np = 2;
+            if (tid < BLOCK) atomicOr(P.flags, 16);    // RDR_FLAG_DIVERGED
+            m.K[1] = 1;
+        }
         m.np[k] = np;
         m.step[k] = 1.0 / ((double)np - 1.0);                    // np.linspace(0,1,np) (delay.py:287)
         m.hs[k] = 0.5e-6 * m.step[k];                            // delay.py:314-315: end points get half of L*1e-6/(np-1)
     }
     __syncthreads();
+    const double poison = m.K[1] ? qnan() : 0.0;   // diverged slice: every output is NaN
     const int flags_in = *P.flags;
     const bool clamp_lo = !(flags_in & 4);   // ALL first samples below zmin  (delay.py:306-307)
     const bool clamp_hi = !(flags_in & 8);   // ALL last samples above zmax   (delay.py:310-311)
@@ -790,7 +802,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
                 }
             }
         }
-        if (active && mine) { P.wet[i] = acc_w; P.hyd[i] = acc_h; }
+        if (active && mine) { P.wet[i] = acc_w + poison; P.hyd[i] = acc_h + poison; }
     }
 }
 

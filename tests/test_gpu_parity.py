@@ -188,3 +188,56 @@ def test_raytrace_domain_sweep(R, region):
         # so the cheap early iterates move the final crossing by ~1e-4 m and the delay by ~1e-9 m
         np.testing.assert_allclose(wet, ow[0], rtol=0, atol=5 * TIGHT, equal_nan=True)
         np.testing.assert_allclose(hyd, oh[0], rtol=0, atol=5 * TIGHT, equal_nan=True)
+
+
+@pytest.mark.parametrize('case', ['steep_80km', 'nonunit_los', 'jittered_axes', 'negative_ht'])
+def test_ray_polynomial_stress(R, case):
+    """Corner cases of the ray-polynomial kernels against the oracle: the longest rays the static classification admits
+    (52-62 deg incidence through an 80 km cube: the classification cuts at ~60 deg there, so both the light and the
+    generic kernels take part), look vectors that are not unit length (the ray
+    parameter is then not metres), x/y axes that are only NEARLY uniform (LDS guess-and-verify instead of the arithmetic
+    cell) and origins below the ellipsoid."""
+    rng = np.random.default_rng(11)
+    if case == 'steep_80km':
+        c = O.synthetic_cube(48, 80, 40, seed=3, ztop=80000.0, y0=20.0, y1=34.0, x0=-125.0, x1=-100.0)
+        ypts = np.linspace(28.0, 26.5, 9); xpts = np.linspace(-114.0, -111.0, 11)
+        inc = rng.uniform(52, 62, (9, 11)); hd = rng.uniform(-180, 180, (9, 11)); ht = 0.0
+    else:
+        c = O.synthetic_cube(40, 44, 36, seed=5, y0=30.0, y1=38.0, x0=-122.0, x1=-110.0)
+        ypts = np.linspace(35.0, 33.0, 12); xpts = np.linspace(-117.5, -114.5, 14)
+        inc = rng.uniform(10, 50, (12, 14)); hd = rng.uniform(-180, 180, (12, 14)); ht = -60.0 if case == 'negative_ht' else 250.0
+    if case == 'jittered_axes':
+        c['xs'] = c['xs'] + 1e-7 * rng.uniform(-1, 1, c['xs'].size)
+        c['ys'] = c['ys'] + 1e-7 * rng.uniform(-1, 1, c['ys'].size)
+    zref = float(c['zs'].max() - 1)
+    cube = R.Cube(c['ys'], c['xs'], c['zs'], c['wet'], c['hydro'], order='zyx')
+    ip = list(O.getInterpolators(c['xs'], c['ys'], c['zs'], c['wet'], c['hydro']))
+    scale = rng.uniform(0.8, 1.2, inc.shape) if case == 'nonunit_los' else 1.0      # (the reference's own iteration diverges beyond |l| cos(inc) = 2)
+    look = lambda ht_, llh, xyz, yy: O.look_vectors_from_inc_hd(inc, hd, llh[1], llh[0], llh[2]) * np.asarray(scale)[..., None]
+    (ow, oh), onp = O.build_cube_ray(xpts, ypts, np.array([ht]), look, ip, MAX_TROPO_HEIGHT=zref, return_nparts=True)
+    xx, yy = np.meshgrid(xpts, ypts)
+    los = look(ht, [xx, yy, np.full(yy.shape, ht)], None, yy)
+    wet, hyd, nparts, _ = cube.raytrace(R.Rays.grid(xpts, ypts, los=np.ascontiguousarray(los)), ht, zref)
+    assert np.array_equal(nparts, onp[0])
+    assert np.array_equal(np.isnan(wet), np.isnan(ow[0])) and np.isfinite(ow[0]).mean() > 0.5
+    tol = 2e-8 if case == 'steep_80km' else 5 * TIGHT       # 5 m of slant delay, and the reference's own 3-step crossings are cm off there
+    np.testing.assert_allclose(wet, ow[0], rtol=0, atol=tol, equal_nan=True)
+    np.testing.assert_allclose(hyd, oh[0], rtol=0, atol=tol, equal_nan=True)
+
+
+def test_diverged_lengths_are_refused(R, c1):
+    """Look vectors 3x unit length make getTopOfAtmosphere's fixed-point iteration diverge (|1 - |l| cos(inc)| > 1, in the
+    reference as well): the per-level maximum length is astronomically large.  The library must not try to integrate
+    ~1e300 parts: synchronous calls raise, asynchronous ones return NaN."""
+    cube = R.Cube(c1['ys'], c1['xs'], c1['zs'], c1['wet'], c1['hydro'], order='zyx')
+    xp = np.linspace(-118.0, -116.0, 9); yp = np.linspace(34.0, 33.0, 7)
+    los = 3.0 * R.Rays.grid(xp, yp, inc=20.0, hd=-167.9).look_vectors()
+    zref = float(c1['zs'].max() - 1)
+    with pytest.raises(Exception, match='diverged'):
+        cube.raytrace(R.Rays.grid(xp, yp, los=np.ascontiguousarray(los)), 0.0, zref)
+    import torch
+    dev = torch.device('cuda:0')
+    rays = R.Rays.grid(torch.from_numpy(xp).to(dev), torch.from_numpy(yp).to(dev), los=torch.from_numpy(np.ascontiguousarray(los)).to(dev))
+    wet, hyd, _, _ = cube.raytrace(rays, 0.0, zref, want_nparts=False)         # device arrays, no host sync: NaN outputs
+    torch.cuda.synchronize()
+    assert torch.isnan(wet).all() and torch.isnan(hyd).all()
