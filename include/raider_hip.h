@@ -131,6 +131,18 @@ int rdr_cube_set_projection(rdr_cube* cube, int kind, const double* params, int 
 int rdr_project_points(rdr_ctx* ctx, const rdr_cube* cube, const double* lat, const double* lon, int64_t n, double* y, double* x, int loc);
 /* temporal blend, cli/raider.py:817-819: out = w1*a + w2*b (f32 cubes blend in f32, f64 in f64) */
 int rdr_cube_blend(rdr_ctx* ctx, const rdr_cube* a, double w1, const rdr_cube* b, double w2, rdr_cube** out);
+/* Azimuth-time-grid temporal interpolation.
+ * rdr_inverse_time_weights = get_inverse_weights_for_dates (s1_azimuth_timing.py:326-399): az[n] = per-voxel acquisition
+ * times and dates[nd] = model times, all in seconds on one epoch; weights[d*n + i] = normalised inverse-|dt| weight of
+ * date d at voxel i, masked to |dt| <= window_s (window_s < 0: min_i |dates[i]-dates[0]|, the inferred model step).
+ * RDR_ERR_INVALID: duplicate dates / no date ("No dates provided are within temporal window").
+ * rdr_cube_blend_weighted = the combination of cli/raider.py:817-819 with those per-voxel weights: weights[d][nz*ny*nx]
+ * in FILE order (z,y,x) (the shape of the reference's time grid), result a new f64 cube (a float64 weight array
+ * promotes the f32 fields in the reference too). */
+int rdr_inverse_time_weights(rdr_ctx* ctx, const double* az, int64_t n, const double* dates, int32_t nd, double window_s,
+                             double regularizer, double* weights, int loc);
+int rdr_cube_blend_weighted(rdr_ctx* ctx, const rdr_cube* const* cubes, int32_t nd, const double* weights, int loc, rdr_cube** out);
+
 /* copy the (blended) fields back, (y,x,z) C-order, dtype of the cube */
 int rdr_cube_read(rdr_ctx* ctx, const rdr_cube* cube, void* wet, void* hydro);
 

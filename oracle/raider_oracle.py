@@ -486,6 +486,75 @@ def time_weights(t, t1, t2):
 
 
 # ----------------------------------------------------------------------------------------------
+# azimuth-time-grid temporal weighting (s1_azimuth_timing.py)
+# ----------------------------------------------------------------------------------------------
+def n_closest_datetimes(ref_time, n_target_times, time_step_hours):
+    """s1_azimuth_timing.py:204-266 without pandas: model times (multiples of the step since midnight) around ref_time,
+    ordered by distance (ties: earlier first), first n."""
+    import datetime as _dt
+    if 24 % time_step_hours != 0:
+        raise ValueError('The time step does not evenly divide 24 hours')
+    step = _dt.timedelta(hours=time_step_hours)
+    day0 = _dt.datetime(ref_time.year, ref_time.month, ref_time.day)
+
+    def floor(t):
+        return day0 + ((t - day0) // step) * step
+
+    def ceil(t):
+        f = floor(t)
+        return f if f == t else f + step
+    found = []
+    for k in range(int(np.ceil(n_target_times / 2))):
+        for t in {floor(ref_time - k * step), ceil(ref_time + k * step)}:
+            found.append(t)
+    found = sorted(found, key=lambda t: (abs(ref_time - t), t))
+    return found[:n_target_times]
+
+
+def times_for_azimuth_interpolation(ref_time, time_step_hours, buffer_in_seconds=300):
+    """s1_azimuth_timing.py:269-323: the 3 closest model times that lie within one step (+ buffer) of ref_time."""
+    bound = time_step_hours * 3600 + buffer_in_seconds
+    return [t for t in n_closest_datetimes(ref_time, 3, time_step_hours) if abs((ref_time - t).total_seconds()) < bound]
+
+
+def inverse_time_weights(az_s, dates_s, window_s=None, regularizer=1e-9):
+    """s1_azimuth_timing.py:326-399 with times in seconds on a common epoch: w_i = m_i / (|t - d_i| + reg) normalised over
+    the dates, m_i = |t - d_i| <= window.  Returns (len(dates),) + az_s.shape; voxels with no date in the window are NaN."""
+    dates_s = [float(d) for d in dates_s]
+    if len(set(dates_s)) != len(dates_s):
+        raise ValueError('Dates provided must be unique')
+    if not dates_s:
+        raise ValueError('No dates provided')
+    if window_s is None:
+        window_s = min(abs(d - dates_s[0]) for d in dates_s[1:])
+    az_s = np.asarray(az_s, dtype=np.float64)
+    diffs = [np.abs(az_s - d) for d in dates_s]
+    masked = [(1.0 / (df + regularizer)) * (df <= window_s).astype(int) for df in diffs]
+    if all((df <= window_s).sum() == 0 for df in diffs):
+        raise ValueError('No dates provided are within temporal window')
+    total = np.sum(np.stack(masked, axis=-1), axis=-1)
+    with np.errstate(invalid='ignore', divide='ignore'):
+        return np.stack([m / total for m in masked])
+
+
+def azimuth_time_grid(st, sp, sv, lat, lon, hgt):
+    """s1_azimuth_timing.py:90-147 with this build's zero-Doppler solver (isce3 is not available: unpinned):
+    seconds (orbit time scale) of the zero-Doppler epoch PLUS the one-way range delay sr/c (:138-139), truncated to
+    milliseconds like the datetime64[ms] array the reference fills."""
+    xyz = np.stack(lla2ecef(lat, lon, hgt), axis=-1)
+    _, t, rg = orbit_look_vectors(st, sp, sv, xyz, threshold=1.0e-7, maxiter=100)
+    return np.floor((t + rg / 299792458.0) * 1e3) / 1e3
+
+
+def combine_weighted(weights, fields):
+    """cli/raider.py:817-819 with per-voxel weights: sum([wgt * ds[var] ...]) = ((0 + w0 f0) + w1 f1) + ...  in f64."""
+    out = 0
+    for w, f in zip(weights, fields):
+        out = out + w * f
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
 # native extension restatements
 # ----------------------------------------------------------------------------------------------
 def _bisect(grid, x):

@@ -460,7 +460,50 @@ def g10():
     save('g10_cube_producer', **out)
 
 
+def g11():
+    """Azimuth-time-grid temporal weighting (s1_azimuth_timing.py:204-399): the reference's own pure date/weight
+    functions on random time grids, plus the per-voxel weighted combination of cli/raider.py:817-819 on small cubes."""
+    import datetime as dtm
+    from RAiDER.s1_azimuth_timing import (get_inverse_weights_for_dates, get_n_closest_datetimes,
+                                          get_times_for_azimuth_interpolation)
+    out = {}
+    rng = np.random.default_rng(11)
+    # --- closest model times / times needed for the interpolation (stored as ISO strings)
+    cases = [(dtm.datetime(2023, 1, 1, 11, 1, 1), 3, 6), (dtm.datetime(2023, 2, 1, 8, 1, 1), 4, 2), (dtm.datetime(2023, 1, 1, 20, 1, 1), 2, 4),
+             (dtm.datetime(2023, 1, 2, 0, 0, 0), 3, 1), (dtm.datetime(2021, 7, 23, 1, 50, 24), 3, 3), (dtm.datetime(2020, 12, 31, 23, 59, 59), 5, 12)]
+    out['closest_in'] = np.array([f'{c[0].isoformat()}|{c[1]}|{c[2]}' for c in cases])
+    out['closest_out'] = np.array(['|'.join(t.isoformat() for t in get_n_closest_datetimes(*c)) for c in cases])
+    az_cases = [(dtm.datetime(2023, 1, 1, 11, 1, 0), 1, 300), (dtm.datetime(2023, 1, 1, 11, 1, 0), 3, 300), (dtm.datetime(2023, 1, 1, 11, 29, 0), 1, 300),
+                (dtm.datetime(2021, 7, 23, 1, 50, 24), 1, 300), (dtm.datetime(2021, 7, 23, 5, 57, 0), 6, 600), (dtm.datetime(2021, 7, 23, 3, 0, 0), 6, 300)]
+    out['aztimes_in'] = np.array([f'{c[0].isoformat()}|{c[1]}|{c[2]}' for c in az_cases])
+    out['aztimes_out'] = np.array(['|'.join(t.isoformat() for t in get_times_for_azimuth_interpolation(*c)) for c in az_cases])
+    # --- inverse weights on random time grids; times as int64 milliseconds since 2021-01-01T00:00:00
+    epoch = np.datetime64('2021-01-01T00:00:00', 'ms')
+    dates3 = [dtm.datetime(2021, 1, 1, 6), dtm.datetime(2021, 1, 1, 12), dtm.datetime(2021, 1, 1, 0)]
+    dates2 = [dtm.datetime(2021, 1, 1, 6), dtm.datetime(2021, 1, 1, 7)]
+    shape = (5, 6, 7)
+    for tag, dates, centre_h, spread_s, window, reg in (('w3', dates3, 6.9, 30.0, None, 1e-9), ('w3b', dates3, 6.0, 4 * 3600.0, 6, 1e-9),
+                                                         ('w3c', dates3, 8.0, 3 * 3600.0, 3, 1e-10), ('w2', dates2, 6.4, 1500.0, None, 1e-9)):
+        ms = np.round(centre_h * 3.6e6 + 1e3 * spread_s * rng.uniform(-1, 1, shape)).astype(np.int64)
+        if tag == 'w3b':
+            ms.flat[:3] = [6 * 3600_000, 12 * 3600_000, 0]          # grid times that coincide with model times (regulariser)
+        grid = epoch + ms.astype('timedelta64[ms]')
+        w = get_inverse_weights_for_dates(grid, dates, inverse_regularizer=reg, temporal_window_hours=window)
+        out[f'{tag}_ms'] = ms
+        out[f'{tag}_dates_s'] = np.array([(d - dtm.datetime(2021, 1, 1)).total_seconds() for d in dates])
+        out[f'{tag}_window_h'] = np.array(np.nan if window is None else float(window))
+        out[f'{tag}_reg'] = np.array(reg)
+        out[f'{tag}_weights'] = np.stack(w)
+    # --- the combination itself: `sum([wgt * ds[var] ...])` with f64 weight arrays and f32 fields (z, y, x)
+    fields = [rng.normal(50.0, 5.0, shape).astype(np.float32) for _ in range(3)]
+    w = [out['w3b_weights'][i] for i in range(3)]
+    out['comb_fields'] = np.stack(fields)
+    out['comb_out'] = sum([wgt * f for (wgt, f) in zip(w, fields)])
+    print('  weights dtype', out['w3_weights'].dtype, 'combined dtype', out['comb_out'].dtype, 'NaNs in w3c', int(np.isnan(out['w3c_weights']).sum()))
+    save('g11_aztime_weights', **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g8', 'g9', 'g10']   # g7: cli.raider needs h5py (absent)
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g8', 'g9', 'g10', 'g11']   # g7: cli.raider needs h5py (absent)
     for w in which:
         globals()[w]()

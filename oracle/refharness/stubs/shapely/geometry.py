@@ -8,3 +8,8 @@ def box(*bounds):
 
 
 Polygon = _Box
+
+
+class Point:
+    def __init__(self, *a, **k):
+        self.coords = a

@@ -171,6 +171,53 @@ __global__ void blend_kernel(const T2* __restrict__ a, T w1, const T2* __restric
     }
 }
 
+// ---- azimuth-time-grid temporal weighting -----------------------------------------------------------------------------
+// get_inverse_weights_for_dates (s1_azimuth_timing.py:326-399): w_d = m_d / (|t - date_d| + reg) / sum_d(...), m_d = 1 when
+// |t - date_d| <= window.  A voxel with no date inside the window divides 0 by 0 -> NaN, as in the reference.
+struct DateSet { int nd; double date[8]; double window, reg; };
+
+__global__ void time_weights_kernel(DateSet D, const double* __restrict__ az, int64_t n, double* __restrict__ w, int* __restrict__ any_in_window) {
+    int seen = 0;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double t = az[i];
+        double m[8], total = 0.0;
+        for (int d = 0; d < D.nd; ++d) {
+            const double diff = fabs(t - D.date[d]);
+            const bool in = diff <= D.window;
+            seen |= in;
+            m[d] = (1.0 / (diff + D.reg)) * (in ? 1.0 : 0.0);
+            total += m[d];
+        }
+        for (int d = 0; d < D.nd; ++d) w[(int64_t)d * n + i] = m[d] / total;
+    }
+    if (seen) atomicOr(any_in_window, 1);
+}
+
+// cli/raider.py:817-819 with per-voxel weights: sum([wgt * ds[var] ...]) = ((0 + w0 a0) + w1 a1) + ... in f64 (a weight ARRAY
+// is float64, so numpy promotes the f32 fields).  Weights are in file order (z, y, x), cubes in device order (y, x, z).
+struct CubeSet { int nd; const void* v[8]; };
+
+template <typename T2>
+__global__ void blend_weighted_kernel(CubeSet S, const double* __restrict__ w, int64_t ny, int64_t nx, int64_t nz, double2* __restrict__ out) {
+    const int64_t total = ny * nx * nz;
+    for (int64_t o = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t iz = o % nz, ix = (o / nz) % nx, iy = o / (nz * nx);
+        const int64_t wi = (iz * ny + iy) * nx + ix;
+        double aw = 0.0, ah = 0.0;
+        for (int d = 0; d < S.nd; ++d) {
+            const T2 v = reinterpret_cast<const T2*>(S.v[d])[o];
+            const double wd = w[(int64_t)d * total + wi];
+            {
+#pragma clang fp contract(off)
+                const double pw = wd * (double)v.x, ph = wd * (double)v.y;
+                aw = aw + pw; ah = ah + ph;
+            }
+        }
+        double2 r; r.x = aw; r.y = ah;
+        out[o] = r;
+    }
+}
+
 // A4/A5: scipy RGI at packed points (n,3) = (y,x,z)
 template <typename T2>
 __global__ __launch_bounds__(256) void interp_points_kernel(CubeView<T2> c, const double* __restrict__ pts, int64_t n,
@@ -902,6 +949,74 @@ int rdr_cube_blend(rdr_ctx* c, const rdr_cube* a, double w1, const rdr_cube* b, 
         else
             hipLaunchKernelGGL((blend_kernel<double, double2>), dim3(g), dim3(256), 0, c->stream, (const double2*)a->d_vals, w1,
                                (const double2*)b->d_vals, w2, (double2*)q->d_vals, total);
+    }
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { rdr_cube_destroy(q); return fail(c, RDR_ERR_HIP, hipGetErrorString(e)); }
+    *out = q;
+    return RDR_OK;
+}
+
+int rdr_inverse_time_weights(rdr_ctx* c, const double* az, int64_t n, const double* dates, int32_t nd, double window_s, double regularizer,
+                             double* weights, int loc) {
+    if (!c || !az || !dates || !weights) return fail(c, RDR_ERR_INVALID, "rdr_inverse_time_weights: NULL argument");
+    if (nd < 1) return fail(c, RDR_ERR_INVALID, "No dates provided");
+    if (nd > 8) return fail(c, RDR_ERR_INVALID, "rdr_inverse_time_weights: at most 8 dates");
+    DateSet D; D.nd = nd; D.reg = regularizer;
+    for (int i = 0; i < nd; ++i) {
+        D.date[i] = dates[i];
+        for (int j = 0; j < i; ++j) if (dates[j] == dates[i]) return fail(c, RDR_ERR_INVALID, "Dates provided must be unique");
+    }
+    if (window_s < 0) {                                  // s1_azimuth_timing.py:375-376: infer the model time step
+        if (nd < 2) return fail(c, RDR_ERR_INVALID, "rdr_inverse_time_weights: the temporal window cannot be inferred from one date");
+        window_s = std::fabs(dates[1] - dates[0]);
+        for (int i = 2; i < nd; ++i) window_s = std::min(window_s, std::fabs(dates[i] - dates[0]));
+    }
+    D.window = window_s;
+    if (n == 0) return RDR_OK;
+    HIPCHECK(c, hipSetDevice(c->device));
+    const void* da; void* dw;
+    int rc = stage_in(c, SLOT_IN0, az, (size_t)n * 8, loc, &da); if (rc) return rc;
+    rc = stage_out(c, SLOT_OUT0, weights, (size_t)n * nd * 8, loc, &dw); if (rc) return rc;
+    HIPCHECK(c, hipMemsetAsync(c->d_flags, 0, sizeof(int), c->stream));
+    hipLaunchKernelGGL(time_weights_kernel, dim3(grid_for(n, 256, c->num_cus * 8)), dim3(256), 0, c->stream, D, (const double*)da, n, (double*)dw, c->d_flags);
+    HIPCHECK(c, hipGetLastError());
+    rc = finish_out(c, weights, dw, (size_t)n * nd * 8, loc); if (rc) return rc;
+    int f = 0;
+    HIPCHECK(c, hipMemcpyAsync(&f, c->d_flags, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    if (!f) return fail(c, RDR_ERR_INVALID, "No dates provided are within temporal window");
+    return RDR_OK;
+}
+
+int rdr_cube_blend_weighted(rdr_ctx* c, const rdr_cube* const* cubes, int32_t nd, const double* weights, int loc, rdr_cube** out) {
+    if (!c || !cubes || !weights || !out) return fail(c, RDR_ERR_INVALID, "rdr_cube_blend_weighted: NULL argument");
+    if (nd < 1 || nd > 8) return fail(c, RDR_ERR_INVALID, "rdr_cube_blend_weighted: 1..8 cubes");
+    const rdr_cube* a = cubes[0];
+    CubeSet S; S.nd = nd;
+    for (int i = 0; i < nd; ++i) {
+        const rdr_cube* b = cubes[i];
+        if (!b) return fail(c, RDR_ERR_INVALID, "rdr_cube_blend_weighted: NULL cube");
+        if (a->ny != b->ny || a->nx != b->nx || a->nz != b->nz || a->dtype != b->dtype || a->ys != b->ys || a->xs != b->xs || a->zs != b->zs)
+            return fail(c, RDR_ERR_INVALID, "rdr_cube_blend_weighted: cubes are not on the same grid / dtype");
+        S.v[i] = b->d_vals;
+    }
+    HIPCHECK(c, hipSetDevice(c->device));
+    const int64_t total = a->ny * a->nx * a->nz;
+    const void* dwt;
+    int rc = stage_in(c, SLOT_IN0, weights, (size_t)total * nd * 8, loc, &dwt); if (rc) return rc;
+    rdr_cube* q = new rdr_cube();
+    q->ctx = c; q->ny = a->ny; q->nx = a->nx; q->nz = a->nz; q->dtype = RDR_F64;
+    q->ys = a->ys; q->xs = a->xs; q->zs = a->zs; q->proj = a->proj;
+    rc = cube_alloc(c, q);
+    if (rc) { rdr_cube_destroy(q); return rc; }
+    const int g = grid_for(total, 256, c->num_cus * 8);
+    {
+        KTimer t(c, 3);
+        if (a->dtype == RDR_F32)
+            hipLaunchKernelGGL((blend_weighted_kernel<float2>), dim3(g), dim3(256), 0, c->stream, S, (const double*)dwt, a->ny, a->nx, a->nz, (double2*)q->d_vals);
+        else
+            hipLaunchKernelGGL((blend_weighted_kernel<double2>), dim3(g), dim3(256), 0, c->stream, S, (const double*)dwt, a->ny, a->nx, a->nz, (double2*)q->d_vals);
     }
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);

@@ -245,3 +245,33 @@ def test_g10_fillna3d(golden):
     a = g['holes_in']
     assert np.array_equal(O.fillna_columns(a, 0.0), g['holes_fill0'])
     assert np.array_equal(O.fillna_columns(a, 1e16), g['holes_fill1e16'])
+
+
+def test_g11_azimuth_time_weighting(golden):
+    """s1_azimuth_timing.py date selection and inverse weights, cli/raider.py:817-819 combination, vs the reference's own
+    functions (golden g11) and the known answers of test/test_s1_time_grid.py:157-205,358-386."""
+    import datetime as dt
+    g = golden('g11_aztime_weights')
+    for spec, want in zip(g['closest_in'], g['closest_out']):
+        t, n, step = str(spec).split('|')
+        got = O.n_closest_datetimes(dt.datetime.fromisoformat(t), int(n), int(step))
+        assert '|'.join(x.isoformat() for x in got) == str(want)
+    for spec, want in zip(g['aztimes_in'], g['aztimes_out']):
+        t, step, buf = str(spec).split('|')
+        got = O.times_for_azimuth_interpolation(dt.datetime.fromisoformat(t), int(step), int(buf))
+        assert '|'.join(x.isoformat() for x in got) == str(want)
+    assert O.n_closest_datetimes(dt.datetime(2023, 1, 1, 11, 1, 1), 3, 6) == [dt.datetime(2023, 1, 1, 12), dt.datetime(2023, 1, 1, 6), dt.datetime(2023, 1, 1, 18)]
+    with pytest.raises(ValueError):
+        O.n_closest_datetimes(dt.datetime(2023, 1, 1, 20, 1, 1), 2, 5)
+    for tag in ('w3', 'w3b', 'w3c', 'w2'):
+        win = float(g[f'{tag}_window_h'])
+        w = O.inverse_time_weights(g[f'{tag}_ms'] * 1e-3, g[f'{tag}_dates_s'], None if np.isnan(win) else win * 3600.0, float(g[f'{tag}_reg']))
+        np.testing.assert_allclose(w, g[f'{tag}_weights'], rtol=1e-13, atol=1e-18)
+        np.testing.assert_allclose(w.sum(0), 1.0, rtol=1e-14)
+    # test_inverse_weighting's table (test_s1_time_grid.py:208-216): 07:00 between 06:00 / 12:00 / 00:00, 6 h window
+    w = O.inverse_time_weights(np.array([7 * 3600.0]), [6 * 3600.0, 12 * 3600.0, 0.0], 6 * 3600.0)
+    np.testing.assert_allclose(w[:, 0], [.833, .167, 0.0], atol=1e-3)
+    with pytest.raises(ValueError):
+        O.inverse_time_weights(np.zeros(3), [1.0, 1.0])
+    comb = O.combine_weighted(list(g['w3b_weights']), list(g['comb_fields']))
+    assert comb.dtype == np.float64 and np.array_equal(comb, g['comb_out'])
