@@ -734,6 +734,17 @@ def cube_from_model_levels(zs, p, t, hum, humidity_type, new_z, k1=0.776, k2=0.2
 # synthetic workloads - shared by tests and bench so GPU and CPU see the
 # same seeded inputs
 # ----------------------------------------------------------------------------------------------
+def ztd_totals(field_yxz, zs):
+    """weatherModel.py:389-403 `_getZTD` on a (y, x, z) field: total[..., l] = 1e-6 * trapz(field[..., l:], zs[l:])."""
+    f = np.asarray(field_yxz)
+    out = np.zeros(f.shape, dtype=np.float64)
+    for lev in range(zs.size):
+        y = f[..., lev:]
+        d = np.diff(zs[lev:])
+        out[..., lev] = 1e-6 * np.sum(d * (y[..., 1:] + y[..., :-1]) / 2.0, axis=-1)
+    return out
+
+
 def synthetic_cube(ny, nx, nz, seed=0, ztop=41000.0, y0=30.0, y1=36.0, x0=-121.0, x1=-113.0):
     """SURVEY §8(d) "Synthetic cube": returns dict(xs, ys, zs, wet, hydro (z,y,x) f32,
     wet_total, hydro_total (z,y,x) f64)."""

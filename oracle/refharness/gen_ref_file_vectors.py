@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Fixtures cut out of the DATA FILES the reference's own tests hold (test infrastructure; run in the build container only).
+
+  tests/golden/ref_files/ERA-5_2019_11_17_T20_51_58_5S_2S_41W_37W.nc
+      a processed weather-model cube written by the real RAiDER (NetCDF-4/HDF5; /root/reference/test/weather_files/),
+      copied verbatim: exercises the built-in HDF5 reader and pins the refractivity and ZTD stages on real output;
+  tests/golden/g12_gmao_time_interp.npz
+      a 145 x 5 x 6 block of the three GMAO cubes of /root/reference/test/gunw_test_data/weather_files/ (12:00, 15:00 and
+      the reference's own `timeInterp` product for 13:52:44): pins the two-epoch temporal blend (cli/raider.py:817-819,
+      877-888) on a file the reference itself produced.
+"""
+import shutil
+import sys
+from pathlib import Path
+
+import numpy as np
+
+REPO = Path(__file__).resolve().parents[2]
+sys.path.insert(0, str(REPO))
+from raider_amd import h5lite  # noqa: E402
+
+REF_TEST = Path('/root/reference/test')
+OUT = REPO / 'tests' / 'golden'
+
+
+def main():
+    (OUT / 'ref_files').mkdir(parents=True, exist_ok=True)
+    src = REF_TEST / 'weather_files' / 'ERA-5_2019_11_17_T20_51_58_5S_2S_41W_37W.nc'
+    shutil.copyfile(src, OUT / 'ref_files' / src.name)
+    d = REF_TEST / 'gunw_test_data' / 'weather_files'
+    names = dict(t12='GMAO_2020_01_30_T12_00_00_32N_36N_121W_114W.nc', t15='GMAO_2020_01_30_T15_00_00_32N_36N_121W_114W.nc',
+                 interp='GMAO_2020_01_30T13_52_44_timeInterp_32N_36N_121W_114W.nc')
+    out = {}
+    blk = (slice(None), slice(5, 10), slice(6, 12))
+    for tag, fn in names.items():
+        f = h5lite.File(d / fn)
+        for v in ('wet', 'hydro', 'wet_total', 'hydro_total'):
+            out[f'{tag}_{v}'] = f[v].read()[blk]
+        out[f'{tag}_datetime'] = np.array(f.attrs['datetime'])
+    f = h5lite.File(d / names['t12'])
+    out['x'], out['y'], out['z'] = f['x'].read()[blk[2]], f['y'].read()[blk[1]], f['z'].read()
+    out['query_time'] = np.array('2020-01-30T13:52:44')
+    np.savez_compressed(OUT / 'g12_gmao_time_interp.npz', **out)
+    print('g12_gmao_time_interp.npz', (OUT / 'g12_gmao_time_interp.npz').stat().st_size // 1024, 'KiB;', src.name, src.stat().st_size // 1024, 'KiB')
+
+
+if __name__ == '__main__':
+    main()

@@ -172,6 +172,34 @@ class DelayCube:
         except KeyError:
             raise AttributeError(k)
 
+    def to_netcdf(self, path):
+        """The delay-cube file of delay.py:329-401 / cli/raider.py (ds.to_netcdf) as NetCDF-3 (64-bit offset) through scipy:
+        dims z, y, x; variables wet, hydro (f64, units m, grid_mapping crs), coordinate variables, the integer `crs`
+        grid-mapping variable and the global attributes.  (NetCDF-4 output needs netCDF4/h5py, which the reference gets
+        from xarray; when xarray is installed writeResultsToXarray returns a real Dataset instead of this class.)"""
+        from scipy.io import netcdf_file
+        v = self.variables
+        with netcdf_file(str(path), 'w', version=2) as f:
+            for k, val in self.attrs.items():
+                setattr(f, k, str(val))
+            for d in ('z', 'y', 'x'):
+                f.createDimension(d, int(np.size(v[d])))
+                cv = f.createVariable(d, 'f8', (d,))
+                cv[:] = np.asarray(v[d], dtype=np.float64)
+            f.variables['z'].axis = 'Z'; f.variables['z'].units = 'm'; f.variables['z'].description = 'height above ellipsoid'
+            degrees = self.attrs.get('_degrees', True)
+            f.variables['y'].units = 'degrees_north' if degrees else 'm'
+            f.variables['x'].units = 'degrees_east' if degrees else 'm'
+            desc = str(self.attrs.get('description', '')).replace('RAiDER geo cube - ', '')
+            for name, long in (('wet', 'wet'), ('hydro', 'hydrostatic')):
+                dv = f.createVariable(name, 'f8', ('z', 'y', 'x'))
+                dv[:] = np.asarray(v[name], dtype=np.float64)
+                dv.units = 'm'; dv.description = f'{long} {desc} delay'; dv.grid_mapping = 'crs'
+            crs = f.createVariable('crs', 'i4', ())
+            crs.data[()] = -2147483647
+            for k, val in (self.attrs.get('_crs_cf') or {}).items():
+                setattr(crs, k, val)
+
 
 def _is_cube_aoi(aoi):
     """delay.py:98 `isinstance(aoi, (BoundingBox, Geocube))`, duck-typed on AOI.type() (llreader.py:50-51,316,373)."""
@@ -385,6 +413,10 @@ def writeResultsToXarray(datetime, xpts, ypts, zpts, crs, wetDelay, hydroDelay, 
     try:
         import xarray as xr
     except ImportError:
+        attrs['_degrees'] = degrees
+        if degrees:
+            attrs['_crs_cf'] = dict(grid_mapping_name='latitude_longitude', semi_major_axis=6378137.0, inverse_flattening=298.257223563,
+                                    longitude_of_prime_meridian=0.0, geographic_crs_name='WGS 84')
         return DelayCube(dict(wet=np.asarray(wetDelay), hydro=np.asarray(hydroDelay), x=np.asarray(xpts), y=np.asarray(ypts),
                               z=np.asarray(zpts), crs=np.array(-2147483647)), attrs)
     ds = xr.Dataset(

@@ -49,6 +49,40 @@ class FieldInterpolator:
         return wet if self.field == 0 else hyd
 
 
+class _Var:
+    """array + attributes, indexable like a netCDF variable (what tropo_delay reads: var[:] and var.attrs['crs_wkt'])"""
+
+    def __init__(self, data, attrs):
+        self.data, self.attrs = data, attrs
+
+    def __getitem__(self, k):
+        return self.data[k]
+
+    def __array__(self, dtype=None, copy=None):
+        return np.asarray(self.data, dtype=dtype)
+
+
+def _read_cube_file(path):
+    """Processed weather-model / delay cube file -> {name: _Var}.  NetCDF-4 (= HDF5, what the reference writes,
+    weatherModel.py:659-724) goes through the built-in reader raider_amd.h5lite, NetCDF-3 through scipy."""
+    with open(path, 'rb') as fh:
+        magic = fh.read(8)
+    if magic[:3] == b'CDF':
+        from scipy.io import netcdf_file
+        with netcdf_file(str(path), 'r', mmap=False) as f:
+            return {k: _Var(np.array(v.data), {a: (b.decode() if isinstance(b, bytes) else b) for a, b in v._attributes.items()})
+                    for k, v in f.variables.items()}
+    from . import h5lite
+    f = h5lite.File(path)
+    out = {}
+    for k in f.keys():
+        obj = f[k]
+        if isinstance(obj, h5lite.Dataset) and obj.dtype is not None and obj.dtype.kind in 'fiu':
+            a = obj.read()
+            out[k] = _Var(a, {n: v for n, v in obj.attrs.items() if not n.startswith('_N') and n not in ('CLASS', 'NAME')})
+    return out
+
+
 def _load_fields(wm_file):
     """Pull x, y, z and the four fields out of a path / xarray.Dataset / mapping."""
     if isinstance(wm_file, (str, Path)):
@@ -56,9 +90,7 @@ def _load_fields(wm_file):
             import xarray as xr
             ds = xr.load_dataset(wm_file)
         except ImportError:
-            from scipy.io import netcdf_file     # NetCDF-3 only
-            with netcdf_file(str(wm_file), 'r', mmap=False) as f:
-                ds = {k: np.array(v[:]) for k, v in f.variables.items()}
+            ds = _read_cube_file(wm_file)
     else:
         ds = wm_file
     var = ds.variables if hasattr(ds, 'variables') else ds

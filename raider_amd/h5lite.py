@@ -1,0 +1,579 @@
+"""A small read-only HDF5 / NetCDF-4 reader (pure Python + NumPy).
+
+The reference reads and writes its processed weather cubes and delay cubes as NetCDF-4 = HDF5
+(models/weatherModel.py:659-724, delay.py:329-401) through xarray + netCDF4/h5py.  None of those libraries is part of
+this build's environment, and the delay path only needs to pull a handful of dense numeric arrays (x, y, z, wet, hydro,
+wet_total, hydro_total) and a few attributes (the `proj` variable's crs_wkt) out of such a file.  This module implements
+exactly that subset of the published HDF5 file format (HDF5 File Format Specification v3):
+
+  * superblock versions 0-3; version-2 object headers (what libhdf5 >= 1.8 writes for NetCDF-4 files) and version-1
+    object headers; header continuation blocks;
+  * groups: compact links (link messages), dense links (fractal heap + version-2 B-tree name index) and old-style
+    symbol tables (B-tree v1 + local heap);
+  * datasets: contiguous, compact, and chunked (version-3 layout, B-tree v1 chunk index) with the deflate and shuffle
+    filters; fixed-point and IEEE floating-point element types of either byte order;
+  * attributes: compact (attribute messages) and dense (fractal heap), numeric or string (fixed or variable length).
+
+Anything else (compound / reference types, version-4 chunk indices, external storage, ...) raises
+`UnsupportedHDF5Feature` - loudly, never a silent wrong answer.
+"""
+import struct
+import zlib
+
+import numpy as np
+
+UNDEF = 0xFFFFFFFFFFFFFFFF
+
+
+class UnsupportedHDF5Feature(NotImplementedError):
+    pass
+
+
+def _u(b, off, n):
+    return int.from_bytes(b[off:off + n], 'little')
+
+
+class _Datatype:
+    def __init__(self, buf, off=0):
+        cv = buf[off]
+        self.cls = cv & 0x0F
+        self.version = cv >> 4
+        bits = buf[off + 1:off + 4]
+        self.size = _u(buf, off + 4, 4)
+        self.bits = bits
+        self.base = None
+        self.vlen_string = False
+        p = off + 8
+        if self.cls == 0:      # fixed point
+            self.nbytes = p + 4 - off
+            order = '>' if bits[0] & 1 else '<'
+            signed = bool(bits[0] & 0x08)
+            self.dtype = np.dtype(f'{order}{"i" if signed else "u"}{self.size}')
+        elif self.cls == 1:    # floating point
+            self.nbytes = p + 12 - off
+            order = '>' if bits[0] & 1 else '<'
+            if self.size not in (2, 4, 8):
+                raise UnsupportedHDF5Feature(f'{self.size}-byte floating point type')
+            self.dtype = np.dtype(f'{order}f{self.size}')
+        elif self.cls == 3:    # fixed-length string
+            self.nbytes = p - off
+            self.dtype = np.dtype(f'S{self.size}')
+        elif self.cls == 9:    # variable length
+            self.base = _Datatype(buf, p)
+            self.nbytes = None if self.base.nbytes is None else p + self.base.nbytes - off
+            self.vlen_string = (bits[0] & 0x0F) == 1
+            self.dtype = None
+        else:
+            self.nbytes = None
+            self.dtype = None
+
+
+def _dataspace(buf):
+    ver = buf[0]
+    rank = buf[1]
+    flags = buf[2]
+    if ver == 1:
+        p = 8
+    elif ver == 2:
+        if buf[3] == 2:          # null dataspace
+            return None
+        p = 4
+    else:
+        raise UnsupportedHDF5Feature(f'dataspace message version {ver}')
+    dims = tuple(_u(buf, p + 8 * i, 8) for i in range(rank))
+    return dims
+
+
+class Dataset:
+    def __init__(self, f, name, msgs):
+        self.file, self.name = f, name
+        self.shape = None
+        self.dt = None
+        self.layout = None
+        self.filters = []
+        self._attr_msgs = []
+        self._attr_info = None
+        for t, body in msgs:
+            if t == 0x01:
+                self.shape = _dataspace(body)
+            elif t == 0x03:
+                self.dt = _Datatype(body)
+            elif t == 0x08:
+                self.layout = body
+            elif t == 0x0B:
+                self.filters = _filters(body)
+            elif t == 0x0C:
+                self._attr_msgs.append(body)
+            elif t == 0x15:
+                self._attr_info = body
+        self.dtype = self.dt.dtype if self.dt is not None else None
+
+    # -- data ---------------------------------------------------------------------------------------------------
+    def __getitem__(self, key):
+        return self.read()[key]
+
+    def read(self):
+        if self.dtype is None or self.dtype.kind == 'S':
+            raise UnsupportedHDF5Feature(f'dataset {self.name}: element type class {self.dt.cls} is not numeric')
+        f, lay = self.file, self.layout
+        shape = self.shape if self.shape is not None else ()
+        count = int(np.prod(shape)) if shape else 1
+        ver = lay[0]
+        if ver not in (3, 4):
+            raise UnsupportedHDF5Feature(f'data layout message version {ver}')
+        cls = lay[1]
+        if cls == 0:       # compact
+            size = _u(lay, 2, 2)
+            raw = lay[4:4 + size]
+            return np.frombuffer(raw, dtype=self.dtype, count=count).reshape(shape).astype(self.dtype.newbyteorder('='))
+        if cls == 1:       # contiguous
+            addr, size = _u(lay, 2, 8), _u(lay, 10, 8)
+            if addr == UNDEF:      # never written: fill value (0)
+                return np.zeros(shape, dtype=self.dtype.newbyteorder('='))
+            raw = f.buf[f.base + addr:f.base + addr + count * self.dtype.itemsize]
+            return np.frombuffer(raw, dtype=self.dtype, count=count).reshape(shape).astype(self.dtype.newbyteorder('='))
+        if cls == 2:
+            if ver != 3:
+                raise UnsupportedHDF5Feature('version-4 chunked layout (fixed/extensible array, B-tree v2 chunk index)')
+            return self._read_chunked(lay, shape)
+        raise UnsupportedHDF5Feature(f'data layout class {cls}')
+
+    def _read_chunked(self, lay, shape):
+        f = self.file
+        nd = lay[2] - 1
+        btree = _u(lay, 3, 8)
+        chunk = tuple(_u(lay, 11 + 4 * i, 4) for i in range(nd))
+        out = np.zeros(shape, dtype=self.dtype.newbyteorder('='))
+        if btree == UNDEF:
+            return out
+        for offs, size, mask, addr in f._chunk_btree(btree, nd):
+            raw = f.buf[f.base + addr:f.base + addr + size]
+            for i, (fid, _) in reversed(list(enumerate(self.filters))):
+                if mask & (1 << i):
+                    continue
+                if fid == 1:
+                    raw = zlib.decompress(raw)
+                elif fid == 2:
+                    a = np.frombuffer(raw, dtype=np.uint8)
+                    n = a.size // self.dtype.itemsize
+                    raw = a[:n * self.dtype.itemsize].reshape(self.dtype.itemsize, n).T.tobytes()
+                elif fid == 3:     # fletcher32: drop the trailing checksum
+                    raw = raw[:-4]
+                else:
+                    raise UnsupportedHDF5Feature(f'filter id {fid}')
+            block = np.frombuffer(raw, dtype=self.dtype, count=int(np.prod(chunk))).reshape(chunk)
+            sel = tuple(slice(o, min(o + c, s)) for o, c, s in zip(offs, chunk, shape))
+            out[sel] = block[tuple(slice(0, s.stop - s.start) for s in sel)]
+        return out
+
+    # -- attributes ---------------------------------------------------------------------------------------------
+    @property
+    def attrs(self):
+        return self.file._attributes(self._attr_msgs, self._attr_info)
+
+
+def _filters(body):
+    ver = body[0]
+    n = body[1]
+    out = []
+    p = 8 if ver == 1 else 2
+    for _ in range(n):
+        fid = _u(body, p, 2)
+        if ver == 1 or fid >= 256:
+            namelen = _u(body, p + 2, 2); p += 4
+        else:
+            namelen = 0; p += 2
+        flags = _u(body, p, 2); ncv = _u(body, p + 2, 2); p += 4
+        if namelen:
+            p += (namelen + 7) // 8 * 8 if ver == 1 else namelen
+        vals = [_u(body, p + 4 * i, 4) for i in range(ncv)]
+        p += 4 * ncv
+        if ver == 1 and ncv % 2:
+            p += 4
+        out.append((fid, vals))
+    return out
+
+
+class Group:
+    def __init__(self, f, name, msgs):
+        self.file, self.name = f, name
+        self._links = None
+        self._msgs = msgs
+        self._attr_msgs = [b for t, b in msgs if t == 0x0C]
+        self._attr_info = next((b for t, b in msgs if t == 0x15), None)
+
+    @property
+    def attrs(self):
+        return self.file._attributes(self._attr_msgs, self._attr_info)
+
+    def links(self):
+        if self._links is None:
+            f = self.file
+            links = {}
+            for t, body in self._msgs:
+                if t == 0x06:
+                    nm, addr = _link_message(body)
+                    if addr is not None:
+                        links[nm] = addr
+                elif t == 0x02:       # link info -> dense storage
+                    flags = body[1]
+                    p = 2 + (8 if flags & 1 else 0)
+                    heap = _u(body, p, 8)
+                    if heap != UNDEF:
+                        for obj in f._fractal_heap_objects(heap):
+                            nm, addr = _link_message(obj)
+                            if addr is not None:
+                                links[nm] = addr
+                elif t == 0x11:       # old-style symbol table
+                    btree, heap = _u(body, 0, 8), _u(body, 8, 8)
+                    links.update(f._symbol_table(btree, heap))
+            self._links = links
+        return self._links
+
+    def keys(self):
+        return list(self.links().keys())
+
+    def __contains__(self, k):
+        return k in self.links()
+
+    def __getitem__(self, k):
+        return self.file._object(self.links()[k], k)
+
+
+def _link_message(b):
+    """(name, object header address | None for soft/external links) of a link message; (None, None) for free space"""
+    if len(b) < 4 or b[0] != 1:
+        return None, None
+    flags = b[1]
+    p = 2
+    ltype = 0
+    if flags & 0x08:
+        ltype = b[p]; p += 1
+    if flags & 0x04:
+        p += 8
+    if flags & 0x10:
+        p += 1
+    lsz = 1 << (flags & 3)
+    n = _u(b, p, lsz); p += lsz
+    name = bytes(b[p:p + n]).decode('utf-8', 'replace'); p += n
+    if ltype != 0:
+        return name, None
+    return name, _u(b, p, 8)
+
+
+class File(Group):
+    """`File(path)['wet'][:]`, `File(path)['proj'].attrs['crs_wkt']`, `File(path).attrs['datetime']`."""
+
+    def __init__(self, path):
+        with open(path, 'rb') as fh:
+            self.buf = fh.read()
+        b = self.buf
+        self.path = str(path)
+        # the superblock may sit at 0, 512, 1024, ...
+        sb = 0
+        while b[sb:sb + 8] != b'\x89HDF\r\n\x1a\n':
+            sb = 512 if sb == 0 else sb * 2
+            if sb >= len(b):
+                raise ValueError(f'{path}: not an HDF5 file')
+        ver = b[sb + 8]
+        if ver in (0, 1):
+            so, sl = b[sb + 13], b[sb + 14]
+            if (so, sl) != (8, 8):
+                raise UnsupportedHDF5Feature('offsets / lengths that are not 8 bytes')
+            p = sb + 24 + (4 if ver == 1 else 0)
+            self.base = _u(b, p, 8)
+            # root group symbol table entry: link name offset, object header address, cache type, reserved, scratch
+            root = _u(b, p + 32 + 8, 8)
+        elif ver in (2, 3):
+            if (b[sb + 9], b[sb + 10]) != (8, 8):
+                raise UnsupportedHDF5Feature('offsets / lengths that are not 8 bytes')
+            self.base = _u(b, sb + 12, 8)
+            root = _u(b, sb + 36, 8)
+        else:
+            raise UnsupportedHDF5Feature(f'superblock version {ver}')
+        self._cache = {}
+        Group.__init__(self, self, '/', self._header_messages(root))
+
+    def close(self):
+        pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+    # -- object headers -----------------------------------------------------------------------------------------
+    def _header_messages(self, addr):
+        b = self.buf
+        a = self.base + addr
+        msgs = []
+        if b[a:a + 4] == b'OHDR':
+            flags = b[a + 5]
+            p = a + 6
+            if flags & 0x20:
+                p += 16
+            if flags & 0x10:
+                p += 4
+            szb = 1 << (flags & 3)
+            size0 = _u(b, p, szb); p += szb
+            blocks = [(p, p + size0)]
+            while blocks:
+                p, end = blocks.pop(0)
+                while p + 4 <= end:
+                    t = b[p]; sz = _u(b, p + 1, 2); p += 4
+                    if flags & 0x04:
+                        p += 2
+                    body = b[p:p + sz]; p += sz
+                    if t == 0x10:
+                        off, ln = _u(body, 0, 8), _u(body, 8, 8)
+                        o = self.base + off
+                        if b[o:o + 4] != b'OCHK':
+                            raise ValueError('corrupt object header continuation')
+                        blocks.append((o + 4, o + ln - 4))
+                    elif t != 0:
+                        msgs.append((t, body))
+            return msgs
+        # version 1 object header
+        if b[a] != 1:
+            raise UnsupportedHDF5Feature(f'object header version {b[a]} at {addr}')
+        nmsg = _u(b, a + 2, 2)
+        size0 = _u(b, a + 8, 4)
+        blocks = [(a + 16, a + 16 + size0)]
+        while blocks and len(msgs) < nmsg + 64:
+            p, end = blocks.pop(0)
+            while p + 8 <= end:
+                t = _u(b, p, 2); sz = _u(b, p + 2, 2); p += 8
+                body = b[p:p + sz]; p += sz
+                if t == 0x10:
+                    off, ln = _u(body, 0, 8), _u(body, 8, 8)
+                    blocks.append((self.base + off, self.base + off + ln))
+                elif t != 0:
+                    msgs.append((t, body))
+        return msgs
+
+    def _object(self, addr, name):
+        if addr not in self._cache:
+            msgs = self._header_messages(addr)
+            types = {t for t, _ in msgs}
+            self._cache[addr] = Dataset(self, name, msgs) if 0x08 in types else Group(self, name, msgs)
+        return self._cache[addr]
+
+    # -- fractal heap (dense links / dense attributes) ---------------------------------------------------------------
+    def _fractal_heap_objects(self, addr):
+        """Every managed object of the heap, in heap order.  Objects are located through the heap's doubling table; inside
+        a direct block they are laid out back to back, which is how this reader walks them (it does not need the B-tree
+        index because the messages stored here - links, attributes - are self-delimiting)."""
+        b = self.buf
+        a = self.base + addr
+        if b[a:a + 4] != b'FRHP':
+            raise ValueError('corrupt fractal heap header')
+        idlen = _u(b, a + 5, 2)
+        filt = _u(b, a + 7, 2)
+        flags = b[a + 9]
+        p = a + 10 + 4 + 8 + 8 + 8 + 8 + 8 + 8 + 8
+        nman = _u(b, p, 8); p += 8
+        p += 8 * 4
+        width = _u(b, p, 2); p += 2
+        start = _u(b, p, 8); p += 8
+        maxdirect = _u(b, p, 8); p += 8
+        maxheapbits = _u(b, p, 2); p += 2
+        p += 2
+        root = _u(b, p, 8); p += 8
+        nrows = _u(b, p, 2); p += 2
+        if filt:
+            raise UnsupportedHDF5Feature('filtered fractal heap')
+        offbytes = (maxheapbits + 7) // 8
+        hdr = 5 + 8 + offbytes + (4 if flags & 2 else 0)
+        objs = []
+
+        def direct(addr_, size):
+            q = self.base + addr_
+            if b[q:q + 4] != b'FHDB':
+                raise ValueError('corrupt fractal heap direct block')
+            objs.append((q + hdr, q + size))
+
+        def indirect(addr_, rows):
+            q = self.base + addr_
+            if b[q:q + 4] != b'FHIB':
+                raise ValueError('corrupt fractal heap indirect block')
+            pp = q + 5 + 8 + offbytes
+            maxdrows = (maxdirect.bit_length() - 1) - (start.bit_length() - 1) + 2
+            for r in range(rows):
+                size = start if r < 2 else start << (r - 1)
+                for _ in range(width):
+                    child = _u(b, pp, 8); pp += 8
+                    if child == UNDEF:
+                        continue
+                    if r < maxdrows:
+                        direct(child, size)
+                    else:
+                        crow = (size // start).bit_length() - 1 - (width.bit_length() - 1) + 1
+                        indirect(child, crow)
+
+        if root == UNDEF:
+            return []
+        if nrows == 0:
+            direct(root, start)
+        else:
+            indirect(root, nrows)
+        out = []
+        for lo, hi in objs:
+            p = lo
+            while p < hi and len(out) < nman:
+                n = self._self_delimited(b, p, hi)
+                if n is None:
+                    break
+                out.append(b[p:p + n]); p += n
+        return out
+
+    @staticmethod
+    def _self_delimited(b, p, hi):
+        """length of the link / attribute message starting at p (None when the bytes there are free space)"""
+        v = b[p]
+        if v == 1:                         # link message
+            flags = b[p + 1]
+            q = p + 2
+            ltype = 0
+            if flags & 0x08:
+                ltype = b[q]; q += 1
+            if flags & 0x04:
+                q += 8
+            if flags & 0x10:
+                q += 1
+            lsz = 1 << (flags & 3)
+            n = _u(b, q, lsz); q += lsz + n
+            if ltype == 0:
+                q += 8
+            elif ltype == 1:
+                q += 2 + _u(b, q, 2)
+            elif ltype == 64:
+                q += 2 + _u(b, q, 2)
+            else:
+                return None
+            return q - p if q <= hi else None
+        if v == 3:                         # attribute message (version 3)
+            nsz, tsz, ssz = _u(b, p + 2, 2), _u(b, p + 4, 2), _u(b, p + 6, 2)
+            q = p + 9 + nsz
+            dt = _Datatype(b, q)
+            dims = _dataspace(b[q + tsz:q + tsz + ssz])
+            count = int(np.prod(dims)) if dims else (0 if dims is None else 1)
+            q += tsz + ssz + count * dt.size
+            return q - p if q <= hi else None
+        return None
+
+    # -- attributes -------------------------------------------------------------------------------------------------
+    def _attributes(self, msgs, info):
+        out = {}
+        bodies = list(msgs)
+        if info is not None:
+            flags = info[1]
+            p = 2 + (2 if flags & 1 else 0)
+            heap = _u(info, p, 8)
+            if heap != UNDEF:
+                bodies.extend(self._fractal_heap_objects(heap))
+        for body in bodies:
+            try:
+                k, v = self._attribute(body)
+            except UnsupportedHDF5Feature:
+                continue
+            out[k] = v
+        return out
+
+    def _attribute(self, m):
+        ver = m[0]
+        if ver == 1:
+            nsz, tsz, ssz = _u(m, 2, 2), _u(m, 4, 2), _u(m, 6, 2)
+            pad = lambda n: (n + 7) // 8 * 8
+            p = 8
+            name = bytes(m[p:p + nsz]).split(b'\0')[0].decode(); p += pad(nsz)
+            dt = _Datatype(m, p); p += pad(tsz)
+            dims = _dataspace(m[p:p + ssz]); p += pad(ssz)
+        elif ver in (2, 3):
+            nsz, tsz, ssz = _u(m, 2, 2), _u(m, 4, 2), _u(m, 6, 2)
+            p = 8 + (1 if ver == 3 else 0)
+            name = bytes(m[p:p + nsz]).split(b'\0')[0].decode(); p += nsz
+            dt = _Datatype(m, p); p += tsz
+            dims = _dataspace(m[p:p + ssz]); p += ssz
+        else:
+            raise UnsupportedHDF5Feature(f'attribute message version {ver}')
+        count = int(np.prod(dims)) if dims else (0 if dims is None else 1)
+        data = m[p:p + count * dt.size]
+        if dt.cls == 3:
+            vals = [bytes(data[i * dt.size:(i + 1) * dt.size]).split(b'\0')[0].decode('utf-8', 'replace') for i in range(count)]
+            return name, (vals[0] if not dims else vals)
+        if dt.cls == 9 and dt.vlen_string:
+            vals = []
+            for i in range(count):
+                q = i * dt.size
+                ln, col, idx = _u(data, q, 4), _u(data, q + 4, 8), _u(data, q + 12, 4)
+                vals.append(self._global_heap(col, idx)[:ln].decode('utf-8', 'replace'))
+            return name, (vals[0] if not dims else vals)
+        if dt.dtype is None or dt.cls not in (0, 1):
+            raise UnsupportedHDF5Feature('attribute type')
+        arr = np.frombuffer(data, dtype=dt.dtype, count=count).astype(dt.dtype.newbyteorder('='))
+        return name, (arr[0] if not dims else arr.reshape(dims))
+
+    def _global_heap(self, addr, index):
+        b = self.buf
+        a = self.base + addr
+        if b[a:a + 4] != b'GCOL':
+            raise ValueError('corrupt global heap collection')
+        size = _u(b, a + 8, 8)
+        p = a + 16
+        while p < a + size:
+            idx = _u(b, p, 2); osz = _u(b, p + 8, 8)
+            if idx == 0:
+                break
+            if idx == index:
+                return bytes(b[p + 16:p + 16 + osz])
+            p += 16 + (osz + 7) // 8 * 8
+        raise KeyError(f'global heap object {index}')
+
+    # -- version-1 B-trees: old-style groups and chunk indices -----------------------------------------------------------
+    def _symbol_table(self, btree, heap):
+        b = self.buf
+        h = self.base + heap
+        if b[h:h + 4] != b'HEAP':
+            raise ValueError('corrupt local heap')
+        data = self.base + _u(b, h + 24, 8)
+        out = {}
+
+        def node(addr):
+            a = self.base + addr
+            if b[a:a + 4] == b'TREE':
+                level = b[a + 5]; n = _u(b, a + 6, 2)
+                p = a + 24
+                for i in range(n):
+                    child = _u(b, p + 8, 8); p += 16
+                    node(child)
+            elif b[a:a + 4] == b'SNOD':
+                n = _u(b, a + 6, 2)
+                p = a + 8
+                for i in range(n):
+                    noff, oaddr = _u(b, p, 8), _u(b, p + 8, 8)
+                    e = b.index(b'\0', data + noff)
+                    out[bytes(b[data + noff:e]).decode()] = oaddr
+                    p += 40
+            else:
+                raise ValueError('corrupt group B-tree')
+        node(btree)
+        return out
+
+    def _chunk_btree(self, addr, nd):
+        b = self.buf
+        a = self.base + addr
+        if b[a:a + 4] != b'TREE':
+            raise ValueError('corrupt chunk B-tree')
+        level = b[a + 5]; n = _u(b, a + 6, 2)
+        keysz = 8 + 8 * (nd + 1)
+        p = a + 24
+        for i in range(n):
+            size, mask = _u(b, p, 4), _u(b, p + 4, 4)
+            offs = tuple(_u(b, p + 8 + 8 * d, 8) for d in range(nd))
+            child = _u(b, p + keysz, 8)
+            p += keysz + 8
+            if level == 0:
+                yield offs, size, mask, child
+            else:
+                yield from self._chunk_btree(child, nd)
