@@ -1283,10 +1283,15 @@ static int launch_march(rdr_ctx* c, const rdr_cube* q, RayParams P, int64_t tb, 
     const int g = ray_grid(c, tc);
     {
         KTimer t(c, 1);
-        if (q->dtype == RDR_F32)
-            hipLaunchKernelGGL((march_kernel<float2, false>), dim3(g), dim3(BLOCK), ray_smem(q), c->stream, make_view<float2>(q), P, q->proj);
-        else
-            hipLaunchKernelGGL((march_kernel<double2, false>), dim3(g), dim3(BLOCK), ray_smem(q), c->stream, make_view<double2>(q), P, q->proj);
+        const auto v32 = make_view<float2>(q);
+        const bool regular = q->exact[0] && q->exact[1] && v32.small && (q->dtype == RDR_F32 || make_view<double2>(q).small);
+        if (q->dtype == RDR_F32) {
+            if (regular) hipLaunchKernelGGL((march_kernel<float2, false, true>), dim3(g), dim3(BLOCK), ray_smem(q), c->stream, v32, P, q->proj);
+            else hipLaunchKernelGGL((march_kernel<float2, false, false>), dim3(g), dim3(BLOCK), ray_smem(q), c->stream, v32, P, q->proj);
+        } else {
+            if (regular) hipLaunchKernelGGL((march_kernel<double2, false, true>), dim3(g), dim3(BLOCK), ray_smem(q), c->stream, make_view<double2>(q), P, q->proj);
+            else hipLaunchKernelGGL((march_kernel<double2, false, false>), dim3(g), dim3(BLOCK), ray_smem(q), c->stream, make_view<double2>(q), P, q->proj);
+        }
     }
     if (q->dtype == RDR_F32)
         hipLaunchKernelGGL((march_kernel<float2, true>), dim3(g), dim3(BLOCK), ray_smem(q), c->stream, make_view<float2>(q), P, q->proj);

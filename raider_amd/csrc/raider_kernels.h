@@ -160,19 +160,35 @@ __device__ __forceinline__ void window_cell(const double2* e, int n, double v, i
     if (!trust || !(t >= 0.0) || !(t <= 1.0)) cell_exact(e, n, v, i, t);      // rare
 }
 
+// The sample is known to sit in model interval `guess` or - within the Newton residual of a level crossing - just above its
+// top node (every evaluated sample but a ray's very first one is interior to its segment or its TOP end): two table
+// entries decide.  Anything else (t outside [0,1]) falls back to the exact search.
+__device__ __forceinline__ void window2_cell(const double2* e, int n, double v, int guess, bool trust, int& i, double& t) {
+    const int i0 = min(max(guess, 0), n - 3);
+    const double2 e0 = e[i0], e1 = e[i0 + 1];
+    const bool up = v >= e1.x;
+    i = i0 + (int)up;
+    t = (v - (up ? e1.x : e0.x)) * (up ? e1.y : e0.y);
+    if (!trust || !(t >= 0.0) || !(t <= 1.0)) cell_exact(e, n, v, i, t);      // rare
+}
+
 // x / y axes.  `exact` (axis uniform to round-off, the usual lat/lon grid): the cell index and the weight come from
 // (v - g0) * (n-1)/(g[n-1]-g0) alone - no table access; they differ from scipy's (v - g[i])/(g[i+1]-g[i]) by the axis's own
 // round-off (<= 1e-11 of a cell, checked on the host), which the continuous interpolant turns into <= 1e-12 relative.
 // Otherwise (nearly uniform axis): read the guessed cell and the next node from the LDS table and verify.
 // Anything else (last node, outside, NaN, irregular axis) takes the exact search.
+// IDX (light rays on an exact axis): v already IS the index-space coordinate (v_real - g0) * inv_d - pass 1 folds that map
+// into the ray polynomial's coefficients.
+template <bool IDX = false>
 __device__ __forceinline__ void cell_xy(const double2* e, int n, double v, double g0, double inv_d, bool exact, bool trust, int& i, double& t) {
     bool ok;
-    const double tf = (v - g0) * inv_d;
+    const double tf = (IDX && exact) ? v : (v - g0) * inv_d;
     if (exact) {
         const double fl = floor(tf);
         i = (int)fl;
         t = tf - fl;
         ok = (tf >= 0.0) & (tf < (double)(n - 1));
+        if (IDX && !ok) v = fma(tf, 1.0 / inv_d, g0);                           // rare: back to the axis's own units
     } else {
         i = min(max((int)tf, 0), n - 2);
         const double2 e0 = e[i];
@@ -193,14 +209,16 @@ struct PendingSample {
     double ty, tx, tz;
 };
 
-template <typename T2>
+// LIGHT: called from the light march loop (index-space x / y on exact axes, two-entry z window).
+template <typename T2, bool LIGHT = false>
 __device__ __forceinline__ void sample_issue(const CubeView<T2>& c, const double2* tab2, double y, double x, double z, int kz,
                                              PendingSample<T2>& s) {
     const double2* ey = tab2; const double2* ex = tab2 + c.ny; const double2* ez = ex + c.nx;
     int iy, ix, iz;
-    cell_xy(ey, c.ny, y, c.y_lo, c.inv_dy, c.exact_y, c.uni_y, iy, s.ty);
-    cell_xy(ex, c.nx, x, c.x_lo, c.inv_dx, c.exact_x, c.uni_x, ix, s.tx);
-    window_cell(ez, c.nz, z, kz, c.nz >= 4, iz, s.tz);
+    cell_xy<LIGHT>(ey, c.ny, y, c.y_lo, c.inv_dy, c.exact_y, c.uni_y, iy, s.ty);
+    cell_xy<LIGHT>(ex, c.nx, x, c.x_lo, c.inv_dx, c.exact_x, c.uni_x, ix, s.tx);
+    if (LIGHT) window2_cell(ez, c.nz, z, kz, c.nz >= 4, iz, s.tz);
+    else window_cell(ez, c.nz, z, kz, c.nz >= 4, iz, s.tz);
     const T2 *p00, *p01, *p10, *p11;
     if (c.small) {              // one 32-bit element offset against four uniform row bases
         const unsigned off = (__umul24(__umul24((unsigned)iy, (unsigned)c.nx) + (unsigned)ix, (unsigned)c.nz) + (unsigned)iz) * (unsigned)sizeof(T2);
@@ -571,6 +589,17 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SLOW || 
             fit_ray_poly<LCC>(base, ox, oy, oz, lx, ly, lz, mid, half, proj, q);
             const double scale = nl * half;                           // ray length per unit of u
             if (w && mine) {
+                // exact-uniform axes: hand pass 2 the INDEX-space coordinate (v - g0) * (n-1)/(g[n-1]-g0) directly (cell_xy<true>)
+                if (c.exact_y) {
+                    q.lat[0] = (q.lat[0] - c.y_lo) * c.inv_dy;
+#pragma unroll
+                    for (int n = 1; n < PN; ++n) q.lat[n] *= c.inv_dy;
+                }
+                if (c.exact_x) {
+                    q.lon[0] = (q.lon[0] - c.x_lo) * c.inv_dx;
+#pragma unroll
+                    for (int n = 1; n < PN; ++n) q.lon[n] *= c.inv_dx;
+                }
                 w[(int64_t)WS_FAST * ns] = 1.0;
 #pragma unroll
                 for (int n = 0; n < PN; ++n) {
@@ -630,9 +659,13 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SLOW || 
 // ---- pass 2: trapezoid integration of both fields along every ray (delay.py:285-323) -------------------------------
 // SLOW as in crossings_kernel: <false> integrates the classified-fast rays with the light geodesy, <true> the rest
 // with the generic one (and returns immediately when there are none).
-template <typename T2, bool SLOW>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 : 3, SLOW ? 8 : 3))) void march_kernel(CubeView<T2> c, RayParams P, LccParams proj) {
+// REGULAR (light kernel only): both horizontal axes are exactly uniform and the cube allows 32-bit offsets (the usual
+// lat/lon or LCC model grid) - known at compile time, so the per-sample code carries no trace of the other variants.
+template <typename T2, bool SLOW, bool REGULAR = false>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 : 3, SLOW ? 8 : 3))) void march_kernel(CubeView<T2> c_in, RayParams P, LccParams proj) {
     if (SLOW && *P.nslow == 0) return;
+    CubeView<T2> c = c_in;
+    if (REGULAR) { c.exact_y = 1; c.exact_x = 1; c.small = 1; }
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const RaySmem m = carve_smem(smem_raw, c.ny, c.nx, c.nz);
     const int K = fill_tables(c, m, P.ht, P.zref);
@@ -703,6 +736,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
             int k = 0, j = 0;
             int np = __builtin_amdgcn_readfirstlane(m.np[0]);
             int kz = __builtin_amdgcn_readfirstlane(m.kz[0]);
+            // the ray's very first sample is the BOTTOM of its segment: when that is a model node (origin at or below it), the
+            // two-entry z window must start one interval lower
+            int kz_first_adj = __builtin_amdgcn_readfirstlane((m.lo[0] <= m.tab2[c.ny + c.nx + kz].x) ? 1 : 0);
             double step = m.step[0], hs = m.hs[0], hs1 = K > 1 ? m.hs[1] : 0.0;
             double u_k = w[(int64_t)WS_U0 * ns];
             double u_last = w[(int64_t)WS_U1 * ns];
@@ -725,7 +761,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
                             const double zceil = (clamp_hi && k == K - 1 && last_j) ? c.z_hi : __builtin_huge_val();
                             ph = fmin(fmax(ph, zfloor), zceil);
                         }
-                        sample_issue(c, m.tab2, plat, plon, ph, kz, pend[b]);          // delay.py:298,319
+                        sample_issue<T2, true>(c, m.tab2, plat, plon, ph, kz - kz_first_adj, pend[b]);   // delay.py:298,319
+                        kz_first_adj = 0;
                         // trapezoid weight per unit of u (delay.py:314-315), both segments for a shared sample
                         double wv = (((j == 0) | last_j) ? hs : 2.0 * hs) * du;
                         if (last_j && k + 1 < K) wv = fma(hs1, du1, wv);
