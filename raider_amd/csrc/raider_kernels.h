@@ -163,9 +163,10 @@ __device__ __forceinline__ void window_cell(const double2* e, int n, double v, i
 // The sample is known to sit in model interval `guess` or - within the Newton residual of a level crossing - just above its
 // top node (every evaluated sample but a ray's very first one is interior to its segment or its TOP end): two table
 // entries decide.  Anything else (t outside [0,1]) falls back to the exact search.
-__device__ __forceinline__ void window2_cell(const double2* e, int n, double v, int guess, bool trust, int& i, double& t) {
-    const int i0 = min(max(guess, 0), n - 3);
-    const double2 e0 = e[i0], e1 = e[i0 + 1];
+__device__ __forceinline__ int window2_base(int n, int guess) { return min(max(guess, 0), n - 3); }
+
+__device__ __forceinline__ void window2_cell(const double2* e, int n, double v, int i0, bool trust, int& i, double& t) {
+    const double2 e0 = e[i0], e1 = e[i0 + 1];                                 // i0 = window2_base(n, guess), slice-uniform
     const bool up = v >= e1.x;
     i = i0 + (int)up;
     t = (v - (up ? e1.x : e0.x)) * (up ? e1.y : e0.y);
@@ -184,9 +185,8 @@ __device__ __forceinline__ void cell_xy(const double2* e, int n, double v, doubl
     bool ok;
     const double tf = (IDX && exact) ? v : (v - g0) * inv_d;
     if (exact) {
-        const double fl = floor(tf);
-        i = (int)fl;
-        t = tf - fl;
+        i = (int)tf;                                                            // = floor for the tf >= 0 this path accepts
+        t = __builtin_amdgcn_fract(tf);
         ok = (tf >= 0.0) & (tf < (double)(n - 1));
         if (IDX && !ok) v = fma(tf, 1.0 / inv_d, g0);                           // rare: back to the axis's own units
     } else {
@@ -739,6 +739,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
             // the ray's very first sample is the BOTTOM of its segment: when that is a model node (origin at or below it), the
             // two-entry z window must start one interval lower
             int kz_first_adj = __builtin_amdgcn_readfirstlane((m.lo[0] <= m.tab2[c.ny + c.nx + kz].x) ? 1 : 0);
+            int zbase = window2_base(c.nz, kz - kz_first_adj);                 // first table entry of the two-entry z window
             double step = m.step[0], hs = m.hs[0], hs1 = K > 1 ? m.hs[1] : 0.0;
             double u_k = w[(int64_t)WS_U0 * ns];
             double u_last = w[(int64_t)WS_U1 * ns];
@@ -761,8 +762,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
                             const double zceil = (clamp_hi && k == K - 1 && last_j) ? c.z_hi : __builtin_huge_val();
                             ph = fmin(fmax(ph, zfloor), zceil);
                         }
-                        sample_issue<T2, true>(c, m.tab2, plat, plon, ph, kz - kz_first_adj, pend[b]);   // delay.py:298,319
-                        kz_first_adj = 0;
+                        sample_issue<T2, true>(c, m.tab2, plat, plon, ph, zbase, pend[b]);   // delay.py:298,319
+                        if (kz_first_adj) { kz_first_adj = 0; zbase = window2_base(c.nz, kz); }
                         // trapezoid weight per unit of u (delay.py:314-315), both segments for a shared sample
                         double wv = (((j == 0) | last_j) ? hs : 2.0 * hs) * du;
                         if (last_j && k + 1 < K) wv = fma(hs1, du1, wv);
@@ -775,6 +776,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
                             j = 1;
                             np = __builtin_amdgcn_readfirstlane(m.np[k]);
                             kz = __builtin_amdgcn_readfirstlane(m.kz[k]);
+                            zbase = window2_base(c.nz, kz);
                             step = m.step[k]; hs = hs1;
                             u_k += du; du = du1; du1 = 0.0; hs1 = 0.0;
                             if (k + 1 < K) {
