@@ -404,6 +404,7 @@ struct RaySmem {
     unsigned long long* mxcol; // [nz][MXCOLS] per-level running maxima of the workgroup, one column per lane%MXCOLS (pass 1)
     double* step;           // [nz] 1/(nParts-1) (pass 2)
     double* hs;             // [nz] 0.5e-6/(nParts-1): half the trapezoid weight per unit of ray length (pass 2)
+    double* trig;           // [64] (sin, cos) of the tile's 16 row latitudes, then of its 16 column longitudes (pass 1, GRID rays)
     int* kz; int* np; int* K;
 };
 constexpr int MXCOLS = 16;
@@ -417,7 +418,8 @@ __device__ __forceinline__ RaySmem carve_smem(unsigned char* raw, int ny, int nx
     m.mxcol = reinterpret_cast<unsigned long long*>(m.hi + nz);
     m.step = reinterpret_cast<double*>(m.mxcol + (size_t)nz * MXCOLS);
     m.hs = m.step + nz;
-    m.kz = reinterpret_cast<int*>(m.hs + nz);
+    m.trig = m.hs + nz;
+    m.kz = reinterpret_cast<int*>(m.trig + 64);
     m.np = m.kz + nz;
     m.K = m.np + nz;
     return m;
@@ -429,7 +431,7 @@ inline size_t ray_smem_bytes(int64_t ny, int64_t nx, int64_t nz) {
     return na * 16 + na * 8                       // tab2, tab
            + (size_t)nz * 8 * 2                   // lo, hi
            + (size_t)nz * 8 * MXCOLS              // mxcol
-           + (size_t)nz * 8 * 2                   // step, hs
+           + (size_t)nz * 8 * 2 + 64 * 8          // step, hs, trig
            + (size_t)nz * 4 * 2 + 16;             // kz, np, K
 }
 
@@ -502,15 +504,40 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SLOW || 
         }
         // ---- origin: llh -> ECEF (delay.py:262-267)
         double lat = 0, lon = 0, ox = qnan(), oy = qnan(), oz = qnan();
-        if (active) {
-            if (P.origin_mode == 0) { lat = P.ypts[row]; lon = P.xpts[col]; }
-            else if (P.lat) { lat = P.lat[i]; lon = P.lon[i]; }
-            if (P.origin_mode == 2) {
-                ox = P.xyz[3 * i]; oy = P.xyz[3 * i + 1]; oz = P.xyz[3 * i + 2];
-                if (!P.lat) { double h0_; ecef2lla(ox, oy, oz, lon, lat, h0_); }   // frame for the delta lat/lon formulas
-            } else lla2ecef(lat, lon, P.ht, ox, oy, oz);
+        RayBase base;
+        if (!SLOW && P.origin_mode == 0) {
+            // a tile has 16 distinct latitudes and 16 distinct longitudes: 32 lanes take the sines / cosines for everybody
+            __syncthreads();
+            if (tid < 32) {
+                const int64_t ty = t / P.tiles_x, tx = t - ty * P.tiles_x;
+                const int64_t r = ty * TILE + (tid & 15), cc = tx * TILE + (tid & 15);
+                const double v = tid < 16 ? (r < P.ny ? P.ypts[r] : 0.0) : (cc < P.nx ? P.xpts[cc] : 0.0);
+                double sv, cv;
+                sincos(v * DEG_TO_RAD, &sv, &cv);
+                m.trig[2 * tid] = sv; m.trig[2 * tid + 1] = cv;
+            }
+            __syncthreads();
+            if (active) { lat = P.ypts[row]; lon = P.xpts[col]; }
+            base.lat0 = lat; base.lon0 = lon;
+            base.s0 = active ? m.trig[2 * (tid >> 4)] : 0.0; base.c0 = active ? m.trig[2 * (tid >> 4) + 1] : 1.0;
+            base.sl0 = active ? m.trig[32 + 2 * (tid & 15)] : 0.0; base.cl0 = active ? m.trig[33 + 2 * (tid & 15)] : 1.0;
+            if (active) {                                          // lla2ecef (geodesy.h) with the shared sines / cosines
+                const double N = WGS84_A / sqrt(1.0 - WGS84_ES * base.s0 * base.s0);
+                ox = (N + P.ht) * base.c0 * base.cl0;
+                oy = (N + P.ht) * base.c0 * base.sl0;
+                oz = (N * (1.0 - WGS84_ES) + P.ht) * base.s0;
+            }
+        } else {
+            if (active) {
+                if (P.origin_mode == 0) { lat = P.ypts[row]; lon = P.xpts[col]; }
+                else if (P.lat) { lat = P.lat[i]; lon = P.lon[i]; }
+                if (P.origin_mode == 2) {
+                    ox = P.xyz[3 * i]; oy = P.xyz[3 * i + 1]; oz = P.xyz[3 * i + 2];
+                    if (!P.lat) { double h0_; ecef2lla(ox, oy, oz, lon, lat, h0_); }   // frame for the delta lat/lon formulas
+                } else lla2ecef(lat, lon, P.ht, ox, oy, oz);
+            }
+            base = make_base(lat, lon);
         }
-        const RayBase base = make_base(lat, lon);
         // ---- look vector (delay.py:270)
         double lx = qnan(), ly = qnan(), lz = qnan();
         if (active) {
@@ -611,7 +638,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SLOW || 
             }
             // getTopOfAtmosphere carried on u: u0 = u(h); u += (h - H(u)) * su / factor   (losreader.py:724-731)
             double u_hi = 0.0, gain = su, inv_cosf = 1.0;
-            double sum_len = 0.0, min_len = __builtin_huge_val();      // NaN / finite bookkeeping for the flags
+            double last_len = 0.0;      // a light ray's lengths are NaN for every level or for none (they all stem from one polynomial)
 #pragma unroll 1
             for (int k = 0; k < K; ++k) {
                 const double lo = m.lo[k], hi = m.hi[k];
@@ -627,19 +654,19 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SLOW || 
                     for (int it = 0; it < 10; ++it) u_hi = fma(hi - poly5(q.h, u_hi), su, u_hi);
                 } else u_hi = level_top_u(q.h, hi, su, ou, gain);
                 const double L = (u_hi - u_lo) * scale;
+                last_len = L;
                 if (k == 0) {
                     inv_cosf = L / (hi - lo); gain = su * inv_cosf;                            // 1/cos_factor, losreader.py:824-825
                     if (w && mine) { w[(int64_t)WS_GAIN * ns] = gain; w[(int64_t)WS_U0 * ns] = u_lo; w[(int64_t)WS_U1 * ns] = u_hi; }
                     if (!reduce) break;                                                        // record complete; lengths not wanted
                 }
                 if (reduce) {
-                    sum_len += L; min_len = fmin(min_len, L);
                     atomicMax(&mxc[k * MXCOLS], (unsigned long long)__double_as_longlong((cnt && L > 0.0) ? L : 0.0));
                     if (k == 0 && cnt && !(poly5(q.h, u_lo) < c.z_lo)) my_flags |= 4;          // first sample of the ray
                     if (k == K - 1 && cnt && !(poly5(q.h, u_hi) > c.z_hi)) my_flags |= 8;      // last sample of the ray
                 }
             }
-            if (reduce && cnt && K > 0) my_flags |= ((sum_len != sum_len) ? 1 : 0) | ((min_len < __builtin_huge_val()) ? 2 : 0);
+            if (reduce && cnt && K > 0) my_flags |= (last_len != last_len) ? 1 : 2;
         }
     }
     if (reduce) {
