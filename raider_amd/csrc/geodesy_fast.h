@@ -30,17 +30,6 @@ __device__ __forceinline__ double rsq_nr(double a) {
     return y;
 }
 
-template <int NR>
-__device__ __forceinline__ double rcp_nr(double b) {
-    double r = __builtin_amdgcn_rcp(b);
-#pragma unroll
-    for (int i = 0; i < NR; ++i) {
-        const double e = fma(-b, r, 1.0);
-        r = fma(r, e, r);
-    }
-    return r;
-}
-
 constexpr double E2S_B = WGS84_E2S * WGS84_B;
 constexpr double ES_A = WGS84_ES * WGS84_A;
 
@@ -87,33 +76,6 @@ __device__ __forceinline__ GeoF geo_fast(double x, double y, double z) {
     return g;
 }
 
-// Height along a ray that passed the static classification (never near a pole / the Earth's centre).
-__device__ __forceinline__ double height_fast_nocheck(double x, double y, double z) {
-    return geo_fast<false>(x, y, z).h;
-}
-
-// Cheap ellipsoidal height for the NON-FINAL Newton iterations of a level crossing: radial height above the ellipse at
-// the geocentric latitude psi, times cos(delta), delta = f sin(2 psi) being the angle between the radial and the normal:
-//     h ~ (r - a / sqrt(1 + e'^2 sin^2 psi)) * (1 - 2 f^2 sin^2 psi cos^2 psi)
-// 22 fp64 instructions (one v_rsq_f64) against 47; error 2e-5 m at the surface, 3e-4 m at 20 km, 1.4e-3 m at 45 km.
-// The crossing iteration contracts by |1 - cos(inc_h)/cos(inc_0)| <= 0.005 (0.02 at 60 deg) per step, so an error eps
-// in an early iterate reaches the final one as <= 0.005^k eps: the final iterate (evaluated with the accurate height)
-// moves by < 1e-5 m, the delays by < 1e-10 m.
-__device__ __forceinline__ double height_cheap(double x, double y, double z) {
-    const double r2 = fma(x, x, fma(y, y, z * z));
-    const double rr = rsq_nr<1>(r2);
-    const double s = z * rr;
-    const double s2 = s * s;
-    const double u = WGS84_E2S * s2;
-    double q = fma(u, 35.0 / 128.0, -5.0 / 16.0);      // (1+u)^(-1/2), u <= 0.0068
-    q = fma(u, q, 3.0 / 8.0);
-    q = fma(u, q, -0.5);
-    q = fma(u, q, 1.0);
-    const double d = fma(-WGS84_A, q, r2 * rr);
-    const double corr = fma(-2.0 * WGS84_F * WGS84_F * s2, 1.0 - s2, 1.0);
-    return d * corr;
-}
-
 // asin(s) for the small angles between a ray sample and the ray origin: odd series through s^7.  The static
 // classification admits only rays whose angular travel stays below 0.03 rad (190 km), where the truncation is
 // < 2e-13 rad (1e-6 m on the ground).
@@ -139,18 +101,6 @@ __device__ __forceinline__ RayBase make_base(double lat_deg, double lon_deg) {
     return b;
 }
 
-// ECEF -> (lon deg, lat deg, h) of a point within 0.03 rad of the ray origin (guaranteed by the per-ray static
-// classification in crossings_kernel; rays that fail it never come here).
-__device__ __forceinline__ void ecef2lla_near(const RayBase& b, double x, double y, double z,
-                                              double& lon_deg, double& lat_deg, double& h) {
-    const GeoF g = geo_fast<true>(x, y, z);
-    const double sd = fma(g.sphi, b.c0, -g.cphi * b.s0);             // sin(phi - phi0)
-    const double sl = fma(b.cl0, y, -b.sl0 * x) * g.rp;              // sin(lam - lam0)
-    lat_deg = fma(asin_small(sd), RAD_TO_DEG, b.lat0);
-    lon_deg = fma(asin_small(sl), RAD_TO_DEG, b.lon0);                // no +-180 wrap: such rays are classified slow
-    h = g.h;
-}
-
 // ---- ray polynomials ------------------------------------------------------------------------------------------------
 // Along a straight ray o + t l the geodetic height, latitude and longitude are smooth functions of t: over the rays the
 // static classification admits (angular travel < 0.03 rad, away from the poles) their degree-5 interpolants at the 6
@@ -170,7 +120,8 @@ __device__ __forceinline__ double poly5(const double* c, double u) {
     return fma(r, u, c[0]);
 }
 
-// ECEF -> (lon - lon0, lat - lat0) in degrees and h, near the ray origin (same formulas as ecef2lla_near)
+// ECEF -> (lon - lon0, lat - lat0) in degrees and h of a point within 0.03 rad of the ray origin (guaranteed by the per-ray
+// static classification in crossings_kernel; rays that fail it never come here): sin(dphi), sin(dlam) from 2 FMAs each
 __device__ __forceinline__ void ecef2lla_delta(const RayBase& b, double x, double y, double z, double& dlon, double& dlat, double& h) {
     const GeoF g = geo_fast<true>(x, y, z);
     const double sd = fma(g.sphi, b.c0, -g.cphi * b.s0);

@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void interp_points_kernel(CubeView<T2> c, cons
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const double y = pts[3 * i], x = pts[3 * i + 1], z = pts[3 * i + 2];
         double w, h;
-        trilinear(c, s_y, s_x, s_z, y, x, z, -1, w, h);
+        trilinear(c, s_y, s_x, s_z, y, x, z, w, h);
         wet[i] = w; hyd[i] = h;
     }
 }
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256) void build_cube_kernel(CubeView<T2> c, LccPara
         const int64_t ix = i % nx, r = i / nx, iy = r % ny, iz = r / ny;
         double w, h, qy = ypts[iy], qx = xpts[ix];
         if (proj.kind == 1) { double px_, py_; lcc_forward(proj, qy, qx, px_, py_); qx = px_; qy = py_; }   // transformPoints, delay.py:207-209
-        trilinear(c, s_y, s_x, s_z, qy, qx, zpts[iz], -1, w, h);
+        trilinear(c, s_y, s_x, s_z, qy, qx, zpts[iz], w, h);
         wet[i] = w; hyd[i] = h;
     }
 }

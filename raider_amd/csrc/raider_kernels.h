@@ -1,24 +1,27 @@
 // Device-side building blocks of libraider_hip (gfx950 / CDNA4 only).
 //
-//   CubeView + trilinear()  : scipy RegularGridInterpolator(linear, fill=nan) on the interleaved
-//                             (wet,hydro) cube          [delayFcns.py:55-56, scipy _rgi.py:405-499]
-//   toa_newton()            : getTopOfAtmosphere        [losreader.py:706-733]
-//   ray_kernel<MODE>        : build_ray fused with the per-level trapezoid of _build_cube_ray
-//                             [losreader.py:772-835, delay.py:283-323]; MODE 0 = pass 1 (per-level
-//                             batch max of ray length + clamp/NaN flags), MODE 1 = pass 2 (integrate)
+//   CubeView + trilinear()     scipy RegularGridInterpolator(linear, fill=nan) on the interleaved (wet,hydro) cube
+//                              [delayFcns.py:55-56, scipy _rgi.py:405-499]               (zenith / station kernels)
+//   sample_issue / _finish     the same interpolation for the ray kernels, split so that several samples' gathers fly together
+//   toa_newton / _t            getTopOfAtmosphere [losreader.py:706-733] (materialising API kernels / generic ray kernels)
+//   crossings_kernel           pass 1: build_ray [losreader.py:772-835] -> per-level batch maximum of the ray length
+//                              (delay.py:283) + NaN / z-clamp flags (delay.py:279,306-311) + the ray records for pass 2
+//   march_kernel               pass 2: the trapezoid of _build_cube_ray [delay.py:285-323]
 //
 // Design notes (MI355X):
-//   * one ray per lane, 64-lane wavefronts, 256-thread workgroups = one 16x16 pixel tile of the
-//     scene: neighbouring rays walk the same few cube columns, so their gathers hit the same
-//     L1/L2 lines; the per-level loop bounds are batch-uniform, so a wave never diverges.
-//   * the cube is stored (y,x,z) with z fastest and (wet,hydro) interleaved per cell: the two z
-//     neighbours of both fields of one column are ONE contiguous 16 B (f32) / 32 B (f64) read.
-//   * grid axes + the level table + the per-level partition live in LDS (a few KB), filled once
-//     per workgroup; nothing per-level is ever materialised in HBM (the reference materialises
-//     K x N x 56 B).
-//   * persistent grid (a few workgroups per CU) walking tiles with an XCD-aware mapping so that the 32
-//     CUs sharing one L2 work on one contiguous band of the scene.
-//   * no MFMA: this is a gather + transcendental-heavy fp64 integrate, there is no contraction.
+//   * one ray per lane, 64-lane wavefronts, 256-thread workgroups = one 16x16 pixel tile of the scene: neighbouring rays
+//     walk the same few cube columns, so their gathers hit the same L1/L2 lines; everything that depends only on the slice
+//     (levels, nParts, the sample schedule) is wave-uniform and lives in SGPRs / LDS, so a wave never diverges.
+//   * light rays (almost all): height, latitude and longitude along the ray are degree-5 polynomials of the ray parameter
+//     fitted once per ray from six full geodesy evaluations (geodesy_fast.h); level crossings and samples are then FMAs.
+//     The few rays the static classification rejects (poles, grazing incidence, +-180 deg) take the generic kernels.
+//   * the cube is stored (y,x,z) with z fastest and (wet,hydro) interleaved per cell: the two z neighbours of both fields
+//     of one column are ONE contiguous 16 B (f32) / 32 B (f64) read, four per sample against uniform row bases.
+//   * grid axes + the level table + the per-level partition live in LDS (a few KB), filled once per workgroup; nothing
+//     per-level is ever materialised in HBM (the reference materialises K x N x 56 B).
+//   * persistent grid (a few workgroups per CU) walking tiles with an XCD-aware mapping so that the 32 CUs sharing one L2
+//     work on one contiguous band of the scene.
+//   * no MFMA: this is a gather + fp64 polynomial/interpolation integrate, there is no contraction.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -66,40 +69,22 @@ __device__ __forceinline__ int find_cell(const double* g, int n, double x, doubl
     return i;
 }
 
-__device__ __forceinline__ int find_cell_hint(const double* g, int n, double x, int hint) {
-    int i = min(max(hint, 0), n - 2);
-    while (i > 0 && x < g[i]) --i;
-    while (i < n - 2 && x >= g[i + 1]) ++i;
-    return i;
-}
-
 __device__ __forceinline__ void ld2(const float2* p, double& a, double& b) { const float2 t = *p; a = (double)t.x; b = (double)t.y; }
 __device__ __forceinline__ void ld2(const double2* p, double& a, double& b) { const double2 t = *p; a = t.x; b = t.y; }
 
-// scipy linear RGI on both fields.  sy/sx/sz: the axes (LDS or global).  zhint >= 0: start the z search
-// at that interval (ray marcher knows the model interval), else use the uniform guess / bisection.
-// RECIP: cell-width reciprocals follow the axes in the table (sy[ny+nx+nz + i]); the ray kernel uses them to turn
-// the three divisions per sample into multiplications (1 ulp difference in the weights).
-template <typename T2, bool RECIP = false>
+// scipy linear RGI on both fields (zenith / station kernels).  sy/sx/sz: the axes (LDS or global).
+template <typename T2>
 __device__ __forceinline__ void trilinear(const CubeView<T2>& c, const double* sy, const double* sx, const double* sz,
-                                          double y, double x, double z, int zhint, double& wet, double& hyd) {
+                                          double y, double x, double z, double& wet, double& hyd) {
     // out of bounds (x < g[0] or x > g[-1]) -> fill_value nan; nan coordinate -> nan   (_rgi.py:437-442,585-592)
     const bool inside = (y >= c.y_lo) && (y <= c.y_hi) && (x >= c.x_lo) && (x <= c.x_hi) && (z >= c.z_lo) && (z <= c.z_hi);
     if (!inside) { wet = qnan(); hyd = qnan(); return; }
     const int iy = find_cell(sy, c.ny, y, c.y_lo, c.inv_dy, c.uni_y);
     const int ix = find_cell(sx, c.nx, x, c.x_lo, c.inv_dx, c.uni_x);
-    const int iz = zhint >= 0 ? find_cell_hint(sz, c.nz, z, zhint) : find_cell(sz, c.nz, z, c.z_lo, c.inv_dz, c.uni_z);
-    double ty, tx, tz;
-    if (RECIP) {
-        const int na = c.ny + c.nx + c.nz;
-        ty = (y - sy[iy]) * sy[na + iy];
-        tx = (x - sx[ix]) * sx[na + ix];
-        tz = (z - sz[iz]) * sz[na + iz];
-    } else {
-        ty = (y - sy[iy]) / (sy[iy + 1] - sy[iy]);
-        tx = (x - sx[ix]) / (sx[ix + 1] - sx[ix]);
-        tz = (z - sz[iz]) / (sz[iz + 1] - sz[iz]);
-    }
+    const int iz = find_cell(sz, c.nz, z, c.z_lo, c.inv_dz, c.uni_z);
+    const double ty = (y - sy[iy]) / (sy[iy + 1] - sy[iy]);
+    const double tx = (x - sx[ix]) / (sx[ix + 1] - sx[ix]);
+    const double tz = (z - sz[iz]) / (sz[iz + 1] - sz[iz]);
     const T2* p00 = c.v + ((int64_t)iy * c.nx + ix) * c.nz + iz;   // (y0,x0)
     const T2* p01 = p00 + c.nz;                                    // (y0,x1)
     const T2* p10 = p00 + (int64_t)c.nx * c.nz;                    // (y1,x0)
@@ -128,10 +113,10 @@ __device__ __forceinline__ void trilinear(const CubeView<T2>& c, const double* s
 
 // ---- ray-kernel sampler ----------------------------------------------------------------------------------------
 // Same scipy semantics as trilinear<> (interval g[i] <= v < g[i+1], last cell closed; outside / NaN -> NaN).
-// Cell search = ONE LDS round trip per axis: the axis table is stored as (g[i], 1/(g[i+1]-g[i])) pairs, a guess i0
-// is made (linear guess on (nearly) uniform axes, the segment's model interval along z), the three entries
-// i0-1, i0, i0+1 are fetched together and the right one is selected in registers.  A lane whose guess is more
-// than one cell off (non-uniform axis, non-converged crossing in sub-metre levels, < 4-node axes) bisects instead.
+// The axis table is stored in LDS as (g[i], 1/(g[i+1]-g[i])) pairs.  x / y: arithmetic cell on exactly-uniform axes,
+// guess-and-verify on nearly uniform ones; z: the segment's model interval is known, a 2- (light kernel) or 3-entry
+// (generic kernel) window around it is fetched and the right entry selected in registers.  A lane whose guess fails
+// (irregular axis, non-converged crossing in sub-metre levels, < 4-node axes, outside the grid) searches exactly.
 __device__ __forceinline__ int bisect_cell2(const double2* e, int n, double v) {
     int lo = 0, hi = n;   // first index with v < g[idx]
     while (lo < hi) {
@@ -277,31 +262,15 @@ __device__ __forceinline__ void toa_newton(double ox, double oy, double oz, doub
     }
 }
 
-// Ray kernels: the same iteration carried on the scalar ray parameter t (pos = o + t*l): t0 = h,
-// t += (h - height(o + t l)) / factor - identical in exact arithmetic to losreader.py:724-731, 2 live doubles per
-// crossing instead of 6 - with the light-fp64 TRUE height (geodesy_fast.h): crossings land within 2e-5 m (at 40 km)
-// of the reference's, which moves the delays by < 1e-10 m.  SLOW = the generic PROJ-formula height, used by the
-// *_kernel<T2, true> instantiations that mop up the rare rays the static classification rejects.
-template <bool SLOW>
-__device__ __forceinline__ double height_sel(double x, double y, double z) {
-    return SLOW ? ecef_height(x, y, z) : height_fast_nocheck(x, y, z);
-}
-
-template <bool SLOW>
+// Generic ray kernels: the same iteration carried on the scalar ray parameter t (pos = o + t*l): t0 = h,
+// t += (h - height(o + t l)) / factor - identical in exact arithmetic to losreader.py:724-731, 2 live doubles per crossing
+// instead of 6 - with the PROJ-formula height.
 __device__ __forceinline__ double toa_newton_t(double ox, double oy, double oz, double lx, double ly, double lz,
                                                double h, int iters, double inv_factor) {
     double t = h;
-    // light path: the early iterates only steer the last ones (the iteration contracts strongly), so they use the
-    // 22-instruction height_cheap; the last iterate of a 3-step crossing / the last 4 of a 10-step one are accurate
-    const int ncheap = SLOW ? 0 : (iters <= 3 ? iters - 1 : iters - 4);
 #pragma unroll 1
-    for (int it = 0; it < ncheap; ++it) {
-        const double hgt = height_cheap(fma(t, lx, ox), fma(t, ly, oy), fma(t, lz, oz));
-        t = fma(h - hgt, inv_factor, t);
-    }
-#pragma unroll 1
-    for (int it = ncheap; it < iters; ++it) {
-        const double hgt = height_sel<SLOW>(fma(t, lx, ox), fma(t, ly, oy), fma(t, lz, oz));
+    for (int it = 0; it < iters; ++it) {
+        const double hgt = ecef_height(fma(t, lx, ox), fma(t, ly, oy), fma(t, lz, oz));
         t = fma(h - hgt, inv_factor, t);
     }
     return t;
@@ -330,7 +299,6 @@ constexpr int WS_FAST = 0, WS_POLY_H = 1, WS_POLY_LAT = 7, WS_POLY_LON = 13, WS_
               WS_U0 = 23, WS_U1 = 24;
 constexpr int WS_ORIGIN = 1, WS_LOS = 4, WS_LAT0 = 7, WS_LON0 = 8, WS_S0 = 9, WS_C0 = 10, WS_SL0 = 11, WS_CL0 = 12;
 constexpr int WS_T = 25;
-constexpr int WS_FIELDS_FIXED = WS_T + 1;     // + K
 
 struct RayParams {
     // geometry
@@ -372,28 +340,6 @@ __device__ inline int build_levels(const double* zs, int nz, double ht, double z
         ++K;
     }
     return min(K, MAX_LEVELS);
-}
-
-// max over the 64 lanes of a wave, DPP only (no LDS round trips): row (16 lanes) butterflies, then the two
-// row-broadcast steps of gfx9 wave64; the result is valid in lane 63.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp_max_step(double v) {
-    const long long b = __double_as_longlong(v);
-    int lo = (int)(b & 0xffffffffLL), hi = (int)(b >> 32);
-    // unselected / out-of-range lanes keep their own value (old = src, bound_ctrl off)
-    const int lo2 = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
-    const int hi2 = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
-    const double o = __longlong_as_double(((long long)hi2 << 32) | (unsigned int)lo2);
-    return fmax(v, o);
-}
-__device__ __forceinline__ double wave_max_lane63(double v) {
-    v = dpp_max_step<0x111, 0xf>(v);   // row_shr:1
-    v = dpp_max_step<0x112, 0xf>(v);   // row_shr:2
-    v = dpp_max_step<0x114, 0xf>(v);   // row_shr:4
-    v = dpp_max_step<0x118, 0xf>(v);   // row_shr:8   -> lane 15 of every row holds the row max
-    v = dpp_max_step<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
-    v = dpp_max_step<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave max
-    return v;
 }
 
 // Shared LDS layout of the two ray kernels.
@@ -583,8 +529,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SLOW || 
                 // first interval: cos_factor is None -> 10 iterations with factor 1 for both ends (losreader.py:812-825);
                 // later intervals reuse the previous top as their bottom (losreader.py:811-812)
                 double t_lo = t_hi;
-                if (k == 0) t_lo = toa_newton_t<true>(ox, oy, oz, lx, ly, lz, lo, 10, 1.0);
-                t_hi = toa_newton_t<true>(ox, oy, oz, lx, ly, lz, hi, k == 0 ? 10 : 3, inv_cosf);
+                if (k == 0) t_lo = toa_newton_t(ox, oy, oz, lx, ly, lz, lo, 10, 1.0);
+                t_hi = toa_newton_t(ox, oy, oz, lx, ly, lz, hi, k == 0 ? 10 : 3, inv_cosf);
                 const double L = (t_hi - t_lo) * nl;
                 if (k == 0) inv_cosf = L / (hi - lo);                                       // 1/cos_factor, losreader.py:824-825
                 if (w && mine) {
