@@ -73,9 +73,9 @@ class Zenith(LOS):
 class Conventional(LOS):
     """Zenith delay projected with 1/cos(inc) (losreader.py:94-133).
 
-    `filename` may be an ISCE-style 2-band LOS raster path (needs rasterio, like the reference) or -
-    array-backed extension - `inc`/`heading` rasters given directly.  The orbit-file branch
-    (losreader.py:122-128) needs isce3 and is out of scope here."""
+    `filename` may be an ISCE-style 2-band LOS raster path (needs rasterio, like the reference), an orbit /
+    state-vector file (losreader.py:122-128: the factor is then cos(look angle) from the zero-Doppler geometry, solved on
+    the GPU instead of through isce3), or - array-backed extension - `inc`/`heading` rasters given directly."""
 
     def __init__(self, filename=None, los_convention='isce', time=None, pad=600, inc=None, heading=None):
         super().__init__()
@@ -97,11 +97,15 @@ class Conventional(LOS):
             raise ValueError('LOS file not set')
         try:
             import rasterio
-        except ImportError as e:
-            raise ImportError('reading an ISCE LOS raster needs rasterio; pass inc=/heading= arrays instead') from e
-        with rasterio.open(self._file) as src:
-            data = src.read()
-        return inc_hd_to_enu(*data)
+            with rasterio.open(self._file) as src:
+                data = src.read()
+            return inc_hd_to_enu(*data)
+        except (ImportError, OSError, TypeError):
+            pass
+        # otherwise treat it as an orbit / state-vector file (losreader.py:122-128)
+        from .orbits import get_sv
+        svs = np.stack(get_sv(self._file, self._time, self._pad), axis=-1)
+        return state_to_los(svs, [self._lats, self._lons, self._heights])
 
     def __call__(self, delays):
         """losreader.py:110-133."""
@@ -196,6 +200,35 @@ def get_orbit(orbit_file, ref_time, pad):
     """losreader.py:736-769: state vectors within `pad` seconds of ref_time, unique and time-ordered."""
     from .orbits import Orbit
     return Orbit.from_file(orbit_file, ref_time, pad)
+
+
+def get_radar_pos(llh, orb):
+    """losreader.py:630-703: look angle (deg) between the line of sight and the ellipsoid normal, and the slant range (m), of
+    the targets llh[:, (lat, lon, h)] at zero Doppler; NaN targets stay NaN.  `orb` is a raider_amd.orbits.Orbit (the
+    reference takes an isce3 Orbit: the geometry solve here is this build's own)."""
+    from .utilFcns import lla2ecef
+    llh = np.asarray(llh, dtype=np.float64)
+    xyz = np.stack(lla2ecef(llh[:, 0], llh[:, 1], llh[:, 2]), axis=-1)
+    los, _, sr = orb.look_vectors(xyz, threshold=1.0e-7, maxiter=30, return_geometry=True)
+    nv = getZenithLookVecs(llh[:, 0], llh[:, 1], llh[:, 2])              # isce3 Ellipsoid.n_vector(lon, lat)
+    ang = np.rad2deg(np.arccos(np.sum(los * nv, axis=-1)))
+    bad = np.isnan(llh).any(axis=-1)
+    ang[bad] = np.nan; sr = np.where(bad, np.nan, sr)
+    return ang, sr
+
+
+def state_to_los(svs, llh_targets):
+    """losreader.py:558-607: cos(look angle) at every (lat, lon, height) target from state vectors svs[n, 7] =
+    (t, x, y, z, vx, vy, vz)."""
+    from .orbits import Orbit
+    svs = np.asarray(svs)
+    if np.min(svs.shape) < 4:
+        raise RuntimeError('state_to_los: At least 4 state vectors are required for orbit interpolation')
+    orb = Orbit(list(svs[:, 0]), svs[:, 1:4].astype(np.float64), svs[:, 4:7].astype(np.float64))
+    in_shape = np.shape(llh_targets[0])
+    target_llh = np.stack([np.asarray(x, dtype=np.float64).flatten() for x in llh_targets], axis=-1)
+    los_ang, _ = get_radar_pos(target_llh, orb)
+    return np.cos(np.deg2rad(los_ang)).reshape(in_shape)
 
 
 def getZenithLookVecs(lats, lons, heights):

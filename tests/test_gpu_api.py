@@ -267,3 +267,36 @@ def test_orbit_look_vectors_and_raytracing():
     ow, oh = O.build_cube_ray(xpts, ypts, zpts, look, list(O.getInterpolators(c['xs'], c['ys'], c['zs'], c['wet'], c['hydro'])), MAX_TROPO_HEIGHT=zref)
     assert np.isfinite(ow).all()
     np.testing.assert_allclose(w, ow, rtol=0, atol=TIGHT); np.testing.assert_allclose(h, oh, rtol=0, atol=TIGHT)
+
+
+def test_conventional_from_orbit_file():
+    """Conventional(filename=<state vectors>) (losreader.py:122-133): delays / cos(look angle), the look angle between the
+    zero-Doppler line of sight and the ellipsoid normal - against the oracle's geometry, and against 1/cos(inc) sanity."""
+    import datetime as dt
+    from pathlib import Path
+    from raider_amd.losreader import Conventional, get_radar_pos, state_to_los
+    from raider_amd import orbits
+    d = Path(__file__).resolve().parent / 'golden' / 'orbit_files'
+    t = dt.datetime(2018, 11, 12, 23, 0, 37)
+    conv = Conventional(str(d / 'S1_sv_file.txt'), time=t)
+    svs = np.stack(orbits.get_sv(str(d / 'S1_sv_file.txt'), t, 600), axis=-1)
+    orb = orbits.Orbit(list(svs[:, 0]), svs[:, 1:4].astype(float), svs[:, 4:7].astype(float))
+    mid, _ = O.orbit_hermite(orb.time, orb.position, orb.velocity, [35.0])
+    lon_s, lat_s, _ = O.ecef2lla(mid[:, 0], mid[:, 1], mid[:, 2])
+    lats = lat_s[0] + np.linspace(0.1, -0.1, 9)[:, None] + np.zeros((9, 11))
+    lons = lon_s[0] - np.linspace(2.5, 4.5, 11)[None, :] + np.zeros((9, 11))
+    hgts = np.full(lats.shape, 250.0); hgts[2, 3] = np.nan
+    conv.setPoints(lats, lons, hgts)
+    delays = np.full(lats.shape, 2.3)
+    out = conv(delays)
+    xyz = np.stack(O.lla2ecef(lats, lons, hgts), -1)
+    olos, _, _ = O.orbit_look_vectors(orb.time, orb.position, orb.velocity, xyz)
+    cosang = np.sum(olos * O.getZenithLookVecs(lats, lons, hgts), -1)
+    np.testing.assert_allclose(out, delays / cosang, rtol=1e-12, equal_nan=True)
+    assert np.isnan(out[2, 3]) and np.isfinite(np.delete(out.ravel(), 2 * 11 + 3)).all()
+    ang, sr = get_radar_pos(np.stack([lats.ravel(), lons.ravel(), hgts.ravel()], -1), orb)
+    ok = np.isfinite(ang)
+    assert 20.0 < ang[ok].min() and ang[ok].max() < 50.0 and 7.0e5 < sr[ok].min() and sr[ok].max() < 1.1e6     # S1 geometry
+    np.testing.assert_allclose(state_to_los(svs, [lats, lons, hgts]), cosang, rtol=1e-12, equal_nan=True)
+    with pytest.raises(RuntimeError):
+        state_to_los(svs[:3], [lats, lons, hgts])
