@@ -1321,9 +1321,9 @@ static int march_chunked(rdr_ctx* c, const rdr_cube* q, const RayParams& P0, int
 }
 
 static int flags_to_status(rdr_ctx* c, int flags) {
-    if (flags & RDR_FLAG_DIVERGED) return fail(c, RDR_ERR_INVALID, "ray lengths diverged: a model level asks for more than 65536 integration parts (are the look vectors unit vectors?)");
     if (!(flags & RDR_FLAG_ANY_FINITE)) return fail(c, RDR_ERR_ALL_NAN, "geo2rdr did not converge. Check orbit coverage");
     if (flags & RDR_FLAG_ANY_NAN) return fail(c, RDR_ERR_NAN_LENGTH, "some ray lengths are NaN: the number of integration parts (delay.py:283) is undefined");
+    if (flags & RDR_FLAG_DIVERGED) return fail(c, RDR_ERR_INVALID, "ray lengths diverged: a model level asks for fewer than 2 or more than 65536 integration parts (are the look vectors unit vectors?)");
     return RDR_OK;
 }
 
@@ -1362,7 +1362,7 @@ int rdr_ray_march(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, double ht, d
     std::vector<double> lo, hi; std::vector<int> kz;
     const int K = levels_host(q->zs, ht, zref, lo, hi, kz);
     if (K == 0) return fail(c, RDR_ERR_NO_LEVELS, "no weather-model interval contributes to the ray integral (build_ray -> None)");
-    for (int k = 0; k < K; ++k) if (nparts[k] < 1 || nparts[k] > MAX_NPARTS) return fail(c, RDR_ERR_INVALID, "rdr_ray_march: nparts out of range (1..65536)");
+    for (int k = 0; k < K; ++k) if (nparts[k] < 2 || nparts[k] > MAX_NPARTS) return fail(c, RDR_ERR_INVALID, "rdr_ray_march: nparts out of range (2..65536)");
     if (r->n == 0) return RDR_OK;
     HIPCHECK(c, hipSetDevice(c->device));
     const bool reuse = wsig_match(c, q, r, ht, zref, K);

@@ -652,7 +652,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
             const double parts = ceil(__longlong_as_double((long long)P.maxlen_bits[k]) / P.max_seg) + 1.0;   // delay.py:283
             np = (parts >= 1.0 && parts <= (double)MAX_NPARTS) ? (int)parts : -1;
         }
-        if (np < 1 || np > MAX_NPARTS) {      // diverged lengths (e.g. look vectors far from unit length): refuse to loop over them
+        if (np < 2 || np > MAX_NPARTS) {      // diverged lengths (e.g. look vectors far from unit length): refuse to loop over them
             np = 2;
             if (tid < BLOCK) atomicOr(P.flags, 16);    // RDR_FLAG_DIVERGED
             m.K[1] = 1;
@@ -743,18 +743,20 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
                         wgt[b] = wv;
                         n = b + 1;
                         ++j;
-                        while (valid && j >= np) {                                      // next level (its j = 0 is already done)
+                        if (j >= np) {                                                  // next level (its j = 0 is already done)
                             ++k;
-                            if (k >= K) { valid = false; break; }
-                            j = 1;
-                            np = __builtin_amdgcn_readfirstlane(m.np[k]);
-                            kz = __builtin_amdgcn_readfirstlane(m.kz[k]);
-                            zbase = window2_base(c.nz, kz);
-                            step = m.step[k]; hs = hs1;
-                            u_k += du; du = du1; du1 = 0.0; hs1 = 0.0;
-                            if (k + 1 < K) {
-                                const double t2 = level_top_u(q.h, m.hi[k + 1], su, ou, gain);
-                                du1 = t2 - u_last; u_last = t2; hs1 = m.hs[k + 1];
+                            if (k >= K) valid = false;
+                            else {
+                                j = 1;
+                                np = __builtin_amdgcn_readfirstlane(m.np[k]);           // >= 2 (fill below)
+                                kz = __builtin_amdgcn_readfirstlane(m.kz[k]);
+                                zbase = window2_base(c.nz, kz);
+                                step = m.step[k]; hs = hs1;
+                                u_k += du; du = du1; du1 = 0.0; hs1 = 0.0;
+                                if (k + 1 < K) {
+                                    const double t2 = level_top_u(q.h, m.hi[k + 1], su, ou, gain);
+                                    du1 = t2 - u_last; u_last = t2; hs1 = m.hs[k + 1];
+                                }
                             }
                         }
                     }
