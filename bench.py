@@ -41,6 +41,7 @@ def main():
     ap.add_argument('--cols', type=int, default=4000)
     ap.add_argument('--cube', type=str, default='300x300x80')
     ap.add_argument('--cube-f64', action='store_true', help='experiment: upload the f32 refractivities as f64 (no cvt in the gather)')
+    ap.add_argument('--coll-device', action='store_true', help='keep collective tensors on the GPU even with --backend gloo (dry run of the async path)')
     ap.add_argument('--backend', type=str, default='nccl', help='torch.distributed backend for N>1 (nccl = RCCL; gloo only for single-GPU dry runs of the N>1 path)')
     ap.add_argument('--cpu-sample', type=int, default=640, help='edge of the square ray block timed on the CPU oracle (0 = skip)')
     args = ap.parse_args()
@@ -68,7 +69,7 @@ def main():
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
-    coll_dev = dev if args.backend == 'nccl' else None      # where the collectives' tensors live
+    coll_dev = dev if (args.backend == 'nccl' or args.coll_device) else None      # where the collectives' tensors live
 
     ctx = R.Context(local)
     # (raider_amd launches on torch's current stream whenever it is handed device tensors)
@@ -116,19 +117,24 @@ def main():
     out_h = torch.empty_like(out_w)
     n_rays = rows * cols
 
+    partition = None      # device-resident pass-1 result (K+4 doubles) the RCCL all-reduce works on
+
     def step():
         if world == 1:
             cube.raytrace(rays, ht, zref, out=(out_w, out_h), want_nparts=False)       # fully asynchronous
-            return None
-        _, _, nparts = D.raytrace_slab(cube, rays, ht, zref, out=(out_w, out_h), device=coll_dev)    # pass 1 -> RCCL MAX all-reduce (K+4 doubles) -> pass 2
-        return nparts
+        elif partition is not None:                                                    # pass 1 -> RCCL MAX all-reduce (K+4 doubles, on the device) -> pass 2
+            D.raytrace_slab_async(cube, rays, ht, zref, partition, out=(out_w, out_h))
+        else:                                                                          # gloo dry run: the partition travels through the host
+            D.raytrace_slab(cube, rays, ht, zref, out=(out_w, out_h), device=coll_dev)
 
-    # nParts / S for the roofline formula (one synchronous untimed call)
+    # nParts / S for the roofline formula (one synchronous untimed call, which also raises the reference's error conditions)
     if world == 1:
         _, _, nparts, flags = cube.raytrace(rays, ht, zref, out=(out_w, out_h), want_nparts=True)
     else:
-        nparts = step()
+        _, _, nparts = D.raytrace_slab(cube, rays, ht, zref, out=(out_w, out_h), device=coll_dev)
     S = int(np.sum(nparts)); K = int(len(nparts))
+    if world > 1 and coll_dev is not None:
+        partition = torch.zeros(K + 4, dtype=torch.float64, device=dev)
 
     for _ in range(args.warmup):
         step()

@@ -167,6 +167,16 @@ int rdr_ray_prepass(rdr_ctx* ctx, const rdr_cube* cube, const rdr_rays* rays, do
                     double* maxlen, int32_t* flags);
 /* nParts = ceil(maxlen/max_seg)+1 (delay.py:283) */
 int rdr_nparts(const double* maxlen, int32_t K, double max_seg, int32_t* nparts);
+/* Device-resident variant of the prepass / march pair for multi-GPU slabs: `partition` is a DEVICE buffer of
+ * K+4 doubles - the per-level maxima of the ray length followed by the four RDR_FLAG_* bits as 0.0 / 1.0 - so that the
+ * caller can run ONE element-wise MAX all-reduce (RCCL) on it between the two calls and no host round trip happens at all.
+ * Rays, outputs and the partition must live on the device; both calls are asynchronous on the ctx stream.  The march
+ * derives nParts = ceil(max/max_seg)+1 (delay.py:283) on the device; error conditions (all-NaN, diverged) are not
+ * reported here (the outputs are NaN) - use rdr_ray_prepass when they must be. */
+int rdr_ray_prepass_device(rdr_ctx* ctx, const rdr_cube* cube, const rdr_rays* rays, double ht, double zref, double* partition);
+int rdr_ray_march_device(rdr_ctx* ctx, const rdr_cube* cube, const rdr_rays* rays, double ht, double zref, double max_seg,
+                         const double* partition, double* wet, double* hydro);
+
 /* Pass 2 (delay.py:285-323 + build_ray recomputed in registers): trapezoid integral of both fields along
  * each ray with the GIVEN partition nparts[K] (host array) and clamp decision `flags`.
  * wet/hydro: [n] outputs (overwritten, not accumulated), location = rays->loc. */

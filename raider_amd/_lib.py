@@ -78,6 +78,8 @@ SYMBOLS = [
     ('rdr_lla2ecef', C.c_int, [_VP, _VP, _VP, _VP, C.c_int64, _VP, C.c_int]),
     ('rdr_ecef2lla', C.c_int, [_VP, _VP, C.c_int64, _VP, _VP, _VP, C.c_int]),
     ('rdr_look_vectors', C.c_int, [_VP, C.POINTER(RdrRays), C.c_double, _VP]),
+    ('rdr_ray_prepass_device', C.c_int, [_VP, _VP, _VP, C.c_double, C.c_double, _VP]),
+    ('rdr_ray_march_device', C.c_int, [_VP, _VP, _VP, C.c_double, C.c_double, C.c_double, _VP, _VP, _VP]),
     ('rdr_inverse_time_weights', C.c_int, [_VP, _VP, C.c_int64, _VP, C.c_int32, C.c_double, C.c_double, _VP, C.c_int]),
     ('rdr_cube_blend_weighted', C.c_int, [_VP, C.POINTER(_VP), C.c_int32, _VP, C.c_int, C.POINTER(_VP)]),
     ('rdr_cubes_from_model_levels', C.c_int, [_VP, _VP, C.c_int64, _VP, C.c_int64, _VP, _VP, _VP, _VP, C.c_int, C.c_int64, _VP, C.c_int64,

@@ -171,6 +171,24 @@ __global__ void blend_kernel(const T2* __restrict__ a, T w1, const T2* __restric
     }
 }
 
+// ---- device-resident exchange of the pass-1 partition (multi-GPU: the all-reduce runs on this buffer, no host round trip) ----
+// partition[0..K) = per-level maxima of the ray length (doubles), partition[K..K+4) = the four RDR_FLAG_* bits as 0.0 / 1.0,
+// so that ONE element-wise MAX all-reduce combines the shards (MAX of non-negative doubles = MAX of their bit patterns).
+__global__ void pack_partition_kernel(const unsigned long long* __restrict__ bits, const int* __restrict__ flags, int K, double* __restrict__ out) {
+    const int f = *flags;
+    for (int k = threadIdx.x; k < K + 4; k += blockDim.x)
+        out[k] = k < K ? __longlong_as_double((long long)bits[k]) : (((f >> (k - K)) & 1) ? 1.0 : 0.0);
+}
+
+__global__ void unpack_partition_kernel(const double* __restrict__ in, int K, unsigned long long* __restrict__ bits, int* __restrict__ flags) {
+    for (int k = threadIdx.x; k < K; k += blockDim.x) bits[k] = (unsigned long long)__double_as_longlong(in[k]);
+    if (threadIdx.x == 0) {
+        int f = 0;
+        for (int b = 0; b < 4; ++b) if (in[K + b] > 0.0) f |= 1 << b;
+        *flags = f;
+    }
+}
+
 // ---- azimuth-time-grid temporal weighting -----------------------------------------------------------------------------
 // get_inverse_weights_for_dates (s1_azimuth_timing.py:326-399): w_d = m_d / (|t - date_d| + reg) / sum_d(...), m_d = 1 when
 // |t - date_d| <= window.  A voxel with no date inside the window divides 0 by 0 -> NaN, as in the reference.
@@ -1353,6 +1371,55 @@ int rdr_ray_prepass(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, double ht,
     HIPCHECK(c, hipStreamSynchronize(c->stream));
     if (flags) *flags = f;
     return RDR_OK;
+}
+
+int rdr_ray_prepass_device(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, double ht, double zref, double* partition) {
+    if (!c || !q || !partition) return fail(c, RDR_ERR_INVALID, "rdr_ray_prepass_device: NULL argument");
+    int rc = check_rays(c, r); if (rc) return rc;
+    if (r->loc != RDR_DEVICE) return fail(c, RDR_ERR_INVALID, "rdr_ray_prepass_device: rays must be device arrays");
+    std::vector<double> lo, hi; std::vector<int> kz;
+    const int K = levels_host(q->zs, ht, zref, lo, hi, kz);
+    if (K == 0) return fail(c, RDR_ERR_NO_LEVELS, "no weather-model interval contributes to the ray integral (build_ray -> None)");
+    HIPCHECK(c, hipSetDevice(c->device));
+    RayParams P;
+    rc = stage_rays(c, r, P); if (rc) return rc;
+    P.ht = ht; P.zref = zref; P.max_seg = 1000.0;
+    HIPCHECK(c, hipMemsetAsync(c->d_maxlen, 0, MAX_LEVELS * sizeof(unsigned long long), c->stream));
+    HIPCHECK(c, hipMemsetAsync(c->d_flags, 0, sizeof(int), c->stream));
+    c->wsig.valid = false;
+    if (r->n > 0) {
+        const bool keep = P.ntiles <= ws_chunk_tiles(c, K);
+        if (keep) { rc = ws_reserve(c, P.ntiles, K, &P.ws); if (rc) return rc; }
+        rc = launch_crossings(c, q, P, 0, P.ntiles); if (rc) return rc;
+        if (keep) wsig_set(c, q, r, ht, zref, K, true);
+    }
+    hipLaunchKernelGGL(pack_partition_kernel, dim3(1), dim3(256), 0, c->stream, c->d_maxlen, c->d_flags, K, partition);
+    HIPCHECK(c, hipGetLastError());
+    return RDR_OK;
+}
+
+int rdr_ray_march_device(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, double ht, double zref, double max_seg, const double* partition,
+                         double* wet, double* hydro) {
+    if (!c || !q || !partition || !wet || !hydro) return fail(c, RDR_ERR_INVALID, "rdr_ray_march_device: NULL argument");
+    if (!(max_seg > 0)) return fail(c, RDR_ERR_INVALID, "rdr_ray_march_device: MAX_SEGMENT_LENGTH must be positive");
+    int rc = check_rays(c, r); if (rc) return rc;
+    if (r->loc != RDR_DEVICE) return fail(c, RDR_ERR_INVALID, "rdr_ray_march_device: rays and outputs must be device arrays");
+    std::vector<double> lo, hi; std::vector<int> kz;
+    const int K = levels_host(q->zs, ht, zref, lo, hi, kz);
+    if (K == 0) return fail(c, RDR_ERR_NO_LEVELS, "no weather-model interval contributes to the ray integral (build_ray -> None)");
+    if (r->n == 0) return RDR_OK;
+    HIPCHECK(c, hipSetDevice(c->device));
+    const bool reuse = wsig_match(c, q, r, ht, zref, K);
+    RayParams P;
+    rc = stage_rays(c, r, P); if (rc) return rc;
+    P.ht = ht; P.zref = zref; P.max_seg = max_seg;
+    P.wet = wet; P.hyd = hydro;
+    hipLaunchKernelGGL(unpack_partition_kernel, dim3(1), dim3(256), 0, c->stream, partition, K, c->d_maxlen, c->d_flags);
+    HIPCHECK(c, hipGetLastError());
+    if (reuse) { P.ws = (double*)c->ws.p; rc = launch_march(c, q, P, 0, P.ntiles); }
+    else rc = march_chunked(c, q, P, K);
+    c->wsig.valid = false;
+    return rc;
 }
 
 int rdr_ray_march(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, double ht, double zref, const int32_t* nparts, int32_t flags,

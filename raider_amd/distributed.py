@@ -83,6 +83,17 @@ def broadcast_cube_fields(fields, src=0, device=None, group=None):
     return out
 
 
+def raytrace_slab_async(cube, rays, ht, zref, partition, max_seg=1000.0, out=None, group=None):
+    """The same slice without any host round trip (device-resident rays, outputs and partition; RCCL all-reduce on the
+    K+4-element device tensor `partition`): pass 1 -> MAX all-reduce -> pass 2, all enqueued asynchronously.  The
+    reference's error conditions (all-NaN slice etc.) are not raised here - the outputs are NaN instead."""
+    cube.ray_prepass_device(rays, ht, zref, partition)
+    if is_distributed():
+        dist = _dist()
+        dist.all_reduce(partition, op=dist.ReduceOp.MAX, group=group)
+    return cube.ray_march_device(rays, ht, zref, partition, max_seg=max_seg, out=out)
+
+
 def raytrace_slab(cube, rays, ht, zref, max_seg=1000.0, out=None, group=None, device=None):
     """One slice of _build_cube_ray for THIS rank's slab of the scene, with the batch-global partition.
     Returns (wet, hydro, nparts)."""

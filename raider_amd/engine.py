@@ -165,6 +165,22 @@ class Cube:
                                            C.byref(flags)), self.ctx.handle)
         return maxlen, flags.value
 
+    def ray_prepass_device(self, rays, ht, zref, partition):
+        """Pass 1 with its result left on the device: `partition` = torch float64 tensor of K+4 elements (per-level maxima,
+        then the 4 flag bits as 0/1) - ready for an element-wise MAX all-reduce.  Asynchronous."""
+        rays.adopt_stream(self.ctx)
+        check(self.ctx.lib.rdr_ray_prepass_device(self.ctx.handle, self.handle, C.byref(rays.struct), float(ht), float(zref), ptr(partition)),
+              self.ctx.handle)
+        return partition
+
+    def ray_march_device(self, rays, ht, zref, partition, max_seg=1000.0, out=None):
+        """Pass 2 driven by a device-resident (all-reduced) partition.  Asynchronous."""
+        rays.adopt_stream(self.ctx)
+        wet, hyd = out if out is not None else rays.empty_outputs()
+        check(self.ctx.lib.rdr_ray_march_device(self.ctx.handle, self.handle, C.byref(rays.struct), float(ht), float(zref), float(max_seg),
+                                                ptr(partition), ptr(wet), ptr(hyd)), self.ctx.handle)
+        return wet, hyd
+
     def ray_march(self, rays, ht, zref, nparts, flags, out=None):
         rays.adopt_stream(self.ctx)
         nparts = np.ascontiguousarray(nparts, dtype=np.int32)

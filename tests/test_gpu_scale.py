@@ -297,3 +297,35 @@ def test_hrrr_lambert_cube(R):
     w, h = _build_cube_ray(lon, lat, zpts, Raytracing(inc=36.0, heading=-167.9), proj_str, 4326, [ifw, ifh], MAX_TROPO_HEIGHT=zref)
     assert np.isfinite(rw).all()
     np.testing.assert_allclose(w, rw, rtol=0, atol=TIGHT); np.testing.assert_allclose(h, rh, rtol=0, atol=TIGHT)
+
+
+def test_device_resident_partition_exchange(R):
+    """rdr_ray_prepass_device / rdr_ray_march_device: two half-slabs driven through a device-resident partition that is
+    MAX-combined on the device (what the RCCL all-reduce does across ranks) reproduce the whole-slice result bit for bit,
+    and the partition holds exactly the host API's per-level maxima and flags."""
+    import torch
+    dev = torch.device('cuda:0')
+    c = O.synthetic_cube(50, 50, 40, seed=0)
+    cube = R.Cube(c['ys'], c['xs'], c['zs'], torch.from_numpy(c['wet']).to(dev), torch.from_numpy(c['hydro']).to(dev), order='zyx')
+    xp = torch.from_numpy(np.linspace(-119.5, -115.5, 64)).to(dev); yp = np.linspace(34.5, 31.5, 64)
+    inc = torch.from_numpy(np.ascontiguousarray(np.broadcast_to(np.linspace(30, 46, 64)[:, None], (64, 64)))).to(dev)   # steeper towards the last rows
+    hd = torch.full((64, 64), -167.9, dtype=torch.float64, device=dev)
+    zref = float(c['zs'].max() - 1)
+    whole = R.Rays.grid(xp, torch.from_numpy(yp).to(dev), inc=inc, hd=hd)
+    ww, wh, nparts, flags = cube.raytrace(whole, 0.0, zref)
+    K = len(nparts)
+    maxlen, fl = cube.ray_prepass(whole, 0.0, zref)
+    halves = [R.Rays.grid(xp, torch.from_numpy(yp[a:b].copy()).to(dev), inc=inc[a:b].contiguous(), hd=hd[a:b].contiguous()) for a, b in ((0, 32), (32, 64))]
+    parts = [torch.zeros(K + 4, dtype=torch.float64, device=dev) for _ in halves]
+    for r, p in zip(halves, parts):
+        cube.ray_prepass_device(r, 0.0, zref, p)
+    glob = torch.maximum(parts[0], parts[1])
+    assert np.array_equal(glob[:K].cpu().numpy(), maxlen)
+    assert [int(v) for v in glob[K:].cpu().numpy()] == [(fl >> b) & 1 for b in range(4)]
+    outs = [cube.ray_march_device(r, 0.0, zref, glob) for r in halves]
+    torch.cuda.synchronize()
+    assert torch.equal(torch.cat([outs[0][0], outs[1][0]]), ww) and torch.equal(torch.cat([outs[0][1], outs[1][1]]), wh)
+    # a shard-local partition is NOT the same thing (SURVEY 0.7)
+    local = cube.ray_march_device(halves[0], 0.0, zref, parts[0])
+    torch.cuda.synchronize()
+    assert not torch.equal(local[1], wh[:32])
