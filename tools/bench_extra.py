@@ -70,5 +70,30 @@ def main():
                       'points_per_s': n / dti, 'ms': dti * 1e3}))
 
 
+
+
+def producer_bench():
+    """cube producer: ERA5-like 300x300 columns x 137 model levels -> 145 output levels"""
+    from raider_amd.weather import cubes_from_model_levels, MODEL_LEVEL_HEIGHTS
+    rng = np.random.default_rng(0)
+    A = B = 300; nl = 137
+    base = np.linspace(0, 1, nl)[None, None, :] ** 1.8
+    zs = -100.0 + 200.0 * rng.uniform(0, 1, (A, B, 1)) + 80000.0 * base
+    t = np.maximum(288.0 - 0.0065 * zs, 200.0); p = 101325.0 * np.exp(-zs / 7600.0); q = 0.012 * np.exp(-zs / 2400.0)
+    dev = torch.device('cuda')
+    arrs = [torch.from_numpy(a).to(dev) for a in (zs, p, t, q)]
+    xs = np.linspace(-120, -110, B); ys = np.linspace(30, 40, A)
+    newz = np.concatenate([MODEL_LEVEL_HEIGHTS, np.linspace(42000, 80000, 65)])
+    fn = lambda: cubes_from_model_levels(xs, ys, *arrs, 'q', newz)
+    dt = timeit(fn, reps=5)
+    cols = A * B
+    print(json.dumps({'what': f'cube producer {A}x{B} columns, {nl} model levels -> {newz.size} levels (device-resident inputs)', 'ms': dt * 1e3,
+                      'columns_per_s': cols / dt, 'GBps_in_plus_out': cols * (32 * nl + 24 * newz.size) / dt / 1e9}))
+
+
 if __name__ == '__main__':
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == 'producer':
+        producer_bench()
+    else:
+        main()
+        producer_bench()
