@@ -503,7 +503,41 @@ def g11():
     save('g11_aztime_weights', **out)
 
 
+def g13():
+    """END TO END on a real cube: the reference's own, unmodified tropo_delay (delay.py:35-130) on the processed ERA-5 cube
+    its test suite holds (test/weather_files/ERA-5_2020_01_30_T13_52_45_32N_35N_120W_115W.nc, read here through the
+    build's HDF5 reader and handed to the xarray stub) for the stations of test/scenario_6/stations.csv - the inputs of
+    test/test_intersect.py::test_gnss_intersect - with (a) the output grid calcDelays builds for that station file
+    (AOI.add_buffer + set_output_xygrid, cli/raider.py:257-260) and (b) the weather model's own grid."""
+    import csv
+    sys.path.insert(0, str(HERE.parents[1]))
+    from raider_amd import h5lite
+    path = ref_import.REF_ROOT / 'test' / 'weather_files' / 'ERA-5_2020_01_30_T13_52_45_32N_35N_120W_115W.nc'
+    f = h5lite.File(path)
+    ds = xr.Dataset(data_vars={k: (['z', 'y', 'x'], f[k].read()) for k in ('wet', 'hydro', 'wet_total', 'hydro_total')},
+                    coords=dict(x=(['x'], f['x'].read()), y=(['y'], f['y'].read()), z=(['z'], f['z'].read())))
+    ds['proj'] = xr.DataArray(np.array(0), attrs={'crs_wkt': EPSG4326.to_wkt()})
+    xr.register_dataset(str(path), ds)
+    with open(ref_import.REF_ROOT / 'test' / 'scenario_6' / 'stations.csv') as fh:
+        rows = list(csv.DictReader(fh))
+    lats = np.array([float(r['Lat']) for r in rows]); lons = np.array([float(r['Lon']) for r in rows]); hgts = np.array([float(r['Hgt_m']) for r in rows])
+    from RAiDER.utilFcns import clip_bbox
+    ll_res = 0.25                                                 # ERA-5 getLLRes() (models/ecmwf.py:32-33)
+    S, N, W, E = lats.min(), lats.max(), lons.min(), lons.max()   # llreader.bounds_from_csv
+    buf = 1.5 * ll_res                                            # AOI.add_buffer (llreader.py:91-128)
+    S, N, W, E = clip_bbox([max(S - buf, -90), min(N + buf, 90), W - buf, E + buf], ll_res)
+    S, N, W, E = (np.round(a, 2) for a in (S, N, W, E))
+    xa = np.arange(W, E + ll_res, ll_res); ya = np.arange(N, S - ll_res, -ll_res)     # AOI.set_output_xygrid (llreader.py:177-192)
+    xm = f['x'].read().astype(np.float64); ym = f['y'].read().astype(np.float64)[::-1]
+    when = dt.datetime(2020, 1, 30, 13, 52, 45)
+    wa, ha = rdelay.tropo_delay(when, str(path), _Stations(lats, lons, hgts, xa, ya), rlos.Zenith(), None, 4326, None)
+    wm_, hm_ = rdelay.tropo_delay(when, str(path), _Stations(lats, lons, hgts, xm, ym), rlos.Zenith(), None, 4326, None)
+    print('  TORP total: AOI grid', wa[1] + ha[1], ' model grid', wm_[1] + hm_[1], ' (test_intersect.py gold 2.34514)')
+    save('g13_gnss_intersect', ids=np.array([r['ID'] for r in rows]), lats=lats, lons=lons, hgts=hgts, x_aoi=xa, y_aoi=ya, x_model=xm, y_model=ym,
+         wet_aoi=wa, hydro_aoi=ha, wet_model=wm_, hydro_model=hm_)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g8', 'g9', 'g10', 'g11']   # g7: cli.raider needs h5py (absent)
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g8', 'g9', 'g10', 'g11', 'g13']   # g12: gen_ref_file_vectors.py; g7: cli.raider needs h5py (absent)
     for w in which:
         globals()[w]()

@@ -4,6 +4,8 @@
   tests/golden/ref_files/ERA-5_2019_11_17_T20_51_58_5S_2S_41W_37W.nc
       a processed weather-model cube written by the real RAiDER (NetCDF-4/HDF5; /root/reference/test/weather_files/),
       copied verbatim: exercises the built-in HDF5 reader and pins the refractivity and ZTD stages on real output;
+  tests/golden/ref_files/ERA-5_2020_01_30_T13_52_45_32N_35N_120W_115W.nc, scenario_6_stations.csv
+      the inputs of the reference's test/test_intersect.py::test_gnss_intersect (golden total zenith delay at station TORP);
   tests/golden/g12_gmao_time_interp.npz
       a 145 x 5 x 6 block of the three GMAO cubes of /root/reference/test/gunw_test_data/weather_files/ (12:00, 15:00 and
       the reference's own `timeInterp` product for 13:52:44): pins the two-epoch temporal blend (cli/raider.py:817-819,
@@ -27,6 +29,10 @@ def main():
     (OUT / 'ref_files').mkdir(parents=True, exist_ok=True)
     src = REF_TEST / 'weather_files' / 'ERA-5_2019_11_17_T20_51_58_5S_2S_41W_37W.nc'
     shutil.copyfile(src, OUT / 'ref_files' / src.name)
+    # test/test_intersect.py::test_gnss_intersect: the processed cube it runs on and its station list (golden ZTD 2.34514 m at TORP)
+    src2 = REF_TEST / 'weather_files' / 'ERA-5_2020_01_30_T13_52_45_32N_35N_120W_115W.nc'
+    shutil.copyfile(src2, OUT / 'ref_files' / src2.name)
+    shutil.copyfile(REF_TEST / 'scenario_6' / 'stations.csv', OUT / 'ref_files' / 'scenario_6_stations.csv')
     d = REF_TEST / 'gunw_test_data' / 'weather_files'
     names = dict(t12='GMAO_2020_01_30_T12_00_00_32N_36N_121W_114W.nc', t15='GMAO_2020_01_30_T15_00_00_32N_36N_121W_114W.nc',
                  interp='GMAO_2020_01_30T13_52_44_timeInterp_32N_36N_121W_114W.nc')
