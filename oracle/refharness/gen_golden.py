@@ -533,7 +533,26 @@ def g13():
     wa, ha = rdelay.tropo_delay(when, str(path), _Stations(lats, lons, hgts, xa, ya), rlos.Zenith(), None, 4326, None)
     wm_, hm_ = rdelay.tropo_delay(when, str(path), _Stations(lats, lons, hgts, xm, ym), rlos.Zenith(), None, 4326, None)
     print('  TORP total: AOI grid', wa[1] + ha[1], ' model grid', wm_[1] + hm_[1], ' (test_intersect.py gold 2.34514)')
-    save('g13_gnss_intersect', ids=np.array([r['ID'] for r in rows]), lats=lats, lons=lons, hgts=hgts, x_aoi=xa, y_aoi=ya, x_model=xm, y_model=ym,
+    # (c) the reference's ray tracer (_build_cube_ray, delay.py:219-326) through the same real 145-level cube: cube AOI,
+    #     per-pixel incidence 30..44 deg, heading -167.9 deg (duck LOS: look vectors from the reference's own inc_hd_to_enu + enu2ecef)
+    class _RayLOS(ArrayLOS):
+        def is_Zenith(self): return False
+        def is_Projected(self): return False
+        def ray_trace(self): return True
+
+    class _Box(_Stations):
+        def type(self): return 'bounding_box'
+    xr_, yr_ = np.linspace(-118.9, -116.4, 9), np.linspace(34.2, 32.7, 7)
+    inc = np.broadcast_to(np.linspace(30.0, 44.0, xr_.size)[None, :], (yr_.size, xr_.size)).copy()
+    zl = [0.0, 1200.0, 20000.0]
+    import RAiDER.llreader as rll
+    box = rll.BoundingBox([32.7, 34.2, -118.9, -116.4])
+    box.xpts, box.ypts = xr_, yr_
+    dsr, _ = rdelay.tropo_delay(when, str(path), box, _RayLOS(inc, -167.9), zl, 4326, None)
+    wr = np.asarray(dsr['wet'][:] if not hasattr(dsr['wet'], 'values') else dsr['wet'].values)
+    hr = np.asarray(dsr['hydro'][:] if not hasattr(dsr['hydro'], 'values') else dsr['hydro'].values)
+    print('  ray-traced cube', wr.shape, 'hydro mean', float(np.nanmean(hr)), 'NaNs', int(np.isnan(hr).sum()))
+    save('g13_gnss_intersect', x_ray=xr_, y_ray=yr_, inc_ray=inc, z_ray=np.array(zl), wet_ray=wr, hydro_ray=hr, ids=np.array([r['ID'] for r in rows]), lats=lats, lons=lons, hgts=hgts, x_aoi=xa, y_aoi=ya, x_model=xm, y_model=ym,
          wet_aoi=wa, hydro_aoi=ha, wet_model=wm_, hydro_model=hm_)
 
 

@@ -170,3 +170,21 @@ def test_reference_gnss_intersect_end_to_end(golden):
     np.testing.assert_allclose(wet_m, g['wet_model'], rtol=0, atol=1e-14); np.testing.assert_allclose(hyd_m, g['hydro_model'], rtol=0, atol=1e-14)
     torp = list(g['ids']).index('TORP')
     np.testing.assert_almost_equal(wet_m[torp] + hyd_m[torp], 2.34514, decimal=4)      # test/test_intersect.py:106,113
+
+
+@pytest.mark.gpu
+def test_reference_raytracing_on_the_real_cube(golden):
+    """The reference's own _build_cube_ray (golden g13, generated by running the unmodified reference on the real 145-level
+    ERA-5 cube of its test suite, rays to 80.3 km at 30-44 deg incidence) vs the GPU ray tracer through tropo_delay on the
+    same file: same NaNs (lateral exits at the cube edge), delays within 1e-9 m."""
+    from raider_amd.delay import GridAOI, tropo_delay
+    from raider_amd.losreader import Raytracing
+    g = golden('g13_gnss_intersect')
+    cube = Path(__file__).parent / 'golden' / 'ref_files' / 'ERA-5_2020_01_30_T13_52_45_32N_35N_120W_115W.nc'
+    ds, none = tropo_delay(dt.datetime(2020, 1, 30, 13, 52, 45), str(cube), GridAOI(g['x_ray'], g['y_ray']),
+                           Raytracing(inc=g['inc_ray'], heading=-167.9), list(g['z_ray']), 4326, None)
+    assert none is None
+    wet, hyd = np.asarray(ds['wet'][:]), np.asarray(ds['hydro'][:])
+    assert np.array_equal(np.isnan(hyd), np.isnan(g['hydro_ray'])) and np.isnan(g['hydro_ray']).sum() == 4
+    np.testing.assert_allclose(wet, g['wet_ray'], rtol=0, atol=1e-9, equal_nan=True)
+    np.testing.assert_allclose(hyd, g['hydro_ray'], rtol=0, atol=1e-9, equal_nan=True)
