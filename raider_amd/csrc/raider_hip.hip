@@ -1226,8 +1226,15 @@ static size_t ray_smem(const rdr_cube* q) {
     return ray_smem_bytes(q->ny, q->nx, q->nz);
 }
 
-static int ray_grid(rdr_ctx* c, int64_t ntiles) {
-    int64_t g = std::min<int64_t>(ntiles, (int64_t)c->num_cus * 8);
+// Semi-persistent grid: `per_cu` workgroups per CU, each walking an equal share of the tiles.  Measured on the bench scene
+// (tools/probe_passes.py with RAIDER_HIP_BLOCKS_PER_CU = 2 .. 64): a grid of exactly the resident workgroups (3-4 per CU) is
+// 8-10 % SLOWER than 24 per CU - the dispatcher does not spread a just-fitting grid evenly and every workgroup then carries
+// the same fixed share to the end; with ~10 tiles per workgroup the tail evens out, and beyond 32 per CU the per-workgroup
+// table set-up starts to show.
+static int ray_grid(rdr_ctx* c, int64_t ntiles, int per_cu) {
+    static const int forced = []() { const char* e = std::getenv("RAIDER_HIP_BLOCKS_PER_CU"); return e ? std::atoi(e) : 0; }();
+    if (forced > 0) per_cu = forced;
+    int64_t g = std::min<int64_t>(ntiles, (int64_t)c->num_cus * per_cu);
     g = std::max<int64_t>(8, (g + 7) / 8 * 8);   // multiple of 8 (one share per XCD)
     return (int)g;
 }
@@ -1273,7 +1280,7 @@ static bool wsig_match(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, double 
 // pass 1 over tiles [tb, tb+tc): optional reduction (P.maxlen_bits != null) and/or record store (P.ws != null)
 static int launch_crossings(rdr_ctx* c, const rdr_cube* q, RayParams P, int64_t tb, int64_t tc) {
     P.tile_begin = tb; P.tile_count = tc; P.nslots = tc * BLOCK;
-    const int g = ray_grid(c, tc);
+    const int g = ray_grid(c, tc, 24);
     HIPCHECK(c, hipMemsetAsync(c->d_nslow, 0, sizeof(int), c->stream));
     {
         KTimer t(c, 0);
@@ -1298,7 +1305,7 @@ static int launch_crossings(rdr_ctx* c, const rdr_cube* q, RayParams P, int64_t 
 
 static int launch_march(rdr_ctx* c, const rdr_cube* q, RayParams P, int64_t tb, int64_t tc) {
     P.tile_begin = tb; P.tile_count = tc; P.nslots = tc * BLOCK;
-    const int g = ray_grid(c, tc);
+    const int g = ray_grid(c, tc, 24);
     {
         KTimer t(c, 1);
         const auto v32 = make_view<float2>(q);
