@@ -42,6 +42,7 @@ struct rdr_ctx {
     int* d_flags = nullptr;                   // [1]
     int* d_nparts = nullptr;                  // [MAX_LEVELS]
     int* d_nslow = nullptr;                   // [1] rays sent to the generic kernels by the last pass 1
+    int* d_tilectr = nullptr;                 // [4][8] per-XCD tile counters of the four ray-kernel launches of a step
     DevBuf ws;                                // pass 1 -> pass 2 workspace (field-major ray records)
     size_t ws_limit = (size_t)48 << 30;       // cap on that workspace; bigger batches are marched in chunks
     // which ray batch the stored records belong to (a later rdr_ray_march reuses them only for the identical batch)
@@ -717,6 +718,7 @@ int rdr_create(int device, rdr_ctx** out) {
     HIPCHECK(nullptr, hipMalloc((void**)&c->d_flags, sizeof(int)));
     HIPCHECK(nullptr, hipMalloc((void**)&c->d_nparts, MAX_LEVELS * sizeof(int)));
     HIPCHECK(nullptr, hipMalloc((void**)&c->d_nslow, sizeof(int)));
+    HIPCHECK(nullptr, hipMalloc((void**)&c->d_tilectr, 32 * sizeof(int)));
     HIPCHECK(nullptr, hipMemset(c->d_nslow, 0, sizeof(int)));
     if (const char* e = std::getenv("RAIDER_HIP_WORKSPACE_BYTES")) c->ws_limit = (size_t)std::strtoull(e, nullptr, 10);
     *out = c;
@@ -732,6 +734,7 @@ void rdr_destroy(rdr_ctx* c) {
     if (c->d_flags) (void)hipFree(c->d_flags);
     if (c->d_nparts) (void)hipFree(c->d_nparts);
     if (c->d_nslow) (void)hipFree(c->d_nslow);
+    if (c->d_tilectr) (void)hipFree(c->d_tilectr);
     if (c->ws.p) (void)hipFree(c->ws.p);
     for (auto& v : c->evs) for (auto& pr : v) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -1226,11 +1229,11 @@ static size_t ray_smem(const rdr_cube* q) {
     return ray_smem_bytes(q->ny, q->nx, q->nz);
 }
 
-// Semi-persistent grid: `per_cu` workgroups per CU, each walking an equal share of the tiles.  Measured on the bench scene
-// (tools/probe_passes.py with RAIDER_HIP_BLOCKS_PER_CU = 2 .. 64): a grid of exactly the resident workgroups (3-4 per CU) is
-// 8-10 % SLOWER than 24 per CU - the dispatcher does not spread a just-fitting grid evenly and every workgroup then carries
-// the same fixed share to the end; with ~10 tiles per workgroup the tail evens out, and beyond 32 per CU the per-workgroup
-// table set-up starts to show.
+// Persistent grid of `per_cu` workgroups per CU; tiles are handed out dynamically (TileWalk: one device atomic per tile and
+// XCD band), so the grid only has to cover the resident workgroups (3-4 per CU) with a little slack.  Measured on the bench
+// scene (tools/probe_passes.py, RAIDER_HIP_BLOCKS_PER_CU = 4 .. 24): 4-8 per CU are equal (march 6.52 ms), 24 costs 2 % in
+// per-workgroup table set-up.  (With a static equal share per workgroup the same sweep needed 24 per CU to hide the
+// imbalance and was still 2-7 % slower.)
 static int ray_grid(rdr_ctx* c, int64_t ntiles, int per_cu) {
     static const int forced = []() { const char* e = std::getenv("RAIDER_HIP_BLOCKS_PER_CU"); return e ? std::atoi(e) : 0; }();
     if (forced > 0) per_cu = forced;
@@ -1280,8 +1283,10 @@ static bool wsig_match(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, double 
 // pass 1 over tiles [tb, tb+tc): optional reduction (P.maxlen_bits != null) and/or record store (P.ws != null)
 static int launch_crossings(rdr_ctx* c, const rdr_cube* q, RayParams P, int64_t tb, int64_t tc) {
     P.tile_begin = tb; P.tile_count = tc; P.nslots = tc * BLOCK;
-    const int g = ray_grid(c, tc, 24);
+    const int g = ray_grid(c, tc, 8);
     HIPCHECK(c, hipMemsetAsync(c->d_nslow, 0, sizeof(int), c->stream));
+    HIPCHECK(c, hipMemsetAsync(c->d_tilectr, 0, 16 * sizeof(int), c->stream));
+    P.tile_ctr = c->d_tilectr;
     {
         KTimer t(c, 0);
         const bool lcc = q->proj.kind == 1;
@@ -1294,6 +1299,7 @@ static int launch_crossings(rdr_ctx* c, const rdr_cube* q, RayParams P, int64_t 
         }
     }
     // generic-geodesy mop-up of the rays the classification rejected (returns at once when there are none)
+    P.tile_ctr = c->d_tilectr + 8;
     if (q->dtype == RDR_F32)
         hipLaunchKernelGGL((crossings_kernel<float2, true>), dim3(g), dim3(BLOCK), ray_smem(q), c->stream, make_view<float2>(q), P, q->proj);
     else
@@ -1305,7 +1311,9 @@ static int launch_crossings(rdr_ctx* c, const rdr_cube* q, RayParams P, int64_t 
 
 static int launch_march(rdr_ctx* c, const rdr_cube* q, RayParams P, int64_t tb, int64_t tc) {
     P.tile_begin = tb; P.tile_count = tc; P.nslots = tc * BLOCK;
-    const int g = ray_grid(c, tc, 24);
+    const int g = ray_grid(c, tc, 8);
+    HIPCHECK(c, hipMemsetAsync(c->d_tilectr + 16, 0, 16 * sizeof(int), c->stream));
+    P.tile_ctr = c->d_tilectr + 16;
     {
         KTimer t(c, 1);
         const auto v32 = make_view<float2>(q);
@@ -1318,6 +1326,7 @@ static int launch_march(rdr_ctx* c, const rdr_cube* q, RayParams P, int64_t tb, 
             else hipLaunchKernelGGL((march_kernel<double2, false, false>), dim3(g), dim3(BLOCK), ray_smem(q), c->stream, make_view<double2>(q), P, q->proj);
         }
     }
+    P.tile_ctr = c->d_tilectr + 24;
     if (q->dtype == RDR_F32)
         hipLaunchKernelGGL((march_kernel<float2, true>), dim3(g), dim3(BLOCK), ray_smem(q), c->stream, make_view<float2>(q), P, q->proj);
     else

@@ -316,6 +316,7 @@ struct RayParams {
     int* flags;                        // RDR_FLAG_* bits (OR-reduced)
     const int* nparts_override;        // [K] or nullptr -> ceil(maxlen/max_seg)+1
     int* nslow;                        // number of rays the static classification sent to the generic (slow) kernels
+    int* tile_ctr;                     // [8] per-XCD next-tile counters of this launch (zeroed by the host)
     // pass 1 -> pass 2 workspace (this launch covers tiles [tile_begin, tile_begin + tile_count))
     double* ws; int64_t nslots;
     int64_t tile_begin, tile_count;
@@ -397,17 +398,21 @@ __device__ __forceinline__ int fill_tables(const CubeView<T2>& c, const RaySmem&
     return *m.K;
 }
 
-// XCD-aware persistent tile walk: workgroup b runs on XCD b%8 -> each XCD sweeps one contiguous band of tiles.
+// XCD-aware tile walk: workgroup b runs on XCD b%8 -> each XCD sweeps one contiguous band of tiles (its cube slab stays in
+// that XCD's L2).  Within a band the workgroups take tiles from a device counter (one atomic per tile), so no workgroup is
+// left holding a fixed share while others have finished.
 struct TileWalk {
-    int64_t chunk, tt; int nslot, xcd;
-    __device__ __forceinline__ TileWalk(int64_t count) {
-        xcd = blockIdx.x & 7; nslot = gridDim.x >> 3; chunk = (count + 7) / 8; tt = blockIdx.x >> 3;
+    int64_t chunk; int xcd; int* ctr; int* slot;
+    __device__ __forceinline__ TileWalk(int64_t count, int* counters, int* lds_slot) {
+        xcd = blockIdx.x & 7; chunk = (count + 7) / 8; ctr = counters + xcd; slot = lds_slot;
     }
     __device__ __forceinline__ bool next(int64_t count, int64_t& local) {
-        if (tt >= chunk) return false;
+        __syncthreads();
+        if (threadIdx.x == 0) *slot = atomicAdd(ctr, 1);
+        __syncthreads();
+        const int64_t tt = *slot;
         local = (int64_t)xcd * chunk + tt;
-        tt += nslot;
-        return local < count;
+        return tt < chunk && local < count;
     }
 };
 
@@ -434,7 +439,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SLOW || 
     // ndarray.max's NaN poisoning is reproduced on the host side.
     unsigned long long* const mxc = m.mxcol + (tid & (MXCOLS - 1));
     int my_flags = 0;
-    TileWalk walk(P.tile_count);
+    TileWalk walk(P.tile_count, P.tile_ctr, m.K + 2);
     int64_t lt;
     while (walk.next(P.tile_count, lt)) {
         const int64_t t = P.tile_begin + lt;
@@ -667,7 +672,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
     const bool clamp_lo = !(flags_in & 4);   // ALL first samples below zmin  (delay.py:306-307)
     const bool clamp_hi = !(flags_in & 8);   // ALL last samples above zmax   (delay.py:310-311)
     const bool clamp_any = clamp_lo | clamp_hi;
-    TileWalk walk(P.tile_count);
+    TileWalk walk(P.tile_count, P.tile_ctr, m.K + 2);
     int64_t lt;
     while (walk.next(P.tile_count, lt)) {
         const int64_t t = P.tile_begin + lt;
