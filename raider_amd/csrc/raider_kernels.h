@@ -458,7 +458,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SLOW || 
         RayBase base;
         if (!SLOW && P.origin_mode == 0) {
             // a tile has 16 distinct latitudes and 16 distinct longitudes: 32 lanes take the sines / cosines for everybody
-            __syncthreads();
+            // (the previous tile's readers are past the barriers of walk.next())
             if (tid < 32) {
                 const int64_t ty = t / P.tiles_x, tx = t - ty * P.tiles_x;
                 const int64_t r = ty * TILE + (tid & 15), cc = tx * TILE + (tid & 15);
@@ -590,9 +590,14 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SLOW || 
             // getTopOfAtmosphere carried on u: u0 = u(h); u += (h - H(u)) * su / factor   (losreader.py:724-731)
             double u_hi = 0.0, gain = su, inv_cosf = 1.0;
             double last_len = 0.0;      // a light ray's lengths are NaN for every level or for none (they all stem from one polynomial)
+            // The level heights are read from LDS ONE LEVEL AHEAD: LDS operations complete in order, so a read issued after
+            // level k's ds_max would have to wait for that atomic; issued before it, it only waits for itself.
+            const double lo = m.lo[0];
+            double hi_next = m.hi[0];
 #pragma unroll 1
             for (int k = 0; k < K; ++k) {
-                const double lo = m.lo[k], hi = m.hi[k];
+                const double hi = hi_next;
+                if (k + 1 < K) hi_next = m.hi[k + 1];
                 double u_lo = u_hi;
                 if (k == 0) {
                     u_lo = fma(lo, su, ou);
