@@ -131,6 +131,24 @@ __device__ __forceinline__ void ecef2lla_delta(const RayBase& b, double x, doubl
     h = g.h;
 }
 
+// The same point projected onto a SPHERICAL Lambert conformal conic grid (HRRR: e = 0), from the sine / cosine of the
+// latitude the geodesy already has: tan(pi/4 - phi/2) = cos(phi) / (1 + sin(phi)), rho = aF t^n = aF exp(n log t) -
+// one log, one exp and one sincos instead of lcc_forward's sin, tan, pow and sincos.
+__device__ __forceinline__ void ecef2lcc_sphere(const RayBase& b, const LccParams& L, double x, double y, double z,
+                                                double& px, double& py, double& h) {
+    const GeoF g = geo_fast<true>(x, y, z);
+    const double sl = fma(b.cl0, y, -b.sl0 * x) * g.rp;
+    double dlam = fma(asin_small(sl), 1.0, b.lon0 * DEG_TO_RAD) - L.lam0;
+    if (dlam > 3.141592653589793) dlam -= 6.283185307179586;
+    else if (dlam < -3.141592653589793) dlam += 6.283185307179586;
+    const double rho = L.aF * exp(L.n * log(g.cphi / (1.0 + g.sphi)));
+    double st, ct;
+    sincos(L.n * dlam, &st, &ct);
+    px = L.x0 + rho * st;
+    py = L.y0 + L.rho0 - rho * ct;
+    h = g.h;
+}
+
 // Interpolant through the Chebyshev nodes u_j = cos(pi (2j+1)/12) of t in [mid - half, mid + half]: coefficient n =
 // sum_j VINV[n][j] f(u_j) (inverse Vandermonde matrix of the nodes).  One node at a time (rolled loop) to keep the
 // register footprint of this once-per-ray step below that of the per-level loop.
@@ -157,11 +175,17 @@ __device__ __forceinline__ void fit_ray_poly(const RayBase& b, double ox, double
     for (int j = 0; j < PN; ++j) {
         const double t = fma(half, RAY_POLY_NODES[j], mid);
         double dx, dy, h;
-        ecef2lla_delta(b, fma(t, lx, ox), fma(t, ly, oy), fma(t, lz, oz), dx, dy, h);
-        if (LCC) {
+        if (LCC && proj.e == 0.0) {
             double px, py;
-            lcc_forward(proj, b.lat0 + dy, b.lon0 + dx, px, py);
+            ecef2lcc_sphere(b, proj, fma(t, lx, ox), fma(t, ly, oy), fma(t, lz, oz), px, py, h);
             dx = px - x0; dy = py - y0;
+        } else {
+            ecef2lla_delta(b, fma(t, lx, ox), fma(t, ly, oy), fma(t, lz, oz), dx, dy, h);
+            if (LCC) {
+                double px, py;
+                lcc_forward(proj, b.lat0 + dy, b.lon0 + dx, px, py);
+                dx = px - x0; dy = py - y0;
+            }
         }
 #pragma unroll
         for (int n = 0; n < PN; ++n) {

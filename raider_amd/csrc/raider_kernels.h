@@ -424,7 +424,7 @@ struct TileWalk {
 // LCC (light kernel only): the cube is on a Lambert-conformal-conic grid; a separate instantiation so that the projection's
 // pow/tan/sincos code does not weigh on the register allocation of the lon/lat one.
 template <typename T2, bool SLOW, bool LCC = false>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((SLOW || LCC) ? 1 : 4, (SLOW || LCC) ? 8 : 4))) void crossings_kernel(CubeView<T2> c, RayParams P, LccParams proj) {
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 : (LCC ? 2 : 4), SLOW ? 8 : (LCC ? 2 : 4)))) void crossings_kernel(CubeView<T2> c, RayParams P, LccParams proj) {
     if (SLOW && *P.nslow == 0) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const RaySmem m = carve_smem(smem_raw, c.ny, c.nx, c.nz);
