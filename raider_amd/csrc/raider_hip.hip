@@ -240,13 +240,17 @@ __global__ void blend_weighted_kernel(CubeSet S, const double* __restrict__ w, i
 // A4/A5: scipy RGI at packed points (n,3) = (y,x,z)
 template <typename T2>
 __global__ __launch_bounds__(256) void interp_points_kernel(CubeView<T2> c, const double* __restrict__ pts, int64_t n,
-                                                            double* __restrict__ wet, double* __restrict__ hyd) {
+                                                            double* __restrict__ wet, double* __restrict__ hyd, int axes_in_lds) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    double* s_y = reinterpret_cast<double*>(smem_raw);
-    double* s_x = s_y + c.ny;
-    double* s_z = s_x + c.nx;
-    for (int i = threadIdx.x; i < c.ny + c.nx + c.nz; i += blockDim.x) s_y[i] = c.axes[i];
-    __syncthreads();
+    const double* s_y = c.axes;                       // very long axes stay in global memory (L1 / L2 hits)
+    if (axes_in_lds) {
+        double* t = reinterpret_cast<double*>(smem_raw);
+        for (int i = threadIdx.x; i < c.ny + c.nx + c.nz; i += blockDim.x) t[i] = c.axes[i];
+        __syncthreads();
+        s_y = t;
+    }
+    const double* s_x = s_y + c.ny;
+    const double* s_z = s_x + c.nx;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const double y = pts[3 * i], x = pts[3 * i + 1], z = pts[3 * i + 2];
         double w, h;
@@ -260,13 +264,17 @@ template <typename T2>
 __global__ __launch_bounds__(256) void build_cube_kernel(CubeView<T2> c, LccParams proj, const double* __restrict__ xpts, int64_t nx,
                                                          const double* __restrict__ ypts, int64_t ny,
                                                          const double* __restrict__ zpts, int64_t nz,
-                                                         double* __restrict__ wet, double* __restrict__ hyd) {
+                                                         double* __restrict__ wet, double* __restrict__ hyd, int axes_in_lds) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    double* s_y = reinterpret_cast<double*>(smem_raw);
-    double* s_x = s_y + c.ny;
-    double* s_z = s_x + c.nx;
-    for (int i = threadIdx.x; i < c.ny + c.nx + c.nz; i += blockDim.x) s_y[i] = c.axes[i];
-    __syncthreads();
+    const double* s_y = c.axes;                       // very long axes stay in global memory (L1 / L2 hits)
+    if (axes_in_lds) {
+        double* t = reinterpret_cast<double*>(smem_raw);
+        for (int i = threadIdx.x; i < c.ny + c.nx + c.nz; i += blockDim.x) t[i] = c.axes[i];
+        __syncthreads();
+        s_y = t;
+    }
+    const double* s_x = s_y + c.ny;
+    const double* s_z = s_x + c.nx;
     const int64_t n = nx * ny * nz;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t ix = i % nx, r = i / nx, iy = r % ny, iz = r / ny;
@@ -832,7 +840,9 @@ static CubeView<T2> make_view(const rdr_cube* q) {
     return v;
 }
 
-static size_t axes_smem(const rdr_cube* q) { return (size_t)(q->ny + q->nx + q->nz) * sizeof(double); }
+// the zenith / station kernels stage the axes in LDS when they fit 48 KB, else read them from global memory
+static bool axes_fit_lds(const rdr_cube* q) { return (size_t)(q->ny + q->nx + q->nz) * sizeof(double) <= (48u << 10); }
+static size_t axes_smem(const rdr_cube* q) { return axes_fit_lds(q) ? (size_t)(q->ny + q->nx + q->nz) * sizeof(double) : 0; }
 
 static int cube_alloc(rdr_ctx* c, rdr_cube* q) {
     const size_t esz = q->dtype == RDR_F32 ? 8 : 16;
@@ -856,7 +866,7 @@ int rdr_cube_create(rdr_ctx* c, const double* ys, int64_t ny, const double* xs, 
     if (!c || !out || !ys || !xs || !zs || !wet || !hydro) return fail(c, RDR_ERR_INVALID, "rdr_cube_create: NULL argument");
     if (dtype != RDR_F32 && dtype != RDR_F64) return fail(c, RDR_ERR_INVALID, "rdr_cube_create: dtype must be RDR_F32 or RDR_F64");
     if (nz > MAX_LEVELS) return fail(c, RDR_ERR_INVALID, "rdr_cube_create: more than 512 z levels");
-    if (ny + nx + nz > 7000) return fail(c, RDR_ERR_INVALID, "rdr_cube_create: axes too long for the LDS-resident axis table");
+    if (ny + nx + nz > 100000) return fail(c, RDR_ERR_INVALID, "rdr_cube_create: axes too long");
     int fy, fx, fz;
     if (axis_check(ys, ny, &fy) || axis_check(xs, nx, &fx) || axis_check(zs, nz, &fz))
         return fail(c, RDR_ERR_INVALID, "The points in each dimension must be strictly ascending or descending (and >= 2)");
@@ -1080,10 +1090,10 @@ int rdr_interp3(rdr_ctx* c, const rdr_cube* q, const double* pts, int64_t n, dou
         KTimer t(c, 2);
         if (q->dtype == RDR_F32)
             hipLaunchKernelGGL((interp_points_kernel<float2>), dim3(g), dim3(256), axes_smem(q), c->stream, make_view<float2>(q),
-                               (const double*)dp, n, (double*)dw, (double*)dh);
+                               (const double*)dp, n, (double*)dw, (double*)dh, (int)axes_fit_lds(q));
         else
             hipLaunchKernelGGL((interp_points_kernel<double2>), dim3(g), dim3(256), axes_smem(q), c->stream, make_view<double2>(q),
-                               (const double*)dp, n, (double*)dw, (double*)dh);
+                               (const double*)dp, n, (double*)dw, (double*)dh, (int)axes_fit_lds(q));
     }
     HIPCHECK(c, hipGetLastError());
     rc = finish_out(c, wet, dw, (size_t)n * 8, loc); if (rc) return rc;
@@ -1109,10 +1119,10 @@ int rdr_build_cube(rdr_ctx* c, const rdr_cube* q, const double* xpts, int64_t nx
         KTimer t(c, 2);
         if (q->dtype == RDR_F32)
             hipLaunchKernelGGL((build_cube_kernel<float2>), dim3(g), dim3(256), axes_smem(q), c->stream, make_view<float2>(q), q->proj,
-                               (const double*)dx, nx, (const double*)dy, ny, (const double*)dz, nz, (double*)dw, (double*)dh);
+                               (const double*)dx, nx, (const double*)dy, ny, (const double*)dz, nz, (double*)dw, (double*)dh, (int)axes_fit_lds(q));
         else
             hipLaunchKernelGGL((build_cube_kernel<double2>), dim3(g), dim3(256), axes_smem(q), c->stream, make_view<double2>(q), q->proj,
-                               (const double*)dx, nx, (const double*)dy, ny, (const double*)dz, nz, (double*)dw, (double*)dh);
+                               (const double*)dx, nx, (const double*)dy, ny, (const double*)dz, nz, (double*)dw, (double*)dh, (int)axes_fit_lds(q));
     }
     HIPCHECK(c, hipGetLastError());
     rc = finish_out(c, wet, dw, (size_t)n * 8, loc); if (rc) return rc;
@@ -1226,7 +1236,7 @@ static int stage_rays(rdr_ctx* c, const rdr_rays* r, RayParams& P) {
 }
 
 static size_t ray_smem(const rdr_cube* q) {
-    return ray_smem_bytes(q->ny, q->nx, q->nz);
+    return ray_smem_bytes(q->ny, q->nx, q->nz, q->exact[0], q->exact[1]);
 }
 
 // Persistent grid of `per_cu` workgroups per CU; tiles are handed out dynamically (TileWalk: one device atomic per tile and

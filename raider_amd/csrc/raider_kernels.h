@@ -111,6 +111,9 @@ __device__ __forceinline__ void trilinear(const CubeView<T2>& c, const double* s
     wet = sw; hyd = sh;
 }
 
+// LDS-resident axis tables of the ray kernels: (g[i], 1/(g[i+1]-g[i])) pairs per axis; ey / ex are null for exact axes
+struct AxisTabs { const double2* ey; const double2* ex; const double2* ez; };
+
 // ---- ray-kernel sampler ----------------------------------------------------------------------------------------
 // Same scipy semantics as trilinear<> (interval g[i] <= v < g[i+1], last cell closed; outside / NaN -> NaN).
 // The axis table is stored in LDS as (g[i], 1/(g[i+1]-g[i])) pairs.  x / y: arithmetic cell on exactly-uniform axes,
@@ -166,14 +169,22 @@ __device__ __forceinline__ void window2_cell(const double2* e, int n, double v, 
 // IDX (light rays on an exact axis): v already IS the index-space coordinate (v_real - g0) * inv_d - pass 1 folds that map
 // into the ray polynomial's coefficients.
 template <bool IDX = false>
-__device__ __forceinline__ void cell_xy(const double2* e, int n, double v, double g0, double inv_d, bool exact, bool trust, int& i, double& t) {
+__device__ __forceinline__ void cell_xy(const double2* e, int n, double v, double g0, double g_last, double inv_d, bool exact, bool trust,
+                                        int& i, double& t) {
     bool ok;
     const double tf = (IDX && exact) ? v : (v - g0) * inv_d;
     if (exact) {
         i = (int)tf;                                                            // = floor for the tf >= 0 this path accepts
         t = __builtin_amdgcn_fract(tf);
         ok = (tf >= 0.0) & (tf < (double)(n - 1));
-        if (IDX && !ok) v = fma(tf, 1.0 / inv_d, g0);                           // rare: back to the axis's own units
+        if (__builtin_expect(!ok, 0)) {                                         // rare: the last node, outside the axis, NaN
+            asm volatile("" ::: "memory");                                      // keep this a skipped branch, not if-converted selects
+            const double vr = IDX ? fma(tf, 1.0 / inv_d, g0) : v;               // (back to the axis's own units)
+            const bool inside = (vr >= g0) & (vr <= g_last);
+            i = inside ? n - 2 : 0;
+            t = inside ? tf - (double)(n - 2) : qnan();
+        }
+        return;
     } else {
         i = min(max((int)tf, 0), n - 2);
         const double2 e0 = e[i];
@@ -187,7 +198,6 @@ __device__ __forceinline__ void cell_xy(const double2* e, int n, double v, doubl
 // One trilinear sample in two halves, so that several samples' gathers can be in flight together:
 //   sample_issue : cell search on the three axes, address, the four 16-byte (32-byte for f64 cubes) corner-pair loads
 //   sample_finish: weights, f32->f64 conversion, the 16 FMAs                    (weights/corner order: _rgi.py:490-498)
-// tab2 = (g, 1/dg) pairs of [ys | xs | zs] in LDS.
 template <typename T2>
 struct PendingSample {
     T2 v[8];              // corners in (y,x,z) lexicographic order
@@ -196,12 +206,12 @@ struct PendingSample {
 
 // LIGHT: called from the light march loop (index-space x / y on exact axes, two-entry z window).
 template <typename T2, bool LIGHT = false>
-__device__ __forceinline__ void sample_issue(const CubeView<T2>& c, const double2* tab2, double y, double x, double z, int kz,
+__device__ __forceinline__ void sample_issue(const CubeView<T2>& c, const AxisTabs& m, double y, double x, double z, int kz,
                                              PendingSample<T2>& s) {
-    const double2* ey = tab2; const double2* ex = tab2 + c.ny; const double2* ez = ex + c.nx;
+    const double2* ez = m.ez;
     int iy, ix, iz;
-    cell_xy<LIGHT>(ey, c.ny, y, c.y_lo, c.inv_dy, c.exact_y, c.uni_y, iy, s.ty);
-    cell_xy<LIGHT>(ex, c.nx, x, c.x_lo, c.inv_dx, c.exact_x, c.uni_x, ix, s.tx);
+    cell_xy<LIGHT>(m.ey, c.ny, y, c.y_lo, c.y_hi, c.inv_dy, c.exact_y, c.uni_y, iy, s.ty);
+    cell_xy<LIGHT>(m.ex, c.nx, x, c.x_lo, c.x_hi, c.inv_dx, c.exact_x, c.uni_x, ix, s.tx);
     if (LIGHT) window2_cell(ez, c.nz, z, kz, c.nz >= 4, iz, s.tz);
     else window_cell(ez, c.nz, z, kz, c.nz >= 4, iz, s.tz);
     const T2 *p00, *p01, *p10, *p11;
@@ -242,10 +252,10 @@ __device__ __forceinline__ void sample_finish(const PendingSample<T2>& s, double
 }
 
 template <typename T2>
-__device__ __forceinline__ void sample_cube(const CubeView<T2>& c, const double2* tab2, double y, double x, double z, int kz,
+__device__ __forceinline__ void sample_cube(const CubeView<T2>& c, const AxisTabs& m, double y, double x, double z, int kz,
                                             double& wet, double& hyd) {
     PendingSample<T2> s;
-    sample_issue(c, tab2, y, x, z, kz, s);
+    sample_issue(c, m, y, x, z, kz, s);
     sample_finish(s, wet, hyd);
 }
 
@@ -343,10 +353,12 @@ __device__ inline int build_levels(const double* zs, int nz, double ht, double z
     return min(K, MAX_LEVELS);
 }
 
-// Shared LDS layout of the two ray kernels.
+// Shared LDS layout of the two ray kernels.  Axis tables are (g[i], 1/(g[i+1]-g[i])) pairs; an x / y axis that is uniform to
+// round-off (CubeView::exact_*) needs no table at all (cell_xy works from g0 and the spacing), so the usual lat/lon or LCC grid
+// costs 16 B per z level only - a CONUS-sized HRRR grid (1059 x 1799 nodes) would otherwise take 69 KB per workgroup.
 struct RaySmem {
-    double* tab;            // [ys | xs | zs]
-    double2* tab2;          // the same axes as (g[i], 1/(g[i+1]-g[i])) pairs (pass 2 cell search)
+    AxisTabs ax;            // axis tables (ey / ex are null for exact axes)
+    double2* tab2;          // backing store of the tables
     double* lo; double* hi; // level table
     unsigned long long* mxcol; // [nz][MXCOLS] per-level running maxima of the workgroup, one column per lane%MXCOLS (pass 1)
     double* step;           // [nz] 1/(nParts-1) (pass 2)
@@ -355,12 +367,17 @@ struct RaySmem {
     int* kz; int* np; int* K;
 };
 constexpr int MXCOLS = 16;
-__device__ __forceinline__ RaySmem carve_smem(unsigned char* raw, int ny, int nx, int nz) {
+__host__ __device__ inline int64_t table_nodes(int64_t ny, int64_t nx, int64_t nz, int exact_y, int exact_x) {
+    return (exact_y ? 0 : ny) + (exact_x ? 0 : nx) + nz;
+}
+__device__ __forceinline__ RaySmem carve_smem(unsigned char* raw, int ny, int nx, int nz, int exact_y, int exact_x) {
     RaySmem m;
-    const int na = ny + nx + nz;
+    const int nyt = exact_y ? 0 : ny, nxt = exact_x ? 0 : nx;
     m.tab2 = reinterpret_cast<double2*>(raw);                 // 16-byte aligned for ds_read_b128
-    m.tab = reinterpret_cast<double*>(m.tab2 + na);
-    m.lo = m.tab + na;
+    m.ax.ey = exact_y ? nullptr : m.tab2;
+    m.ax.ex = exact_x ? nullptr : m.tab2 + nyt;
+    m.ax.ez = m.tab2 + nyt + nxt;
+    m.lo = reinterpret_cast<double*>(m.tab2 + nyt + nxt + nz);
     m.hi = m.lo + nz;
     m.mxcol = reinterpret_cast<unsigned long long*>(m.hi + nz);
     m.step = reinterpret_cast<double*>(m.mxcol + (size_t)nz * MXCOLS);
@@ -373,9 +390,8 @@ __device__ __forceinline__ RaySmem carve_smem(unsigned char* raw, int ny, int nx
 }
 
 // bytes carve_smem lays out (the launch's dynamic LDS size) - keep the two in step
-inline size_t ray_smem_bytes(int64_t ny, int64_t nx, int64_t nz) {
-    const size_t na = (size_t)(ny + nx + nz);
-    return na * 16 + na * 8                       // tab2, tab
+inline size_t ray_smem_bytes(int64_t ny, int64_t nx, int64_t nz, int exact_y, int exact_x) {
+    return (size_t)table_nodes(ny, nx, nz, exact_y, exact_x) * 16     // axis tables
            + (size_t)nz * 8 * 2                   // lo, hi
            + (size_t)nz * 8 * MXCOLS              // mxcol
            + (size_t)nz * 8 * 2 + 64 * 8          // step, hs, trig
@@ -384,16 +400,17 @@ inline size_t ray_smem_bytes(int64_t ny, int64_t nx, int64_t nz) {
 
 template <typename T2>
 __device__ __forceinline__ int fill_tables(const CubeView<T2>& c, const RaySmem& m, double ht, double zref) {
-    const int na = c.ny + c.nx + c.nz;
     const int tid = threadIdx.x;
-    for (int i = tid; i < na; i += BLOCK) m.tab[i] = c.axes[i];
-    __syncthreads();
-    for (int i = tid; i < na; i += BLOCK) {
-        const bool last = (i == c.ny - 1) || (i == c.ny + c.nx - 1) || (i == na - 1);
-        double2 e; e.x = m.tab[i]; e.y = last ? 0.0 : 1.0 / (m.tab[i + 1] - m.tab[i]);
-        m.tab2[i] = e;
-    }
-    if (tid == 0) *m.K = build_levels(m.tab + c.ny + c.nx, c.nz, ht, zref, m.lo, m.hi, m.kz);
+    auto fill = [&](double2* dst, const double* g, int n) {
+        for (int i = tid; i < n; i += BLOCK) {
+            double2 e; e.x = g[i]; e.y = (i == n - 1) ? 0.0 : 1.0 / (g[i + 1] - g[i]);
+            dst[i] = e;
+        }
+    };
+    if (m.ax.ey) fill(const_cast<double2*>(m.ax.ey), c.axes, c.ny);
+    if (m.ax.ex) fill(const_cast<double2*>(m.ax.ex), c.axes + c.ny, c.nx);
+    fill(const_cast<double2*>(m.ax.ez), c.axes + c.ny + c.nx, c.nz);
+    if (tid == 0) *m.K = build_levels(c.axes + c.ny + c.nx, c.nz, ht, zref, m.lo, m.hi, m.kz);
     __syncthreads();
     return *m.K;
 }
@@ -427,7 +444,7 @@ template <typename T2, bool SLOW, bool LCC = false>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 : (LCC ? 2 : 4), SLOW ? 8 : (LCC ? 2 : 4)))) void crossings_kernel(CubeView<T2> c, RayParams P, LccParams proj) {
     if (SLOW && *P.nslow == 0) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const RaySmem m = carve_smem(smem_raw, c.ny, c.nx, c.nz);
+    const RaySmem m = carve_smem(smem_raw, c.ny, c.nx, c.nz, c.exact_y, c.exact_x);
     const int K = fill_tables(c, m, P.ht, P.zref);
     const int tid = threadIdx.x;
     const bool reduce = P.maxlen_bits != nullptr;
@@ -650,7 +667,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
     CubeView<T2> c = c_in;
     if (REGULAR) { c.exact_y = 1; c.exact_x = 1; c.small = 1; }
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const RaySmem m = carve_smem(smem_raw, c.ny, c.nx, c.nz);
+    const RaySmem m = carve_smem(smem_raw, c.ny, c.nx, c.nz, c.exact_y, c.exact_x);
     const int K = fill_tables(c, m, P.ht, P.zref);
     const int tid = threadIdx.x;
     if (tid == 0) m.K[1] = 0;
@@ -721,7 +738,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
             int kz = __builtin_amdgcn_readfirstlane(m.kz[0]);
             // the ray's very first sample is the BOTTOM of its segment: when that is a model node (origin at or below it), the
             // two-entry z window must start one interval lower
-            int kz_first_adj = __builtin_amdgcn_readfirstlane((m.lo[0] <= m.tab2[c.ny + c.nx + kz].x) ? 1 : 0);
+            int kz_first_adj = __builtin_amdgcn_readfirstlane((m.lo[0] <= m.ax.ez[kz].x) ? 1 : 0);
             int zbase = window2_base(c.nz, kz - kz_first_adj);                 // first table entry of the two-entry z window
             double step = m.step[0], hs = m.hs[0], hs1 = K > 1 ? m.hs[1] : 0.0;
             double u_k = w[(int64_t)WS_U0 * ns];
@@ -745,7 +762,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
                             const double zceil = (clamp_hi && k == K - 1 && last_j) ? c.z_hi : __builtin_huge_val();
                             ph = fmin(fmax(ph, zfloor), zceil);
                         }
-                        sample_issue<T2, true>(c, m.tab2, plat, plon, ph, zbase, pend[b]);   // delay.py:298,319
+                        sample_issue<T2, true>(c, m.ax, plat, plon, ph, zbase, pend[b]);   // delay.py:298,319
                         if (kz_first_adj) { kz_first_adj = 0; zbase = window2_base(c.nz, kz); }
                         // trapezoid weight per unit of u (delay.py:314-315), both segments for a shared sample
                         double wv = (((j == 0) | last_j) ? hs : 2.0 * hs) * du;
@@ -819,7 +836,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
                         ph = fmin(fmax(ph, zfloor), zceil);
                     }
                     double vw, vh;
-                    sample_cube(c, m.tab2, plat, plon, ph, kz, vw, vh);                   // delay.py:298,319
+                    sample_cube(c, m.ax, plat, plon, ph, kz, vw, vh);                   // delay.py:298,319
                     const double wt = ((j == 0) | (j == np - 1)) ? 0.5 * segw : segw;     // delay.py:314-315
                     acc_w = fma(wt, vw, acc_w); acc_h = fma(wt, vh, acc_h);               // delay.py:323
                     vw_top = vw; vh_top = vh;                                             // after the loop: value at j = np-1

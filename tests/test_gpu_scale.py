@@ -329,3 +329,32 @@ def test_device_resident_partition_exchange(R):
     local = cube.ray_march_device(halves[0], 0.0, zref, parts[0])
     torch.cuda.synchronize()
     assert not torch.equal(local[1], wh[:32])
+
+
+def test_continental_grid_axes(R):
+    """A CONUS-sized model grid (1059 x 1799 nodes - HRRR's lattice - x 12 levels): exactly-uniform axes need no LDS table in the
+    ray kernels (69 KB per workgroup otherwise) and exceed what the zenith kernels stage in LDS (they read them from global
+    memory then).  Ray tracing and the zenith gather against the oracle on a patch of it."""
+    ny, nx, nz = 1059, 1799, 12
+    ys = 21.0 + 0.03 * np.arange(ny); xs = -135.0 + 0.03 * np.arange(nx)
+    zs = np.round(-100 + 30000 * np.linspace(0, 1, nz) ** 2, 3)
+    rng = np.random.default_rng(2)
+    base = np.exp(-zs / 7000.0)[:, None, None]
+    bump = (1 + 0.02 * np.sin(ys / 3.0)[None, :, None] * np.cos(xs / 2.0)[None, None, :]).astype(np.float32)
+    hyd = (270.0 * base * bump).astype(np.float32); wet = (50.0 * np.exp(-zs / 2500.0)[:, None, None] * bump).astype(np.float32)
+    cube = R.Cube(ys, xs, zs, wet, hyd, order='zyx')
+    zref = float(zs.max() - 1)
+    xp = np.linspace(-101.0, -100.2, 13); yp = np.linspace(40.4, 39.9, 11)
+    w, h, nparts, _ = cube.raytrace(R.Rays.grid(xp, yp, inc=37.0, hd=-167.9), 300.0, zref)
+    sl_y = slice(600, 660); sl_x = slice(1100, 1180)                   # the patch the rays stay in
+    ip = list(O.getInterpolators(xs[sl_x], ys[sl_y], zs, wet[:, sl_y, sl_x], hyd[:, sl_y, sl_x]))
+    look = lambda ht_, llh, xyz, yy: O.look_vectors_from_inc_hd(np.full(yy.shape, 37.0), np.full(yy.shape, -167.9), llh[1], llh[0], llh[2])
+    (ow, oh), onp = O.build_cube_ray(xp, yp, np.array([300.0]), look, ip, MAX_TROPO_HEIGHT=zref, return_nparts=True)
+    assert np.array_equal(nparts, onp[0]) and np.isfinite(ow).all()
+    np.testing.assert_allclose(w, ow[0], rtol=0, atol=5e-9); np.testing.assert_allclose(h, oh[0], rtol=0, atol=5e-9)
+    gw, gh = cube.build_cube(xp, yp, np.array([0.0, 2500.0]))
+    cw, ch = O.build_cube(xp, yp, np.array([0.0, 2500.0]), ip)
+    np.testing.assert_allclose(gw, cw, rtol=0, atol=1e-12); np.testing.assert_allclose(gh, ch, rtol=0, atol=1e-12)
+    # points outside the grid are NaN on this path too
+    wo, ho, _, _ = cube.raytrace(R.Rays.grid(np.array([-136.0, -120.0]), np.array([30.0]), inc=20.0, hd=0.0), 0.0, zref)
+    assert np.isnan(wo[0, 0]) and np.isfinite(wo[0, 1])
