@@ -76,9 +76,9 @@ __device__ __forceinline__ GeoF geo_fast(double x, double y, double z) {
     return g;
 }
 
-// asin(s) for the small angles between a ray sample and the ray origin: odd series through s^7.  The static
-// classification admits only rays whose angular travel stays below 0.03 rad (190 km), where the truncation is
-// < 2e-13 rad (1e-6 m on the ground).
+// asin(s) for the small angles between a fit node and the ray origin: odd series through s^7.  The static classification
+// admits only rays that turn by less than 0.08 rad in longitude (0.035 rad in latitude), where the truncation (35/1152 s^9)
+// is < 4e-12 rad (2.5e-5 m on the ground at the far end of the longest admitted ray).
 __device__ __forceinline__ double asin_small(double s) {
     const double s2 = s * s;
     double q = fma(s2, 5.0 / 112.0, 3.0 / 40.0);
@@ -103,9 +103,9 @@ __device__ __forceinline__ RayBase make_base(double lat_deg, double lon_deg) {
 
 // ---- ray polynomials ------------------------------------------------------------------------------------------------
 // Along a straight ray o + t l the geodetic height, latitude and longitude are smooth functions of t: over the rays the
-// static classification admits (angular travel < 0.03 rad, away from the poles) their degree-5 interpolants at the 6
-// Chebyshev nodes of the ray's parameter range reproduce them to < 8e-8 m (h) and < 3e-7 m on the ground (lat, lon) in
-// the worst admitted case and to the fp64 noise floor (~4e-9 m) for rays shorter than 100 km
+// static classification admits (angular travel < 0.035 rad, < 0.08 rad of longitude, away from the poles) their degree-5
+// interpolants at the 6 Chebyshev nodes of the ray's parameter range reproduce them to < 3e-7 m (h) and < 2.2e-5 m on the
+// ground (lat, lon) in the worst admitted case, and to 5e-9 m / 5e-6 m for rays shorter than 100 km
 // (sweep: tools/ray_poly_probe.py).  The ray kernels therefore evaluate the full geodesy 6 times per ray and replace
 // every later evaluation (3 per model level in the Newton level crossings, 1 per integration sample) by 5 FMAs per
 // quantity.  u = su * t + ou maps the range to [-1, 1]; coefficients are monomial in u (well conditioned on [-1, 1]).

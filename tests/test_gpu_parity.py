@@ -190,7 +190,7 @@ def test_raytrace_domain_sweep(R, region):
         np.testing.assert_allclose(hyd, oh[0], rtol=0, atol=5 * TIGHT, equal_nan=True)
 
 
-@pytest.mark.parametrize('case', ['steep_80km', 'nonunit_los', 'jittered_axes', 'negative_ht'])
+@pytest.mark.parametrize('case', ['steep_80km', 'arctic_80km', 'nonunit_los', 'jittered_axes', 'negative_ht'])
 def test_ray_polynomial_stress(R, case):
     """Corner cases of the ray-polynomial kernels against the oracle: the longest rays the static classification admits
     (52-62 deg incidence through an 80 km cube: the classification cuts at ~60 deg there, so both the light and the
@@ -202,6 +202,10 @@ def test_ray_polynomial_stress(R, case):
         c = O.synthetic_cube(48, 80, 40, seed=3, ztop=80000.0, y0=20.0, y1=34.0, x0=-125.0, x1=-100.0)
         ypts = np.linspace(28.0, 26.5, 9); xpts = np.linspace(-114.0, -111.0, 11)
         inc = rng.uniform(52, 62, (9, 11)); hd = rng.uniform(-180, 180, (9, 11)); ht = 0.0
+    elif case == 'arctic_80km':       # a real-model-sized top (80 km) at 69-75 deg N: up to 0.07 rad of longitude travel on the light path
+        c = O.synthetic_cube(60, 90, 40, seed=8, ztop=80000.0, y0=64.0, y1=79.0, x0=-175.0, x1=-130.0)
+        ypts = np.linspace(75.0, 69.0, 10); xpts = np.linspace(-158.0, -150.0, 12)
+        inc = rng.uniform(25, 45, (10, 12)); hd = rng.uniform(-180, 180, (10, 12)); ht = 0.0
     else:
         c = O.synthetic_cube(40, 44, 36, seed=5, y0=30.0, y1=38.0, x0=-122.0, x1=-110.0)
         ypts = np.linspace(35.0, 33.0, 12); xpts = np.linspace(-117.5, -114.5, 14)

@@ -3,7 +3,7 @@
 (design probe for the ray-polynomial kernels, CPU only).  For random rays it interpolates the exact geodetic
 coordinates at the N+1 Chebyshev nodes of the ray's parameter range [min(0,ht)-1, max(zref,(zref-ht)/cos(inc))+1] and
 reports the worst interpolation error over the rays the kernels' static classification admits
-(cos(inc) > 0.05, cos(lat) > gam + 0.02, gam < 0.03 (cos(lat) - gam), gam = (zref-ht)/(6.3e6 cos(inc))).
+(cos(inc) > 0.05, cos(lat) > gam + 0.02, gam < 0.08 (cos(lat) - gam), gam < 0.035, gam = (zref-ht)/(6.3e6 cos(inc))).
 usage: ray_poly_probe.py [degree=5] [nrays=3000]"""
 import sys
 from pathlib import Path
@@ -60,7 +60,7 @@ def main():
         rows.append((gam, c0, cosi, tb, eh, ep, el))
     r = np.array(rows)
     gam, c0, cosi, tb, eh, ep, el = r.T
-    ok = (cosi > 0.05) & (c0 > gam + 0.02) & (gam < 0.03 * (c0 - gam))
+    ok = (cosi > 0.05) & (c0 > gam + 0.02) & (gam < 0.08 * (c0 - gam)) & (gam < 0.035)
     print(f'degree {deg}: {ok.sum()} of {nrays} rays admitted by the classification')
     for lim in (100e3, 1e9):
         m = ok & (tb < lim)
