@@ -523,16 +523,30 @@ def g13():
     lats = np.array([float(r['Lat']) for r in rows]); lons = np.array([float(r['Lon']) for r in rows]); hgts = np.array([float(r['Hgt_m']) for r in rows])
     from RAiDER.utilFcns import clip_bbox
     ll_res = 0.25                                                 # ERA-5 getLLRes() (models/ecmwf.py:32-33)
-    S, N, W, E = lats.min(), lats.max(), lons.min(), lons.max()   # llreader.bounds_from_csv
-    buf = 1.5 * ll_res                                            # AOI.add_buffer (llreader.py:91-128)
-    S, N, W, E = clip_bbox([max(S - buf, -90), min(N + buf, 90), W - buf, E + buf], ll_res)
-    S, N, W, E = (np.round(a, 2) for a in (S, N, W, E))
-    xa = np.arange(W, E + ll_res, ll_res); ya = np.arange(N, S - ll_res, -ll_res)     # AOI.set_output_xygrid (llreader.py:177-192)
+    from RAiDER.constants import _CUBE_SPACING_IN_M
+    spacing = _CUBE_SPACING_IN_M / 1e5                            # AOI.set_output_spacing: the default runtime_group.cube_spacing_in_m (cli/types.py:173)
+
+    def aoi_grid(S, N, W, E):                                     # AOI.add_buffer + set_output_xygrid (llreader.py:91-128,177-192; cli/raider.py:257-260)
+        buf = 1.5 * ll_res
+        S, N, W, E = clip_bbox([max(S - buf, -90), min(N + buf, 90), W - buf, E + buf], spacing)
+        S, N, W, E = (np.round(a, 2) for a in (S, N, W, E))
+        return np.arange(W, E + spacing, spacing), np.arange(N, S - spacing, -spacing)
+    xa, ya = aoi_grid(lats.min(), lats.max(), lons.min(), lons.max())   # llreader.bounds_from_csv
     xm = f['x'].read().astype(np.float64); ym = f['y'].read().astype(np.float64)[::-1]
     when = dt.datetime(2020, 1, 30, 13, 52, 45)
     wa, ha = rdelay.tropo_delay(when, str(path), _Stations(lats, lons, hgts, xa, ya), rlos.Zenith(), None, 4326, None)
     wm_, hm_ = rdelay.tropo_delay(when, str(path), _Stations(lats, lons, hgts, xm, ym), rlos.Zenith(), None, 4326, None)
     print('  TORP total: AOI grid', wa[1] + ha[1], ' model grid', wm_[1] + hm_[1], ' (test_intersect.py gold 2.34514)')
+    # (b2) test/test_slant.py::test_slant_proj: bounding box [33, 34, -118.25, -116.75], heights 0/100/500/1000, a PROJECTED LOS on a
+    #      cube AOI (= zenith delays); the test reads the node nearest (33.4, -117.8, 0) and expects 2.333865144 (7 decimals)
+    import RAiDER.llreader as rll_
+    bb = rll_.BoundingBox([33, 34, -118.25, -116.75])
+    bb.xpts, bb.ypts = aoi_grid(33, 34, -118.25, -116.75)
+    dsp, _ = rdelay.tropo_delay(when, str(path), bb, rlos.Conventional('orbit_file_never_opened_for_a_cube_aoi.EOF'), [0, 100, 500, 1000], 4326, None)
+    getv = lambda d, k: np.asarray(d[k].values if hasattr(d[k], 'values') else d[k][:])
+    wp, hp = getv(dsp, 'wet'), getv(dsp, 'hydro')
+    iy, ix = np.abs(bb.ypts - 33.4).argmin(), np.abs(bb.xpts + 117.8).argmin()
+    print('  test_slant_proj node', bb.ypts[iy], bb.xpts[ix], 'total', wp[0, iy, ix] + hp[0, iy, ix], '(gold 2.333865144)')
     # (c) the reference's ray tracer (_build_cube_ray, delay.py:219-326) through the same real 145-level cube: cube AOI,
     #     per-pixel incidence 30..44 deg, heading -167.9 deg (duck LOS: look vectors from the reference's own inc_hd_to_enu + enu2ecef)
     class _RayLOS(ArrayLOS):
@@ -552,7 +566,7 @@ def g13():
     wr = np.asarray(dsr['wet'][:] if not hasattr(dsr['wet'], 'values') else dsr['wet'].values)
     hr = np.asarray(dsr['hydro'][:] if not hasattr(dsr['hydro'], 'values') else dsr['hydro'].values)
     print('  ray-traced cube', wr.shape, 'hydro mean', float(np.nanmean(hr)), 'NaNs', int(np.isnan(hr).sum()))
-    save('g13_gnss_intersect', x_ray=xr_, y_ray=yr_, inc_ray=inc, z_ray=np.array(zl), wet_ray=wr, hydro_ray=hr, ids=np.array([r['ID'] for r in rows]), lats=lats, lons=lons, hgts=hgts, x_aoi=xa, y_aoi=ya, x_model=xm, y_model=ym,
+    save('g13_gnss_intersect', x_proj=bb.xpts, y_proj=bb.ypts, wet_proj=wp, hydro_proj=hp, x_ray=xr_, y_ray=yr_, inc_ray=inc, z_ray=np.array(zl), wet_ray=wr, hydro_ray=hr, ids=np.array([r['ID'] for r in rows]), lats=lats, lons=lons, hgts=hgts, x_aoi=xa, y_aoi=ya, x_model=xm, y_model=ym,
          wet_aoi=wa, hydro_aoi=ha, wet_model=wm_, hydro_model=hm_)
 
 

@@ -130,28 +130,29 @@ def test_gpu_blend_and_tropo_delay_from_netcdf4(golden):
     np.testing.assert_allclose(np.asarray(ds['hydro'][:]), rh, rtol=0, atol=5e-9)
 
 
-def _station_aoi_grid(lats, lons, ll_res=0.25, digits=2):
-    """llreader.py:91-128,177-192 for a station file: bounds from the stations, AOI.add_buffer(model.getLLRes()) (1.5 cells,
-    clipped outwards to multiples of the spacing, cli/raider.py:257) and set_output_xygrid(4326)."""
-    S, N, W, E = lats.min(), lats.max(), lons.min(), lons.max()
+def _aoi_grid(S, N, W, E, ll_res=0.25, cube_spacing_in_m=2000.0, digits=2):
+    """The output grid calcDelays builds (cli/raider.py:257-260): AOI.add_buffer(model.getLLRes()) = 1.5 model cells, clipped
+    outwards to multiples of the OUTPUT spacing (the default runtime_group.cube_spacing_in_m = 2000 m -> 0.02 deg,
+    constants.py:22, llreader.py:76-89), rounded to 2 digits; then AOI.set_output_xygrid(4326) (llreader.py:177-192)."""
+    sp = cube_spacing_in_m / 1e5
     buf = 1.5 * ll_res
     S, N, W, E = max(S - buf, -90), min(N + buf, 90), W - buf, E + buf
-    S, N, W, E = (np.floor(S / ll_res) * ll_res, np.ceil(N / ll_res) * ll_res, np.floor(W / ll_res) * ll_res, np.ceil(E / ll_res) * ll_res)
+    S, N, W, E = (np.floor(S / sp) * sp, np.ceil(N / sp) * sp, np.floor(W / sp) * sp, np.ceil(E / sp) * sp)
     S, N, W, E = (np.round(a, digits) for a in (S, N, W, E))
-    return np.arange(W, E + ll_res, ll_res), np.arange(N, S - ll_res, -ll_res)
+    return np.arange(W, E + sp, sp), np.arange(N, S - sp, -sp)
+
+
+REF_CUBE_0130 = Path(__file__).parent / 'golden' / 'ref_files' / 'ERA-5_2020_01_30_T13_52_45_32N_35N_120W_115W.nc'
+WHEN_0130 = dt.datetime(2020, 1, 30, 13, 52, 45)
 
 
 @pytest.mark.gpu
 def test_reference_gnss_intersect_end_to_end(golden):
-    """END TO END on the inputs of the reference's test/test_intersect.py::test_gnss_intersect: the processed ERA-5 cube of
-    2020-01-30T13:52:45 (NetCDF-4, read by h5lite) and scenario_6/stations.csv, zenith delays through tropo_delay.
-      * golden g13 = the reference's own unmodified tropo_delay run on that very file in the build container, with the
-        output grid calcDelays builds for the station file and with the model's own grid: the GPU path must reproduce both
-        (observed: bit-identical);
-      * the reference's test expects a total of 2.34514 m (4 decimals) at station TORP.  That number is what the path gives
-        when the output grid coincides with the weather-model lattice (2.345132 - as for a cube downloaded on the 0.25 deg
-        lattice in the reference's CI); with the cube file the repository actually holds (lattice offset by 0.1 deg) the
-        reference's own code gives 2.346170, and so do we."""
+    """END TO END against the reference's own test suite: test/test_intersect.py::test_gnss_intersect runs `raider.py` on the
+    processed ERA-5 cube of 2020-01-30T13:52:45 for scenario_6/stations.csv and expects a total zenith delay of 2.34514 m
+    (4 decimals) at station TORP.  Same cube file (NetCDF-4, read by h5lite), same stations, same AOI buffering / output grid,
+    tropo_delay on the GPU - and golden g13 = what the reference's own, unmodified tropo_delay returns for these inputs in the
+    build container (to 1e-14 m)."""
     import csv
     from raider_amd.delay import PointsAOI, tropo_delay
     from raider_amd.losreader import Zenith
@@ -160,16 +161,33 @@ def test_reference_gnss_intersect_end_to_end(golden):
         rows = list(csv.DictReader(fh))
     lats = np.array([float(r['Lat']) for r in rows]); lons = np.array([float(r['Lon']) for r in rows]); hgts = np.array([float(r['Hgt_m']) for r in rows])
     assert np.array_equal(lats, g['lats']) and [r['ID'] for r in rows] == list(g['ids'])
-    xa, ya = _station_aoi_grid(lats, lons)                    # ERA-5: getLLRes() = 0.25 (models/ecmwf.py:32-33)
+    xa, ya = _aoi_grid(lats.min(), lats.max(), lons.min(), lons.max())      # llreader.bounds_from_csv; ERA-5 getLLRes() = 0.25
     assert np.array_equal(xa, g['x_aoi']) and np.array_equal(ya, g['y_aoi'])
-    cube = Path(__file__).parent / 'golden' / 'ref_files' / 'ERA-5_2020_01_30_T13_52_45_32N_35N_120W_115W.nc'
-    when = dt.datetime(2020, 1, 30, 13, 52, 45)
-    wet, hyd = tropo_delay(when, str(cube), PointsAOI(lats, lons, hgts, xa, ya), Zenith(), height_levels=None, out_proj=4326, zref=None)
+    wet, hyd = tropo_delay(WHEN_0130, str(REF_CUBE_0130), PointsAOI(lats, lons, hgts, xa, ya), Zenith(), height_levels=None, out_proj=4326, zref=None)
     np.testing.assert_allclose(wet, g['wet_aoi'], rtol=0, atol=1e-14); np.testing.assert_allclose(hyd, g['hydro_aoi'], rtol=0, atol=1e-14)
-    wet_m, hyd_m = tropo_delay(when, str(cube), PointsAOI(lats, lons, hgts, g['x_model'], g['y_model']), Zenith())
-    np.testing.assert_allclose(wet_m, g['wet_model'], rtol=0, atol=1e-14); np.testing.assert_allclose(hyd_m, g['hydro_model'], rtol=0, atol=1e-14)
     torp = list(g['ids']).index('TORP')
-    np.testing.assert_almost_equal(wet_m[torp] + hyd_m[torp], 2.34514, decimal=4)      # test/test_intersect.py:106,113
+    np.testing.assert_almost_equal(wet[torp] + hyd[torp], 2.34514, decimal=4)          # test/test_intersect.py:106,113
+    wet_m, hyd_m = tropo_delay(WHEN_0130, str(REF_CUBE_0130), PointsAOI(lats, lons, hgts, g['x_model'], g['y_model']), Zenith())
+    np.testing.assert_allclose(wet_m, g['wet_model'], rtol=0, atol=1e-14); np.testing.assert_allclose(hyd_m, g['hydro_model'], rtol=0, atol=1e-14)
+
+
+@pytest.mark.gpu
+def test_reference_slant_proj_end_to_end(golden):
+    """test/test_slant.py::test_slant_proj: bounding box [33, 34, -118.25, -116.75], heights 0/100/500/1000 m, `ray_trace: False`
+    with an orbit file - i.e. a PROJECTED line of sight on a cube AOI, which the reference turns into zenith delays (SURVEY
+    0.8) - on the same ERA-5 cube; the test reads the node nearest (33.4, -117.8, 0) and expects 2.333865144 m to 7 decimals."""
+    from raider_amd.delay import GridAOI, tropo_delay
+    from raider_amd.losreader import Conventional
+    g = golden('g13_gnss_intersect')
+    xp, yp = _aoi_grid(33, 34, -118.25, -116.75)
+    assert np.array_equal(xp, g['x_proj']) and np.array_equal(yp, g['y_proj'])
+    ds, none = tropo_delay(WHEN_0130, str(REF_CUBE_0130), GridAOI(xp, yp), Conventional('orbit_file_never_opened_for_a_cube_aoi.EOF'),
+                           [0, 100, 500, 1000], 4326, None)
+    assert none is None
+    wet, hyd = np.asarray(ds['wet'][:]), np.asarray(ds['hydro'][:])
+    np.testing.assert_allclose(wet, g['wet_proj'], rtol=0, atol=1e-14); np.testing.assert_allclose(hyd, g['hydro_proj'], rtol=0, atol=1e-14)
+    iy, ix = np.abs(yp - 33.4).argmin(), np.abs(xp + 117.8).argmin()
+    np.testing.assert_almost_equal(2.333865144, wet[0, iy, ix] + hyd[0, iy, ix])       # test/test_slant.py:49,57 (decimal=7)
 
 
 @pytest.mark.gpu
