@@ -139,3 +139,4 @@ def test_processed_model_is_a_weather_model_for_tropo_delay():
         assert np.array_equal(np.asarray(a['wet'][:]), np.asarray(b['wet'][:]))
         assert np.array_equal(np.asarray(a['hydro'][:]), np.asarray(b['hydro'][:]))
         assert np.isfinite(np.asarray(a['hydro'][:])).all()
+

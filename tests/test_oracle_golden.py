@@ -275,3 +275,46 @@ def test_g11_azimuth_time_weighting(golden):
         O.inverse_time_weights(np.zeros(3), [1.0, 1.0])
     comb = O.combine_weighted(list(g['w3b_weights']), list(g['comb_fields']))
     assert comb.dtype == np.float64 and np.array_equal(comb, g['comb_out'])
+
+
+def test_uniform_in_z_known_answer():
+    """test/test_weather_model.py::test_uniform_in_z_small replayed on the oracle's restatement of _uniform_in_z
+    (weatherModel.py:603-629): uneven per-column heights averaging to [1, 2]; a query ON a column's lowest node returns the
+    value, ON its top node the NaN fill (the native interpolate_along_axis edge rule)."""
+    nan = np.nan
+    zs = np.array([[[1., 2.], [0.9, 1.1]], [[1., 2.6], [1.1, 2.3]]])
+    p = np.arange(8, dtype=np.float64).reshape(2, 2, 2)
+    new_z = np.nanmean(zs, axis=(0, 1))
+    np.testing.assert_allclose(new_z, [1.0, 2.0], rtol=0, atol=1e-15)
+    r = O.cube_from_model_levels(zs, p, p * 2, np.zeros_like(p), 'q', new_z, zmin=1.0)
+    want = np.array([[[0, nan], [2.5, nan]], [[4., 4.625], [nan, 6.75]]])
+    assert np.allclose(r['p_u'], want, equal_nan=True, rtol=0)
+    assert np.allclose(r['t_u'], want * 2, equal_nan=True, rtol=0)
+
+
+def _mock_model():
+    """test/test_weather_model.py:96-136 MockWeatherModel.load_weather (k1 = k2 = k3 = 1)"""
+    nz = 32
+    ys = np.arange(-2, 3) + 0.0; xs = np.arange(-3, 4) + 0.0
+    zs = np.linspace(0, 1e5, nz)
+    t = np.ones((ys.size, xs.size, nz)); e = t.copy(); e[:, 3:, :] = 2
+    pl = np.arange(31, -1, -1).astype(np.float64)
+    p = np.broadcast_to(pl, t.shape).copy()
+    true_wet_ztd = 1e-6 * 2 * np.broadcast_to(np.flip(zs), t.shape).copy(); true_wet_ztd[:, 3:] *= 2
+    true_hydro_ztd = np.zeros(t.shape)
+    for layer in range(nz):
+        true_hydro_ztd[:, :, layer] = 1e-6 * 0.5 * (zs[-1] - zs[layer]) * pl[layer]
+    true_wet_refr = 2 * np.ones(t.shape); true_wet_refr[:, 3:] = 4
+    return dict(ys=ys, xs=xs, zs=zs, t=t, e=e, p=p, wet_refr=true_wet_refr, hydro_refr=p.copy(), wet_ztd=true_wet_ztd, hydro_ztd=true_hydro_ztd)
+
+
+def test_reference_known_answers_find_svp_and_ztd():
+    """test/test_weather_model.py::test_find_svp (10 tabulated saturation pressures) and ::test_ztd (MockWeatherModel with
+    closed-form refractivities and ZTDs) replayed on the oracle's restatements."""
+    svp_true = np.array([611.21, 1227.5981, 2337.2825, 4243.5093, 7384.1753, 12369.2295, 20021.443, 31419.297, 47940.574, 71305.16])
+    assert np.allclose(O.find_svp(np.arange(0, 100, 10) + 273.15), svp_true)
+    m = _mock_model()
+    wet = 1 * m['e'] / m['t'] + 1 * m['e'] / m['t'] ** 2                          # weatherModel.py:355-357 with k2 = k3 = 1
+    hyd = 1 * m['p'] / m['t']
+    assert np.allclose(wet, m['wet_refr']) and np.allclose(hyd, m['hydro_refr'])
+    assert np.allclose(O.ztd_totals(wet, m['zs']), m['wet_ztd']) and np.allclose(O.ztd_totals(hyd, m['zs']), m['hydro_ztd'])
