@@ -182,6 +182,7 @@ def main():
             'roofline': {'bound': 'hbm', 'kernel': 'march_kernel<float2,false,true>', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': PMC_TRAFFIC_BYTES.get((rows, cols, args.cube)) if world == 1 else None,
                          'traffic_unit': 'bytes per march_kernel launch (PMC, profiles/r01_v8_hbm_traffic_pmc.txt)',
+                         'traffic_GBps': (PMC_TRAFFIC_BYTES[(rows, cols, args.cube)] / (march_ms * 1e-3) / 1e9) if (world == 1 and (rows, cols, args.cube) in PMC_TRAFFIC_BYTES) else None,
                          'algorithmic_bytes_per_ray': bytes_per_ray, 'compulsory_bytes_per_ray': 64 + (ny * nx * nz * 8) / n_rays,
                          'march_ms_per_step': march_ms, 'crossings_ms_per_step': pre_ms, 'march_launches_timed': n_march,
                          'note': 'achieved = (64*S+64) B/ray (SURVEY 8d gather model, S = reference samples/ray) x rays / march_kernel time; '
