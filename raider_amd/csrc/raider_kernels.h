@@ -664,7 +664,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
 // REGULAR (light kernel only): both horizontal axes are exactly uniform and the cube allows 32-bit offsets (the usual
 // lat/lon or LCC model grid) - known at compile time, so the per-sample code carries no trace of the other variants.
 template <typename T2, bool SLOW, bool REGULAR = false>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 : 3, SLOW ? 8 : 3))) void march_kernel(CubeView<T2> c_in, RayParams P, LccParams proj) {
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 : 4, SLOW ? 8 : 4))) void march_kernel(CubeView<T2> c_in, RayParams P, LccParams proj) {
     if (SLOW && *P.nslow == 0) return;
     CubeView<T2> c = c_in;
     if (REGULAR) { c.exact_y = 1; c.exact_x = 1; c.small = 1; }
@@ -722,7 +722,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
             // in scalar registers.  A sample shared by two segments (top of k = bottom of k+1, losreader.py:811-812) is
             // evaluated once and carries both trapezoid end weights.  Each batch first issues the gathers of all its
             // samples, then finishes them: BATCH x 4 loads are in flight per lane instead of 4.
-            constexpr int BATCH = sizeof(T2) == 8 ? 3 : 2;
+            constexpr int BATCH = 1;
             RayPoly q;
 #pragma unroll
             for (int n = 0; n < PN; ++n) {
