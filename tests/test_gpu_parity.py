@@ -190,7 +190,7 @@ def test_raytrace_domain_sweep(R, region):
         np.testing.assert_allclose(hyd, oh[0], rtol=0, atol=5 * TIGHT, equal_nan=True)
 
 
-@pytest.mark.parametrize('case', ['steep_80km', 'arctic_80km', 'nonunit_los', 'jittered_axes', 'negative_ht'])
+@pytest.mark.parametrize('case', ['steep_80km', 'arctic_80km', 'nonunit_los', 'jittered_axes', 'mixed_axes', 'negative_ht'])
 def test_ray_polynomial_stress(R, case):
     """Corner cases of the ray-polynomial kernels against the oracle: the longest rays the static classification admits
     (52-62 deg incidence through an 80 km cube: the classification cuts at ~60 deg there, so both the light and the
@@ -212,6 +212,8 @@ def test_ray_polynomial_stress(R, case):
         inc = rng.uniform(10, 50, (12, 14)); hd = rng.uniform(-180, 180, (12, 14)); ht = -60.0 if case == 'negative_ht' else 250.0
     if case == 'jittered_axes':
         c['xs'] = c['xs'] + 1e-7 * rng.uniform(-1, 1, c['xs'].size)
+        c['ys'] = c['ys'] + 1e-7 * rng.uniform(-1, 1, c['ys'].size)
+    if case == 'mixed_axes':          # x exactly uniform (index-space polynomial), y only nearly (LDS table): both in one kernel
         c['ys'] = c['ys'] + 1e-7 * rng.uniform(-1, 1, c['ys'].size)
     zref = float(c['zs'].max() - 1)
     cube = R.Cube(c['ys'], c['xs'], c['zs'], c['wet'], c['hydro'], order='zyx')
