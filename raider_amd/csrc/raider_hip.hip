@@ -30,6 +30,7 @@ enum { SLOT_IN0 = 0, SLOT_IN1, SLOT_IN2, SLOT_IN3, SLOT_IN4, SLOT_IN5, SLOT_OUT0
 struct rdr_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
+    hipStream_t copy_stream = nullptr;      // host<->device transfers of the pipelined host-buffer ray tracing
     hipStream_t stream = nullptr;
     int num_cus = 256;
     size_t total_mem = 0;
@@ -721,6 +722,7 @@ int rdr_create(int device, rdr_ctx** out) {
     c->name = prop.name;
     if (c->name.empty()) c->name = std::string("AMD ") + prop.gcnArchName;   // amdgpu.ids may be absent on the box
     HIPCHECK(nullptr, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    HIPCHECK(nullptr, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
     HIPCHECK(nullptr, hipMalloc((void**)&c->d_maxlen, MAX_LEVELS * sizeof(unsigned long long)));
     HIPCHECK(nullptr, hipMalloc((void**)&c->d_flags, sizeof(int)));
@@ -746,6 +748,7 @@ void rdr_destroy(rdr_ctx* c) {
     if (c->ws.p) (void)hipFree(c->ws.p);
     for (auto& v : c->evs) for (auto& pr : v) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     delete c;
 }
 
@@ -1291,10 +1294,12 @@ static bool wsig_match(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, double 
 }
 
 // pass 1 over tiles [tb, tb+tc): optional reduction (P.maxlen_bits != null) and/or record store (P.ws != null)
-static int launch_crossings(rdr_ctx* c, const rdr_cube* q, RayParams P, int64_t tb, int64_t tc) {
-    P.tile_begin = tb; P.tile_count = tc; P.nslots = tc * BLOCK;
+// nslots_total > 0: the launch is one chunk of a larger record buffer (field stride nslots_total, P.ws already offset to the
+// chunk's first slot) and the slow-ray count accumulates over the chunks (reset_nslow only for the first one).
+static int launch_crossings(rdr_ctx* c, const rdr_cube* q, RayParams P, int64_t tb, int64_t tc, int64_t nslots_total = 0, bool reset_nslow = true) {
+    P.tile_begin = tb; P.tile_count = tc; P.nslots = nslots_total > 0 ? nslots_total : tc * BLOCK;
     const int g = ray_grid(c, tc, 8);
-    HIPCHECK(c, hipMemsetAsync(c->d_nslow, 0, sizeof(int), c->stream));
+    if (reset_nslow) HIPCHECK(c, hipMemsetAsync(c->d_nslow, 0, sizeof(int), c->stream));
     HIPCHECK(c, hipMemsetAsync(c->d_tilectr, 0, 16 * sizeof(int), c->stream));
     P.tile_ctr = c->d_tilectr;
     {
@@ -1319,8 +1324,8 @@ static int launch_crossings(rdr_ctx* c, const rdr_cube* q, RayParams P, int64_t 
     return RDR_OK;
 }
 
-static int launch_march(rdr_ctx* c, const rdr_cube* q, RayParams P, int64_t tb, int64_t tc) {
-    P.tile_begin = tb; P.tile_count = tc; P.nslots = tc * BLOCK;
+static int launch_march(rdr_ctx* c, const rdr_cube* q, RayParams P, int64_t tb, int64_t tc, int64_t nslots_total = 0) {
+    P.tile_begin = tb; P.tile_count = tc; P.nslots = nslots_total > 0 ? nslots_total : tc * BLOCK;
     const int g = ray_grid(c, tc, 8);
     HIPCHECK(c, hipMemsetAsync(c->d_tilectr + 16, 0, 16 * sizeof(int), c->stream));
     P.tile_ctr = c->d_tilectr + 16;
@@ -1362,6 +1367,56 @@ static int march_chunked(rdr_ctx* c, const rdr_cube* q, const RayParams& P0, int
         rc = launch_march(c, q, P, tb, tc); if (rc) return rc;
     }
     return RDR_OK;
+}
+
+// Host-buffer ray tracing with the PCIe transfers overlapped: the look vectors (24 B per ray, the bulk of the input) go up in
+// row chunks on the copy stream while pass 1 runs on the chunks that have arrived; after the last chunk the slice-level
+// partition is complete, pass 2 runs chunk by chunk and each chunk's outputs come down while the next is integrated.
+// (hipMemcpyAsync from pageable memory blocks the HOST thread, not the device: kernels launched before it keep running.)
+static int raytrace_pipelined(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, RayParams P, int K, double* d_los, double* dw, double* dh,
+                              double* wet, double* hydro) {
+    const int64_t tile_rows = P.ntiles / P.tiles_x;
+    const int nchunk = (int)std::min<int64_t>(8, tile_rows);
+    double* ws;
+    int rc = ws_reserve(c, P.ntiles, K, &ws); if (rc) return rc;
+    const int64_t nslots_total = P.ntiles * BLOCK;
+    if (d_los) P.los = d_los;                  // (else the look vectors come from inc / heading or zenith: nothing to upload)
+    std::vector<hipEvent_t> ev(2 * nchunk, nullptr);
+    for (auto& e : ev) HIPCHECK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    auto range = [&](int k, int64_t& tb, int64_t& tc, int64_t& r0, int64_t& cnt) {
+        const int64_t t0 = tile_rows * k / nchunk, t1 = tile_rows * (k + 1) / nchunk;
+        tb = t0 * P.tiles_x; tc = (t1 - t0) * P.tiles_x;
+        if (r->origin_mode == RDR_ORIGIN_GRID) { r0 = t0 * TILE * r->nx; cnt = std::min<int64_t>(t1 * TILE, r->ny) * r->nx - r0; }
+        else { r0 = tb * BLOCK; cnt = std::min<int64_t>((tb + tc) * BLOCK, r->n) - r0; }
+    };
+    int status = RDR_OK;
+    auto cleanup = [&]() { for (auto& e : ev) if (e) (void)hipEventDestroy(e); };
+    for (int k = 0; k < nchunk && status == RDR_OK; ++k) {
+        int64_t tb, tc, r0, cnt; range(k, tb, tc, r0, cnt);
+        if (d_los && (hipMemcpyAsync(d_los + 3 * r0, r->los + 3 * r0, (size_t)cnt * 24, hipMemcpyHostToDevice, c->copy_stream) != hipSuccess ||
+                      hipEventRecord(ev[k], c->copy_stream) != hipSuccess || hipStreamWaitEvent(c->stream, ev[k], 0) != hipSuccess)) {
+            status = fail(c, RDR_ERR_HIP, "pipelined ray tracing: look-vector upload failed"); break;
+        }
+        RayParams Pk = P; Pk.ws = ws + tb * BLOCK;
+        status = launch_crossings(c, q, Pk, tb, tc, nslots_total, k == 0);
+    }
+    for (int k = 0; k < nchunk && status == RDR_OK; ++k) {
+        int64_t tb, tc, r0, cnt; range(k, tb, tc, r0, cnt);
+        RayParams Pk = P; Pk.ws = ws + tb * BLOCK;
+        status = launch_march(c, q, Pk, tb, tc, nslots_total);
+        if (status == RDR_OK && hipEventRecord(ev[nchunk + k], c->stream) != hipSuccess) status = fail(c, RDR_ERR_HIP, "pipelined ray tracing: event");
+    }
+    for (int k = 0; k < nchunk && status == RDR_OK; ++k) {
+        int64_t tb, tc, r0, cnt; range(k, tb, tc, r0, cnt);
+        if (hipStreamWaitEvent(c->copy_stream, ev[nchunk + k], 0) != hipSuccess ||
+            hipMemcpyAsync(wet + r0, dw + r0, (size_t)cnt * 8, hipMemcpyDeviceToHost, c->copy_stream) != hipSuccess ||
+            hipMemcpyAsync(hydro + r0, dh + r0, (size_t)cnt * 8, hipMemcpyDeviceToHost, c->copy_stream) != hipSuccess)
+            status = fail(c, RDR_ERR_HIP, "pipelined ray tracing: output download failed");
+    }
+    if (hipStreamSynchronize(c->copy_stream) != hipSuccess && status == RDR_OK) status = fail(c, RDR_ERR_HIP, "pipelined ray tracing: sync");
+    if (hipStreamSynchronize(c->stream) != hipSuccess && status == RDR_OK) status = fail(c, RDR_ERR_HIP, "pipelined ray tracing: sync");
+    cleanup();
+    return status;
 }
 
 static int flags_to_status(rdr_ctx* c, int flags) {
@@ -1492,7 +1547,21 @@ int rdr_raytrace(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, double ht, do
     if (r->n == 0) return RDR_OK;
     HIPCHECK(c, hipSetDevice(c->device));
     RayParams P;
-    rc = stage_rays(c, r, P); if (rc) return rc;
+    // large host-buffer batches with per-ray look vectors: overlap the PCIe transfers with the two passes (raytrace_pipelined)
+    static const bool no_pipeline = std::getenv("RAIDER_HIP_NO_PIPELINE") != nullptr;
+    bool pipelined = r->loc == RDR_HOST && r->n >= (1 << 21) && !no_pipeline;
+    const bool los_chunks = pipelined && r->los_mode == RDR_LOS_VEC;
+    rdr_rays rr = *r;
+    if (los_chunks) rr.los = nullptr;                      // the look vectors are uploaded chunk by chunk below
+    rc = stage_rays(c, &rr, P); if (rc) return rc;
+    if (pipelined && P.ntiles > ws_chunk_tiles(c, K)) {   // records do not fit: ordinary (chunked-march) path
+        if (los_chunks) {
+            const void* d;
+            rc = stage_in(c, SLOT_IN3, r->los, (size_t)r->n * 24, r->loc, &d); if (rc) return rc;
+            P.los = (const double*)d;
+        }
+        pipelined = false;
+    }
     P.ht = ht; P.zref = zref; P.max_seg = max_seg;
     void *dw, *dh;
     rc = stage_out(c, SLOT_OUT0, wet, (size_t)r->n * 8, r->loc, &dw); if (rc) return rc;
@@ -1501,7 +1570,11 @@ int rdr_raytrace(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, double ht, do
     HIPCHECK(c, hipMemsetAsync(c->d_maxlen, 0, MAX_LEVELS * sizeof(unsigned long long), c->stream));
     HIPCHECK(c, hipMemsetAsync(c->d_flags, 0, sizeof(int), c->stream));
     c->wsig.valid = false;
-    if (P.ntiles <= ws_chunk_tiles(c, K)) {
+    if (pipelined) {
+        void* dl = nullptr;
+        if (los_chunks) { rc = ensure(c, SLOT_IN3, (size_t)r->n * 24, &dl); if (rc) return rc; }
+        rc = raytrace_pipelined(c, q, r, P, K, (double*)dl, (double*)dw, (double*)dh, wet, hydro); if (rc) return rc;
+    } else if (P.ntiles <= ws_chunk_tiles(c, K)) {
         // whole batch fits: pass 1 reduces AND stores the ray records, pass 2 streams them back
         rc = ws_reserve(c, P.ntiles, K, &P.ws); if (rc) return rc;
         rc = launch_crossings(c, q, P, 0, P.ntiles); if (rc) return rc;
@@ -1512,8 +1585,10 @@ int rdr_raytrace(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, double ht, do
         rc = launch_crossings(c, q, P, 0, P.ntiles); if (rc) return rc;
         rc = march_chunked(c, q, P, K); if (rc) return rc;
     }
-    rc = finish_out(c, wet, dw, (size_t)r->n * 8, r->loc); if (rc) return rc;
-    rc = finish_out(c, hydro, dh, (size_t)r->n * 8, r->loc); if (rc) return rc;
+    if (!pipelined) {
+        rc = finish_out(c, wet, dw, (size_t)r->n * 8, r->loc); if (rc) return rc;
+        rc = finish_out(c, hydro, dh, (size_t)r->n * 8, r->loc); if (rc) return rc;
+    }
     const bool need_sync = r->loc == RDR_HOST || nparts_out || flags_out;
     if (need_sync) {
         std::vector<double> ml(K);

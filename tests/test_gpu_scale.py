@@ -358,3 +358,32 @@ def test_continental_grid_axes(R):
     # points outside the grid are NaN on this path too
     wo, ho, _, _ = cube.raytrace(R.Rays.grid(np.array([-136.0, -120.0]), np.array([30.0]), inc=20.0, hd=0.0), 0.0, zref)
     assert np.isnan(wo[0, 0]) and np.isfinite(wo[0, 1])
+
+
+def test_host_buffer_pipeline_matches_device_path(R):
+    """>= 2 M rays with per-ray look vectors handed over as NumPy arrays take the pipelined path (look vectors up / outputs down
+    in row chunks overlapped with the two passes): bit-identical to the device-resident path, ragged scene edges included,
+    for GRID and for point-list origins."""
+    import torch
+    dev = torch.device('cuda:0')
+    c = O.synthetic_cube(60, 60, 30, seed=1)
+    cube = R.Cube(c['ys'], c['xs'], c['zs'], c['wet'], c['hydro'], order='zyx')
+    ny, nx = 1453, 1501                                  # 2.18 M rays, neither dimension a multiple of the 16-pixel tile
+    xp = np.linspace(-119.5, -115.5, nx); yp = np.linspace(34.5, 31.5, ny)
+    inc = np.broadcast_to(np.linspace(25, 45, nx)[None, :], (ny, nx)).copy()
+    los = R.Rays.grid(xp, yp, inc=inc, hd=np.full((ny, nx), -167.9)).look_vectors()          # NumPy (ny, nx, 3)
+    los[7, 11] = np.nan                                                                        # one NaN ray
+    zref = float(c['zs'].max() - 1)
+    with pytest.raises(ValueError, match='NaN'):                                              # the NaN poisons the slice maximum (delay.py:283)
+        cube.raytrace(R.Rays.grid(xp, yp, los=los), 120.0, zref)
+    los[7, 11] = los[7, 12]
+    hw, hh, hn, hf = cube.raytrace(R.Rays.grid(xp, yp, los=los), 120.0, zref)                  # host buffers -> pipelined
+    dw, dh, dn, df = cube.raytrace(R.Rays.grid(torch.from_numpy(xp).to(dev), torch.from_numpy(yp).to(dev), los=torch.from_numpy(los).to(dev)), 120.0, zref)
+    assert np.array_equal(hn, dn) and hf == df
+    assert np.array_equal(hw, dw.cpu().numpy()) and np.array_equal(hh, dh.cpu().numpy())
+    assert np.isfinite(hw).mean() > 0.9
+    # point-list origins (LLH) through the same path
+    xx, yy = np.meshgrid(xp, yp)
+    pw, ph, pn, pf = cube.raytrace(R.Rays.points(lat=yy.ravel(), lon=xx.ravel(), los=los.reshape(-1, 3)), 120.0, zref)
+    assert np.array_equal(pn, dn)
+    np.testing.assert_array_equal(pw.reshape(ny, nx), hw); np.testing.assert_array_equal(ph.reshape(ny, nx), hh)
