@@ -296,6 +296,27 @@ __device__ __forceinline__ double level_top_u(const double* hpoly, double hi, do
     return u;
 }
 
+// N independent level crossings carried side by side (same arithmetic per level as level_top_u).
+constexpr int LEVEL_ILP = 2;
+template <int N>
+__device__ __forceinline__ void level_top_u_n(const double* hpoly, const double* hi, double su, double ou, double gain, double* u) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) u[j] = fma(hi[j], su, ou);
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+        double p[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) p[j] = hpoly[PN - 1];
+#pragma unroll
+        for (int n = PN - 2; n >= 0; --n) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) p[j] = fma(p[j], u[j], hpoly[n]);
+        }
+#pragma unroll
+        for (int j = 0; j < N; ++j) u[j] = fma(hi[j] - p[j], gain, u[j]);
+    }
+}
+
 // Workspace record handed from pass 1 (crossings_kernel) to pass 2 (march_kernel): one column per ray SLOT
 // (slot = local tile * 256 + thread), field-major so every field access is a perfectly coalesced 512 B per wave:
 //   ws[f * nslots + slot]
@@ -611,35 +632,50 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
             double last_len = 0.0;      // a light ray's lengths are NaN for every level or for none (they all stem from one polynomial)
             // The level heights are read from LDS ONE LEVEL AHEAD: LDS operations complete in order, so a read issued after
             // level k's ds_max would have to wait for that atomic; issued before it, it only waits for itself.
-            const double lo = m.lo[0];
-            double hi_next = m.hi[0];
-#pragma unroll 1
-            for (int k = 0; k < K; ++k) {
-                const double hi = hi_next;
-                if (k + 1 < K) hi_next = m.hi[k + 1];
-                double u_lo = u_hi;
-                if (k == 0) {
-                    u_lo = fma(lo, su, ou);
-#pragma unroll 1
-                    for (int it = 0; it < 10; ++it) u_lo = fma(lo - poly5(q.h, u_lo), su, u_lo);
-                }
+            // Level 0 (ten plain Newton steps per end, losreader.py:770-777) sets the gain of every later level.
+            if (K > 0) {
+                const double lo = m.lo[0], hi = m.hi[0];
+                double u_lo = fma(lo, su, ou);
                 u_hi = fma(hi, su, ou);
-                if (k == 0) {
 #pragma unroll 1
-                    for (int it = 0; it < 10; ++it) u_hi = fma(hi - poly5(q.h, u_hi), su, u_hi);
-                } else u_hi = level_top_u(q.h, hi, su, ou, gain);
+                for (int it = 0; it < 10; ++it) {
+                    u_lo = fma(lo - poly5(q.h, u_lo), su, u_lo);
+                    u_hi = fma(hi - poly5(q.h, u_hi), su, u_hi);
+                }
                 const double L = (u_hi - u_lo) * scale;
                 last_len = L;
-                if (k == 0) {
-                    inv_cosf = L / (hi - lo); gain = su * inv_cosf;                            // 1/cos_factor, losreader.py:824-825
-                    if (w && mine) { w[(int64_t)WS_GAIN * ns] = gain; w[(int64_t)WS_U0 * ns] = u_lo; w[(int64_t)WS_U1 * ns] = u_hi; }
-                    if (!reduce) break;                                                        // record complete; lengths not wanted
-                }
+                inv_cosf = L / (hi - lo); gain = su * inv_cosf;                                // 1/cos_factor, losreader.py:824-825
+                if (w && mine) { w[(int64_t)WS_GAIN * ns] = gain; w[(int64_t)WS_U0 * ns] = u_lo; w[(int64_t)WS_U1 * ns] = u_hi; }
                 if (reduce) {
-                    atomicMax(&mxc[k * MXCOLS], (unsigned long long)__double_as_longlong((cnt && L > 0.0) ? L : 0.0));
-                    if (k == 0 && cnt && !(poly5(q.h, u_lo) < c.z_lo)) my_flags |= 4;          // first sample of the ray
-                    if (k == K - 1 && cnt && !(poly5(q.h, u_hi) > c.z_hi)) my_flags |= 8;      // last sample of the ray
+                    atomicMax(&mxc[0], (unsigned long long)__double_as_longlong((cnt && L > 0.0) ? L : 0.0));
+                    if (cnt && !(poly5(q.h, u_lo) < c.z_lo)) my_flags |= 4;                    // first sample of the ray
                 }
+            }
+            // Later levels: their Newton chains are independent of one another (each starts from its own level height), so
+            // LEVEL_ILP of them are carried side by side to fill the FMA pipeline's dependent-issue bubbles.
+            if (reduce) {
+                int k = 1;
+                for (; k + LEVEL_ILP <= K; k += LEVEL_ILP) {
+                    double hk[LEVEL_ILP], uk[LEVEL_ILP];
+#pragma unroll
+                    for (int j = 0; j < LEVEL_ILP; ++j) hk[j] = m.hi[k + j];
+                    level_top_u_n<LEVEL_ILP>(q.h, hk, su, ou, gain, uk);
+#pragma unroll
+                    for (int j = 0; j < LEVEL_ILP; ++j) {
+                        const double L = (uk[j] - u_hi) * scale;
+                        u_hi = uk[j];
+                        last_len = L;
+                        atomicMax(&mxc[(k + j) * MXCOLS], (unsigned long long)__double_as_longlong((cnt && L > 0.0) ? L : 0.0));
+                    }
+                }
+                for (; k < K; ++k) {
+                    const double u_top = level_top_u(q.h, m.hi[k], su, ou, gain);
+                    const double L = (u_top - u_hi) * scale;
+                    u_hi = u_top;
+                    last_len = L;
+                    atomicMax(&mxc[k * MXCOLS], (unsigned long long)__double_as_longlong((cnt && L > 0.0) ? L : 0.0));
+                }
+                if (K > 0 && cnt && !(poly5(q.h, u_hi) > c.z_hi)) my_flags |= 8;               // last sample of the ray
             }
             if (reduce && cnt && K > 0) my_flags |= (last_len != last_len) ? 1 : 2;
         }
