@@ -753,12 +753,11 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
         if (SLOW && !__any(mine)) continue;
         double acc_w = 0.0, acc_h = 0.0;
         if constexpr (!SLOW) {
-            // ---- light rays: one flat loop over the ray's distinct sample points, BATCH at a time -----------------------
-            // The sample schedule (level k, fraction j/(np-1)) is the same for every ray of the slice, so the iterator lives
-            // in scalar registers.  A sample shared by two segments (top of k = bottom of k+1, losreader.py:811-812) is
-            // evaluated once and carries both trapezoid end weights.  Each batch first issues the gathers of all its
-            // samples, then finishes them: BATCH x 4 loads are in flight per lane instead of 4.
-            constexpr int BATCH = 1;
+            // ---- light rays: every distinct sample point of the ray once, level by level --------------------------------
+            // The sample schedule (level k, fraction j/(np-1)) is the same for every ray of the slice, so the loop counters
+            // live in scalar registers.  A sample shared by two segments (top of k = bottom of k+1, losreader.py:811-812) is
+            // evaluated once and carries both trapezoid end weights; a level is its interior samples (usually none or one)
+            // plus its top sample.  Latency is hidden by the four waves per SIMD, not by batching samples inside a lane.
             RayPoly q;
 #pragma unroll
             for (int n = 0; n < PN; ++n) {
@@ -767,72 +766,52 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
                 q.lon[n] = w[(int64_t)(WS_POLY_LON + n) * ns];
             }
             const double scale = w[(int64_t)WS_SCALE * ns];              // ray length per unit of u
-            // per-level lane state: u at the bottom of level k, du_k, du_{k+1}; uniform state: j, np_k, step_k, hs_k, hs_{k+1}.
             // The level crossings are re-derived from h(u) as the loop reaches them (no global loads inside the loop besides
-            // the gathers, so the only memory waits are on a batch's own samples).
+            // the gathers, so the only memory waits are on a sample's own corners).
             const double su = w[(int64_t)WS_SU * ns], ou = w[(int64_t)WS_OU * ns], gain = w[(int64_t)WS_GAIN * ns];
-            int k = 0, j = 0;
-            int np = __builtin_amdgcn_readfirstlane(m.np[0]);
+            auto sample = [&](double us, double wv, int zbase, bool floor_it, bool ceil_it) {
+                double ph = poly5(q.h, us);
+                const double plat = poly5(q.lat, us), plon = poly5(q.lon, us);       // delay.py:295 through the ray polynomials
+                // all-pixels z-clamp of the very first / very last sample (delay.py:306-311): when it applies every pixel is
+                // below (above) the cube, so "set to zmin" == max(ph, zmin)
+                if (floor_it) ph = fmax(ph, c.z_lo);
+                if (ceil_it) ph = fmin(ph, c.z_hi);
+                PendingSample<T2> s;
+                sample_issue<T2, true>(c, m.ax, plat, plon, ph, zbase, s);           // delay.py:298,319
+                double vw, vh;
+                sample_finish(s, vw, vh);
+                acc_w = fma(wv, vw, acc_w); acc_h = fma(wv, vh, acc_h);              // delay.py:323
+            };
+            int np = __builtin_amdgcn_readfirstlane(m.np[0]);                        // >= 2 (fill above)
             int kz = __builtin_amdgcn_readfirstlane(m.kz[0]);
-            // the ray's very first sample is the BOTTOM of its segment: when that is a model node (origin at or below it), the
-            // two-entry z window must start one interval lower
-            int kz_first_adj = __builtin_amdgcn_readfirstlane((m.lo[0] <= m.ax.ez[kz].x) ? 1 : 0);
-            int zbase = window2_base(c.nz, kz - kz_first_adj);                 // first table entry of the two-entry z window
-            double step = m.step[0], hs = m.hs[0], hs1 = K > 1 ? m.hs[1] : 0.0;
+            double step = m.step[0], hs = m.hs[0];
             double u_k = w[(int64_t)WS_U0 * ns];
             double u_last = w[(int64_t)WS_U1 * ns];
-            double du = u_last - u_k, du1 = 0.0;
-            if (K > 1) { const double t2 = level_top_u(q.h, m.hi[1], su, ou, gain); du1 = t2 - u_last; u_last = t2; }
-            bool valid = true;
-            while (valid) {
-                PendingSample<T2> pend[BATCH];
-                double wgt[BATCH];
-                int n = 0;
-#pragma unroll
-                for (int b = 0; b < BATCH; ++b) {
-                    if (valid) {
-                        const double us = fma((double)j * step, du, u_k);           // low + frac * (high - low), delay.py:292
-                        double ph = poly5(q.h, us);
-                        const double plat = poly5(q.lat, us), plon = poly5(q.lon, us);   // delay.py:295 through the ray polynomials
-                        const bool last_j = j == np - 1;
-                        if (clamp_any) {   // all-pixels z-clamp of the very first / very last sample (delay.py:306-311)
-                            const double zfloor = (clamp_lo && k == 0 && j == 0) ? c.z_lo : -__builtin_huge_val();
-                            const double zceil = (clamp_hi && k == K - 1 && last_j) ? c.z_hi : __builtin_huge_val();
-                            ph = fmin(fmax(ph, zfloor), zceil);
-                        }
-                        sample_issue<T2, true>(c, m.ax, plat, plon, ph, zbase, pend[b]);   // delay.py:298,319
-                        if (kz_first_adj) { kz_first_adj = 0; zbase = window2_base(c.nz, kz); }
-                        // trapezoid weight per unit of u (delay.py:314-315), both segments for a shared sample
-                        double wv = (((j == 0) | last_j) ? hs : 2.0 * hs) * du;
-                        if (last_j && k + 1 < K) wv = fma(hs1, du1, wv);
-                        wgt[b] = wv;
-                        n = b + 1;
-                        ++j;
-                        if (j >= np) {                                                  // next level (its j = 0 is already done)
-                            ++k;
-                            if (k >= K) valid = false;
-                            else {
-                                j = 1;
-                                np = __builtin_amdgcn_readfirstlane(m.np[k]);           // >= 2 (fill below)
-                                kz = __builtin_amdgcn_readfirstlane(m.kz[k]);
-                                zbase = window2_base(c.nz, kz);
-                                step = m.step[k]; hs = hs1;
-                                u_k += du; du = du1; du1 = 0.0; hs1 = 0.0;
-                                if (k + 1 < K) {
-                                    const double t2 = level_top_u(q.h, m.hi[k + 1], su, ou, gain);
-                                    du1 = t2 - u_last; u_last = t2; hs1 = m.hs[k + 1];
-                                }
-                            }
-                        }
-                    }
+            double du = u_last - u_k;
+            // the ray's very first sample is the BOTTOM of its segment: when that is a model node (origin at or below it), the
+            // two-entry z window must start one interval lower
+            if (K > 0) sample(fma(0.0 * step, du, u_k), hs * du, window2_base(c.nz, kz - ((m.lo[0] <= m.ax.ez[kz].x) ? 1 : 0)), clamp_lo, false);
+#pragma unroll 1
+            for (int k = 0; k < K; ++k) {
+                const int zbase = window2_base(c.nz, kz);                            // first table entry of the two-entry z window
+                const bool more = k + 1 < K;
+                double du1 = 0.0, hs1 = 0.0;
+                if (more) {
+                    const double t2 = level_top_u(q.h, m.hi[k + 1], su, ou, gain);
+                    du1 = t2 - u_last; u_last = t2; hs1 = m.hs[k + 1];
                 }
-#pragma unroll
-                for (int b = 0; b < BATCH; ++b) {
-                    if (b < n) {
-                        double vw, vh;
-                        sample_finish(pend[b], vw, vh);
-                        acc_w = fma(wgt[b], vw, acc_w); acc_h = fma(wgt[b], vh, acc_h);    // delay.py:323
-                    }
+                // trapezoid weights per unit of u (delay.py:314-315): interior samples, and the top one with both its segments
+                const double w_mid = (2.0 * hs) * du;
+                double w_top = hs * du;
+                if (more) w_top = fma(hs1, du1, w_top);
+#pragma unroll 1
+                for (int j = 1; j < np - 1; ++j) sample(fma((double)j * step, du, u_k), w_mid, zbase, false, false);   // low + frac * (high - low), delay.py:292
+                sample(fma((double)(np - 1) * step, du, u_k), w_top, zbase, false, clamp_hi && !more);
+                u_k += du; du = du1; hs = hs1;
+                if (more) {
+                    np = __builtin_amdgcn_readfirstlane(m.np[k + 1]);
+                    kz = __builtin_amdgcn_readfirstlane(m.kz[k + 1]);
+                    step = m.step[k + 1];
                 }
             }
             acc_w *= scale; acc_h *= scale;
