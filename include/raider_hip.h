@@ -143,6 +143,11 @@ int rdr_inverse_time_weights(rdr_ctx* ctx, const double* az, int64_t n, const do
                              double regularizer, double* weights, int loc);
 int rdr_cube_blend_weighted(rdr_ctx* ctx, const rdr_cube* const* cubes, int32_t nd, const double* weights, int loc, rdr_cube** out);
 
+/* GUNW radian conversion (aria/calcGUNW.py:54-59): out = delay * (-4 pi / wavelength) for both fields;
+ * dtype RDR_F32 multiplies in f32 by the f32-rounded factor (NumPy weak-scalar rule), RDR_F64 in f64.  In place allowed. */
+int rdr_delays_to_phase(rdr_ctx* ctx, const void* wet, const void* hydro, int64_t n, int dtype, double wavelength,
+                        void* wet_out, void* hydro_out, int loc);
+
 /* copy the (blended) fields back, (y,x,z) C-order, dtype of the cube */
 int rdr_cube_read(rdr_ctx* ctx, const rdr_cube* cube, void* wet, void* hydro);
 

@@ -554,6 +554,13 @@ def combine_weighted(weights, fields):
     return out
 
 
+def gunw_phase(delay, wavelength):
+    """aria/calcGUNW.py:54-59: `ds['wet'] * phase2range`, phase2range = (-4 * np.pi) / float(wavelength).  A Python-float
+    factor keeps the array's dtype (float32 delays stay float32)."""
+    phase2range = (-4 * np.pi) / float(wavelength)
+    return np.asarray(delay) * phase2range
+
+
 # ----------------------------------------------------------------------------------------------
 # native extension restatements
 # ----------------------------------------------------------------------------------------------

@@ -1059,6 +1059,44 @@ int rdr_cube_blend_weighted(rdr_ctx* c, const rdr_cube* const* cubes, int32_t nd
     return RDR_OK;
 }
 
+// ---- GUNW phase conversion (aria/calcGUNW.py:54-59): delay [m] -> interferometric phase [rad] ------------------------
+// ds['wet'] * phase2range with phase2range = -4 pi / wavelength; a Python float is a weak scalar, so f32 delays are
+// multiplied in f32 by the f32-rounded factor and f64 delays in f64.
+template <typename T>
+__global__ __launch_bounds__(256) void phase_kernel(const T* __restrict__ wet, const T* __restrict__ hyd, int64_t n, T factor,
+                                                    T* __restrict__ owet, T* __restrict__ ohyd) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        owet[i] = wet[i] * factor;
+        ohyd[i] = hyd[i] * factor;
+    }
+}
+
+int rdr_delays_to_phase(rdr_ctx* c, const void* wet, const void* hydro, int64_t n, int dtype, double wavelength, void* wet_out, void* hydro_out, int loc) {
+    if (!c || !wet || !hydro || !wet_out || !hydro_out) return fail(c, RDR_ERR_INVALID, "rdr_delays_to_phase: NULL argument");
+    if (dtype != RDR_F32 && dtype != RDR_F64) return fail(c, RDR_ERR_INVALID, "rdr_delays_to_phase: dtype must be RDR_F32 or RDR_F64");
+    if (!(wavelength > 0.0)) return fail(c, RDR_ERR_INVALID, "rdr_delays_to_phase: wavelength must be positive");
+    if (n <= 0) return RDR_OK;
+    HIPCHECK(c, hipSetDevice(c->device));
+    const size_t bytes = (size_t)n * (dtype == RDR_F32 ? 4 : 8);
+    const void *dw, *dh; void *ow, *oh;
+    int rc = stage_in(c, SLOT_IN0, wet, bytes, loc, &dw); if (rc) return rc;
+    rc = stage_in(c, SLOT_IN1, hydro, bytes, loc, &dh); if (rc) return rc;
+    rc = stage_out(c, SLOT_OUT0, wet_out, bytes, loc, &ow); if (rc) return rc;
+    rc = stage_out(c, SLOT_OUT1, hydro_out, bytes, loc, &oh); if (rc) return rc;
+    const double phase2range = (-4.0 * 3.141592653589793) / wavelength;       // calcGUNW.py:54
+    const int g = grid_for(n, 256, c->num_cus * 8);
+    if (dtype == RDR_F32)
+        hipLaunchKernelGGL(phase_kernel<float>, dim3(g), dim3(256), 0, c->stream, (const float*)dw, (const float*)dh, n, (float)phase2range, (float*)ow, (float*)oh);
+    else
+        hipLaunchKernelGGL(phase_kernel<double>, dim3(g), dim3(256), 0, c->stream, (const double*)dw, (const double*)dh, n, phase2range, (double*)ow, (double*)oh);
+    HIPCHECK(c, hipGetLastError());
+    rc = finish_out(c, wet_out, ow, bytes, loc); if (rc) return rc;
+    rc = finish_out(c, hydro_out, oh, bytes, loc); if (rc) return rc;
+    if (loc == RDR_HOST) HIPCHECK(c, hipStreamSynchronize(c->stream));
+    return RDR_OK;
+}
+
 int rdr_cube_read(rdr_ctx* c, const rdr_cube* q, void* wet, void* hydro) {
     if (!c || !q || !wet || !hydro) return fail(c, RDR_ERR_INVALID, "rdr_cube_read: NULL argument");
     HIPCHECK(c, hipSetDevice(c->device));

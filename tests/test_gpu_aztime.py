@@ -109,3 +109,42 @@ def test_weighted_combination_and_time_grid(golden):
     np.testing.assert_allclose(pw.read()[0].transpose(2, 0, 1), O.combine_weighted(list(ow), [f[0], f[1], f[2]]), rtol=1e-14)
     assert 0.94 < ow[0].mean() < 0.96                                              # 06:57 + ~0 s: mostly the 07:00 model
     assert np.array_equal(pw.read()[0], tot.read()[0])
+
+
+def test_gunw_phase_conversion(tmp_path):
+    """aria/calcGUNW.py:54-59 (delay -> radians) bit-exact in f32 and f64, host and device buffers; then compute_delays_slc on
+    two delay-cube files: later date = reference, GUNW layer names, float32 *Meta coordinates."""
+    import torch
+    from oracle import raider_oracle as O
+    from raider_amd.delay import DelayCube
+    from raider_amd.gunw import DIM_NAMES, compute_delays_slc, delays_to_phase
+    rng = np.random.default_rng(5)
+    lam = 0.05546576
+    for dtype in (np.float32, np.float64):
+        wet = rng.uniform(0, 0.4, (7, 33, 41)).astype(dtype); hyd = rng.uniform(1.5, 2.6, (7, 33, 41)).astype(dtype)
+        wet[0, 0, 0] = np.nan
+        pw, ph = delays_to_phase(wet, hyd, lam)
+        assert pw.dtype == dtype and ph.dtype == dtype
+        assert np.array_equal(pw, O.gunw_phase(wet, lam), equal_nan=True) and np.array_equal(ph, O.gunw_phase(hyd, lam))
+        dw, dh = delays_to_phase(torch.from_numpy(wet).cuda(), torch.from_numpy(hyd).cuda(), lam)
+        assert np.array_equal(dw.cpu().numpy(), pw, equal_nan=True) and np.array_equal(dh.cpu().numpy(), ph)
+    assert pw[1, 1, 1] < 0 and abs(pw[1, 1, 1] / wet[1, 1, 1] + 4 * np.pi / lam) < 1e-9
+    with pytest.raises(ValueError):
+        delays_to_phase(wet, hyd, 0.0)
+    # two dates through files
+    z, y, x = np.array([0.0, 500.0, 1000.0]), np.linspace(34.0, 33.0, 5), np.linspace(-118.0, -117.0, 6)
+    paths = []
+    for i, stamp in enumerate(('20200130T135245', '20200118T135245')):
+        ds = DelayCube({'wet': np.full((3, 5, 6), 0.1 * (i + 1)), 'hydro': np.full((3, 5, 6), 2.0 + i), 'z': z, 'y': y, 'x': x},
+                       {'model_times_used': f'mt{i}', 'reference_time': f'rt{i}', 'interpolation_method': 'none', '_degrees': True})
+        p = tmp_path / f'ERA5_tropo_{stamp}_ray.nc'
+        ds.to_netcdf(p); paths.append(p)
+    slc = compute_delays_slc(paths, lam)
+    k = -4 * np.pi / lam
+    assert np.array_equal(slc['reference_troposphereWet'], np.full((3, 5, 6), 0.1) * k)          # 2020-01-30 is the later date
+    assert np.array_equal(slc['secondary_troposphereHydrostatic'], np.full((3, 5, 6), 3.0) * k)
+    assert all(slc[d].dtype == np.float32 for d in DIM_NAMES) and np.array_equal(slc['latitudeMeta'], y.astype(np.float32))
+    assert slc.attrs == {'model': 'ERA5', 'method': 'ray tracing'}
+    la = slc.layer_attrs['secondary_troposphereWet']
+    assert la['units'] == 'radians' and la['model_times_used'] == 'mt1' and la['scene_center_time'] == 'rt1'
+    assert la['description'] == 'Delay due to Wet component of troposphere'
