@@ -74,8 +74,8 @@ typedef struct rdr_rays {
     const double* xyz;  /* XYZ: [n,3]; with an inc/heading or zenith LOS lat/lon are needed too */
     const double* los;  /* LOS_VEC: [n,3]                                                       */
     const double* inc;  /* LOS_INC_HD: [n]                                                      */
-    const double* hd;   /* LOS_INC_HD: [n]                                                      */
-    double inc0, hd0;   /* LOS_INC_HD_SCALAR                                                    */
+    const double* hd;   /* LOS_INC_HD: [n], or NULL: heading hd0 for every ray                  */
+    double inc0, hd0;   /* LOS_INC_HD_SCALAR (hd0 also: LOS_INC_HD with hd == NULL)             */
     int32_t loc;        /* RDR_HOST / RDR_DEVICE for every pointer above                        */
     int32_t _pad;
 } rdr_rays;

@@ -324,7 +324,7 @@ __global__ void look_kernel(RayParams P, double* __restrict__ los) {
         else { lat = P.lat[i]; lon = P.lon[i]; }
         double u, v, w;
         if (P.los_mode == 0) { u = P.los[3 * i]; v = P.los[3 * i + 1]; w = P.los[3 * i + 2]; }
-        else if (P.los_mode == 1) inc_hd_to_ecef(P.inc[i], P.hd[i], lat, lon, u, v, w);
+        else if (P.los_mode == 1) inc_hd_to_ecef(P.inc[i], P.hd ? P.hd[i] : P.hd0, lat, lon, u, v, w);
         else if (P.los_mode == 2) inc_hd_to_ecef(P.inc0, P.hd0, lat, lon, u, v, w);
         else {
             double sla, cla, slo, clo;
@@ -1238,7 +1238,7 @@ static int check_rays(rdr_ctx* c, const rdr_rays* r) {
         if (r->los_mode != RDR_LOS_VEC && (!r->lat || !r->lon)) return fail(c, RDR_ERR_INVALID, "XYZ rays with inc/heading or zenith LOS need lat and lon too");
     } else return fail(c, RDR_ERR_INVALID, "unknown origin_mode");
     if (r->los_mode == RDR_LOS_VEC) { if (!r->los) return fail(c, RDR_ERR_INVALID, "LOS_VEC needs los"); }
-    else if (r->los_mode == RDR_LOS_INC_HD) { if (!r->inc || !r->hd) return fail(c, RDR_ERR_INVALID, "LOS_INC_HD needs inc and hd"); }
+    else if (r->los_mode == RDR_LOS_INC_HD) { if (!r->inc) return fail(c, RDR_ERR_INVALID, "LOS_INC_HD needs inc (and hd, or hd0 for one heading)"); }
     else if (r->los_mode != RDR_LOS_INC_HD_SCALAR && r->los_mode != RDR_LOS_ZENITH) return fail(c, RDR_ERR_INVALID, "unknown los_mode");
     return RDR_OK;
 }
@@ -1262,7 +1262,7 @@ static int stage_rays(rdr_ctx* c, const rdr_rays* r, RayParams& P) {
     if (r->los_mode == RDR_LOS_VEC) { rc = stage_in(c, SLOT_IN3, r->los, (size_t)r->n * 24, loc, &d); if (rc) return rc; P.los = (const double*)d; }
     else if (r->los_mode == RDR_LOS_INC_HD) {
         rc = stage_in(c, SLOT_IN4, r->inc, (size_t)r->n * 8, loc, &d); if (rc) return rc; P.inc = (const double*)d;
-        rc = stage_in(c, SLOT_IN5, r->hd, (size_t)r->n * 8, loc, &d); if (rc) return rc; P.hd = (const double*)d;
+        if (r->hd) { rc = stage_in(c, SLOT_IN5, r->hd, (size_t)r->n * 8, loc, &d); if (rc) return rc; P.hd = (const double*)d; }   // NULL: hd0 for every ray
     }
     if (r->origin_mode == RDR_ORIGIN_GRID) {
         P.tiles_x = (int)((r->nx + TILE - 1) / TILE);

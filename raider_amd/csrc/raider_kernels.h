@@ -531,7 +531,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
         double lx = qnan(), ly = qnan(), lz = qnan();
         if (active) {
             if (P.los_mode == 0) { lx = P.los[3 * i]; ly = P.los[3 * i + 1]; lz = P.los[3 * i + 2]; }
-            else if (P.los_mode == 1) inc_hd_to_ecef(P.inc[i], P.hd[i], lat, lon, lx, ly, lz);
+            else if (P.los_mode == 1) inc_hd_to_ecef(P.inc[i], P.hd ? P.hd[i] : P.hd0, lat, lon, lx, ly, lz);
             else if (P.los_mode == 2) inc_hd_to_ecef(P.inc0, P.hd0, lat, lon, lx, ly, lz);
             else { lx = base.c0 * base.cl0; ly = base.c0 * base.sl0; lz = base.s0; }   // zenith (losreader.py:302-316)
         }

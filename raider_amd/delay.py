@@ -276,7 +276,7 @@ def tropo_delay(datetime, weather_model_file, aoi, los, height_levels=None, out_
         zref = toa
         logger.warning(f'Requested integration height (zref) is higher than top of weather model. Forcing to top ({toa}).')
 
-    ds = _get_delays_on_cube(datetime, weather_model_file, wm_proj, aoi, height_levels, los, crs, zref)
+    ds = _get_delays_on_cube(datetime, weather_model_file, wm_proj, aoi, height_levels, los, crs, zref, _loaded=var)
     if _is_cube_aoi(aoi):
         return ds, None
 
@@ -301,9 +301,23 @@ def tropo_delay(datetime, weather_model_file, aoi, los, height_levels=None, out_
 getDelays = tropo_delay   # legacy name used by BASELINE.json's north_star
 
 
-def _get_delays_on_cube(datetime, weather_model_file, wm_proj, aoi, heights, los, crs, zref, nproc=1):
-    """delay.py:133-193."""
+def _has_nan(a):
+    """np.isnan(a).any() (delay.py:187) without the boolean temporary: a NaN anywhere makes the (threaded BLAS) dot product of
+    the array with itself NaN, and nothing else does (squares cannot cancel); non-f64 / tiny inputs take the plain route."""
+    a = np.asarray(a)
+    if a.dtype != np.float64 or a.size < (1 << 16) or not a.flags.c_contiguous:
+        return bool(np.isnan(a).any())
+    flat = a.reshape(-1)
+    return bool(np.isnan(np.dot(flat, flat)))
+
+
+def _get_delays_on_cube(datetime, weather_model_file, wm_proj, aoi, heights, los, crs, zref, nproc=1, _loaded=None):
+    """delay.py:133-193.  `_loaded`: the already-opened variables of `weather_model_file` (tropo_delay opens the file once;
+    the reference loads it three times, delay.py:66,76 and delayFcns.py:36)."""
     zpts = np.array(heights)
+    wm_source = weather_model_file
+    if _loaded is not None:
+        weather_model_file = _loaded
     try:
         aoi.xpts
     except AttributeError:
@@ -327,10 +341,10 @@ def _get_delays_on_cube(datetime, weather_model_file, wm_proj, aoi, heights, los
         else:
             raise NotImplementedError     # delay.py:178-185 (multi-GPU: see raider_amd.distributed)
 
-    if np.isnan(wetDelay).any() or np.isnan(hydroDelay).any():
+    if _has_nan(wetDelay) or _has_nan(hydroDelay):
         logger.critical('There are missing delay values. Check your inputs.')
 
-    return writeResultsToXarray(datetime, aoi.xpts, aoi.ypts, zpts, crs, wetDelay, hydroDelay, weather_model_file, out_type)
+    return writeResultsToXarray(datetime, aoi.xpts, aoi.ypts, zpts, crs, wetDelay, hydroDelay, wm_source, out_type)
 
 
 def _build_cube(xpts, ypts, zpts, model_crs, pts_crs, interpolators):
@@ -368,7 +382,9 @@ def _build_cube_ray(xpts, ypts, zpts, los, model_crs, pts_crs, interpolators, ou
     output_created_here = False
     if outputArrs is None:
         output_created_here = True
-        outputArrs = [np.zeros((zpts.size, ypts.size, xpts.size)) for _ in interpolators]
+        # the reference starts from zeros and accumulates (delay.py:245-248,323); a fresh cube is simply written slice by slice
+        outputArrs = [np.empty((zpts.size, ypts.size, xpts.size)) for _ in interpolators]
+    direct = output_created_here and list(fields) == [0, 1]
 
     grid_is_ll = _is_4326(pts_crs)
     for hh, ht in enumerate(zpts):
@@ -389,14 +405,23 @@ def _build_cube_ray(xpts, ypts, zpts, los, model_crs, pts_crs, interpolators, ou
             else:
                 rays = Rays.points(lat=llh[1], lon=llh[0], los=LOS)
         try:
-            wet, hyd, _nparts, _flags = cube.raytrace(rays, ht, MAX_TROPO_HEIGHT, MAX_SEGMENT_LENGTH)
+            wet, hyd, _nparts, _flags = cube.raytrace(rays, ht, MAX_TROPO_HEIGHT, MAX_SEGMENT_LENGTH,
+                                                      out=(outputArrs[0][hh], outputArrs[1][hh]) if direct else None)
         except NoLevels:
-            if ht == zpts[-1]:                                             # delay.py:276-277
+            if ht == zpts[-1]:                                             # delay.py:276-277: the slice stays zero
+                if output_created_here:
+                    for arr in outputArrs:
+                        arr[hh, ...] = 0.0
                 continue
             raise TypeError("ufunc 'isnan' not supported for the input types (build_ray returned None)")   # delay.py:279
+        if direct:
+            continue
         res = (wet, hyd)
         for mm, f in enumerate(fields):
-            outputArrs[mm][hh, ...] += res[f].reshape(ypts.size, xpts.size)
+            if output_created_here:
+                outputArrs[mm][hh, ...] = res[f].reshape(ypts.size, xpts.size)
+            else:
+                outputArrs[mm][hh, ...] += res[f].reshape(ypts.size, xpts.size)
     if output_created_here:
         return outputArrs
 

@@ -50,10 +50,18 @@ class FieldInterpolator:
 
 
 class _Var:
-    """array + attributes, indexable like a netCDF variable (what tropo_delay reads: var[:] and var.attrs['crs_wkt'])"""
+    """array + attributes, indexable like a netCDF variable (what tropo_delay reads: var[:] and var.attrs['crs_wkt']).
+    `data` may be a zero-argument loader: the array is then read from the file on first use (a ray-traced run never touches
+    the f64 `*_total` fields, two thirds of a processed-cube file)."""
 
     def __init__(self, data, attrs):
-        self.data, self.attrs = data, attrs
+        self._data, self.attrs = data, attrs
+
+    @property
+    def data(self):
+        if callable(self._data):
+            self._data = self._data()
+        return self._data
 
     def __getitem__(self, k):
         return self.data[k]
@@ -63,23 +71,25 @@ class _Var:
 
 
 def _read_cube_file(path):
-    """Processed weather-model / delay cube file -> {name: _Var}.  NetCDF-4 (= HDF5, what the reference writes,
-    weatherModel.py:659-724) goes through the built-in reader raider_amd.h5lite, NetCDF-3 through scipy."""
+    """Processed weather-model / delay cube file -> {name: _Var}, variables read on first use.  NetCDF-4 (= HDF5, what the
+    reference writes, weatherModel.py:659-724) goes through the built-in reader raider_amd.h5lite, NetCDF-3 through scipy."""
     with open(path, 'rb') as fh:
         magic = fh.read(8)
     if magic[:3] == b'CDF':
         from scipy.io import netcdf_file
-        with netcdf_file(str(path), 'r', mmap=False) as f:
-            return {k: _Var(np.array(v.data), {a: (b.decode() if isinstance(b, bytes) else b) for a, b in v._attributes.items()})
-                    for k, v in f.variables.items()}
+        f = netcdf_file(str(path), 'r', mmap=True)          # stays open (kept alive by the loaders) until the mapping is dropped
+
+        def loader(name):
+            return lambda: np.array(f.variables[name].data)  # a private copy: nothing refers to the mapped file afterwards
+        return {k: _Var(loader(k), {a: (b.decode() if isinstance(b, bytes) else b) for a, b in v._attributes.items()})
+                for k, v in f.variables.items()}
     from . import h5lite
     f = h5lite.File(path)
     out = {}
     for k in f.keys():
         obj = f[k]
         if isinstance(obj, h5lite.Dataset) and obj.dtype is not None and obj.dtype.kind in 'fiu':
-            a = obj.read()
-            out[k] = _Var(a, {n: v for n, v in obj.attrs.items() if not n.startswith('_N') and n not in ('CLASS', 'NAME')})
+            out[k] = _Var(obj.read, {n: v for n, v in obj.attrs.items() if not n.startswith('_N') and n not in ('CLASS', 'NAME')})
     return out
 
 

@@ -289,13 +289,19 @@ class Rays:
                 self.struct.los_mode = L.LOS_INC_HD_SCALAR
                 self.struct.inc0, self.struct.hd0 = float(inc), float(hd)
             else:
+                one_heading = np.ndim(hd) == 0 and not _is_dev(hd)          # incidence raster + one heading: no heading array
                 if not _is_dev(inc):
                     inc = np.broadcast_to(np.asarray(inc, dtype=np.float64), self.shape)
-                    hd = np.broadcast_to(np.asarray(hd, dtype=np.float64), self.shape)
-                    if np.any(inc < 0):
+                    if not one_heading:
+                        hd = np.broadcast_to(np.asarray(hd, dtype=np.float64), self.shape)
+                    if inc.min() < 0:
                         raise ValueError('inc_hd_to_enu: Incidence angle cannot be less than 0')
                 self.struct.los_mode = L.LOS_INC_HD
-                self._set('inc', inc); self._set('hd', hd)
+                self._set('inc', inc)
+                if one_heading:
+                    self.struct.hd0 = float(hd)
+                else:
+                    self._set('hd', hd)
         else:
             raise ValueError('a ray batch needs look vectors, inc/heading, or zenith=True')
         self.struct.loc = L.RDR_DEVICE if self._torch_device is not None else L.RDR_HOST

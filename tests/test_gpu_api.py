@@ -204,6 +204,29 @@ def test_nan_look_vectors(c1):
         cube.raytrace(R.Rays.grid(xp, yp, los=los), 0.0, 30000.0)
 
 
+def test_incidence_raster_with_one_heading(c1):
+    """An incidence raster with ONE heading (the usual Conventional / array-backed Raytracing input) needs no heading array:
+    bit-identical to the fully broadcast form, for host and device buffers and through the materialised look vectors."""
+    import torch
+    import raider_amd as R
+    cube = R.Cube(c1['ys'], c1['xs'], c1['zs'], c1['wet'], c1['hydro'], order='zyx')
+    xp = np.linspace(-119, -116, 40); yp = np.linspace(34, 32, 24)
+    inc = np.broadcast_to(30.0 + 16.0 * np.arange(40) / 40, (24, 40)).copy()
+    zref = float(c1['zs'].max() - 1)
+    w1, h1, n1, _ = cube.raytrace(R.Rays.grid(xp, yp, inc=inc, hd=-167.9), 0.0, zref)
+    w2, h2, n2, _ = cube.raytrace(R.Rays.grid(xp, yp, inc=inc, hd=np.full((24, 40), -167.9)), 0.0, zref)
+    assert np.array_equal(w1, w2) and np.array_equal(h1, h2) and np.array_equal(n1, n2) and np.isfinite(h1).all()
+    dev = torch.device('cuda:0')
+    r3 = R.Rays.grid(torch.from_numpy(xp).to(dev), torch.from_numpy(yp).to(dev), inc=torch.from_numpy(inc).to(dev), hd=-167.9)
+    w3, h3, _, _ = cube.raytrace(r3, 0.0, zref)
+    assert np.array_equal(w3.cpu().numpy(), w1) and np.array_equal(h3.cpu().numpy(), h1)
+    lv1 = R.Rays.grid(xp, yp, inc=inc, hd=-167.9).look_vectors()
+    lv2 = R.Rays.grid(xp, yp, inc=inc, hd=np.full((24, 40), -167.9)).look_vectors()
+    assert np.array_equal(lv1, lv2)
+    with pytest.raises(ValueError, match='Incidence angle cannot be less than 0'):
+        R.Rays.grid(xp, yp, inc=-inc, hd=-167.9)
+
+
 def test_temporal_blend(c1):
     """Two-epoch blend on device (cli/raider.py:817-819): f32 stays f32, mean of epochs at the centre time
     (test/test_temporal_interpolate.py), and delays are linear in the cube."""
