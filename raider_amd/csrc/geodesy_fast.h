@@ -76,12 +76,15 @@ __device__ __forceinline__ GeoF geo_fast(double x, double y, double z) {
     return g;
 }
 
-// asin(s) for the small angles between a fit node and the ray origin: odd series through s^7.  The static classification
-// admits only rays that turn by less than 0.08 rad in longitude (0.035 rad in latitude), where the truncation (35/1152 s^9)
-// is < 4e-12 rad (2.5e-5 m on the ground at the far end of the longest admitted ray).
+// asin(s) for the small angles between a fit node and the ray origin: odd series through s^11.  The static classification
+// admits only rays that turn by less than LON_TRAVEL_MAX = 0.2 rad in longitude (0.035 rad in latitude), where the truncation
+// (231/13312 s^13) is < 1.4e-11 rad (9e-5 m on the ground at the far end of the longest admitted ray).  Used only at the six
+// fit nodes of a ray, never per sample.
 __device__ __forceinline__ double asin_small(double s) {
     const double s2 = s * s;
-    double q = fma(s2, 5.0 / 112.0, 3.0 / 40.0);
+    double q = fma(s2, 63.0 / 2816.0, 35.0 / 1152.0);
+    q = fma(s2, q, 5.0 / 112.0);
+    q = fma(s2, q, 3.0 / 40.0);
     q = fma(s2, q, 1.0 / 6.0);
     return fma(s * s2, q, s);
 }
@@ -103,7 +106,7 @@ __device__ __forceinline__ RayBase make_base(double lat_deg, double lon_deg) {
 
 // ---- ray polynomials ------------------------------------------------------------------------------------------------
 // Along a straight ray o + t l the geodetic height, latitude and longitude are smooth functions of t: over the rays the
-// static classification admits (angular travel < 0.035 rad, < 0.08 rad of longitude, away from the poles) their degree-5
+// static classification admits (angular travel < 0.035 rad, < 0.2 rad of longitude, away from the poles) their degree-5
 // interpolants at the 6 Chebyshev nodes of the ray's parameter range reproduce them to < 3e-7 m (h) and < 2.2e-5 m on the
 // ground (lat, lon) in the worst admitted case, and to 5e-9 m / 5e-6 m for rays shorter than 100 km
 // (sweep: tools/ray_poly_probe.py).  The ray kernels therefore evaluate the full geodesy 6 times per ray and replace

@@ -540,13 +540,13 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
         const double nl = nl2 * rsq_nr<2>(nl2);
         // Static classification: may the ray polynomials be used along the WHOLE ray?  gam bounds the angular travel
         // (t_max <= (zref-ht)/cos(inc) because the local zenith angle of a straight ray decreases with height); the ray must
-        // stay clear of the poles (cos(lat) > gam + 0.02), turn by less than 0.08 rad in longitude (gam / (cos(lat) - gam)) and
+        // stay clear of the poles (cos(lat) > gam + 0.02), turn by less than 0.2 rad in longitude (gam / (cos(lat) - gam)) and
         // be shorter than 0.035 rad - inside that region the degree-5 interpolants are good to 1e-7 m in height and 2e-5 m
         // on the ground (tools/ray_poly_probe.py), which moves delays by < 1e-10 m - and must not reach the +-180 meridian
         // (the light path does not wrap longitudes).
         const double cosi = (lx * base.c0 * base.cl0 + ly * base.c0 * base.sl0 + lz * base.s0) / nl;
         const double gam = (P.zref - P.ht) / (cosi * 6.3e6);
-        const bool fast_ok = !active || ((cosi > 0.05) && (base.c0 > gam + 0.02) && (gam < 0.08 * (base.c0 - gam)) && (gam < 0.035) &&
+        const bool fast_ok = !active || ((cosi > 0.05) && (base.c0 > gam + 0.02) && (gam < 0.2 * (base.c0 - gam)) && (gam < 0.035) &&
                                          (fabs(lon) + 5.0 < 180.0));
         const int64_t slot = lt * BLOCK + tid;
         if (!SLOW) {

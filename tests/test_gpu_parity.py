@@ -190,7 +190,7 @@ def test_raytrace_domain_sweep(R, region):
         np.testing.assert_allclose(hyd, oh[0], rtol=0, atol=5 * TIGHT, equal_nan=True)
 
 
-@pytest.mark.parametrize('case', ['steep_80km', 'arctic_80km', 'nonunit_los', 'jittered_axes', 'mixed_axes', 'negative_ht'])
+@pytest.mark.parametrize('case', ['steep_80km', 'arctic_80km', 'polar_80km', 'nonunit_los', 'jittered_axes', 'mixed_axes', 'negative_ht'])
 def test_ray_polynomial_stress(R, case):
     """Corner cases of the ray-polynomial kernels against the oracle: the longest rays the static classification admits
     (52-62 deg incidence through an 80 km cube: the classification cuts at ~60 deg there, so both the light and the
@@ -206,6 +206,10 @@ def test_ray_polynomial_stress(R, case):
         c = O.synthetic_cube(60, 90, 40, seed=8, ztop=80000.0, y0=64.0, y1=79.0, x0=-175.0, x1=-130.0)
         ypts = np.linspace(75.0, 69.0, 10); xpts = np.linspace(-158.0, -150.0, 12)
         inc = rng.uniform(25, 45, (10, 12)); hd = rng.uniform(-180, 180, (10, 12)); ht = 0.0
+    elif case == 'polar_80km':        # 79-85.5 deg N: up to the classification's 0.2 rad of longitude travel (the hand-over to the generic
+        c = O.synthetic_cube(90, 120, 40, seed=8, ztop=80000.0, y0=70.0, y1=89.5, x0=-175.0, x1=-95.0)       # kernels sits near 84.5 deg N here)
+        ypts = np.linspace(85.5, 79.0, 14); xpts = np.linspace(-150.0, -120.0, 10)
+        inc = rng.uniform(25, 46, (14, 10)); hd = rng.uniform(-180, 180, (14, 10)); ht = 0.0
     else:
         c = O.synthetic_cube(40, 44, 36, seed=5, y0=30.0, y1=38.0, x0=-122.0, x1=-110.0)
         ypts = np.linspace(35.0, 33.0, 12); xpts = np.linspace(-117.5, -114.5, 14)

@@ -4,7 +4,7 @@
 coordinates at the N+1 Chebyshev nodes of the ray's parameter range [min(0,ht)-1, max(zref,(zref-ht)/cos(inc))+1] and
 reports the worst interpolation error over the rays the kernels' static classification admits
 (cos(inc) > 0.05, cos(lat) > gam + 0.02, gam < 0.08 (cos(lat) - gam), gam < 0.035, gam = (zref-ht)/(6.3e6 cos(inc))).
-usage: ray_poly_probe.py [degree=5] [nrays=3000]"""
+usage: ray_poly_probe.py [degree=5] [nrays=3000] [lon_travel_limit=0.2]"""
 import sys
 from pathlib import Path
 
@@ -35,6 +35,7 @@ def exact_llh(o, l, t):
 def main():
     deg = int(sys.argv[1]) if len(sys.argv) > 1 else 5
     nrays = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
+    lon_lim = float(sys.argv[3]) if len(sys.argv) > 3 else 0.2
     rng = np.random.default_rng(0)
     n = deg + 1
     u = np.cos(np.pi * (2 * np.arange(n) + 1) / (2 * n))
@@ -60,8 +61,8 @@ def main():
         rows.append((gam, c0, cosi, tb, eh, ep, el))
     r = np.array(rows)
     gam, c0, cosi, tb, eh, ep, el = r.T
-    ok = (cosi > 0.05) & (c0 > gam + 0.02) & (gam < 0.08 * (c0 - gam)) & (gam < 0.035)
-    print(f'degree {deg}: {ok.sum()} of {nrays} rays admitted by the classification')
+    ok = (cosi > 0.05) & (c0 > gam + 0.02) & (gam < lon_lim * (c0 - gam)) & (gam < 0.035)
+    print(f'degree {deg}, longitude-travel limit {lon_lim}: {ok.sum()} of {nrays} rays admitted by the classification')
     for lim in (100e3, 1e9):
         m = ok & (tb < lim)
         print(f'  rays shorter than {lim / 1e3:.0f} km: n={m.sum():5d}  max interpolation error  h {eh[m].max():.1e} m   lat {ep[m].max():.1e} m   lon {el[m].max():.1e} m (on the ground)')
