@@ -134,21 +134,49 @@ __device__ __forceinline__ void ecef2lla_delta(const RayBase& b, double x, doubl
     h = g.h;
 }
 
-// The same point projected onto a SPHERICAL Lambert conformal conic grid (HRRR: e = 0), from the sine / cosine of the
-// latitude the geodesy already has: tan(pi/4 - phi/2) = cos(phi) / (1 + sin(phi)), rho = aF t^n = aF exp(n log t) -
-// one log, one exp and one sincos instead of lcc_forward's sin, tan, pow and sincos.
-__device__ __forceinline__ void ecef2lcc_sphere(const RayBase& b, const LccParams& L, double x, double y, double z,
-                                                double& px, double& py, double& h) {
+// The same point projected onto a SPHERICAL Lambert conformal conic grid (HRRR: e = 0), RELATIVE to the projection of the
+// ray origin (done once per ray with the full lcc_forward): with t = tan(pi/4 - phi/2) = cos(phi) / (1 + sin(phi)),
+//   rho / rho_origin = (t / t_origin)^n = exp(n D),  D = log(t / t_origin) = 2 atanh(z),  z = (t - t_o) / (t + t_o)
+//   theta - theta_origin = n (lam - lam_origin)
+// and both D and the angle are small for a node of an admitted ray (|z| < 0.05 by the LCC clause of the static
+// classification, |n dlam| < 0.2), so short series replace log, exp and sincos: atanh through z^9 (next term 9e-15
+// relative), exp through x^9 (3e-17), sin / cos through x^11 / x^12 (< 1e-19).  No libm call per node - which is what lets
+// the LCC instantiation of crossings_kernel keep the register budget of the lon/lat one.
+struct LccOrigin { double rho, st, ct; };      // rho_origin and sin / cos of theta_origin (either sign convention of rho works:
+                                               // only rho * st and rho * ct are used)
+
+__device__ __forceinline__ void ecef2lcc_sphere(const RayBase& b, const LccParams& L, const LccOrigin& o, double x, double y, double z,
+                                                double& dpx, double& dpy, double& h) {
     const GeoF g = geo_fast<true>(x, y, z);
     const double sl = fma(b.cl0, y, -b.sl0 * x) * g.rp;
-    double dlam = fma(asin_small(sl), 1.0, b.lon0 * DEG_TO_RAD) - L.lam0;
-    if (dlam > 3.141592653589793) dlam -= 6.283185307179586;
-    else if (dlam < -3.141592653589793) dlam += 6.283185307179586;
-    const double rho = L.aF * exp(L.n * log(g.cphi / (1.0 + g.sphi)));
-    double st, ct;
-    sincos(L.n * dlam, &st, &ct);
-    px = L.x0 + rho * st;
-    py = L.y0 + L.rho0 - rho * ct;
+    const double ang = L.n * asin_small(sl);                                   // theta - theta_origin
+    // z = (t - t_o) / (t + t_o) with the common denominator (1 + sin phi)(1 + sin phi_o) removed
+    const double ta = g.cphi * (1.0 + b.s0), tb = b.c0 * (1.0 + g.sphi);
+    const double den = ta + tb;
+    double iden = __builtin_amdgcn_rcp(den);
+    iden = fma(fma(-den, iden, 1.0), iden, iden);
+    iden = fma(fma(-den, iden, 1.0), iden, iden);
+    const double zz = (ta - tb) * iden, z2 = zz * zz;
+    double q = fma(z2, 1.0 / 9.0, 1.0 / 7.0);
+    q = fma(z2, q, 1.0 / 5.0);
+    q = fma(z2, q, 1.0 / 3.0);
+    const double xe = L.n * (2.0 * fma(zz * z2, q, zz));                       // n log(t / t_o)
+    double e = fma(xe, 1.0 / 362880.0, 1.0 / 40320.0);
+    e = fma(xe, e, 1.0 / 5040.0); e = fma(xe, e, 1.0 / 720.0); e = fma(xe, e, 1.0 / 120.0); e = fma(xe, e, 1.0 / 24.0);
+    e = fma(xe, e, 1.0 / 6.0); e = fma(xe, e, 0.5); e = fma(xe, e, 1.0);
+    const double em1 = xe * e;                                                 // exp(xe) - 1
+    const double a2 = ang * ang;
+    double sn = fma(a2, -1.0 / 39916800.0, 1.0 / 362880.0);
+    sn = fma(a2, sn, -1.0 / 5040.0); sn = fma(a2, sn, 1.0 / 120.0); sn = fma(a2, sn, -1.0 / 6.0);
+    sn = fma(ang * a2, sn, ang);                                               // sin(ang)
+    double cm = fma(a2, 1.0 / 479001600.0, -1.0 / 3628800.0);
+    cm = fma(a2, cm, 1.0 / 40320.0); cm = fma(a2, cm, -1.0 / 720.0); cm = fma(a2, cm, 1.0 / 24.0); cm = fma(a2, cm, -0.5);
+    cm = a2 * cm;                                                              // cos(ang) - 1
+    // rho sin(theta) - rho_o sin(theta_o) and rho cos(theta) - rho_o cos(theta_o), kept as DIFFERENCES (no cancellation):
+    //   rho/rho_o = 1 + em1,  sin(theta) = st (1 + cm) + ct sn,  cos(theta) = ct (1 + cm) - st sn
+    const double ds = fma(o.st, cm, o.ct * sn), dc = fma(o.ct, cm, -o.st * sn);
+    dpx = o.rho * fma(em1, o.st + ds, ds);                                     //  x - x_origin
+    dpy = -o.rho * fma(em1, o.ct + dc, dc);                                    //  y - y_origin
     h = g.h;
 }
 
@@ -171,25 +199,27 @@ template <bool LCC>
 __device__ __forceinline__ void fit_ray_poly(const RayBase& b, double ox, double oy, double oz, double lx, double ly, double lz,
                                              double mid, double half, const LccParams& proj, RayPoly& q) {
     double x0 = b.lon0, y0 = b.lat0;
-    if (LCC) lcc_forward(proj, b.lat0, b.lon0, x0, y0);
+    LccOrigin org = {0.0, 0.0, 0.0};
+    if (LCC) {
+        // Spherical cone (the static classification sends every ray of an ELLIPSOIDAL LCC cube to the generic kernels):
+        // rho = aF t^n with t = cos(phi) / (1 + sin(phi)) from the base's own sine / cosine - one log, one exp and one sincos
+        // per ray instead of lcc_forward's sin, tan, pow and sincos.
+        double dlam = b.lon0 * DEG_TO_RAD - proj.lam0;
+        if (dlam > 3.141592653589793) dlam -= 6.283185307179586;
+        else if (dlam < -3.141592653589793) dlam += 6.283185307179586;
+        org.rho = proj.aF * exp(proj.n * log(b.c0 / (1.0 + b.s0)));
+        sincos(proj.n * dlam, &org.st, &org.ct);
+        x0 = fma(org.rho, org.st, proj.x0);
+        y0 = proj.y0 + proj.rho0 - org.rho * org.ct;
+    }
 #pragma unroll
     for (int n = 0; n < PN; ++n) { q.h[n] = 0.0; q.lat[n] = 0.0; q.lon[n] = 0.0; }
 #pragma unroll 1
     for (int j = 0; j < PN; ++j) {
         const double t = fma(half, RAY_POLY_NODES[j], mid);
         double dx, dy, h;
-        if (LCC && proj.e == 0.0) {
-            double px, py;
-            ecef2lcc_sphere(b, proj, fma(t, lx, ox), fma(t, ly, oy), fma(t, lz, oz), px, py, h);
-            dx = px - x0; dy = py - y0;
-        } else {
-            ecef2lla_delta(b, fma(t, lx, ox), fma(t, ly, oy), fma(t, lz, oz), dx, dy, h);
-            if (LCC) {
-                double px, py;
-                lcc_forward(proj, b.lat0 + dy, b.lon0 + dx, px, py);
-                dx = px - x0; dy = py - y0;
-            }
-        }
+        if (LCC) ecef2lcc_sphere(b, proj, org, fma(t, lx, ox), fma(t, ly, oy), fma(t, lz, oz), dx, dy, h);
+        else ecef2lla_delta(b, fma(t, lx, ox), fma(t, ly, oy), fma(t, lz, oz), dx, dy, h);
 #pragma unroll
         for (int n = 0; n < PN; ++n) {
             const double v = RAY_POLY_VINV[j][n];

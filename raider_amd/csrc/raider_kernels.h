@@ -462,7 +462,7 @@ struct TileWalk {
 // LCC (light kernel only): the cube is on a Lambert-conformal-conic grid; a separate instantiation so that the projection's
 // pow/tan/sincos code does not weigh on the register allocation of the lon/lat one.
 template <typename T2, bool SLOW, bool LCC = false>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 : (LCC ? 2 : 4), SLOW ? 8 : (LCC ? 2 : 4)))) void crossings_kernel(CubeView<T2> c, RayParams P, LccParams proj) {
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 : 4, SLOW ? 8 : 4))) void crossings_kernel(CubeView<T2> c, RayParams P, LccParams proj) {
     if (SLOW && *P.nslow == 0) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const RaySmem m = carve_smem(smem_raw, c.ny, c.nx, c.nz, c.exact_y, c.exact_x);
@@ -546,8 +546,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
         // (the light path does not wrap longitudes).
         const double cosi = (lx * base.c0 * base.cl0 + ly * base.c0 * base.sl0 + lz * base.s0) / nl;
         const double gam = (P.zref - P.ht) / (cosi * 6.3e6);
+        // LCC cubes: spherical cones only (HRRR), and the node projections use short series in log(t/t_origin) <= gam / cos(lat)
+        // (geodesy_fast.h); an ellipsoidal cone goes to the generic kernels (lcc_forward) ray by ray.
         const bool fast_ok = !active || ((cosi > 0.05) && (base.c0 > gam + 0.02) && (gam < 0.2 * (base.c0 - gam)) && (gam < 0.035) &&
-                                         (fabs(lon) + 5.0 < 180.0));
+                                         (fabs(lon) + 5.0 < 180.0) && (proj.kind != 1 || (proj.e == 0.0 && gam < 0.09 * base.c0)));   // (run-time test: the generic kernels must classify identically)
         const int64_t slot = lt * BLOCK + tid;
         if (!SLOW) {
             const unsigned long long slow_mask = __ballot(!fast_ok);

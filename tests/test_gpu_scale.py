@@ -299,6 +299,38 @@ def test_hrrr_lambert_cube(R):
     np.testing.assert_allclose(w, rw, rtol=0, atol=TIGHT); np.testing.assert_allclose(h, rh, rtol=0, atol=TIGHT)
 
 
+def test_ellipsoidal_lambert_cube(R):
+    """An LCC cube on an ELLIPSOIDAL cone (two standard parallels, WGS84): the polynomial kernels only know the spherical cone
+    (HRRR), so every ray is handed to the generic kernels, which evaluate the full PROJ formulas - same parity bar."""
+    from raider_amd.delay import _build_cube_ray
+    from raider_amd.delayFcns import interpolators_from_cube
+    from raider_amd.losreader import Raytracing
+    ell = dict(lat_1=33.0, lat_2=45.0, lat_0=38.5, lon_0=262.5, x_0=1000.0, y_0=-2000.0, a=6378137.0, es=0.0066943799901413165)
+    lat = np.linspace(38.4, 37.6, 13); lon = np.linspace(-106.5, -104.9, 15)
+    cx, cy = O.lcc_forward(*np.meshgrid(lat, lon, indexing='ij'), **ell)
+    ny, nx, nz = 90, 110, 30
+    ys = cy.min() - 60e3 + 3000.0 * np.arange(ny); xs = cx.min() - 60e3 + 3000.0 * np.arange(nx)
+    assert ys[-1] > cy.max() + 30e3 and xs[-1] > cx.max() + 30e3
+    zs = np.round(-100 + 26100 * np.linspace(0, 1, nz) ** 2, 3)
+    rng = np.random.default_rng(10)
+    z3 = zs[:, None, None]
+    wet = (60 * np.exp(-z3 / 2000) * (1 + 0.1 * rng.standard_normal((ny, nx))[None])).astype(np.float32)
+    hyd = (270 * np.exp(-z3 / 8000) * (1 + 0.01 * rng.standard_normal((ny, nx))[None])).astype(np.float32)
+    cube = R.Cube(ys, xs, zs, wet, hyd, order='zyx')
+    cube.set_projection_lcc(**ell)
+    py, px = cube.project(*np.meshgrid(lat, lon, indexing='ij'))
+    np.testing.assert_allclose(px, cx, rtol=0, atol=1e-6); np.testing.assert_allclose(py, cy, rtol=0, atol=1e-6)
+    ip = list(O.getInterpolators(xs, ys, zs, wet, hyd))
+    look = lambda ht, llh, xyz, yy: O.look_vectors_from_inc_hd(np.full(yy.shape, 36.0), np.full(yy.shape, -167.9), llh[1], llh[0], llh[2])
+    zref = float(zs.max() - 1)
+    zpts = np.array([0.0, 1500.0])
+    (rw, rh), _ = O.build_cube_ray(lon, lat, zpts, look, ip, MAX_TROPO_HEIGHT=zref, return_nparts=True, model_proj=ell)
+    w, h = _build_cube_ray(lon, lat, zpts, Raytracing(inc=36.0, heading=-167.9), dict(proj='lcc', **ell), 4326, list(interpolators_from_cube(cube)),
+                           MAX_TROPO_HEIGHT=zref)
+    assert np.isfinite(rw).all()
+    np.testing.assert_allclose(w, rw, rtol=0, atol=TIGHT); np.testing.assert_allclose(h, rh, rtol=0, atol=TIGHT)
+
+
 def test_device_resident_partition_exchange(R):
     """rdr_ray_prepass_device / rdr_ray_march_device: two half-slabs driven through a device-resident partition that is
     MAX-combined on the device (what the RCCL all-reduce does across ranks) reproduce the whole-slice result bit for bit,
