@@ -251,3 +251,21 @@ def test_diverged_lengths_are_refused(R, c1):
     wet, hyd, _, _ = cube.raytrace(rays, 0.0, zref, want_nparts=False)         # device arrays, no host sync: NaN outputs
     torch.cuda.synchronize()
     assert torch.isnan(wet).all() and torch.isnan(hyd).all()
+
+
+def test_randomised_sweep():
+    """tools/fuzz_parity.py (random cubes, axes kinds incl. a descending latitude axis, scenes partly outside the cube, heights,
+    integration tops, incidence to 70 deg, NaN look vectors, segment lengths): 80 trials here; 2550 trials over 7 seeds were run
+    when it was written - no mismatch in nParts, NaN pattern, error behaviour; worst |delay difference| 1.1e-9 m."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    out = subprocess.run([sys.executable, str(root / 'tools' / 'fuzz_parity.py'), '80', '21'], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    res = json.loads(lines[0])
+    assert res['stats']['trials'] == 80 and res['stats']['rays'] > 2000
+    assert res['n_bad'] == 0, lines[1:6]
+    assert max(res['worst_abs_m'].values()) < 5e-9

@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep: GPU ray tracer vs the NumPy oracle over random cubes (size, extent, model top, uniform / jittered /
+stretched axes), scenes (anywhere on the globe short of the poles and the date line, partly outside the cube), heights,
+integration tops, incidence angles up to 70 degrees and segment lengths.  Not part of the test suite (minutes of CPU for the
+oracle): a tool to shake out rare-path bugs.   usage: fuzz_parity.py [ntrials=200] [seed=0]"""
+import json
+import sys
+from pathlib import Path
+
+import numpy as np
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import raider_amd as R                      # noqa: E402
+from oracle import raider_oracle as O       # noqa: E402
+
+ntrials = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+rng = np.random.default_rng(seed)
+worst = dict(wet=0.0, hydro=0.0)
+bad = []
+stats = dict(trials=0, all_nan_slices=0, no_level_slices=0, nan_rays=0, rays=0)
+for trial in range(ntrials):
+    ny, nx, nz = int(rng.integers(6, 50)), int(rng.integers(6, 50)), int(rng.integers(5, 48))
+    lat_c = rng.uniform(-80, 80); lon_c = rng.uniform(-160, 160)
+    dlat = rng.uniform(1.5, 8.0); dlon = min(rng.uniform(1.5, 8.0) / max(np.cos(np.radians(lat_c)), 0.2), 30.0)
+    ztop = float(rng.choice([15000.0, 26000.0, 41000.0, 80000.0]))
+    c = O.synthetic_cube(ny, nx, nz, seed=int(rng.integers(1 << 30)), ztop=ztop, y0=lat_c - dlat, y1=lat_c + dlat, x0=lon_c - dlon, x1=lon_c + dlon)
+    axes_kind = rng.choice(['exact', 'jitter', 'stretch'])
+    if axes_kind == 'jitter':
+        c['xs'] = c['xs'] + 1e-7 * rng.uniform(-1, 1, nx); c['ys'] = c['ys'] + 1e-7 * rng.uniform(-1, 1, ny)
+    elif axes_kind == 'stretch':
+        c['xs'] = c['xs'][0] + (c['xs'] - c['xs'][0]) * (1 + 0.15 * np.linspace(0, 1, nx)); c['ys'] = c['ys'][0] + (c['ys'] - c['ys'][0]) * (1 + 0.1 * np.linspace(0, 1, ny))
+    if rng.random() < 0.25:          # latitude axis stored north to south (scipy's RGI flips descending axes, _rgi.py:280-281)
+        c['ys'] = c['ys'][::-1].copy(); c['wet'] = c['wet'][:, ::-1, :].copy(); c['hydro'] = c['hydro'][:, ::-1, :].copy()
+        axes_kind = str(axes_kind) + '+descending_y'
+    gy, gx = int(rng.integers(3, 14)), int(rng.integers(3, 14))
+    f = rng.uniform(0.3, 1.15)                                   # > 1: part of the scene starts outside the cube
+    ypts = np.linspace(lat_c + f * dlat, lat_c - f * dlat, gy) if rng.random() < 0.7 else np.linspace(lat_c - f * dlat, lat_c + f * dlat, gy)
+    xpts = np.linspace(lon_c - f * dlon, lon_c + f * dlon, gx)
+    ht = float(rng.choice([0.0, -80.0, 250.0, 1234.5, 3000.0, float(c['zs'][3]), float(c['zs'].max() + 5.0)]))
+    zref = float(min(rng.choice([c['zs'].max() - 1, 0.6 * c['zs'].max(), c['zs'].max() + 500.0]), c['zs'].max() - 1))     # delay.py:86-93
+    max_seg = float(rng.choice([1000.0, 1000.0, 400.0, 2500.0]))
+    inc = rng.uniform(0, 70, (gy, gx)) if rng.random() < 0.8 else np.full((gy, gx), rng.uniform(15, 50))
+    hd = rng.uniform(-180, 180, (gy, gx)) if rng.random() < 0.5 else np.full((gy, gx), -167.9)
+    nan_los = rng.random() < 0.15
+    look = lambda ht_, llh, xyz, yy: O.look_vectors_from_inc_hd(inc, hd, llh[1], llh[0], llh[2])
+    xx, yy = np.meshgrid(xpts, ypts)
+    los = look(ht, [xx, yy, np.full(yy.shape, ht)], None, yy)
+    if nan_los:
+        los[rng.random((gy, gx)) < 0.2] = np.nan
+    look2 = lambda ht_, llh, xyz, yy_: los
+    ip = list(O.getInterpolators(c['xs'], c['ys'], c['zs'], c['wet'], c['hydro']))
+    cube = R.Cube(c['ys'], c['xs'], c['zs'], c['wet'], c['hydro'], order='zyx')
+    tag = dict(trial=trial, cube=[ny, nx, nz], ztop=ztop, axes=str(axes_kind), lat=round(lat_c, 2), lon=round(lon_c, 2), ht=ht, zref=zref, max_seg=max_seg, scene=[gy, gx])
+    stats['trials'] += 1
+    try:
+        o_err = None
+        (ow, oh), onp = O.build_cube_ray(xpts, ypts, np.array([ht]), look2, ip, MAX_SEGMENT_LENGTH=max_seg, MAX_TROPO_HEIGHT=zref, return_nparts=True)
+    except Exception as e:           # the reference's own failure modes (all-NaN lengths, no levels on a non-top slice, ...)
+        o_err = type(e).__name__
+    try:
+        g_err = None
+        wet, hyd, nparts, _ = cube.raytrace(R.Rays.grid(xpts, ypts, los=np.ascontiguousarray(los)), ht, zref, max_seg)
+    except R.NoLevels:
+        g_err = 'NoLevels'
+    except Exception as e:
+        g_err = type(e).__name__
+    if o_err or g_err:
+        # oracle: build_ray returning None on the (only = last) slice leaves zeros (delay.py:276-277) - the engine raises NoLevels
+        if g_err == 'NoLevels' and o_err is None and np.all(ow == 0):
+            stats['no_level_slices'] += 1
+            continue
+        if o_err == 'ValueError' and g_err == 'ValueError':
+            stats['all_nan_slices'] += 1
+            continue
+        bad.append(dict(tag, kind='error mismatch', oracle=o_err, gpu=g_err))
+        continue
+    stats['rays'] += gy * gx; stats['nan_rays'] += int(np.isnan(oh[0]).sum())
+    if not np.array_equal(nparts, onp[0]):
+        bad.append(dict(tag, kind='nparts', gpu=nparts.tolist(), oracle=list(map(int, onp[0]))))
+        continue
+    if not np.array_equal(np.isnan(hyd), np.isnan(oh[0])) or not np.array_equal(np.isnan(wet), np.isnan(ow[0])):
+        bad.append(dict(tag, kind='nan pattern', gpu_nan=int(np.isnan(hyd).sum()), oracle_nan=int(np.isnan(oh[0]).sum())))
+        continue
+    dw = float(np.nanmax(np.abs(wet - ow[0]))) if np.isfinite(ow[0]).any() else 0.0
+    dh = float(np.nanmax(np.abs(hyd - oh[0]))) if np.isfinite(oh[0]).any() else 0.0
+    worst['wet'] = max(worst['wet'], dw); worst['hydro'] = max(worst['hydro'], dh)
+    if max(dw, dh) > 2e-8:
+        bad.append(dict(tag, kind='value', d_wet=dw, d_hydro=dh, max_inc=float(inc.max())))
+print(json.dumps(dict(stats=stats, worst_abs_m=worst, n_bad=len(bad))))
+for b in bad[:40]:
+    print(json.dumps(b))
