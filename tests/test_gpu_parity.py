@@ -269,3 +269,20 @@ def test_randomised_sweep():
     assert res['stats']['trials'] == 80 and res['stats']['rays'] > 2000
     assert res['n_bad'] == 0, lines[1:6]
     assert max(res['worst_abs_m'].values()) < 5e-9
+
+
+def test_randomised_sweep_other_entry_points():
+    """tools/fuzz_natives.py: the zenith cube, station queries, `interpolate` 1-3 D, `interpolate_along_axis` and `makePoints0D..3D`
+    over random grids (exact / jittered / irregular / descending axes, NaN cells), queries outside / on the last node / NaN, fill
+    values: 120 trials here (2000 when written: bit-exact natives and makePoints, <= 6e-16 relative for the scipy-RGI gathers)."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    out = subprocess.run([sys.executable, str(root / 'tools' / 'fuzz_natives.py'), '120', '5'], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    res = json.loads(lines[0])
+    assert res['trials'] == 120 and res['n_bad'] == 0, lines[1:6]
+    assert max(res['worst_rel'].values()) < 1e-13
