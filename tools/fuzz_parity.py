@@ -99,6 +99,21 @@ for trial in range(ntrials):
     dw = float(np.nanmax(np.abs(wet - ow[0]))) if np.isfinite(ow[0]).any() else 0.0
     dh = float(np.nanmax(np.abs(hyd - oh[0]))) if np.isfinite(oh[0]).any() else 0.0
     worst['wet'] = max(worst['wet'], dw); worst['hydro'] = max(worst['hydro'], dh)
+    # the same rays as a POINT list (per-ray lat/lon, or per-ray ECEF origins): different tile mapping, no shared tile trigonometry
+    if trial % 3 == 0:
+        lo_c = np.ascontiguousarray(los).reshape(-1, 3)
+        if trial % 6 == 0:
+            rp = R.Rays.points(lat=yy.ravel().copy(), lon=xx.ravel().copy(), los=lo_c)
+        else:
+            xyz = np.stack(O.lla2ecef(yy.ravel(), xx.ravel(), np.full(yy.size, ht)), -1)
+            rp = R.Rays.points(xyz=np.ascontiguousarray(xyz), lat=yy.ravel().copy(), lon=xx.ravel().copy(), los=lo_c)
+        pw, ph, pn, _ = cube.raytrace(rp, ht, zref, max_seg)
+        stats['point_list_trials'] = stats.get('point_list_trials', 0) + 1
+        dp = max(float(np.nanmax(np.abs(pw.reshape(gy, gx) - wet))) if np.isfinite(wet).any() else 0.0,
+                 float(np.nanmax(np.abs(ph.reshape(gy, gx) - hyd))) if np.isfinite(hyd).any() else 0.0)
+        worst['points_vs_grid'] = max(worst.get('points_vs_grid', 0.0), dp)
+        if not np.array_equal(pn, nparts) or not np.array_equal(np.isnan(ph.reshape(gy, gx)), np.isnan(hyd)) or dp > 2e-9:
+            bad.append(dict(tag, kind='point list vs grid', d=dp, nparts_equal=bool(np.array_equal(pn, nparts))))
     if max(dw, dh) > 2e-8:
         bad.append(dict(tag, kind='value', d_wet=dw, d_hydro=dh, max_inc=float(inc.max())))
 print(json.dumps(dict(stats=stats, worst_abs_m=worst, n_bad=len(bad))))
