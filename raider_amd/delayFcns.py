@@ -80,7 +80,8 @@ def _read_cube_file(path):
         f = netcdf_file(str(path), 'r', mmap=True)          # stays open (kept alive by the loaders) until the mapping is dropped
 
         def loader(name):
-            return lambda: np.array(f.variables[name].data)  # a private copy: nothing refers to the mapped file afterwards
+            # a private native-endian copy (NetCDF-3 is big-endian): nothing refers to the mapped file afterwards
+            return lambda: np.array(f.variables[name].data, dtype=f.variables[name].data.dtype.newbyteorder('='))
         return {k: _Var(loader(k), {a: (b.decode() if isinstance(b, bytes) else b) for a, b in v._attributes.items()})
                 for k, v in f.variables.items()}
     from . import h5lite

@@ -176,3 +176,36 @@ def test_oracle_orbit_geometry():
     up = O.getZenithLookVecs(lat, lon, 0)
     inc = np.degrees(np.arccos(np.sum(los * up, -1)))
     assert inc.min() > 15 and inc.max() < 50
+
+
+def test_cube_file_variables_are_read_lazily(tmp_path):
+    """Processed-cube files: variables are read on first use (a ray-traced run never touches the *_total fields), values and
+    attributes survive the NetCDF-3 round trip, and the cheap NaN test agrees with np.isnan(...).any()."""
+    from scipy.io import netcdf_file
+    from raider_amd.delay import _has_nan
+    from raider_amd.delayFcns import _read_cube_file
+    p = tmp_path / 'cube.nc'
+    rng = np.random.default_rng(0)
+    wet = rng.random((4, 5, 6)).astype(np.float32); tot = rng.random((4, 5, 6))
+    with netcdf_file(str(p), 'w', version=2) as f:
+        for d, n in (('z', 4), ('y', 5), ('x', 6)):
+            f.createDimension(d, n)
+            f.createVariable(d, 'f8', (d,))[:] = np.arange(n, dtype=np.float64)
+        f.createVariable('wet', 'f4', ('z', 'y', 'x'))[:] = wet
+        f.createVariable('wet_total', 'f8', ('z', 'y', 'x'))[:] = tot
+        pj = f.createVariable('proj', 'i4', ())
+        pj.data[()] = 0
+        pj.crs_wkt = 'GEOGCRS["WGS 84",ID["EPSG",4326]]'
+    v = _read_cube_file(str(p))
+    assert callable(v['wet_total']._data) and callable(v['wet']._data)            # nothing read yet
+    assert v['proj'].attrs['crs_wkt'].endswith('4326]]')
+    got = v['wet'][:]
+    assert got.dtype == np.float32 and np.array_equal(got, wet) and v['wet'].data.flags.owndata
+    assert not callable(v['wet']._data) and callable(v['wet_total']._data)        # only what was asked for
+    assert np.array_equal(np.asarray(v['wet_total']), tot)
+    big = rng.random((70, 40, 40))
+    assert not _has_nan(big) and not _has_nan(big[::2])
+    big[33, 7, 9] = np.nan
+    assert _has_nan(big) and _has_nan(big[1::2]) and _has_nan(big.astype(np.float32)) and not _has_nan(np.zeros(5))
+    big[33, 7, 9] = np.inf
+    assert not _has_nan(big)
