@@ -419,3 +419,32 @@ def test_host_buffer_pipeline_matches_device_path(R):
     pw, ph, pn, pf = cube.raytrace(R.Rays.points(lat=yy.ravel(), lon=xx.ravel(), los=los.reshape(-1, 3)), 120.0, zref)
     assert np.array_equal(pn, dn)
     np.testing.assert_array_equal(pw.reshape(ny, nx), hw); np.testing.assert_array_equal(ph.reshape(ny, nx), hh)
+
+
+def test_two_contexts_in_two_threads(R):
+    """SURVEY 8(b) threading contract: a context is not thread-safe, DISTINCT contexts are.  Two threads, each with its own
+    context / cube / stream, trace different scenes concurrently (ctypes releases the GIL); results equal the serial ones."""
+    import threading
+    c = O.synthetic_cube(50, 50, 40, seed=0)
+    zref = float(c['zs'].max() - 1)
+    scenes = [(np.linspace(-119.5, -115.5, 300), np.linspace(34.5, 31.5, 280), 33.0), (np.linspace(-118.0, -116.0, 310), np.linspace(33.0, 32.0, 290), 41.0)]
+
+    def run(ctx, scene, out, reps):
+        cube = R.Cube(c['ys'], c['xs'], c['zs'], c['wet'], c['hydro'], order='zyx', ctx=ctx)
+        xp, yp, inc = scene
+        for _ in range(reps):
+            w, h, n, _f = cube.raytrace(R.Rays.grid(xp, yp, inc=inc, hd=-167.9), 0.0, zref)
+        out.append((w, h, n))
+
+    serial = []
+    for s in scenes:
+        run(R.Context(0), s, serial, 1)
+    outs = [[], []]
+    threads = [threading.Thread(target=run, args=(R.Context(0), scenes[i], outs[i], 6)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for i in range(2):
+        assert len(outs[i]) == 1
+        assert np.array_equal(outs[i][0][0], serial[i][0]) and np.array_equal(outs[i][0][1], serial[i][1]) and np.array_equal(outs[i][0][2], serial[i][2])
