@@ -209,6 +209,16 @@ int rdr_ecef2lla(rdr_ctx* ctx, const double* xyz, int64_t n, double* lon, double
 /* look vectors for a ray batch (any los_mode) -> los[n,3] */
 int rdr_look_vectors(rdr_ctx* ctx, const rdr_rays* rays, double ht, double* los);
 
+/* Front end of the cube producer for ECMWF hybrid model levels (ERA-5, HRES): utilFcns.calcgeoh (:781-859) +
+ * utilFcns.geo_to_ht (:378-410) + the re-ordering of models/ecmwf.py:92-110.  z_surf (surface geopotential) and lnsp: [ny*nx] f32;
+ * t, q: [nlev, ny, nx] f32 with level 1 = model top (file order); lats[ny] f32; a, b: [nlev+1] hybrid coefficients (host).
+ * p_out, zs_out: [ny, nx, nlev] f64, BOTTOM level first - the layout rdr_cubes_from_model_levels takes.  Arithmetic is float64
+ * on the float32 inputs: the reference's float32 evaluation of these formulas is ill-conditioned (heights off by up to 2.4 m,
+ * platform dependent in the last bit of logf); DESIGN.md 6.5. */
+int rdr_ecmwf_model_levels(rdr_ctx* ctx, const float* z_surf, const float* lnsp, const float* t, const float* q, const float* lats,
+                           const double* a, const double* b, int32_t nlev, int64_t ny, int64_t nx, double R_d,
+                           double* p_out, double* zs_out, int loc);
+
 /* Cube producer (models/weatherModel.py:235-262: _find_e -> _uniform_in_z -> _checkForNans -> wet/hydro refractivity ->
  * _adjust_grid -> _getZTD): model-level columns zs3/p/t/hum [ny, nx, nlev] (heights ascending along the last axis,
  * humidity_type 0 = specific humidity q, 1 = relative humidity %) are resampled to the uniform levels new_z[nz] and

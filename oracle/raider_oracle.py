@@ -741,6 +741,83 @@ def cube_from_model_levels(zs, p, t, hum, humidity_type, new_z, k1=0.776, k2=0.2
 # synthetic workloads - shared by tests and bench so GPU and CPU see the
 # same seeded inputs
 # ----------------------------------------------------------------------------------------------
+def read_ecmwf_model_level_file(path, ll_bounds=None):
+    """models/ecmwf.py:305-337 `_makeDataCubes` + :58-79 for a raw ERA-5 / HRES model-level file (NetCDF-3 as the CDS writes
+    it: packed int16 `z, t, q, lnsp` on (time, level, latitude, longitude)): CF-decode to float32 (what xarray did for int16
+    data when the reference's test cubes were made: `data.astype(float32) * scale_factor + add_offset`, in float32), wrap the
+    longitudes to [-180, 180), keep the nodes inside ll_bounds = (S, N, W, E), make latitude / longitude ascending.
+    Returns dict(lats, lons, z (ny,nx), lnsp (ny,nx), t, q (nlev,ny,nx))."""
+    from scipy.io import netcdf_file
+    with netcdf_file(str(path), 'r', mmap=False) as f:
+        def dec(name):
+            v = f.variables[name]
+            raw = np.array(v.data)
+            out = raw.astype(np.float32)
+            out *= np.float32(v.scale_factor)
+            out += np.float32(v.add_offset)
+            out[raw == v._FillValue] = np.nan
+            return out
+        z, t, q, lnsp = (np.squeeze(dec(k)) for k in ('z', 't', 'q', 'lnsp'))
+        lats = np.array(f.variables['latitude'].data, dtype=np.float32)
+        lons = np.array(f.variables['longitude'].data, dtype=np.float32)
+    lons = ((lons + 180) % 360) - 180                                              # ecmwf.py:314
+    z, lnsp = z[0], lnsp[0]                                                        # :322,325 (the surface fields sit on level 1)
+    if ll_bounds is not None:
+        S, N, W, E = ll_bounds
+        my = (S <= lats) & (N >= lats); mx = (W <= lons) & (E >= lons)             # :317-319
+        lats, lons = lats[my], lons[mx]
+        z, lnsp, t, q = z[my][:, mx], lnsp[my][:, mx], t[:, my][:, :, mx], q[:, my][:, :, mx]
+    if lats[0] > lats[1]:                                                          # :63-68
+        z, lnsp, t, q, lats = z[::-1], lnsp[::-1], t[:, ::-1], q[:, ::-1], lats[::-1]
+    if lons[0] > lons[1]:                                                          # :70-75
+        z, lnsp, t, q, lons = z[..., ::-1], lnsp[..., ::-1], t[..., ::-1], q[..., ::-1], lons[::-1]
+    return dict(lats=lats, lons=lons, z=np.ascontiguousarray(z), lnsp=np.ascontiguousarray(lnsp), t=np.ascontiguousarray(t), q=np.ascontiguousarray(q))
+
+
+def ecmwf_model_levels(z_surf, lnsp, t, q, lats, a, b, R_d=287.06, g0=9.80665, dtype=np.float32):
+    """utilFcns.calcgeoh (:781-859) + geo_to_ht (:378-410, with _get_g_ll :351-353 and get_Re :356-376) + the re-ordering of
+    ecmwf.py:92-110: hybrid-level pressures, geopotential integrated upwards from the surface, geopotential height, geometric
+    height.  dtype=float32 is what the reference really ran when its test cubes were written: float32 arrays decoded from the
+    packed file, Python-float constants, NumPy-1 value-based casting, so every operation is float32.  That evaluation is
+    ill-conditioned - dlogP = log(P1) - log(P0) and alpha = 1 - P0/(P1-P0) dlogP lose 3-4 digits - and lands up to 2.4 m from
+    the float64 evaluation of the same formulas (dtype=float64), with a last-bit change in log() moving a height by metres.
+    t, q: (nlev, ny, nx) with level 1 = model top; returns (p, hgt) as (ny, nx, nlev) `dtype`, bottom level first."""
+    ft = np.dtype(dtype).type
+    t = np.asarray(t, dtype=ft); q = np.asarray(q, dtype=ft)
+    z_surf = np.asarray(z_surf, dtype=ft); lnsp = np.asarray(lnsp, dtype=ft)
+    nlev = t.shape[0]
+    a = [float(v) for v in a]; b = [float(v) for v in b]
+    if len(a) != nlev + 1 or len(b) != nlev + 1:
+        raise ValueError(f'I have here a model with {nlev} levels, but parameters a and b have lengths {len(a)} and {len(b)} '
+                         'respectively. Of course, these three numbers should be equal.')
+    pres = np.zeros_like(t); gh = np.zeros_like(t)
+    sp = np.exp(lnsp)
+    z_h = 0
+    for lev in range(nlev, 0, -1):
+        il = lev - 1
+        tl = t[il] * (1 + ft(0.609133) * q[il])                                    # moist temperature
+        ph = ft(a[lev - 1]) + (ft(b[lev - 1]) * sp); ph1 = ft(a[lev]) + (ft(b[lev]) * sp)
+        pres[il] = ph
+        if lev == 1:
+            dlogp = np.log(ph1 / ft(0.1)); alpha = ft(np.log(2))
+        else:
+            dlogp = np.log(ph1) - np.log(ph)
+            alpha = 1 - ((ph / (ph1 - ph)) * dlogp)
+        trd = tl * ft(R_d)
+        z_f = z_h + trd * alpha + z_surf
+        gh[il] = z_f / ft(g0)
+        z_h = z_h + trd * dlogp
+    hgt = gh.transpose(1, 2, 0)
+    latf = np.broadcast_to(np.asarray(lats, dtype=ft)[:, None, None], hgt.shape)
+    c2 = np.cos(np.radians(2 * latf))
+    g_ll = ft(9.80616) * (1 - ft(0.002637) * c2 + ft(0.0000059) * c2 ** 2)
+    cl, sl = np.cos(np.radians(latf)), np.sin(np.radians(latf))
+    re = np.sqrt(1 / (((cl ** 2) / ft(6378137 ** 2)) + ((sl ** 2) / ft(6356752 ** 2))))
+    h = (hgt * re) / (g_ll / ft(g0) * re - hgt)
+    assert h.dtype == ft and pres.dtype == ft
+    return np.flip(pres.transpose(1, 2, 0), axis=2).copy(), np.flip(h, axis=2).copy()
+
+
 def ztd_totals(field_yxz, zs):
     """weatherModel.py:389-403 `_getZTD` on a (y, x, z) field: total[..., l] = 1e-6 * trapz(field[..., l:], zs[l:])."""
     f = np.asarray(field_yxz)

@@ -10,6 +10,14 @@
       a 145 x 5 x 6 block of the three GMAO cubes of /root/reference/test/gunw_test_data/weather_files/ (12:00, 15:00 and
       the reference's own `timeInterp` product for 13:52:44): pins the two-epoch temporal blend (cli/raider.py:817-819,
       877-888) on a file the reference itself produced.
+  tests/golden/ref_files/ERA-5_2019_11_17_T20_51_58.nc, ERA-5_2022_08_29_T17_00_01.nc (+ the latter's processed cube
+      ERA-5_2022_08_29_T17_00_01_69N_73N_159W_152W.nc)
+      RAW ERA-5 model-level files (NetCDF-3, packed int16 z / t / q / lnsp on 137 levels) whose processed counterparts sit
+      beside them: the whole producer chain raw file -> processed cube is replayed against what the real RAiDER wrote.
+  raider_amd/data/ecmwf_l137.npz
+      ECMWF's published L137 hybrid-level coefficients a, b (138 each) and the 145 output heights every ECMWF model is
+      resampled to, as DATA (read off the reference's models/model_levels.py tables A_137_HRES, B_137_HRES,
+      LEVELS_137_HEIGHTS by importing it).
 """
 import shutil
 import sys
@@ -47,6 +55,15 @@ def main():
     out['x'], out['y'], out['z'] = f['x'].read()[blk[2]], f['y'].read()[blk[1]], f['z'].read()
     out['query_time'] = np.array('2020-01-30T13:52:44')
     np.savez_compressed(OUT / 'g12_gmao_time_interp.npz', **out)
+    for fn in ('ERA-5_2019_11_17_T20_51_58.nc', 'ERA-5_2022_08_29_T17_00_01.nc', 'ERA-5_2022_08_29_T17_00_01_69N_73N_159W_152W.nc'):
+        shutil.copyfile(REF_TEST / 'weather_files' / fn, OUT / 'ref_files' / fn)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('model_levels', '/root/reference/tools/RAiDER/models/model_levels.py')
+    ml = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ml)
+    (REPO / 'raider_amd' / 'data').mkdir(exist_ok=True)
+    np.savez(REPO / 'raider_amd' / 'data' / 'ecmwf_l137.npz', a=np.array(ml.A_137_HRES, dtype=np.float64), b=np.array(ml.B_137_HRES, dtype=np.float64),
+             level_heights=np.array(ml.LEVELS_137_HEIGHTS, dtype=np.float64))
     print('g12_gmao_time_interp.npz', (OUT / 'g12_gmao_time_interp.npz').stat().st_size // 1024, 'KiB;', src.name, src.stat().st_size // 1024, 'KiB')
 
 

@@ -83,6 +83,7 @@ SYMBOLS = [
     ('rdr_inverse_time_weights', C.c_int, [_VP, _VP, C.c_int64, _VP, C.c_int32, C.c_double, C.c_double, _VP, C.c_int]),
     ('rdr_cube_blend_weighted', C.c_int, [_VP, C.POINTER(_VP), C.c_int32, _VP, C.c_int, C.POINTER(_VP)]),
     ('rdr_delays_to_phase', C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_int, C.c_double, _VP, _VP, C.c_int]),
+    ('rdr_ecmwf_model_levels', C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int32, C.c_int64, C.c_int64, C.c_double, _VP, _VP, C.c_int]),
     ('rdr_cubes_from_model_levels', C.c_int, [_VP, _VP, C.c_int64, _VP, C.c_int64, _VP, _VP, _VP, _VP, C.c_int, C.c_int64, _VP, C.c_int64,
                                               C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.POINTER(_VP), C.POINTER(_VP), _VP, _VP, _VP]),
     ('rdr_orbit_look_vectors', C.c_int, [_VP, _VP, _VP, _VP, C.c_int64, _VP, C.c_int64, C.c_double, C.c_int, _VP, _VP, _VP, C.c_int]),

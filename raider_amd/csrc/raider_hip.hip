@@ -510,6 +510,49 @@ __global__ __launch_bounds__(256) void producer_kernel(ProducerParams P) {
     }
 }
 
+// ---- ECMWF hybrid model levels -> pressure and geometric height (front end of the cube producer) ----------------------------
+// utilFcns.calcgeoh (:781-859): half-level pressures a + b sp, geopotential integrated upwards from the surface with the moist
+// temperature, geopotential height; utilFcns.geo_to_ht (:378-410): geometric height with latitude-dependent gravity and Earth
+// radius; models/ecmwf.py:92-110: (lev, y, x) top-first -> (y, x, lev) bottom-first.  One column per thread.
+// FLOAT64 arithmetic on the float32 inputs.  The reference evaluates these formulas in float32 (NumPy-1 casting rules), where
+// dlogP = log(P1) - log(P0) and alpha = 1 - P0/(P1-P0) dlogP lose 3-4 digits: its heights sit up to 2.4 m from the float64
+// values and move by METRES with a last-bit change of logf - no other platform can reproduce that realisation of the round-off
+// (the test suite's float32 NumPy restatement does, on x86: tests/test_ref_files.py), and a float32 evaluation here would only
+// add a second, different one.  DESIGN.md 6.5.
+__global__ __launch_bounds__(256) void ecmwf_levels_kernel(const float* __restrict__ z_surf, const float* __restrict__ lnsp,
+                                                           const float* __restrict__ t, const float* __restrict__ q,
+                                                           const float* __restrict__ lats, const double* __restrict__ a,
+                                                           const double* __restrict__ b, int nlev, int64_t ny, int64_t nx, double R_d,
+                                                           double* __restrict__ p_out, double* __restrict__ zs_out) {
+    const int64_t ncol = ny * nx;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const double g0 = 9.80665;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ncol; i += stride) {
+        const double lat = (double)lats[i / nx] * DEG_TO_RAD;
+        const double c2 = cos(2.0 * lat);
+        const double g_ll = 9.80616 * (1.0 - 0.002637 * c2 + 0.0000059 * (c2 * c2));         // _get_g_ll
+        const double cl = cos(lat), sl = sin(lat);
+        const double re = sqrt(1.0 / ((cl * cl) / (6378137.0 * 6378137.0) + (sl * sl) / (6356752.0 * 6356752.0)));   // get_Re
+        const double gre = g_ll / g0 * re;
+        const double sp = exp((double)lnsp[i]), zs0 = (double)z_surf[i];
+        double z_h = 0.0;
+        for (int lev = nlev; lev >= 1; --lev) {
+            const int64_t g = (int64_t)(lev - 1) * ncol + i;
+            const double tl = (double)t[g] * (1.0 + 0.609133 * (double)q[g]);               // moist temperature
+            const double ph = a[lev - 1] + b[lev - 1] * sp, ph1 = a[lev] + b[lev] * sp;
+            double dlogp, alpha;
+            if (lev == 1) { dlogp = log(ph1 / 0.1); alpha = 0.6931471805599453; }
+            else { dlogp = log(ph1 / ph); alpha = 1.0 - (ph / (ph1 - ph)) * dlogp; }
+            const double trd = tl * R_d;
+            const double gh = (z_h + trd * alpha + zs0) / g0;
+            z_h += trd * dlogp;
+            const int64_t o = i * nlev + (nlev - lev);
+            p_out[o] = ph;
+            zs_out[o] = (gh * re) / (gre - gh);                                              // geo_to_ht
+        }
+    }
+}
+
 // ---- look vectors from orbit state vectors ----------------------------------------------------------------------------
 // Replaces the per-pixel Python loop over isce3.geometry.geo2rdr + Orbit.interpolate of Raytracing.getLookVectors
 // (losreader.py:219-255).  isce3 is a third-party dependency that is not under /root/reference: this restates the published
@@ -1806,6 +1849,36 @@ int rdr_cubes_from_model_levels(rdr_ctx* c, const double* ys, int64_t ny, const 
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) return bail(fail(c, RDR_ERR_HIP, std::string("producer_kernel: ") + hipGetErrorString(e)));
     *pointwise = q[0]; *total = q[1];
+    return RDR_OK;
+}
+
+int rdr_ecmwf_model_levels(rdr_ctx* c, const float* z_surf, const float* lnsp, const float* t, const float* q, const float* lats,
+                           const double* a, const double* b, int32_t nlev, int64_t ny, int64_t nx, double R_d, double* p_out, double* zs_out, int loc) {
+    if (!c || !z_surf || !lnsp || !t || !q || !lats || !a || !b || !p_out || !zs_out) return fail(c, RDR_ERR_INVALID, "rdr_ecmwf_model_levels: NULL argument");
+    if (nlev < 1 || ny < 1 || nx < 1) return fail(c, RDR_ERR_INVALID, "rdr_ecmwf_model_levels: empty grid");
+    HIPCHECK(c, hipSetDevice(c->device));
+    const int64_t ncol = ny * nx;
+    // the small tables (latitudes, a, b) always come from the host; the fields and the outputs follow `loc`
+    void* aux;
+    int rc = ensure(c, SLOT_AUX, (size_t)(2 * (nlev + 1)) * 8 + (size_t)ny * 4, &aux); if (rc) return rc;
+    double* da = (double*)aux; double* db = da + (nlev + 1); float* dl = (float*)(db + (nlev + 1));
+    HIPCHECK(c, hipMemcpyAsync(da, a, (size_t)(nlev + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(db, b, (size_t)(nlev + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(dl, lats, (size_t)ny * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    const void *dz, *ds, *dt_, *dq; void *dp, *dh;
+    rc = stage_in(c, SLOT_IN0, z_surf, (size_t)ncol * 4, loc, &dz); if (rc) return rc;
+    rc = stage_in(c, SLOT_IN1, lnsp, (size_t)ncol * 4, loc, &ds); if (rc) return rc;
+    rc = stage_in(c, SLOT_IN2, t, (size_t)ncol * nlev * 4, loc, &dt_); if (rc) return rc;
+    rc = stage_in(c, SLOT_IN3, q, (size_t)ncol * nlev * 4, loc, &dq); if (rc) return rc;
+    rc = stage_out(c, SLOT_OUT0, p_out, (size_t)ncol * nlev * 8, loc, &dp); if (rc) return rc;
+    rc = stage_out(c, SLOT_OUT1, zs_out, (size_t)ncol * nlev * 8, loc, &dh); if (rc) return rc;
+    hipLaunchKernelGGL(ecmwf_levels_kernel, dim3(grid_for(ncol, 256, c->num_cus * 8)), dim3(256), 0, c->stream, (const float*)dz, (const float*)ds,
+                       (const float*)dt_, (const float*)dq, dl, da, db, (int)nlev, ny, nx, R_d, (double*)dp, (double*)dh);
+    HIPCHECK(c, hipGetLastError());
+    rc = finish_out(c, p_out, dp, (size_t)ncol * nlev * 8, loc); if (rc) return rc;
+    rc = finish_out(c, zs_out, dh, (size_t)ncol * nlev * 8, loc); if (rc) return rc;
+    HIPCHECK(c, hipStreamSynchronize(c->stream));       // the tables in SLOT_AUX must outlive the kernel
     return RDR_OK;
 }
 

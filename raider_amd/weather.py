@@ -100,3 +100,98 @@ def cubes_from_model_levels(xs, ys, zs, p, t, hum, humidity_type='q', new_z=None
         ctx.handle)
     pw, tot = Cube._from_handle(ctx, hp), Cube._from_handle(ctx, ht)
     return ProcessedModel(pw, tot, pw.grid[2].copy(), *state)
+
+
+# ------------------------------------------------------------------------------------------------
+# ECMWF hybrid model levels (ERA-5 / HRES raw files) -> the producer's inputs
+# ------------------------------------------------------------------------------------------------
+def ecmwf_l137():
+    """ECMWF's L137 hybrid coefficients and the 145 heights ECMWF models are resampled to (models/ecmwf.py:42-46 with the
+    tables of models/model_levels.py, shipped as data): dict(a[138], b[138], level_heights[145] descending)."""
+    from pathlib import Path
+    d = np.load(Path(__file__).resolve().parent / 'data' / 'ecmwf_l137.npz')
+    return {k: d[k] for k in d.files}
+
+
+def read_ecmwf_model_level_file(path, ll_bounds=None):
+    """Raw ERA-5 / HRES model-level file as the CDS / MARS write it (NetCDF-3, packed int16 `z, t, q, lnsp` on
+    (time, level, latitude, longitude)) -> dict(lats, lons, z, lnsp (ny, nx), t, q (nlev, ny, nx)), float32, latitude and
+    longitude ascending, longitudes in [-180, 180), cut to ll_bounds = (S, N, W, E).  Mirrors ECMWF._makeDataCubes and the
+    flips of _load_model_level (models/ecmwf.py:305-337, 58-79); host-side I/O (scipy), no GPU work."""
+    from scipy.io import netcdf_file
+    with netcdf_file(str(path), 'r', mmap=False) as f:
+        def decode(name):                     # CF scale/offset decoding in float32, as xarray does for int16 data
+            v = f.variables[name]
+            raw = np.array(v.data)
+            out = raw.astype(np.float32)
+            out *= np.float32(getattr(v, 'scale_factor', 1.0))
+            out += np.float32(getattr(v, 'add_offset', 0.0))
+            fill = getattr(v, '_FillValue', None)
+            if fill is not None:
+                out[raw == fill] = np.nan
+            return np.squeeze(out)
+        z, t, q, lnsp = decode('z'), decode('t'), decode('q'), decode('lnsp')
+        lats = np.array(f.variables['latitude'].data, dtype=np.float32)
+        lons = np.array(f.variables['longitude'].data, dtype=np.float32)
+    lons = ((lons + 180) % 360) - 180
+    z, lnsp = z[0], lnsp[0]                   # the two surface fields are stored on level 1
+    if ll_bounds is not None:
+        S, N, W, E = ll_bounds
+        my, mx = (S <= lats) & (N >= lats), (W <= lons) & (E >= lons)
+        lats, lons = lats[my], lons[mx]
+        z, lnsp, t, q = z[my][:, mx], lnsp[my][:, mx], t[:, my][:, :, mx], q[:, my][:, :, mx]
+    if z.size == 0:
+        raise RuntimeError('There is no data in z, you may have a problem with your mask')           # ecmwf.py:334-335
+    if lats.size > 1 and lats[0] > lats[1]:
+        z, lnsp, t, q, lats = z[::-1], lnsp[::-1], t[:, ::-1], q[:, ::-1], lats[::-1]
+    if lons.size > 1 and lons[0] > lons[1]:
+        z, lnsp, t, q, lons = z[..., ::-1], lnsp[..., ::-1], t[..., ::-1], q[..., ::-1], lons[::-1]
+    c = np.ascontiguousarray
+    return dict(lats=c(lats), lons=c(lons), z=c(z), lnsp=c(lnsp), t=c(t), q=c(q))
+
+
+def ecmwf_model_levels(z_surf, lnsp, t, q, lats, a=None, b=None, R_d=287.06, ctx=None):
+    """utilFcns.calcgeoh + geo_to_ht + the re-ordering of ecmwf.py:92-110 on the GPU (rdr_ecmwf_model_levels): surface
+    geopotential and log surface pressure (ny, nx), temperature and specific humidity (nlev, ny, nx) with level 1 = model top,
+    latitudes (ny,) -> (p, zs), both (ny, nx, nlev) float64 with the bottom level first (the producer's layout).  NumPy in ->
+    NumPy out; torch tensors on the GPU in -> tensors out."""
+    ctx = ctx or Context.default()
+    if a is None or b is None:
+        tab = ecmwf_l137()
+        a, b = tab['a'], tab['b']
+    a, b = f64(a), f64(b)
+    dev = _is_dev(t)
+    lats = np.ascontiguousarray(lats.cpu().numpy() if _is_dev(lats) else lats, dtype=np.float32)
+    if dev:
+        import torch
+        zt, lt, tt, qt = (v.to(torch.float32).contiguous() for v in (z_surf, lnsp, t, q))
+        ctx.adopt_torch_stream(tt)
+        nlev, ny, nx = (int(v) for v in tt.shape)
+        p = torch.empty((ny, nx, nlev), dtype=torch.float64, device=tt.device); zs = torch.empty_like(p)
+    else:
+        zt, lt, tt, qt = (np.ascontiguousarray(v, dtype=np.float32) for v in (z_surf, lnsp, t, q))
+        nlev, ny, nx = tt.shape
+        p = np.empty((ny, nx, nlev)); zs = np.empty_like(p)
+    if tuple(qt.shape) != (nlev, ny, nx) or tuple(zt.shape) != (ny, nx) or tuple(lt.shape) != (ny, nx) or lats.size != ny:
+        raise ValueError('ecmwf_model_levels: t, q must be (nlev, ny, nx); z_surf, lnsp (ny, nx); lats (ny,)')
+    if a.size != nlev + 1 or b.size != nlev + 1:
+        raise ValueError(f'I have here a model with {nlev} levels, but parameters a and b have lengths {a.size} and {b.size} '
+                         'respectively. Of course, these three numbers should be equal.')                   # utilFcns.py:813-817
+    check(ctx.lib.rdr_ecmwf_model_levels(ctx.handle, ptr(zt), ptr(lt), ptr(tt), ptr(qt), ptr(lats), ptr(a), ptr(b), nlev, ny, nx, float(R_d),
+                                         ptr(p), ptr(zs), L.RDR_DEVICE if dev else L.RDR_HOST), ctx.handle)
+    return p, zs
+
+
+def load_ecmwf_model_levels(path, ll_bounds=None, new_z=None, return_state=False, ctx=None):
+    """WeatherModel.load for a raw ERA-5 / HRES model-level file (weatherModel.py:235-262 with ECMWF._load_model_level): file ->
+    hybrid-level pressures and geometric heights -> e -> uniform z levels -> NaN fill -> refractivities -> padded bottom level ->
+    ZTDs, everything after the file read on the GPU.  Returns the ProcessedModel that tropo_delay / getInterpolators take."""
+    ctx = ctx or Context.default()
+    raw = read_ecmwf_model_level_file(path, ll_bounds)
+    tab = ecmwf_l137()
+    p, zs = ecmwf_model_levels(raw['z'], raw['lnsp'], raw['t'], raw['q'], raw['lats'], tab['a'], tab['b'], ctx=ctx)
+    up = lambda v: np.ascontiguousarray(np.flip(v.transpose(1, 2, 0), axis=2), dtype=np.float64)          # ecmwf.py:98-106
+    if new_z is None:
+        new_z = np.flipud(tab['level_heights'])                                                            # ecmwf.py:44
+    return cubes_from_model_levels(raw['lons'].astype(np.float64), raw['lats'].astype(np.float64), zs, p, up(raw['t']), up(raw['q']), 'q',
+                                   new_z=new_z, return_state=return_state, ctx=ctx)
