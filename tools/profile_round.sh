@@ -1,7 +1,7 @@
 set -x
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-O=$R/gpurun_out/v10; mkdir -p $O
+O=$R/gpurun_out/${PROFILE_TAG:-v11}; mkdir -p $O
 python $R/bench.py > $O/bench.json 2> $O/bench.err
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python $R/bench.py --steps 10 --warmup 3 --cpu-sample 0 > $O/kt.log 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python $R/tools/pmc_probe.py > $O/fetch.log 2>&1
