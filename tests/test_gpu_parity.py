@@ -274,7 +274,9 @@ def test_randomised_sweep():
 def test_randomised_sweep_other_entry_points():
     """tools/fuzz_natives.py: the zenith cube, station queries, `interpolate` 1-3 D, `interpolate_along_axis` and `makePoints0D..3D`
     over random grids (exact / jittered / irregular / descending axes, NaN cells), queries outside / on the last node / NaN, fill
-    values: 120 trials here (2000 when written: bit-exact natives and makePoints, <= 6e-16 relative for the scipy-RGI gathers)."""
+    values: 120 trials here (3650 when written: bit-exact natives and makePoints, <= 6e-16 relative for the scipy-RGI gathers).  When
+    the reference's own extensions are there as binaries (oracle/_ref, built by oracle/build_ref.sh) the GPU results are compared
+    with THEM as well, bit for bit."""
     import json
     import subprocess
     import sys

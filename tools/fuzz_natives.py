@@ -15,6 +15,21 @@ from oracle import raider_oracle as O                                         # 
 from raider_amd.interpolate import interpolate, interpolate_along_axis        # noqa: E402
 from raider_amd import makePoints as MP                                       # noqa: E402
 
+# the reference's OWN two native extensions, compiled from their sources by oracle/build_ref.sh (checker only): when the binaries
+# are there (they travel to the GPU box with the repo), every native-extension trial is also compared with them directly
+REFN = None
+_so = Path(__file__).resolve().parent.parent / 'oracle' / '_ref' / 'RAiDER'
+if any(_so.glob('interpolate*.so')) and 'RAiDER' not in sys.modules:
+    import types
+    _pkg = types.ModuleType('RAiDER'); _pkg.__path__ = [str(_so)]
+    sys.modules['RAiDER'] = _pkg
+    try:
+        import RAiDER.interpolate as _ri      # noqa: E402
+        import RAiDER.makePoints as _rm       # noqa: E402
+        REFN = (_ri, _rm)
+    except ImportError:
+        REFN = None
+
 ntrials = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 worst = {}
@@ -79,7 +94,10 @@ for trial in range(ntrials):
     if rng.random() < 0.5:
         q[0] = [g[-1] for g in grids]; q[-1] = [g[0] for g in grids]
     fill = None if rng.random() < 0.5 else float(rng.choice([np.nan, 0.0, -7.5]))
-    note(f'interpolate {nd}D', interpolate(grids, vals, q, fill_value=fill), O.native_interpolate(grids, vals, q, fill_value=fill), 1e-12, dict(tag, nd=nd, fill=str(fill)))
+    got_i = interpolate(grids, vals, q, fill_value=fill)
+    note(f'interpolate {nd}D', got_i, O.native_interpolate(grids, vals, q, fill_value=fill), 1e-12, dict(tag, nd=nd, fill=str(fill)))
+    if REFN:
+        note(f'interpolate {nd}D vs compiled reference', got_i, REFN[0].interpolate(grids, vals, q, fill_value=fill, assume_sorted=False, max_threads=2), 0.0, dict(tag, nd=nd, fill=str(fill)))
     # ---- native `interpolate_along_axis` ---------------------------------------------------------------------------------------
     nd = int(rng.integers(1, 4)); ax = int(rng.integers(0, nd))
     shape = [int(rng.integers(2, 12)) for _ in range(nd)]
@@ -91,6 +109,9 @@ for trial in range(ntrials):
     try:
         got = interpolate_along_axis(base, vals, qq, axis=ax, fill_value=fill, max_threads=1)
         note('interpolate_along_axis', got, O.native_interpolate_along_axis(base, vals, qq, axis=ax, fill_value=fill), 1e-12, dict(tag, nd=nd, axis=ax, fill=str(fill)))
+        if REFN:
+            note('interpolate_along_axis vs compiled reference', got, REFN[0].interpolate_along_axis(base, vals, qq, axis=ax, fill_value=fill, assume_sorted=False, max_threads=1),
+                 0.0, dict(tag, nd=nd, axis=ax, fill=str(fill)))
     except Exception as e:
         bad.append(dict(tag, what='interpolate_along_axis', kind=type(e).__name__, msg=str(e)[:200], nd=nd, axis=ax))
     # ---- makePoints ----------------------------------------------------------------------------------------------------------------
@@ -102,6 +123,11 @@ for trial in range(ntrials):
     want = O.makePoints(max_len, sp, slv, step)
     if got.shape != want.shape or not np.array_equal(got, want):
         bad.append(dict(tag, what=f'makePoints{k}D', kind='not bit-exact', shape=list(got.shape)))
-print(json.dumps(dict(trials=ntrials, worst_rel=worst, n_bad=len(bad))))
+    if REFN:
+        ref = np.asarray(getattr(REFN[1], f'makePoints{k}D')(max_len, sp, slv, step))
+        if got.shape != ref.shape or not np.array_equal(got, ref):
+            bad.append(dict(tag, what=f'makePoints{k}D vs compiled reference', kind='not bit-exact', shape=list(got.shape), ref_shape=list(ref.shape)))
+        worst['makePoints vs compiled reference'] = 0.0
+print(json.dumps(dict(trials=ntrials, compiled_reference_natives=bool(REFN), worst_rel=worst, n_bad=len(bad))))
 for b in bad[:40]:
     print(json.dumps(b))
