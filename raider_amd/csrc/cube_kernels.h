@@ -1,0 +1,245 @@
+// Cube packing / blending, look vectors, zenith gathers, partition exchange, azimuth-time weights.
+// Part of libraider_hip.so (single translation unit: included by raider_hip.hip).  gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "raider_kernels.h"
+
+using namespace rdr;
+
+// ------------------------------------------------------------------------------------------------
+// small kernels
+// ------------------------------------------------------------------------------------------------
+template <typename T, typename T2>
+__global__ void pack_cube_kernel(const T* __restrict__ wet, const T* __restrict__ hyd, T2* __restrict__ dst,
+                                 int64_t ny, int64_t nx, int64_t nz, int64_t sy, int64_t sx, int64_t sz,
+                                 int fy, int fx, int fz) {
+    const int64_t total = ny * nx * nz;
+    for (int64_t o = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t iz = o % nz, r = o / nz, ix = r % nx, iy = r / nx;
+        const int64_t jy = fy ? ny - 1 - iy : iy, jx = fx ? nx - 1 - ix : ix, jz = fz ? nz - 1 - iz : iz;
+        const int64_t s = jy * sy + jx * sx + jz * sz;
+        T2 v; v.x = wet[s]; v.y = hyd[s];
+        dst[o] = v;
+    }
+}
+
+template <typename T, typename T2>
+__global__ void unpack_cube_kernel(const T2* __restrict__ src, T* __restrict__ wet, T* __restrict__ hyd, int64_t total) {
+    for (int64_t o = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x) {
+        const T2 v = src[o]; wet[o] = v.x; hyd[o] = v.y;
+    }
+}
+
+// cli/raider.py:817-819: sum([w*ds[var]]) = 0 + w1*a + w2*b in the array dtype (numpy<2 value-based casting)
+template <typename T, typename T2>
+__global__ void blend_kernel(const T2* __restrict__ a, T w1, const T2* __restrict__ b, T w2, T2* __restrict__ out, int64_t total) {
+    for (int64_t o = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x) {
+        const T2 va = a[o], vb = b[o];
+        T2 r;
+        {
+#pragma clang fp contract(off)
+            const T p = w1 * va.x, q = w2 * vb.x; r.x = p + q;
+            const T p2 = w1 * va.y, q2 = w2 * vb.y; r.y = p2 + q2;
+        }
+        out[o] = r;
+    }
+}
+
+// ---- device-resident exchange of the pass-1 partition (multi-GPU: the all-reduce runs on this buffer, no host round trip) ----
+// partition[0..K) = per-level maxima of the ray length (doubles), partition[K..K+4) = the four RDR_FLAG_* bits as 0.0 / 1.0,
+// so that ONE element-wise MAX all-reduce combines the shards (MAX of non-negative doubles = MAX of their bit patterns).
+__global__ void pack_partition_kernel(const unsigned long long* __restrict__ bits, const int* __restrict__ flags, int K, double* __restrict__ out) {
+    const int f = *flags;
+    for (int k = threadIdx.x; k < K + 4; k += blockDim.x)
+        out[k] = k < K ? __longlong_as_double((long long)bits[k]) : (((f >> (k - K)) & 1) ? 1.0 : 0.0);
+}
+
+__global__ void unpack_partition_kernel(const double* __restrict__ in, int K, unsigned long long* __restrict__ bits, int* __restrict__ flags) {
+    for (int k = threadIdx.x; k < K; k += blockDim.x) bits[k] = (unsigned long long)__double_as_longlong(in[k]);
+    if (threadIdx.x == 0) {
+        int f = 0;
+        for (int b = 0; b < 4; ++b) if (in[K + b] > 0.0) f |= 1 << b;
+        *flags = f;
+    }
+}
+
+// ---- azimuth-time-grid temporal weighting -----------------------------------------------------------------------------
+// get_inverse_weights_for_dates (s1_azimuth_timing.py:326-399): w_d = m_d / (|t - date_d| + reg) / sum_d(...), m_d = 1 when
+// |t - date_d| <= window.  A voxel with no date inside the window divides 0 by 0 -> NaN, as in the reference.
+struct DateSet { int nd; double date[8]; double window, reg; };
+
+__global__ void time_weights_kernel(DateSet D, const double* __restrict__ az, int64_t n, double* __restrict__ w, int* __restrict__ any_in_window) {
+    int seen = 0;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double t = az[i];
+        double m[8], total = 0.0;
+        for (int d = 0; d < D.nd; ++d) {
+            const double diff = fabs(t - D.date[d]);
+            const bool in = diff <= D.window;
+            seen |= in;
+            m[d] = (1.0 / (diff + D.reg)) * (in ? 1.0 : 0.0);
+            total += m[d];
+        }
+        for (int d = 0; d < D.nd; ++d) w[(int64_t)d * n + i] = m[d] / total;
+    }
+    if (seen) atomicOr(any_in_window, 1);
+}
+
+// cli/raider.py:817-819 with per-voxel weights: sum([wgt * ds[var] ...]) = ((0 + w0 a0) + w1 a1) + ... in f64 (a weight ARRAY
+// is float64, so numpy promotes the f32 fields).  Weights are in file order (z, y, x), cubes in device order (y, x, z).
+struct CubeSet { int nd; const void* v[8]; };
+
+template <typename T2>
+__global__ void blend_weighted_kernel(CubeSet S, const double* __restrict__ w, int64_t ny, int64_t nx, int64_t nz, double2* __restrict__ out) {
+    const int64_t total = ny * nx * nz;
+    for (int64_t o = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t iz = o % nz, ix = (o / nz) % nx, iy = o / (nz * nx);
+        const int64_t wi = (iz * ny + iy) * nx + ix;
+        double aw = 0.0, ah = 0.0;
+        for (int d = 0; d < S.nd; ++d) {
+            const T2 v = reinterpret_cast<const T2*>(S.v[d])[o];
+            const double wd = w[(int64_t)d * total + wi];
+            {
+#pragma clang fp contract(off)
+                const double pw = wd * (double)v.x, ph = wd * (double)v.y;
+                aw = aw + pw; ah = ah + ph;
+            }
+        }
+        double2 r; r.x = aw; r.y = ah;
+        out[o] = r;
+    }
+}
+
+// A4/A5: scipy RGI at packed points (n,3) = (y,x,z)
+template <typename T2>
+__global__ __launch_bounds__(256) void interp_points_kernel(CubeView<T2> c, const double* __restrict__ pts, int64_t n,
+                                                            double* __restrict__ wet, double* __restrict__ hyd, int axes_in_lds) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const double* s_y = c.axes;                       // very long axes stay in global memory (L1 / L2 hits)
+    if (axes_in_lds) {
+        double* t = reinterpret_cast<double*>(smem_raw);
+        for (int i = threadIdx.x; i < c.ny + c.nx + c.nz; i += blockDim.x) t[i] = c.axes[i];
+        __syncthreads();
+        s_y = t;
+    }
+    const double* s_x = s_y + c.ny;
+    const double* s_z = s_x + c.nx;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double y = pts[3 * i], x = pts[3 * i + 1], z = pts[3 * i + 2];
+        double w, h;
+        trilinear(c, s_y, s_x, s_z, y, x, z, w, h);
+        wet[i] = w; hyd[i] = h;
+    }
+}
+
+// _build_cube (delay.py:196-216): points generated on the fly from (xpts, ypts, zpts)
+template <typename T2>
+__global__ __launch_bounds__(256) void build_cube_kernel(CubeView<T2> c, LccParams proj, const double* __restrict__ xpts, int64_t nx,
+                                                         const double* __restrict__ ypts, int64_t ny,
+                                                         const double* __restrict__ zpts, int64_t nz,
+                                                         double* __restrict__ wet, double* __restrict__ hyd, int axes_in_lds) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const double* s_y = c.axes;                       // very long axes stay in global memory (L1 / L2 hits)
+    if (axes_in_lds) {
+        double* t = reinterpret_cast<double*>(smem_raw);
+        for (int i = threadIdx.x; i < c.ny + c.nx + c.nz; i += blockDim.x) t[i] = c.axes[i];
+        __syncthreads();
+        s_y = t;
+    }
+    const double* s_x = s_y + c.ny;
+    const double* s_z = s_x + c.nx;
+    const int64_t n = nx * ny * nz;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t ix = i % nx, r = i / nx, iy = r % ny, iz = r / ny;
+        double w, h, qy = ypts[iy], qx = xpts[ix];
+        if (proj.kind == 1) { double px_, py_; lcc_forward(proj, qy, qx, px_, py_); qx = px_; qy = py_; }   // transformPoints, delay.py:207-209
+        trilinear(c, s_y, s_x, s_z, qy, qx, zpts[iz], w, h);
+        wet[i] = w; hyd[i] = h;
+    }
+}
+
+__global__ void project_kernel(double* wet, double* hyd, const double* __restrict__ inc, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double up = cos(inc[i] * DEG_TO_RAD);   // inc_hd_to_enu(...)[..., -1] = cosd(inc)
+        wet[i] = wet[i] / up; hyd[i] = hyd[i] / up;
+    }
+}
+
+__global__ void lcc_kernel(LccParams proj, const double* __restrict__ lat, const double* __restrict__ lon, int64_t n,
+                           double* __restrict__ y, double* __restrict__ x) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        double px, py; lcc_forward(proj, lat[i], lon[i], px, py);
+        x[i] = px; y[i] = py;
+    }
+}
+
+__global__ void lla2ecef_kernel(const double* __restrict__ lat, const double* __restrict__ lon, const double* __restrict__ h,
+                                int64_t n, double* __restrict__ xyz) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        double x, y, z; lla2ecef(lat[i], lon[i], h[i], x, y, z);
+        xyz[3 * i] = x; xyz[3 * i + 1] = y; xyz[3 * i + 2] = z;
+    }
+}
+
+__global__ void ecef2lla_kernel(const double* __restrict__ xyz, int64_t n, double* __restrict__ lon, double* __restrict__ lat,
+                                double* __restrict__ h) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        double lo, la, hh; ecef2lla(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], lo, la, hh);
+        lon[i] = lo; lat[i] = la; h[i] = hh;
+    }
+}
+
+__global__ void look_kernel(RayParams P, double* __restrict__ los) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < P.n; i += (int64_t)gridDim.x * blockDim.x) {
+        double lat, lon;
+        if (P.origin_mode == 0) { lat = P.ypts[i / P.nx]; lon = P.xpts[i % P.nx]; }
+        else { lat = P.lat[i]; lon = P.lon[i]; }
+        double u, v, w;
+        if (P.los_mode == 0) { u = P.los[3 * i]; v = P.los[3 * i + 1]; w = P.los[3 * i + 2]; }
+        else if (P.los_mode == 1) inc_hd_to_ecef(P.inc[i], P.hd ? P.hd[i] : P.hd0, lat, lon, u, v, w);
+        else if (P.los_mode == 2) inc_hd_to_ecef(P.inc0, P.hd0, lat, lon, u, v, w);
+        else {
+            double sla, cla, slo, clo;
+            sincos(lat * DEG_TO_RAD, &sla, &cla); sincos(lon * DEG_TO_RAD, &slo, &clo);
+            u = cla * clo; v = cla * slo; w = sla;
+        }
+        los[3 * i] = u; los[3 * i + 1] = v; los[3 * i + 2] = w;
+    }
+}
+
+__global__ void toa_kernel(const double* __restrict__ xyz, const double* __restrict__ los, int64_t n, double h,
+                           const double* __restrict__ factor, double* __restrict__ pos) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        double px, py, pz;
+        toa_newton(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], los[3 * i], los[3 * i + 1], los[3 * i + 2], h,
+                   factor ? 3 : 10, factor ? factor[i] : 1.0, px, py, pz);
+        pos[3 * i] = px; pos[3 * i + 1] = py; pos[3 * i + 2] = pz;
+    }
+}
+
+// build_ray materialised (losreader.py:772-835): levels passed in a small device table
+__global__ void build_ray_kernel(const double* __restrict__ xyz, const double* __restrict__ los, int64_t n, int K,
+                                 const double* __restrict__ lo_hi, double* __restrict__ lengths, double* __restrict__ low,
+                                 double* __restrict__ high) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double ox = xyz[3 * i], oy = xyz[3 * i + 1], oz = xyz[3 * i + 2];
+        const double lx = los[3 * i], ly = los[3 * i + 1], lz = los[3 * i + 2];
+        double hx = 0, hy = 0, hz = 0, cosf = 1.0;
+        for (int k = 0; k < K; ++k) {
+            const double lo = lo_hi[k], hi = lo_hi[K + k];
+            double bx, by, bz;
+            if (k == 0) toa_newton(ox, oy, oz, lx, ly, lz, lo, 10, 1.0, bx, by, bz);
+            else { bx = hx; by = hy; bz = hz; }
+            toa_newton(ox, oy, oz, lx, ly, lz, hi, k == 0 ? 10 : 3, cosf, hx, hy, hz);
+            const double dx = hx - bx, dy = hy - by, dz = hz - bz;
+            const double L = sqrt(dx * dx + dy * dy + dz * dz);
+            if (k == 0) cosf = (hi - lo) / L;
+            lengths[(int64_t)k * n + i] = L;
+            double* pl = low + ((int64_t)k * n + i) * 3; pl[0] = bx; pl[1] = by; pl[2] = bz;
+            double* ph = high + ((int64_t)k * n + i) * 3; ph[0] = hx; ph[1] = hy; ph[2] = hz;
+        }
+    }
+}

@@ -134,607 +134,11 @@ static inline int grid_for(int64_t n, int block, int max_blocks) {
     return (int)std::max<int64_t>(1, std::min<int64_t>(g, max_blocks));
 }
 
-// ------------------------------------------------------------------------------------------------
-// small kernels
-// ------------------------------------------------------------------------------------------------
-template <typename T, typename T2>
-__global__ void pack_cube_kernel(const T* __restrict__ wet, const T* __restrict__ hyd, T2* __restrict__ dst,
-                                 int64_t ny, int64_t nx, int64_t nz, int64_t sy, int64_t sx, int64_t sz,
-                                 int fy, int fx, int fz) {
-    const int64_t total = ny * nx * nz;
-    for (int64_t o = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t iz = o % nz, r = o / nz, ix = r % nx, iy = r / nx;
-        const int64_t jy = fy ? ny - 1 - iy : iy, jx = fx ? nx - 1 - ix : ix, jz = fz ? nz - 1 - iz : iz;
-        const int64_t s = jy * sy + jx * sx + jz * sz;
-        T2 v; v.x = wet[s]; v.y = hyd[s];
-        dst[o] = v;
-    }
-}
-
-template <typename T, typename T2>
-__global__ void unpack_cube_kernel(const T2* __restrict__ src, T* __restrict__ wet, T* __restrict__ hyd, int64_t total) {
-    for (int64_t o = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x) {
-        const T2 v = src[o]; wet[o] = v.x; hyd[o] = v.y;
-    }
-}
-
-// cli/raider.py:817-819: sum([w*ds[var]]) = 0 + w1*a + w2*b in the array dtype (numpy<2 value-based casting)
-template <typename T, typename T2>
-__global__ void blend_kernel(const T2* __restrict__ a, T w1, const T2* __restrict__ b, T w2, T2* __restrict__ out, int64_t total) {
-    for (int64_t o = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x) {
-        const T2 va = a[o], vb = b[o];
-        T2 r;
-        {
-#pragma clang fp contract(off)
-            const T p = w1 * va.x, q = w2 * vb.x; r.x = p + q;
-            const T p2 = w1 * va.y, q2 = w2 * vb.y; r.y = p2 + q2;
-        }
-        out[o] = r;
-    }
-}
-
-// ---- device-resident exchange of the pass-1 partition (multi-GPU: the all-reduce runs on this buffer, no host round trip) ----
-// partition[0..K) = per-level maxima of the ray length (doubles), partition[K..K+4) = the four RDR_FLAG_* bits as 0.0 / 1.0,
-// so that ONE element-wise MAX all-reduce combines the shards (MAX of non-negative doubles = MAX of their bit patterns).
-__global__ void pack_partition_kernel(const unsigned long long* __restrict__ bits, const int* __restrict__ flags, int K, double* __restrict__ out) {
-    const int f = *flags;
-    for (int k = threadIdx.x; k < K + 4; k += blockDim.x)
-        out[k] = k < K ? __longlong_as_double((long long)bits[k]) : (((f >> (k - K)) & 1) ? 1.0 : 0.0);
-}
-
-__global__ void unpack_partition_kernel(const double* __restrict__ in, int K, unsigned long long* __restrict__ bits, int* __restrict__ flags) {
-    for (int k = threadIdx.x; k < K; k += blockDim.x) bits[k] = (unsigned long long)__double_as_longlong(in[k]);
-    if (threadIdx.x == 0) {
-        int f = 0;
-        for (int b = 0; b < 4; ++b) if (in[K + b] > 0.0) f |= 1 << b;
-        *flags = f;
-    }
-}
-
-// ---- azimuth-time-grid temporal weighting -----------------------------------------------------------------------------
-// get_inverse_weights_for_dates (s1_azimuth_timing.py:326-399): w_d = m_d / (|t - date_d| + reg) / sum_d(...), m_d = 1 when
-// |t - date_d| <= window.  A voxel with no date inside the window divides 0 by 0 -> NaN, as in the reference.
-struct DateSet { int nd; double date[8]; double window, reg; };
-
-__global__ void time_weights_kernel(DateSet D, const double* __restrict__ az, int64_t n, double* __restrict__ w, int* __restrict__ any_in_window) {
-    int seen = 0;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const double t = az[i];
-        double m[8], total = 0.0;
-        for (int d = 0; d < D.nd; ++d) {
-            const double diff = fabs(t - D.date[d]);
-            const bool in = diff <= D.window;
-            seen |= in;
-            m[d] = (1.0 / (diff + D.reg)) * (in ? 1.0 : 0.0);
-            total += m[d];
-        }
-        for (int d = 0; d < D.nd; ++d) w[(int64_t)d * n + i] = m[d] / total;
-    }
-    if (seen) atomicOr(any_in_window, 1);
-}
-
-// cli/raider.py:817-819 with per-voxel weights: sum([wgt * ds[var] ...]) = ((0 + w0 a0) + w1 a1) + ... in f64 (a weight ARRAY
-// is float64, so numpy promotes the f32 fields).  Weights are in file order (z, y, x), cubes in device order (y, x, z).
-struct CubeSet { int nd; const void* v[8]; };
-
-template <typename T2>
-__global__ void blend_weighted_kernel(CubeSet S, const double* __restrict__ w, int64_t ny, int64_t nx, int64_t nz, double2* __restrict__ out) {
-    const int64_t total = ny * nx * nz;
-    for (int64_t o = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t iz = o % nz, ix = (o / nz) % nx, iy = o / (nz * nx);
-        const int64_t wi = (iz * ny + iy) * nx + ix;
-        double aw = 0.0, ah = 0.0;
-        for (int d = 0; d < S.nd; ++d) {
-            const T2 v = reinterpret_cast<const T2*>(S.v[d])[o];
-            const double wd = w[(int64_t)d * total + wi];
-            {
-#pragma clang fp contract(off)
-                const double pw = wd * (double)v.x, ph = wd * (double)v.y;
-                aw = aw + pw; ah = ah + ph;
-            }
-        }
-        double2 r; r.x = aw; r.y = ah;
-        out[o] = r;
-    }
-}
-
-// A4/A5: scipy RGI at packed points (n,3) = (y,x,z)
-template <typename T2>
-__global__ __launch_bounds__(256) void interp_points_kernel(CubeView<T2> c, const double* __restrict__ pts, int64_t n,
-                                                            double* __restrict__ wet, double* __restrict__ hyd, int axes_in_lds) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const double* s_y = c.axes;                       // very long axes stay in global memory (L1 / L2 hits)
-    if (axes_in_lds) {
-        double* t = reinterpret_cast<double*>(smem_raw);
-        for (int i = threadIdx.x; i < c.ny + c.nx + c.nz; i += blockDim.x) t[i] = c.axes[i];
-        __syncthreads();
-        s_y = t;
-    }
-    const double* s_x = s_y + c.ny;
-    const double* s_z = s_x + c.nx;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const double y = pts[3 * i], x = pts[3 * i + 1], z = pts[3 * i + 2];
-        double w, h;
-        trilinear(c, s_y, s_x, s_z, y, x, z, w, h);
-        wet[i] = w; hyd[i] = h;
-    }
-}
-
-// _build_cube (delay.py:196-216): points generated on the fly from (xpts, ypts, zpts)
-template <typename T2>
-__global__ __launch_bounds__(256) void build_cube_kernel(CubeView<T2> c, LccParams proj, const double* __restrict__ xpts, int64_t nx,
-                                                         const double* __restrict__ ypts, int64_t ny,
-                                                         const double* __restrict__ zpts, int64_t nz,
-                                                         double* __restrict__ wet, double* __restrict__ hyd, int axes_in_lds) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const double* s_y = c.axes;                       // very long axes stay in global memory (L1 / L2 hits)
-    if (axes_in_lds) {
-        double* t = reinterpret_cast<double*>(smem_raw);
-        for (int i = threadIdx.x; i < c.ny + c.nx + c.nz; i += blockDim.x) t[i] = c.axes[i];
-        __syncthreads();
-        s_y = t;
-    }
-    const double* s_x = s_y + c.ny;
-    const double* s_z = s_x + c.nx;
-    const int64_t n = nx * ny * nz;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t ix = i % nx, r = i / nx, iy = r % ny, iz = r / ny;
-        double w, h, qy = ypts[iy], qx = xpts[ix];
-        if (proj.kind == 1) { double px_, py_; lcc_forward(proj, qy, qx, px_, py_); qx = px_; qy = py_; }   // transformPoints, delay.py:207-209
-        trilinear(c, s_y, s_x, s_z, qy, qx, zpts[iz], w, h);
-        wet[i] = w; hyd[i] = h;
-    }
-}
-
-__global__ void project_kernel(double* wet, double* hyd, const double* __restrict__ inc, int64_t n) {
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const double up = cos(inc[i] * DEG_TO_RAD);   // inc_hd_to_enu(...)[..., -1] = cosd(inc)
-        wet[i] = wet[i] / up; hyd[i] = hyd[i] / up;
-    }
-}
-
-__global__ void lcc_kernel(LccParams proj, const double* __restrict__ lat, const double* __restrict__ lon, int64_t n,
-                           double* __restrict__ y, double* __restrict__ x) {
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        double px, py; lcc_forward(proj, lat[i], lon[i], px, py);
-        x[i] = px; y[i] = py;
-    }
-}
-
-__global__ void lla2ecef_kernel(const double* __restrict__ lat, const double* __restrict__ lon, const double* __restrict__ h,
-                                int64_t n, double* __restrict__ xyz) {
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        double x, y, z; lla2ecef(lat[i], lon[i], h[i], x, y, z);
-        xyz[3 * i] = x; xyz[3 * i + 1] = y; xyz[3 * i + 2] = z;
-    }
-}
-
-__global__ void ecef2lla_kernel(const double* __restrict__ xyz, int64_t n, double* __restrict__ lon, double* __restrict__ lat,
-                                double* __restrict__ h) {
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        double lo, la, hh; ecef2lla(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], lo, la, hh);
-        lon[i] = lo; lat[i] = la; h[i] = hh;
-    }
-}
-
-__global__ void look_kernel(RayParams P, double* __restrict__ los) {
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < P.n; i += (int64_t)gridDim.x * blockDim.x) {
-        double lat, lon;
-        if (P.origin_mode == 0) { lat = P.ypts[i / P.nx]; lon = P.xpts[i % P.nx]; }
-        else { lat = P.lat[i]; lon = P.lon[i]; }
-        double u, v, w;
-        if (P.los_mode == 0) { u = P.los[3 * i]; v = P.los[3 * i + 1]; w = P.los[3 * i + 2]; }
-        else if (P.los_mode == 1) inc_hd_to_ecef(P.inc[i], P.hd ? P.hd[i] : P.hd0, lat, lon, u, v, w);
-        else if (P.los_mode == 2) inc_hd_to_ecef(P.inc0, P.hd0, lat, lon, u, v, w);
-        else {
-            double sla, cla, slo, clo;
-            sincos(lat * DEG_TO_RAD, &sla, &cla); sincos(lon * DEG_TO_RAD, &slo, &clo);
-            u = cla * clo; v = cla * slo; w = sla;
-        }
-        los[3 * i] = u; los[3 * i + 1] = v; los[3 * i + 2] = w;
-    }
-}
-
-__global__ void toa_kernel(const double* __restrict__ xyz, const double* __restrict__ los, int64_t n, double h,
-                           const double* __restrict__ factor, double* __restrict__ pos) {
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        double px, py, pz;
-        toa_newton(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], los[3 * i], los[3 * i + 1], los[3 * i + 2], h,
-                   factor ? 3 : 10, factor ? factor[i] : 1.0, px, py, pz);
-        pos[3 * i] = px; pos[3 * i + 1] = py; pos[3 * i + 2] = pz;
-    }
-}
-
-// build_ray materialised (losreader.py:772-835): levels passed in a small device table
-__global__ void build_ray_kernel(const double* __restrict__ xyz, const double* __restrict__ los, int64_t n, int K,
-                                 const double* __restrict__ lo_hi, double* __restrict__ lengths, double* __restrict__ low,
-                                 double* __restrict__ high) {
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const double ox = xyz[3 * i], oy = xyz[3 * i + 1], oz = xyz[3 * i + 2];
-        const double lx = los[3 * i], ly = los[3 * i + 1], lz = los[3 * i + 2];
-        double hx = 0, hy = 0, hz = 0, cosf = 1.0;
-        for (int k = 0; k < K; ++k) {
-            const double lo = lo_hi[k], hi = lo_hi[K + k];
-            double bx, by, bz;
-            if (k == 0) toa_newton(ox, oy, oz, lx, ly, lz, lo, 10, 1.0, bx, by, bz);
-            else { bx = hx; by = hy; bz = hz; }
-            toa_newton(ox, oy, oz, lx, ly, lz, hi, k == 0 ? 10 : 3, cosf, hx, hy, hz);
-            const double dx = hx - bx, dy = hy - by, dz = hz - bz;
-            const double L = sqrt(dx * dx + dy * dy + dz * dz);
-            if (k == 0) cosf = (hi - lo) / L;
-            lengths[(int64_t)k * n + i] = L;
-            double* pl = low + ((int64_t)k * n + i) * 3; pl[0] = bx; pl[1] = by; pl[2] = bz;
-            double* ph = high + ((int64_t)k * n + i) * 3; ph[0] = hx; ph[1] = hy; ph[2] = hz;
-        }
-    }
-}
-
-// ---- cube producer ---------------------------------------------------------------------------------------------------
-// models/weatherModel.py:235-262 for one model-level column per wavefront (lanes = levels): _find_e (:332-353, find_svp
-// :750-780), _uniform_in_z (:603-629: native interpolate_1d with NaN fill, results cast to f32), _checkForNans (:631-635 =
-// interpolator.fillna3D :110-130: leading NaNs <- first valid value, interior runs linear in the index, trailing NaNs <- fill),
-// refractivities (:355-361, f32 arithmetic), _adjust_grid (:371-387: extra bottom level at zmin) and _getZTD (:389-403).
-// Output goes straight into the two device cubes the delay kernels read (interleaved (wet,hydro), (y,x,z)).
-__device__ __forceinline__ float svp_pa(double t) {
-    const double t1 = 273.15, t2 = 250.15;
-    const double tref = t - t1;
-    const double wgt = (t - t2) / (t1 - t2);
-    const double svpw = 6.1121 * exp((17.502 * tref) / (240.97 + tref));
-    const double svpi = 6.1121 * exp((22.587 * tref) / (273.86 + tref));
-    double svp = svpi + (svpw - svpi) * (wgt * wgt);
-    if (t > t1) svp = svpw;
-    if (t < t2) svp = svpi;
-    return (float)(svp * 100.0);
-}
-
-// interpolate_1d (interpolate.h:78-118) with fill NaN on an LDS-resident column
-__device__ __forceinline__ double interp_col(const double* xs, const double* ys, int n, double x) {
-    int left = 0, right = n;
-    while (right != left) { const int mid = (left + right) / 2; if (x < xs[mid]) right = mid; else left = mid + 1; }
-    if (right < 1 || right > n - 1) return qnan();
-    const double x0 = xs[right - 1], x1 = xs[right], y0 = ys[right - 1], y1 = ys[right];
-    double r;
-    {
-#pragma clang fp contract(off)
-        const double slope = (y1 - y0) / (x1 - x0);
-        r = y0 + slope * (x - x0);
-    }
-    return r;
-}
-
-// fillna3D on one column held in LDS (float col[n]); every lane fixes its own levels
-__device__ __forceinline__ void fillna_col(float* col, int n, float fill, int lane) {
-    int first = n, last = -1;
-    for (int j = lane; j < n; j += 64) if (col[j] == col[j]) { first = min(first, j); last = max(last, j); }
-    for (int off = 32; off > 0; off >>= 1) { first = min(first, __shfl_xor(first, off, 64)); last = max(last, __shfl_xor(last, off, 64)); }
-    float fixed[8];                                   // nz <= 512 -> <= 8 levels per lane
-    int cnt = 0;
-    for (int j = lane; j < n; j += 64, ++cnt) {
-        float v = col[j];
-        if (!(v == v)) {
-            if (last < 0 || j > last) v = fill;
-            else if (j < first) v = col[first];
-            else {                                    // interior run: np.interp on the index
-                int i = j - 1; while (!(col[i] == col[i])) --i;
-                int k = j + 1; while (!(col[k] == col[k])) ++k;
-                {
-#pragma clang fp contract(off)
-                    const double a = (double)col[i], b = (double)col[k]; const double slope = (b - a) / (double)(k - i); v = (float)(slope * (double)(j - i) + a);
-                }
-            }
-        }
-        fixed[cnt] = v;
-    }
-    __builtin_amdgcn_wave_barrier();
-    cnt = 0;
-    for (int j = lane; j < n; j += 64, ++cnt) col[j] = fixed[cnt];
-    __builtin_amdgcn_wave_barrier();
-}
-
-struct ProducerParams {
-    const double* zs; const double* p; const double* t; const double* hum;   // [ncol, nlev]
-    int64_t ncol; int nlev; int hum_type;                                     // 0 = q, 1 = rh
-    const double* new_z; int nz; int pad;                                     // output levels (without the pad level)
-    float k1, k2, k3; double zmin, R_v, R_d;
-    float2* pw; double2* tot;                                                 // [ncol, nzo] interleaved (wet, hydro)
-    float* t_out; float* p_out; float* e_out;                                 // optional [ncol, nzo]
-};
-
-__global__ __launch_bounds__(256) void producer_kernel(ProducerParams P) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int nzo = P.nz + P.pad;
-    // per-wave LDS: zs,p,t,e at model levels (f64) | t,p,e,wet,hyd at output levels (f32) | output level heights (f64)
-    double* wbase = reinterpret_cast<double*>(smem_raw) + (size_t)wave * (4 * P.nlev + nzo + (5 * nzo + 1) / 2 + 1);
-    double* c_z = wbase; double* c_p = c_z + P.nlev; double* c_t = c_p + P.nlev; double* c_e = c_t + P.nlev;
-    double* o_z = c_e + P.nlev;
-    float* o_t = reinterpret_cast<float*>(o_z + nzo); float* o_p = o_t + nzo; float* o_e = o_p + nzo; float* o_w = o_e + nzo; float* o_h = o_w + nzo;
-    for (int j = lane; j < nzo; j += 64) o_z[j] = (P.pad && j == 0) ? P.zmin : P.new_z[j - P.pad];
-    const int64_t wstride = (int64_t)gridDim.x * 4;
-    for (int64_t col = (int64_t)blockIdx.x * 4 + wave; col < P.ncol; col += wstride) {
-        __builtin_amdgcn_wave_barrier();
-        for (int k = lane; k < P.nlev; k += 64) {
-            const int64_t g = col * P.nlev + k;
-            const double t = P.t[g], p = P.p[g], h = P.hum[g];
-            const float svp = svp_pa(t);
-            double e;
-            {
-#pragma clang fp contract(off)
-                if (P.hum_type == 0) { const double w = h / (1.0 - h); e = w * P.R_v * (p - (double)svp) / P.R_d; }   // weatherModel.py:343-348
-                else e = h / 100.0 * (double)svp;                                                                      // :350-353
-            }
-            c_z[k] = P.zs[g]; c_p[k] = p; c_t[k] = t; c_e[k] = e;
-        }
-        __builtin_amdgcn_wave_barrier();
-        for (int j = lane; j < P.nz; j += 64) {
-            const double x = P.new_z[j];
-            o_t[j + P.pad] = (float)interp_col(c_z, c_t, P.nlev, x);
-            o_p[j + P.pad] = (float)interp_col(c_z, c_p, P.nlev, x);
-            o_e[j + P.pad] = (float)interp_col(c_z, c_e, P.nlev, x);
-        }
-        __builtin_amdgcn_wave_barrier();
-        fillna_col(o_p + P.pad, P.nz, 0.0f, lane);
-        fillna_col(o_t + P.pad, P.nz, 1e16f, lane);
-        fillna_col(o_e + P.pad, P.nz, 0.0f, lane);
-        for (int j = lane; j < P.nz; j += 64) {
-            const float t = o_t[j + P.pad], p = o_p[j + P.pad], e = o_e[j + P.pad];
-            float w, h;
-            {
-#pragma clang fp contract(off)
-                const float a = (P.k2 * e) / t; const float b = (P.k3 * e) / (t * t); w = a + b;                      // weatherModel.py:355-357
-                h = (P.k1 * p) / t;                                                                                    // :359-361
-            }
-            o_w[j + P.pad] = w; o_h[j + P.pad] = h;
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (P.pad && lane == 0) { o_t[0] = o_t[1]; o_p[0] = o_p[1]; o_e[0] = o_e[1]; o_w[0] = o_w[1]; o_h[0] = o_h[1]; }   // utilFcns.padLower
-        __builtin_amdgcn_wave_barrier();
-        for (int j = lane; j < nzo; j += 64) {
-            const int64_t g = col * nzo + j;
-            float2 v; v.x = o_w[j]; v.y = o_h[j];
-            P.pw[g] = v;
-            if (P.t_out) { P.t_out[g] = o_t[j]; P.p_out[g] = o_p[j]; P.e_out[g] = o_e[j]; }
-            // _getZTD: 1e-6 * trapz(f[level:], zs[level:]); np.trapz = sum(d * (y[1:] + y[:-1]) / 2)
-            double sw = 0.0, sh = 0.0;
-            {
-#pragma clang fp contract(off)
-                for (int k = j; k < nzo - 1; ++k) {
-                    const double d = o_z[k + 1] - o_z[k];
-                    sw += d * (double)(o_w[k + 1] + o_w[k]) / 2.0;
-                    sh += d * (double)(o_h[k + 1] + o_h[k]) / 2.0;
-                }
-            }
-            double2 tt; tt.x = 1e-6 * sw; tt.y = 1e-6 * sh;
-            P.tot[g] = tt;
-        }
-    }
-}
-
-// ---- ECMWF hybrid model levels -> pressure and geometric height (front end of the cube producer) ----------------------------
-// utilFcns.calcgeoh (:781-859): half-level pressures a + b sp, geopotential integrated upwards from the surface with the moist
-// temperature, geopotential height; utilFcns.geo_to_ht (:378-410): geometric height with latitude-dependent gravity and Earth
-// radius; models/ecmwf.py:92-110: (lev, y, x) top-first -> (y, x, lev) bottom-first.  One column per thread.
-// FLOAT64 arithmetic on the float32 inputs.  The reference evaluates these formulas in float32 (NumPy-1 casting rules), where
-// dlogP = log(P1) - log(P0) and alpha = 1 - P0/(P1-P0) dlogP lose 3-4 digits: its heights sit up to 2.4 m from the float64
-// values and move by METRES with a last-bit change of logf - no other platform can reproduce that realisation of the round-off
-// (the test suite's float32 NumPy restatement does, on x86: tests/test_ref_files.py), and a float32 evaluation here would only
-// add a second, different one.  DESIGN.md 6.5.
-__global__ __launch_bounds__(256) void ecmwf_levels_kernel(const float* __restrict__ z_surf, const float* __restrict__ lnsp,
-                                                           const float* __restrict__ t, const float* __restrict__ q,
-                                                           const float* __restrict__ lats, const double* __restrict__ a,
-                                                           const double* __restrict__ b, int nlev, int64_t ny, int64_t nx, double R_d,
-                                                           double* __restrict__ p_out, double* __restrict__ zs_out) {
-    const int64_t ncol = ny * nx;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    const double g0 = 9.80665;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ncol; i += stride) {
-        const double lat = (double)lats[i / nx] * DEG_TO_RAD;
-        const double c2 = cos(2.0 * lat);
-        const double g_ll = 9.80616 * (1.0 - 0.002637 * c2 + 0.0000059 * (c2 * c2));         // _get_g_ll
-        const double cl = cos(lat), sl = sin(lat);
-        const double re = sqrt(1.0 / ((cl * cl) / (6378137.0 * 6378137.0) + (sl * sl) / (6356752.0 * 6356752.0)));   // get_Re
-        const double gre = g_ll / g0 * re;
-        const double sp = exp((double)lnsp[i]), zs0 = (double)z_surf[i];
-        double z_h = 0.0;
-        for (int lev = nlev; lev >= 1; --lev) {
-            const int64_t g = (int64_t)(lev - 1) * ncol + i;
-            const double tl = (double)t[g] * (1.0 + 0.609133 * (double)q[g]);               // moist temperature
-            const double ph = a[lev - 1] + b[lev - 1] * sp, ph1 = a[lev] + b[lev] * sp;
-            double dlogp, alpha;
-            if (lev == 1) { dlogp = log(ph1 / 0.1); alpha = 0.6931471805599453; }
-            else { dlogp = log(ph1 / ph); alpha = 1.0 - (ph / (ph1 - ph)) * dlogp; }
-            const double trd = tl * R_d;
-            const double gh = (z_h + trd * alpha + zs0) / g0;
-            z_h += trd * dlogp;
-            const int64_t o = i * nlev + (nlev - lev);
-            p_out[o] = ph;
-            zs_out[o] = (gh * re) / (gre - gh);                                              // geo_to_ht
-        }
-    }
-}
-
-// ---- look vectors from orbit state vectors ----------------------------------------------------------------------------
-// Replaces the per-pixel Python loop over isce3.geometry.geo2rdr + Orbit.interpolate of Raytracing.getLookVectors
-// (losreader.py:219-255).  isce3 is a third-party dependency that is not under /root/reference: this restates the published
-// algorithm as the call site uses it (empty Doppler LUT => zero-Doppler): Newton on azimuth time t for
-// f(t) = (T - S(t)) . V(t) = 0 with f'(t) ~ -|V|^2, S/V from 4-point Hermite interpolation of the state vectors,
-// threshold 1e-7 s, <= 30 iterations; los = (S(t) - T)/|S(t) - T|; failures -> NaN.  PARITY WITH isce3 IS UNPINNED.
-__device__ inline void orbit_hermite(const double* __restrict__ st, const double* __restrict__ sp, const double* __restrict__ sv,
-                                     int n, double t, double* pos, double* vel) {
-    // 4 state vectors bracketing t (two on each side where possible)
-    int lo = 0, hi = n;                      // first index with t < st[idx]
-    while (lo < hi) { const int mid = (lo + hi) >> 1; if (t < st[mid]) hi = mid; else lo = mid + 1; }
-    int i0 = min(max(lo - 2, 0), n - 4);
-    double tt[4], h[4], hdot[4], f0[4], f1[4], g0[4], g1[4];
-    for (int i = 0; i < 4; ++i) tt[i] = st[i0 + i];
-    for (int i = 0; i < 4; ++i) {
-        f1[i] = t - tt[i];
-        double sum = 0.0;
-        for (int j = 0; j < 4; ++j) if (j != i) sum += 1.0 / (tt[i] - tt[j]);
-        f0[i] = 1.0 - 2.0 * (t - tt[i]) * sum;
-        double prod = 1.0;
-        for (int k = 0; k < 4; ++k) if (k != i) prod *= (t - tt[k]) / (tt[i] - tt[k]);
-        h[i] = prod;
-        double s2 = 0.0;
-        for (int j = 0; j < 4; ++j) {
-            if (j == i) continue;
-            double p2 = 1.0;
-            for (int k = 0; k < 4; ++k) if (k != i && k != j) p2 *= (t - tt[k]) / (tt[i] - tt[k]);
-            s2 += p2 / (tt[i] - tt[j]);
-        }
-        hdot[i] = s2;
-        g1[i] = h[i] + 2.0 * (t - tt[i]) * hdot[i];
-        g0[i] = 2.0 * (f0[i] * hdot[i] - h[i] * sum);
-    }
-    for (int k = 0; k < 3; ++k) {
-        double sx = 0.0, sv_ = 0.0;
-        for (int i = 0; i < 4; ++i) {
-            const double x = sp[3 * (i0 + i) + k], v = sv[3 * (i0 + i) + k];
-            sx += (x * f0[i] + v * f1[i]) * h[i] * h[i];
-            sv_ += (x * g0[i] + v * g1[i]) * h[i];
-        }
-        pos[k] = sx; vel[k] = sv_;
-    }
-}
-
-__global__ void orbit_los_kernel(const double* __restrict__ st, const double* __restrict__ sp, const double* __restrict__ sv, int nsv,
-                                 const double* __restrict__ xyz, int64_t n, double threshold, int maxiter,
-                                 double* __restrict__ los, double* __restrict__ aztime, double* __restrict__ srange) {
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const double tx = xyz[3 * i], ty = xyz[3 * i + 1], tz = xyz[3 * i + 2];
-        double t = 0.5 * (st[0] + st[nsv - 1]);          // start at the orbit mid time
-        double pos[3], vel[3];
-        bool ok = false;
-        for (int it = 0; it < maxiter; ++it) {
-            orbit_hermite(st, sp, sv, nsv, t, pos, vel);
-            const double dx = tx - pos[0], dy = ty - pos[1], dz = tz - pos[2];
-            const double fn = dx * vel[0] + dy * vel[1] + dz * vel[2];            // zero-Doppler condition
-            const double fnp = -(vel[0] * vel[0] + vel[1] * vel[1] + vel[2] * vel[2]);
-            const double step = fn / fnp;
-            t -= step;
-            if (fabs(step) < threshold) { ok = true; break; }
-        }
-        double l0 = qnan(), l1 = qnan(), l2 = qnan(), rg = qnan();
-        if (ok && t >= st[0] && t <= st[nsv - 1] && tx == tx && ty == ty && tz == tz) {
-            orbit_hermite(st, sp, sv, nsv, t, pos, vel);
-            const double dx = pos[0] - tx, dy = pos[1] - ty, dz = pos[2] - tz;
-            rg = sqrt(dx * dx + dy * dy + dz * dz);
-            l0 = dx / rg; l1 = dy / rg; l2 = dz / rg;                               // losreader.py:251-252
-        } else t = qnan();
-        los[3 * i] = l0; los[3 * i + 1] = l1; los[3 * i + 2] = l2;
-        if (aztime) aztime[i] = t;
-        if (srange) srange[i] = rg;
-    }
-}
-
-// ---- native extension kernels -------------------------------------------------------------------
-// interpolate.h:23-38 bisect_left: first index with x < a[i]
-__device__ __forceinline__ int upper_bound_idx(const double* a, int n, double x) {
-    int left = 0, right = n;
-    while (right != left) {
-        const int mid = (left + right) / 2;
-        if (x < a[mid]) right = mid; else left = mid + 1;
-    }
-    return right;
-}
-
-struct NdParams {
-    int ndim;
-    int64_t len[8];
-    int64_t off[8];      // offset of axis d inside `axes`
-    int64_t stride[8];   // C-order element strides of `values`
-};
-
-__global__ void interp_nd_kernel(NdParams P, const double* __restrict__ axes, const double* __restrict__ values,
-                                 const double* __restrict__ q, int64_t n, int has_fill, double fill, double* __restrict__ out) {
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        int lo[8], hi[8];
-        double d0[8], d1[8];
-        double vol = 1.0;
-        bool filled = false;
-        for (int d = 0; d < P.ndim; ++d) {
-            const double* g = axes + P.off[d];
-            const int N = (int)P.len[d];
-            const double x = q[i * P.ndim + d];
-            int h = upper_bound_idx(g, N, x);
-            if (has_fill) { if (h < 1 || h > N - 1) { filled = true; } }
-            h = min(max(h, 1), N - 1);
-            hi[d] = h; lo[d] = h - 1;
-            const double x0 = g[h - 1], x1 = g[h];
-            vol *= x1 - x0;
-            d0[d] = x - x0; d1[d] = x1 - x;
-        }
-        if (filled) { out[i] = fill; continue; }
-        double r;
-        {
-#pragma clang fp contract(off)
-        if (P.ndim == 1) {
-            const double* g = axes + P.off[0];
-            const double x0 = g[lo[0]], x1 = g[hi[0]], y0 = values[lo[0]], y1 = values[hi[0]];
-            const double slope = (y1 - y0) / (x1 - x0);                                   // interpolate.h:115-116
-            r = y0 + slope * (q[i] - x0);
-        } else if (P.ndim == 2) {
-            const int64_t s0 = P.stride[0];
-            const double z00 = values[lo[0] * s0 + lo[1]], z01 = values[lo[0] * s0 + hi[1]];
-            const double z10 = values[hi[0] * s0 + lo[1]], z11 = values[hi[0] * s0 + hi[1]];
-            r = (d1[0] * (z00 * d1[1] + z01 * d0[1]) + d0[0] * (z10 * d1[1] + z11 * d0[1])) / vol;   // interpolate.cpp:78-81
-        } else if (P.ndim == 3) {
-            const int64_t s0 = P.stride[0], s1 = P.stride[1];
-            const double w000 = values[lo[0] * s0 + lo[1] * s1 + lo[2]], w001 = values[lo[0] * s0 + lo[1] * s1 + hi[2]];
-            const double w010 = values[lo[0] * s0 + hi[1] * s1 + lo[2]], w011 = values[lo[0] * s0 + hi[1] * s1 + hi[2]];
-            const double w100 = values[hi[0] * s0 + lo[1] * s1 + lo[2]], w101 = values[hi[0] * s0 + lo[1] * s1 + hi[2]];
-            const double w110 = values[hi[0] * s0 + hi[1] * s1 + lo[2]], w111 = values[hi[0] * s0 + hi[1] * s1 + hi[2]];
-            r = (d1[0] * (d1[1] * (d1[2] * w000 + d0[2] * w001) + d0[1] * (d1[2] * w010 + d0[2] * w011)) +
-                 d0[0] * (d1[1] * (d1[2] * w100 + d0[2] * w101) + d0[1] * (d1[2] * w110 + d0[2] * w111))) / vol;   // interpolate.cpp:164-174
-        } else {
-            r = 0.0;
-            for (int j = 0; j < (1 << P.ndim); ++j) {                                      // interpolate.cpp:236-252
-                int64_t idx = 0;
-                double term = 1.0;
-                for (int d = 0; d < P.ndim; ++d) idx += (int64_t)(((j >> d) & 1) ? hi[d] : lo[d]) * P.stride[d];
-                term = values[idx];
-                for (int d = 0; d < P.ndim; ++d) term *= ((j >> d) & 1) ? d0[d] : d1[d];
-                r += term;
-            }
-            r /= vol;
-        }
-        }
-        out[i] = r;
-    }
-}
-
-// interpolate_1d along the last axis of [ncol, m] (interpolate.h:78-118)
-__global__ void along_axis_kernel(const double* __restrict__ xs, const double* __restrict__ ys, int64_t ncol, int64_t m,
-                                  const double* __restrict__ q, int64_t mq, int has_fill, double fill, double* __restrict__ out) {
-    const int64_t total = ncol * mq;
-    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t col = t / mq;
-        const double* g = xs + col * m;
-        const double* v = ys + col * m;
-        const double x = q[t];
-        int h = upper_bound_idx(g, (int)m, x);
-        if (has_fill && (h < 1 || h > m - 1)) { out[t] = fill; continue; }
-        h = min(max(h, 1), (int)m - 1);
-        const double x0 = g[h - 1], x1 = g[h], y0 = v[h - 1], y1 = v[h];
-        {
-#pragma clang fp contract(off)
-            const double slope = (y1 - y0) / (x1 - x0); out[t] = y0 + slope * (x - x0);
-        }
-    }
-}
-
-// makePoints.pyx:35-40: ray[r,c,k] = SP[r,c] + basespace[k]*SLV[r,c], basespace = arange(0, max_len+step, step)
-__global__ void make_points_kernel(const double* __restrict__ sp, const double* __restrict__ slv, int64_t nrays, int64_t npts,
-                                   double step, double* __restrict__ out) {
-    const int64_t total = nrays * 3 * npts;
-    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t k = t % npts, rc = t / npts;
-        {
-#pragma clang fp contract(off)
-            const double b = (double)k * step; const double p = b * slv[rc]; out[t] = sp[rc] + p;
-        }
-    }
-}
+// ---- kernels other than the two ray passes (raider_kernels.h) ---------------------------------------------------------
+#include "cube_kernels.h"
+#include "producer_kernels.h"
+#include "orbit_kernels.h"
+#include "native_kernels.h"
 
 // ------------------------------------------------------------------------------------------------
 // C ABI
