@@ -323,3 +323,48 @@ def test_conventional_from_orbit_file():
     np.testing.assert_allclose(state_to_los(svs, [lats, lons, hgts]), cosang, rtol=1e-12, equal_nan=True)
     with pytest.raises(RuntimeError):
         state_to_los(svs[:3], [lats, lons, hgts])
+
+
+def test_integration_md_stub_runs_as_printed(c1):
+    """The ctypes stub of INTEGRATION.md section A, executed verbatim against the built library (only the library path is
+    substituted): zenith cube and one ray-traced slice equal the mirror package's results bit for bit."""
+    import re
+    import subprocess
+    import sys
+    import textwrap
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    md = (root / 'INTEGRATION.md').read_text()
+    code = re.search(r'```python\n(# tools/RAiDER/_hip\.py.*?)```', md, re.S).group(1)
+    assert "C.CDLL('libraider_hip.so')" in code
+    code = code.replace("C.CDLL('libraider_hip.so')", f"C.CDLL({str(root / 'raider_amd' / 'libraider_hip.so')!r})")
+    driver = textwrap.dedent('''
+        import sys, numpy as np
+        sys.path.insert(0, ROOT)
+        from oracle import raider_oracle as O
+        c = O.synthetic_cube(50, 50, 40, seed=0)
+        xp = np.linspace(-119.5, -115.5, 30); yp = np.linspace(34.5, 31.5, 26); zp = np.array([0.0, 500.0])
+        tot = upload_cube(c['xs'], c['ys'], c['zs'], c['wet_total'], c['hydro_total'])
+        zw, zh = build_cube(tot, xp, yp, zp)
+        pw = upload_cube(c['xs'], c['ys'], c['zs'], c['wet'], c['hydro'])
+        xx, yy = np.meshgrid(xp, yp)
+        LOS = np.ascontiguousarray(O.look_vectors_from_inc_hd(np.full(yy.shape, 39.0), np.full(yy.shape, -167.9), yy, xx, 0.0))
+        zref = float(c['zs'].max() - 1)
+        w, h = raytrace_slice(pw, xp, yp, 0.0, LOS, zref)
+        assert raytrace_slice(pw, xp, yp, zref + 10.0, LOS, zref) is None
+        np.savez(OUT, zw=zw, zh=zh, w=w, h=h, LOS=LOS)
+    ''')
+    import tempfile
+    out = Path(tempfile.mkdtemp()) / 'stub.npz'
+    prog = f'ROOT = {str(root)!r}\nOUT = {str(out)!r}\n' + code + driver
+    res = subprocess.run([sys.executable, '-c', prog], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-3000:]
+    got = np.load(out)
+    import raider_amd as R
+    xp = np.linspace(-119.5, -115.5, 30); yp = np.linspace(34.5, 31.5, 26)
+    tot = R.Cube(c1['ys'], c1['xs'], c1['zs'], c1['wet_total'], c1['hydro_total'], order='zyx')
+    zw, zh = tot.build_cube(xp, yp, np.array([0.0, 500.0]))
+    assert np.array_equal(got['zw'], zw) and np.array_equal(got['zh'], zh)
+    pw = R.Cube(c1['ys'], c1['xs'], c1['zs'], c1['wet'], c1['hydro'], order='zyx')
+    w, h, _, _ = pw.raytrace(R.Rays.grid(xp, yp, los=got['LOS']), 0.0, float(c1['zs'].max() - 1))
+    assert np.array_equal(got['w'], w) and np.array_equal(got['h'], h) and np.isfinite(h).all()
