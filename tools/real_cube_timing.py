@@ -26,3 +26,11 @@ for rep in range(4):
 h = np.asarray(ds['hydro'][:])
 out.update(grid=[int(y.size), int(x.size)], rays=int(4 * x.size * y.size), nan_share=float(np.isnan(h).mean()), mean_hydro=float(np.nanmean(h)))
 print(json.dumps(out))
+if len(sys.argv) > 1 and sys.argv[1] == 'profile':
+    import cProfile
+    import pstats
+    pr = cProfile.Profile(); pr.enable()
+    for _ in range(10):
+        tropo_delay(dt.datetime(2020, 1, 30, 13, 52, 45), str(cube), GridAOI(x, y), Raytracing(inc=inc, heading=-167.9), [0.0, 500.0, 1500.0, 3000.0], 4326, None)
+    pr.disable()
+    pstats.Stats(pr).sort_stats('tottime').print_stats(18)
