@@ -86,8 +86,8 @@ for trial in range(ntrials):
     gw, gh = cube.interp(pts)
     note('interp wet', gw, ip[0](pts), 1e-13, tag); note('interp hydro', gh, ip[1](pts), 1e-13, tag)
     # ---- native `interpolate` ------------------------------------------------------------------------------------------------
-    nd = int(rng.integers(1, 4))
-    shape = tuple(int(rng.integers(2, 24)) for _ in range(nd))
+    nd = int(rng.integers(1, 6))                       # 1-D ... 5-D (test_interpolator.py goes to 4-D)
+    shape = tuple(int(rng.integers(2, 24 if nd < 4 else 9)) for _ in range(nd))
     grids = tuple(axis(s, -1.0, 2.0, str(rng.choice(['exact', 'irregular']))) for s in shape)
     vals = rng.standard_normal(shape)
     q = rng.uniform(-1.4, 2.4, (int(rng.integers(1, 3000)), nd))
