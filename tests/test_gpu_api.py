@@ -368,3 +368,32 @@ def test_integration_md_stub_runs_as_printed(c1):
     pw = R.Cube(c1['ys'], c1['xs'], c1['zs'], c1['wet'], c1['hydro'], order='zyx')
     w, h, _, _ = pw.raytrace(R.Rays.grid(xp, yp, los=got['LOS']), 0.0, float(c1['zs'].max() - 1))
     assert np.array_equal(got['w'], w) and np.array_equal(got['h'], h) and np.isfinite(h).all()
+
+
+def test_interpolate_large_batch_and_unsorted_queries():
+    """test/test_interpolator.py's 'large' (2 M points) and 'unsorted' cases on the analytic field f(x,y,z) = x^2 + 3y - z: the
+    mirror equals scipy's RGI to 1e-15 (the reference's own bar) and, when the reference's compiled extension is there
+    (oracle/_ref), equals IT bit for bit."""
+    import sys
+    import types
+    from pathlib import Path
+    from scipy.interpolate import RegularGridInterpolator
+    from raider_amd.interpolate import interpolate
+    rng = np.random.default_rng(0)
+    x, y, z = np.linspace(0, 10, 41), np.linspace(-4, 6, 33), np.linspace(1, 5, 27)
+    f = x[:, None, None] ** 2 + 3 * y[None, :, None] - z[None, None, :]
+    q = np.stack([rng.uniform(0, 10, 2_000_000), rng.uniform(-4, 6, 2_000_000), rng.uniform(1, 5, 2_000_000)], -1)     # unsorted
+    got = interpolate((x, y, z), f, q, assume_sorted=False, max_threads=8)
+    want = RegularGridInterpolator((x, y, z), f, bounds_error=False, fill_value=None)(q)
+    assert got.shape == (2_000_000,) and np.abs(got - want).max() <= 2e-14 * np.abs(want).max()
+    so = Path(__file__).resolve().parent.parent / 'oracle' / '_ref' / 'RAiDER'
+    if any(so.glob('interpolate*.so')) and 'RAiDER' not in sys.modules:
+        pkg = types.ModuleType('RAiDER'); pkg.__path__ = [str(so)]
+        sys.modules['RAiDER'] = pkg
+        try:
+            import RAiDER.interpolate as ref
+            assert np.array_equal(got, ref.interpolate((x, y, z), f, q, assume_sorted=False, max_threads=8))
+            qs = q[np.argsort(q[:, 0])][:200_000]                          # sorted along the first axis: the assume_sorted fast path
+            assert np.array_equal(interpolate((x, y, z), f, qs, assume_sorted=True), ref.interpolate((x, y, z), f, qs, assume_sorted=False, max_threads=2))
+        finally:
+            sys.modules.pop('RAiDER', None); sys.modules.pop('RAiDER.interpolate', None)
