@@ -448,3 +448,17 @@ def test_two_contexts_in_two_threads(R):
     for i in range(2):
         assert len(outs[i]) == 1
         assert np.array_equal(outs[i][0][0], serial[i][0]) and np.array_equal(outs[i][0][1], serial[i][1]) and np.array_equal(outs[i][0][2], serial[i][2])
+
+
+def test_lcc_projection_against_snyders_worked_examples(R):
+    """The device's Lambert-conformal-conic forward (rdr_project_points) on Snyder's published numerical examples (USGS PP 1395,
+    pp. 295-298; see tests/test_oracle_golden.py): sphere and Clarke 1866 ellipsoid."""
+    ys, xs, zs = np.linspace(0.0, 1.0, 4), np.linspace(0.0, 1.0, 4), np.linspace(0.0, 1.0, 4)
+    cube = R.Cube(ys, xs, zs, np.zeros((4, 4, 4), np.float32), np.zeros((4, 4, 4), np.float32), order='zyx')
+    par = dict(lat_1=33.0, lat_2=45.0, lat_0=23.0, lon_0=-96.0)
+    cube.set_projection_lcc(a=1.0, es=0.0, **par)
+    y, x = cube.project(np.array([35.0]), np.array([-75.0]))
+    assert abs(x[0] - 0.2966785) < 5e-8 and abs(y[0] - 0.2462112) < 5e-8
+    cube.set_projection_lcc(a=6378206.4, es=0.00676866, **par)
+    y, x = cube.project(np.array([35.0]), np.array([-75.0]))
+    assert abs(x[0] - 1894410.9) < 0.05 and abs(y[0] - 1564649.5) < 0.05

@@ -318,3 +318,15 @@ def test_reference_known_answers_find_svp_and_ztd():
     hyd = 1 * m['p'] / m['t']
     assert np.allclose(wet, m['wet_refr']) and np.allclose(hyd, m['hydro_refr'])
     assert np.allclose(O.ztd_totals(wet, m['zs']), m['wet_ztd']) and np.allclose(O.ztd_totals(hyd, m['zs']), m['hydro_ztd'])
+
+
+def test_lcc_against_snyders_worked_examples():
+    """Lambert conformal conic forward: J. P. Snyder, Map Projections - A Working Manual (USGS Prof. Paper 1395, 1987), numerical
+    examples pp. 295-298: standard parallels 33 and 45 N, origin 23 N / 96 W, point 35 N / 75 W.  Unit sphere: x = 0.2966785,
+    y = 0.2462112; Clarke 1866 ellipsoid (a = 6378206.4 m, e^2 = 0.00676866): x = 1 894 410.9 m, y = 1 564 649.5 m.  An authority
+    independent of PROJ (which implements the same formulas) for the projection the HRRR cubes live on."""
+    par = dict(lat_1=33.0, lat_2=45.0, lat_0=23.0, lon_0=-96.0)
+    x, y = O.lcc_forward(35.0, -75.0, a=1.0, es=0.0, **par)
+    assert abs(x - 0.2966785) < 5e-8 and abs(y - 0.2462112) < 5e-8
+    x, y = O.lcc_forward(35.0, -75.0, a=6378206.4, es=0.00676866, **par)
+    assert abs(x - 1894410.9) < 0.05 and abs(y - 1564649.5) < 0.05
