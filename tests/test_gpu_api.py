@@ -397,3 +397,13 @@ def test_interpolate_large_batch_and_unsorted_queries():
             assert np.array_equal(interpolate((x, y, z), f, qs, assume_sorted=True), ref.interpolate((x, y, z), f, qs, assume_sorted=False, max_threads=2))
         finally:
             sys.modules.pop('RAiDER', None); sys.modules.pop('RAiDER.interpolate', None)
+
+
+def test_wgs84_conversion_against_the_epsg_guidance_note_example():
+    """The device's lla2ecef / ecef2lla on the worked example of IOGP Guidance Note 7-2 (see tests/test_oracle_golden.py)."""
+    from raider_amd.utilFcns import ecef2lla, lla2ecef
+    lat, lon, h = 53 + 48 / 60 + 33.820 / 3600, 2 + 7 / 60 + 46.380 / 3600, 73.0
+    x, y, z = lla2ecef(np.array([lat]), np.array([lon]), np.array([h]))
+    assert abs(x[0] - 3771793.968) < 1e-3 and abs(y[0] - 140253.342) < 1e-3 and abs(z[0] - 5124304.349) < 1e-3
+    lo, la, hh = ecef2lla(np.array([3771793.968]), np.array([140253.342]), np.array([5124304.349]))
+    assert abs(la[0] - lat) < 1e-8 and abs(lo[0] - lon) < 1e-8 and abs(hh[0] - h) < 1e-3

@@ -330,3 +330,14 @@ def test_lcc_against_snyders_worked_examples():
     assert abs(x - 0.2966785) < 5e-8 and abs(y - 0.2462112) < 5e-8
     x, y = O.lcc_forward(35.0, -75.0, a=6378206.4, es=0.00676866, **par)
     assert abs(x - 1894410.9) < 0.05 and abs(y - 1564649.5) < 0.05
+
+
+def test_wgs84_conversion_against_the_epsg_guidance_note_example():
+    """Geographic <-> geocentric (EPSG method 9602), the worked example of IOGP Guidance Note 7-2 (WGS 84): 53 48'33.820" N,
+    2 07'46.380" E, h = 73.0 m  <->  X = 3 771 793.968 m, Y = 140 253.342 m, Z = 5 124 304.349 m.  An authority independent of PROJ
+    for utilFcns.lla2ecef / ecef2lla (which the reference delegates to pyproj)."""
+    lat, lon, h = 53 + 48 / 60 + 33.820 / 3600, 2 + 7 / 60 + 46.380 / 3600, 73.0
+    x, y, z = O.lla2ecef(np.array([lat]), np.array([lon]), np.array([h]))
+    assert abs(x[0] - 3771793.968) < 1e-3 and abs(y[0] - 140253.342) < 1e-3 and abs(z[0] - 5124304.349) < 1e-3
+    lo, la, hh = O.ecef2lla(np.array([3771793.968]), np.array([140253.342]), np.array([5124304.349]))
+    assert abs(la[0] - lat) < 1e-8 and abs(lo[0] - lon) < 1e-8 and abs(hh[0] - h) < 1e-3
