@@ -11,14 +11,20 @@ Pinned against the reference itself: `oracle/refharness/gen_golden.py` imports t
 reference from /root/reference (in the build container), runs its `_build_cube`,
 `_build_cube_ray`, `build_ray`, `getTopOfAtmosphere`, `inc_hd_to_enu`, `enu2ecef`,
 `getZenithLookVecs`, `Conventional.__call__` arithmetic, the native `interpolate`,
-`interpolate_along_axis` and `makePoints*D` on seeded inputs and commits inputs+outputs under
-tests/golden/*.npz; `tests/test_oracle_golden.py` checks every function below against them.
-UNPINNED (stated in DESIGN.md): the WGS84<->ECEF arithmetic itself.  The reference calls
-pyproj/PROJ (`utilFcns.py:77-88`, `delay.py:238,252-253`), which is not installed in this image and
-is not under /root/reference; the formulas in `ecef2lla`/`lla2ecef` restate PROJ's published
-`cart` conversion (PROJ src/conversions/cart.cpp) and are pinned only by the three exact ECEF
-values of `test/test_delayFcns.py:86-99` and round trips.  isce3 look-vector generation is out of
-scope (look vectors are an input array).
+`interpolate_along_axis` and `makePoints*D`, the `WeatherModel` processing methods, the azimuth-time
+weighting functions and the orbit-file readers on seeded inputs and commits inputs+outputs under
+tests/golden/*.npz; `tests/test_oracle_golden.py` checks every function below against them, and
+`tests/test_oracle_vs_reference.py` re-runs the comparison LIVE on fresh random cases wherever the
+reference tree is present.  Data files of the reference's own test suite pin the rest: processed
+ERA-5 cubes written by the real RAiDER, the raw model-level files they were made from, its GMAO
+time-interpolation product (tests/golden/ref_files, tests/test_ref_files.py).
+UNPINNED against the reference's third-party dependencies (stated in DESIGN.md 6): pyproj/PROJ is
+not installed here and not under /root/reference, so `ecef2lla`/`lla2ecef` restate PROJ's published
+`cart` conversion and `lcc_forward` its `lcc` projection; both ARE pinned on authorities independent
+of PROJ (IOGP Guidance Note 7-2's worked example; Snyder's USGS PP 1395 numerical examples) and on
+the three exact ECEF values of `test/test_delayFcns.py:86-99`, but not on PROJ's own binary.
+isce3's geo2rdr (orbit -> look vectors) is absent too: `orbit_look_vectors` restates the zero-Doppler
+solve from its call sites and is pinned by geometry only.
 
 Every function cites the reference file:line (relative to /root/reference/) it follows.
 """
