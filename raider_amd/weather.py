@@ -53,6 +53,51 @@ class ProcessedModel:
         if k in ('wet_total', 'hydro_total'): return np.ascontiguousarray(self.total.read()[k == 'hydro_total'].transpose(2, 0, 1))
         raise KeyError(k)
 
+    def to_netcdf(self, path, time=None, model_name='ERA-5'):
+        """The processed weather-model file of WeatherModel.write (weatherModel.py:659-724): dims z, y, x; variables wet, hydro
+        (f32), wet_total, hydro_total (f64) - and t, p, e (f32) when the model was produced with return_state=True - with the
+        reference's units / standard_name / grid_mapping attributes, 2-D latitude / longitude, the `proj` grid-mapping variable
+        carrying `crs_wkt`, and the global attributes.  Written as NetCDF-3 (64-bit offset) through scipy - readable by xarray /
+        netCDF4 and by this package's own tropo_delay / getInterpolators; the reference writes NetCDF-4 through xarray."""
+        import datetime as dt
+        from scipy.io import netcdf_file
+        if not isinstance(self.proj, int) or self.proj != 4326:
+            raise NotImplementedError('ProcessedModel.to_netcdf: only EPSG:4326 models carry a crs_wkt here (no pyproj in the image)')
+        ys, xs, zs = self.pointwise.grid
+        wet, hyd = self.pointwise.read(); wt, ht = self.total.read()                     # (y, x, z)
+        zyx = lambda v: np.ascontiguousarray(np.asarray(v).transpose(2, 0, 1))
+        fields = [('wet', wet, 'f4', 'dimentionless', 'wet_refractivity'), ('hydro', hyd, 'f4', 'dimentionless', 'hydrostatic_refractivity'),
+                  ('wet_total', wt, 'f8', 'm', 'total_wet_refractivity'), ('hydro_total', ht, 'f8', 'm', 'total_hydrostatic_refractivity')]
+        if self.t is not None:
+            fields = [('t', self.t, 'f4', 'K', 'temperature'), ('p', self.p, 'f4', 'Pa', 'pressure'), ('e', self.e, 'f4', 'Pa', 'humidity')] + fields
+        with netcdf_file(str(path), 'w', version=2) as f:
+            f.Conventions = 'CF-1.6'
+            f.title = 'Weather model data and delay calculations'
+            f.model_name = str(model_name)
+            if time is not None:
+                f.datetime = time.strftime('%Y_%m_%dT%H_%M_%S')
+            f.date_created = dt.datetime.now().strftime('%Y_%m_%dT%H_%M_%S')
+            for d, v in (('z', zs), ('y', ys), ('x', xs)):
+                f.createDimension(d, int(np.size(v)))
+                f.createVariable(d, 'f8', (d,))[:] = np.asarray(v, dtype=np.float64)
+            lon2, lat2 = np.meshgrid(xs, ys)
+            f.createVariable('latitude', 'f8', ('y', 'x'))[:] = lat2
+            f.createVariable('longitude', 'f8', ('y', 'x'))[:] = lon2
+            for name, arr, typ, units, std in fields:
+                v = f.createVariable(name, typ, ('z', 'y', 'x'))
+                v[:] = zyx(arr)
+                v.units = units; v.standard_name = std; v.grid_mapping = 'proj'
+            pj = f.createVariable('proj', 'i4', ())
+            pj.data[()] = 0
+            pj.crs_wkt = ('GEOGCRS["WGS 84",DATUM["World Geodetic System 1984",ELLIPSOID["WGS 84",6378137,298.257223563,LENGTHUNIT["metre",1]]],'
+                          'PRIMEM["Greenwich",0,ANGLEUNIT["degree",0.0174532925199433]],CS[ellipsoidal,2],AXIS["geodetic latitude (Lat)",north,'
+                          'ORDER[1],ANGLEUNIT["degree",0.0174532925199433]],AXIS["geodetic longitude (Lon)",east,ORDER[2],'
+                          'ANGLEUNIT["degree",0.0174532925199433]],ID["EPSG",4326]]')
+            pj.grid_mapping_name = 'latitude_longitude'
+            pj.semi_major_axis = 6378137.0; pj.inverse_flattening = 298.257223563; pj.longitude_of_prime_meridian = 0.0
+            pj.reference_ellipsoid_name = 'WGS 84'
+        return str(path)
+
     def interpolators(self, kind='pointwise'):
         """getInterpolators(wm_file, kind) (delayFcns.py:23-58) without the file"""
         from .delayFcns import interpolators_from_cube

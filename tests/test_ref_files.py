@@ -306,3 +306,29 @@ def test_gpu_producer_chain_from_raw_era5_file(raw, proc):
     dist = {k: float(np.nanmax(np.abs(got[k].transpose(2, 0, 1).astype(np.float64) - g[k].read().astype(np.float64))[np.abs(g[k].read()) < 1e15])) for k in got}
     assert all(np.array_equal(np.isnan(got[k].transpose(2, 0, 1)), np.isnan(g[k].read())) for k in got)
     assert dist['t'] < 0.5 and dist['p'] < 500.0 and dist['hydro_total'] < 7e-4 and dist['wet_total'] < 7e-4, dist
+
+
+@pytest.mark.gpu
+def test_processed_model_file_roundtrip(tmp_path):
+    """ProcessedModel.to_netcdf writes the processed-cube layout of WeatherModel.write (as NetCDF-3): read back by path it gives the
+    same delays as the device-resident model, and its variables / attributes are the reference's."""
+    from scipy.io import netcdf_file
+    from raider_amd.delay import GridAOI, tropo_delay
+    from raider_amd.losreader import Raytracing, Zenith
+    from raider_amd.weather import load_ecmwf_model_levels
+    d = Path(__file__).parent / 'golden' / 'ref_files'
+    model = load_ecmwf_model_levels(d / 'ERA-5_2019_11_17_T20_51_58.nc', return_state=True)
+    when = dt.datetime(2019, 11, 17, 20, 51, 58)
+    path = model.to_netcdf(tmp_path / 'ERA-5_2019_11_17_T20_51_58_5S_2S_41W_37W.nc', time=when)
+    with netcdf_file(path, 'r', mmap=False) as f:
+        assert set(f.variables) >= {'x', 'y', 'z', 't', 'p', 'e', 'wet', 'hydro', 'wet_total', 'hydro_total', 'latitude', 'longitude', 'proj'}
+        assert f.variables['wet'].dimensions == ('z', 'y', 'x') and f.variables['wet'].data.dtype.itemsize == 4 and f.variables['wet_total'].data.dtype.itemsize == 8
+        assert f.variables['hydro'].standard_name == b'hydrostatic_refractivity' and f.variables['t'].units == b'K' and f.variables['p'].grid_mapping == b'proj'
+        assert f.datetime == b'2019_11_17T20_51_58' and b'4326' in f.variables['proj'].crs_wkt
+    x, y = model['x'], model['y']
+    aoi = GridAOI(x[2:-2], y[2:-2][::-1])
+    for los in (Zenith(), Raytracing(inc=35.0, heading=-167.9)):
+        a, _ = tropo_delay(when, model, aoi, los, [0.0, 1200.0], 4326, None)
+        b, _ = tropo_delay(when, path, aoi, los, [0.0, 1200.0], 4326, None)
+        assert np.array_equal(np.asarray(a['hydro'][:]), np.asarray(b['hydro'][:]), equal_nan=True)
+        assert np.array_equal(np.asarray(a['wet'][:]), np.asarray(b['wet'][:]), equal_nan=True) and np.isfinite(np.asarray(a['hydro'][:])).any()
