@@ -181,7 +181,8 @@ class DelayCube:
         v = self.variables
         with netcdf_file(str(path), 'w', version=2) as f:
             for k, val in self.attrs.items():
-                setattr(f, k, str(val))
+                if not k.startswith('_'):                      # (_degrees / _crs_cf steer the writer, they are not file attributes)
+                    setattr(f, k, str(val))
             for d in ('z', 'y', 'x'):
                 f.createDimension(d, int(np.size(v[d])))
                 cv = f.createVariable(d, 'f8', (d,))
