@@ -771,15 +771,16 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
             // The level crossings are re-derived from h(u) as the loop reaches them (no global loads inside the loop besides
             // the gathers, so the only memory waits are on a sample's own corners).
             const double su = w[(int64_t)WS_SU * ns], ou = w[(int64_t)WS_OU * ns], gain = w[(int64_t)WS_GAIN * ns];
-            auto sample = [&](double us, double wv, int zbase, bool floor_it, bool ceil_it) {
+            auto issue = [&](double us, int zbase, bool floor_it, bool ceil_it, PendingSample<T2>& s) {
                 double ph = poly5(q.h, us);
                 const double plat = poly5(q.lat, us), plon = poly5(q.lon, us);       // delay.py:295 through the ray polynomials
                 // all-pixels z-clamp of the very first / very last sample (delay.py:306-311): when it applies every pixel is
                 // below (above) the cube, so "set to zmin" == max(ph, zmin)
                 if (floor_it) ph = fmax(ph, c.z_lo);
                 if (ceil_it) ph = fmin(ph, c.z_hi);
-                PendingSample<T2> s;
                 sample_issue<T2, true>(c, m.ax, plat, plon, ph, zbase, s);           // delay.py:298,319
+            };
+            auto finish = [&](const PendingSample<T2>& s, double wv) {
                 double vw, vh;
                 sample_finish(s, vw, vh);
                 acc_w = fma(wv, vw, acc_w); acc_h = fma(wv, vh, acc_h);              // delay.py:323
@@ -792,23 +793,35 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
             double du = u_last - u_k;
             // the ray's very first sample is the BOTTOM of its segment: when that is a model node (origin at or below it), the
             // two-entry z window must start one interval lower
-            if (K > 0) sample(fma(0.0 * step, du, u_k), hs * du, window2_base(c.nz, kz - ((m.lo[0] <= m.ax.ez[kz].x) ? 1 : 0)), clamp_lo, false);
+            if (K > 0) {
+                PendingSample<T2> s;
+                issue(fma(0.0 * step, du, u_k), window2_base(c.nz, kz - ((m.lo[0] <= m.ax.ez[kz].x) ? 1 : 0)), clamp_lo, false, s);
+                finish(s, hs * du);
+            }
 #pragma unroll 1
             for (int k = 0; k < K; ++k) {
                 const int zbase = window2_base(c.nz, kz);                            // first table entry of the two-entry z window
                 const bool more = k + 1 < K;
+                // trapezoid weights per unit of u (delay.py:314-315): interior samples, and the top one with both its segments
+                const double w_mid = (2.0 * hs) * du;
+#pragma unroll 1
+                for (int j = 1; j < np - 1; ++j) {                                   // low + frac * (high - low), delay.py:292
+                    PendingSample<T2> s;
+                    issue(fma((double)j * step, du, u_k), zbase, false, false, s);
+                    finish(s, w_mid);
+                }
+                // top sample: its gathers are issued first, the next level's crossing (21 dependent FMAs that need no memory) is
+                // computed while they are in flight, then the sample is finished with the weight of both its segments
+                PendingSample<T2> top;
+                issue(fma((double)(np - 1) * step, du, u_k), zbase, false, clamp_hi && !more, top);
                 double du1 = 0.0, hs1 = 0.0;
+                double w_top = hs * du;
                 if (more) {
                     const double t2 = level_top_u(q.h, m.hi[k + 1], su, ou, gain);
                     du1 = t2 - u_last; u_last = t2; hs1 = m.hs[k + 1];
+                    w_top = fma(hs1, du1, w_top);
                 }
-                // trapezoid weights per unit of u (delay.py:314-315): interior samples, and the top one with both its segments
-                const double w_mid = (2.0 * hs) * du;
-                double w_top = hs * du;
-                if (more) w_top = fma(hs1, du1, w_top);
-#pragma unroll 1
-                for (int j = 1; j < np - 1; ++j) sample(fma((double)j * step, du, u_k), w_mid, zbase, false, false);   // low + frac * (high - low), delay.py:292
-                sample(fma((double)(np - 1) * step, du, u_k), w_top, zbase, false, clamp_hi && !more);
+                finish(top, w_top);
                 u_k += du; du = du1; hs = hs1;
                 if (more) {
                     np = __builtin_amdgcn_readfirstlane(m.np[k + 1]);
