@@ -27,13 +27,13 @@ sys.path.insert(0, str(REPO))
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 # HBM bytes per march_kernel launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate runs,
-# FETCH_SIZE x2 per the gfx950 correction, verified on a 1 GiB calibration copy): profiles/r01_v11_hbm_traffic_pmc.txt.
+# FETCH_SIZE x2 per the gfx950 correction, verified on a 1 GiB calibration copy): profiles/r01_v12_hbm_traffic_pmc.txt.
 # Only valid for the default workload; any other shape reports null.
 PMC_TRAFFIC_BYTES = {(4000, 4000, '300x300x80'): 3.346e9 + 0.258e9}
 # march_kernel is bound by vector-ALU issue, not by HBM: SQ_INSTS_VALU per 64-ray wave on the default cube/scene geometry
-# (profiles/r01_v11_sq_counters_per_raywave.txt; per ray, so independent of the number of rays) against the issue peak
+# (profiles/r01_v12_sq_counters_per_raywave.txt; per ray, so independent of the number of rays) against the issue peak
 # 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction (fp64 FMA is full rate on CDNA4) = 614.4 G wave-instr/s.
-VALU_PER_RAYWAVE = {'300x300x80': 12638.0}
+VALU_PER_RAYWAVE = {'300x300x80': 12410.0}
 VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4
 
 
@@ -186,17 +186,17 @@ def main():
                        'mean_hydro_m': mean_h, 'mean_wet_m': mean_w, 'nan_fraction': nan_frac},
             'roofline': {'bound': 'hbm', 'kernel': 'march_kernel<float2,false,true>', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': PMC_TRAFFIC_BYTES.get((rows, cols, args.cube)) if world == 1 else None,
-                         'traffic_unit': 'bytes per march_kernel launch (PMC, profiles/r01_v11_hbm_traffic_pmc.txt)',
+                         'traffic_unit': 'bytes per march_kernel launch (PMC, profiles/r01_v12_hbm_traffic_pmc.txt)',
                          'traffic_GBps': (PMC_TRAFFIC_BYTES[(rows, cols, args.cube)] / (march_ms * 1e-3) / 1e9) if (world == 1 and (rows, cols, args.cube) in PMC_TRAFFIC_BYTES) else None,
                          'algorithmic_bytes_per_ray': bytes_per_ray, 'compulsory_bytes_per_ray': 64 + (ny * nx * nz * 8) / n_rays,
                          'march_ms_per_step': march_ms, 'crossings_ms_per_step': pre_ms, 'march_launches_timed': n_march,
                          'note': 'achieved = (64*S+64) B/ray (SURVEY 8d gather model, S = reference samples/ray) x rays / march_kernel time; '
                                  'the kernel evaluates only the S-(K-1) distinct sample points (level-boundary samples are shared by two '
                                  'segments) and its gathers are served by L2/MALL, so this is an algorithmic-throughput figure, not DRAM traffic. '
-                                 'The limiter is the fp64 vector ALU: SQ counters (profiles/r01_v11_sq_counters_per_raywave.txt) show the VALU '
-                                 'busy 92% of a resident wave\'s time in march_kernel (12.6k VALU instructions per 64-ray wave) and 87% in crossings_kernel (3.4k); '
+                                 'The limiter is the fp64 vector ALU: SQ counters (profiles/r01_v12_sq_counters_per_raywave.txt) show the VALU '
+                                 'busy 93% of a resident wave\'s time in march_kernel (12.4k VALU instructions per 64-ray wave) and 87% in crossings_kernel (3.3k); '
                                  'see "valu" for the issue-rate roofline computed from this run\'s kernel time',
-                         'valu_busy_frac': 0.92,
+                         'valu_busy_frac': 0.93,
                          'valu': ({'bound': 'fp64 vector-ALU issue', 'achieved': VALU_PER_RAYWAVE[args.cube] * (n_rays / 64.0) / (march_ms * 1e-3) / 1e9,
                                    'peak': VALU_ISSUE_PEAK / 1e9, 'unit': 'G wave64-instr/s',
                                    'frac': VALU_PER_RAYWAVE[args.cube] * (n_rays / 64.0) / (march_ms * 1e-3) / VALU_ISSUE_PEAK,
