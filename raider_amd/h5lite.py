@@ -23,7 +23,6 @@ tests/test_ref_files.py checks what is read against physics identities and again
 version-0/1 superblock, symbol-table groups and chunked / deflate / shuffle branches follow the specification but no file
 in this environment exercises them (there is no HDF5 writer here to make one).
 """
-import struct
 import zlib
 
 import numpy as np

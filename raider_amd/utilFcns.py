@@ -4,7 +4,6 @@ lla2ecef / ecef2lla run on the GPU (the reference goes through pyproj/PROJ, util
 the ENU rotations and degree trig are the same few NumPy expressions the reference uses and are kept
 on the host because the reference's callers use them on tiny arrays outside the hot loops (inside the
 ray kernels the same conversions are fused on-device, csrc/geodesy.h)."""
-import ctypes as C
 
 import numpy as np
 
