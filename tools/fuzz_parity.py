@@ -45,6 +45,9 @@ for trial in range(ntrials):
     if proj is None and rng.random() < 0.25:          # latitude axis stored north to south (scipy's RGI flips descending axes, _rgi.py:280-281)
         c['ys'] = c['ys'][::-1].copy(); c['wet'] = c['wet'][:, ::-1, :].copy(); c['hydro'] = c['hydro'][:, ::-1, :].copy()
         axes_kind = str(axes_kind) + '+descending_y'
+    if rng.random() < 0.2:           # float64 fields (the double2 instantiations of the ray kernels)
+        c['wet'] = c['wet'].astype(np.float64) * (1 + 1e-9 * rng.standard_normal(c['wet'].shape)); c['hydro'] = c['hydro'].astype(np.float64) * (1 + 1e-9 * rng.standard_normal(c['hydro'].shape))
+        axes_kind = str(axes_kind) + '+f64'
     gy, gx = int(rng.integers(3, 14)), int(rng.integers(3, 14))
     f = rng.uniform(0.3, 1.15)                                   # > 1: part of the scene starts outside the cube
     ypts = np.linspace(lat_c + f * dlat, lat_c - f * dlat, gy) if rng.random() < 0.7 else np.linspace(lat_c - f * dlat, lat_c + f * dlat, gy)
