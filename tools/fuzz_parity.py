@@ -102,6 +102,13 @@ for trial in range(ntrials):
     dw = float(np.nanmax(np.abs(wet - ow[0]))) if np.isfinite(ow[0]).any() else 0.0
     dh = float(np.nanmax(np.abs(hyd - oh[0]))) if np.isfinite(oh[0]).any() else 0.0
     worst['wet'] = max(worst['wet'], dw); worst['hydro'] = max(worst['hydro'], dh)
+    # look vectors generated INSIDE the kernels from incidence / heading rasters (inc_hd_to_enu + enu2ecef on the device)
+    if not nan_los and trial % 4 == 1:
+        iw, ih, inp, _ = cube.raytrace(R.Rays.grid(xpts, ypts, inc=inc, hd=hd), ht, zref, max_seg)
+        di = max(float(np.nanmax(np.abs(iw - wet))) if np.isfinite(wet).any() else 0.0, float(np.nanmax(np.abs(ih - hyd))) if np.isfinite(hyd).any() else 0.0)
+        worst['inc_hd_mode_vs_vectors'] = max(worst.get('inc_hd_mode_vs_vectors', 0.0), di)
+        if not np.array_equal(inp, nparts) or not np.array_equal(np.isnan(ih), np.isnan(hyd)) or di > 2e-9:
+            bad.append(dict(tag, kind='inc/heading LOS mode vs look vectors', d=di))
     # the same rays as a POINT list (per-ray lat/lon, or per-ray ECEF origins): different tile mapping, no shared tile trigonometry
     if trial % 3 == 0:
         lo_c = np.ascontiguousarray(los).reshape(-1, 3)
