@@ -288,3 +288,26 @@ def test_randomised_sweep_other_entry_points():
     res = json.loads(lines[0])
     assert res['trials'] == 120 and res['n_bad'] == 0, lines[1:6]
     assert max(res['worst_rel'].values()) < 1e-13
+
+
+def test_survey_sanity_numbers_slant_to_zenith_ratio(R):
+    """SURVEY.md 8(a) / 8(d), measured there with the reference-faithful probe: on the 80-level synthetic profile (laterally uniform
+    here) a 35 deg ray from ht = 0 takes S = 169 samples and its hydrostatic delay is 1.22005 x the zenith delay - below
+    1/cos(35 deg) = 1.22077 because the Earth curves away under the ray.  The ray tracer reproduces both numbers."""
+    ys = np.linspace(30, 36, 300); xs = np.linspace(-121, -113, 300); zs = np.round(-100 + 41000 * np.linspace(0, 1, 80) ** 2, 3)
+    hyd = np.broadcast_to((270.0 * np.exp(-zs / 8000.0)).astype(np.float32)[:, None, None], (80, 300, 300)).copy()
+    wet = np.broadcast_to((60.0 * np.exp(-zs / 2000.0)).astype(np.float32)[:, None, None], (80, 300, 300)).copy()
+    cube = R.Cube(ys, xs, zs, wet, hyd, order='zyx')
+    xp = np.linspace(-118.0, -117.0, 5); yp = np.linspace(33.5, 32.5, 5)
+    zref = float(zs.max() - 1)
+    wz, hz, nz_, _ = cube.raytrace(R.Rays.grid(xp, yp, zenith=True), 0.0, zref)
+    for hd in (-167.9, 0.0, 90.0):
+        w, h, n, _ = cube.raytrace(R.Rays.grid(xp, yp, inc=35.0, hd=hd), 0.0, zref)
+        assert int(n.sum()) == 169
+        ratio = h / hz
+        assert np.all(np.abs(ratio - 1.22005) < 1e-5) and np.all(ratio < 1 / np.cos(np.radians(35.0)))
+    # zenith rays integrate the profile itself: the trapezoid of the (piecewise linear) refractivity over [0, zref]
+    f = 270.0 * np.exp(-zs / 8000.0)
+    zz = np.concatenate([[0.0], zs[zs > 0]]); zz[-1] = zref
+    prof = np.interp(zz, zs, f.astype(np.float32).astype(np.float64))
+    assert abs(hz.mean() - 1e-6 * np.sum(0.5 * (prof[1:] + prof[:-1]) * np.diff(zz))) < 1e-9
