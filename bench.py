@@ -25,16 +25,50 @@ import numpy as np
 REPO = Path(__file__).resolve().parent
 sys.path.insert(0, str(REPO))
 
-HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
-# HBM bytes per march_kernel launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate runs,
-# FETCH_SIZE x2 per the gfx950 correction, verified on a 1 GiB calibration copy): profiles/r01_v12_hbm_traffic_pmc.txt.
-# Only valid for the default workload; any other shape reports null.
-PMC_TRAFFIC_BYTES = {(4000, 4000, '300x300x80'): 3.346e9 + 0.258e9}
-# march_kernel is bound by vector-ALU issue, not by HBM: SQ_INSTS_VALU per 64-ray wave on the default cube/scene geometry
-# (profiles/r01_v12_sq_counters_per_raywave.txt; per ray, so independent of the number of rays) against the issue peak
-# 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction (fp64 FMA is full rate on CDNA4) = 614.4 G wave-instr/s.
-VALU_PER_RAYWAVE = {'300x300x80': 12410.0}
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s HBM3E spec
+# vector-ALU issue peak: 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction (fp64 FMA is full rate on CDNA4)
 VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4
+
+
+def kernel_source_hash():
+    """sha256 over the HIP sources of libraider_hip.so: ties the counter digests under profiles/ to the code they measured."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted((REPO / 'raider_amd' / 'csrc').glob('*')):
+        if f.suffix in ('.h', '.hip'):
+            h.update(f.name.encode()); h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
+def load_counters(cube, rows, cols):
+    """The newest profiles/r*_counters.json (written by tools/profile_digest.py from rocprofv3 --pmc passes) whose source hash
+    equals the current kernels' and whose workload matches; (dict, path) or (None, reason).  Nothing measured is a literal
+    in this file: a kernel change without a fresh profile yields nulls in the bench line."""
+    cands = sorted((REPO / 'profiles').glob('r*_counters.json'), reverse=True)
+    want = kernel_source_hash()
+    why = 'no profiles/r*_counters.json'
+    for f in cands:
+        try:
+            d = json.loads(f.read_text())
+        except (OSError, ValueError):
+            continue
+        if d.get('source_hash') != want:
+            why = f'{f.name}: source hash {d.get("source_hash")} != current {want} (stale profile)'
+            continue
+        return d, str(f.relative_to(REPO))
+    return None, why
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` invoked plainly: re-exec through torch.distributed.run with N ranks on this node."""
+    import socket
+    import subprocess
+    with socket.socket() as s_:
+        s_.bind(('127.0.0.1', 0)); port = s_.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def main():
@@ -47,9 +81,12 @@ def main():
     ap.add_argument('--cube', type=str, default='300x300x80')
     ap.add_argument('--cube-f64', action='store_true', help='experiment: upload the f32 refractivities as f64 (no cvt in the gather)')
     ap.add_argument('--coll-device', action='store_true', help='keep collective tensors on the GPU even with --backend gloo (dry run of the async path)')
-    ap.add_argument('--backend', type=str, default='nccl', help='torch.distributed backend for N>1 (nccl = RCCL; gloo only for single-GPU dry runs of the N>1 path)')
+    ap.add_argument('--backend', type=str, default='auto', help='torch.distributed backend for N>1: nccl (= RCCL), gloo, or auto = nccl when every rank has '
+                                                                'its own GPU, else gloo with device-resident collective tensors (ranks sharing a GPU: RCCL refuses duplicates)')
     ap.add_argument('--cpu-sample', type=int, default=640, help='edge of the square ray block timed on the CPU oracle (0 = skip)')
     args = ap.parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        self_launch(args)
 
     import torch
     import torch.distributed as dist
@@ -61,13 +98,17 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...')
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (no CPU fallback)')
-    local = local % torch.cuda.device_count()
+    ndev = torch.cuda.device_count()
+    local = local % ndev
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
+    if args.backend == 'auto':
+        args.backend = 'nccl' if world <= ndev else 'gloo'
+        if args.backend == 'gloo':
+            args.coll_device = True
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if args.backend == 'nccl':
@@ -173,7 +214,17 @@ def main():
         # per-STEP kernel time (a step may launch a kernel several times when the batch is marched in chunks)
         march_ms = ms_march / args.steps
         pre_ms = ms_pre / args.steps
-        achieved = bytes_per_ray * n_rays / (march_ms * 1e-3) / 1e9
+        gather_GBps = bytes_per_ray * n_rays / (march_ms * 1e-3) / 1e9
+        # SQ / HBM counters of THIS source version on THIS workload, from the tracked digest tools/profile_digest.py wrote
+        prof, prof_src = load_counters(args.cube, rows, cols)
+        wl_ok = prof is not None and prof.get('cube') == args.cube
+        km = (prof or {}).get('kernels', {}).get('march_kernel', {}) if wl_ok else {}
+        kc = (prof or {}).get('kernels', {}).get('crossings_kernel', {}) if wl_ok else {}
+        valu_rw = km.get('valu_per_raywave')                      # per 64-ray wave: independent of the number of rays
+        scene_ok = wl_ok and prof.get('hbm_scene') == [rows, cols] and world == 1
+        traffic = (km.get('hbm_read_bytes', 0) + km.get('hbm_write_bytes', 0)) if (scene_ok and 'hbm_read_bytes' in km) else None
+        step_traffic = (traffic + kc.get('hbm_read_bytes', 0) + kc.get('hbm_write_bytes', 0)) if (traffic is not None and 'hbm_read_bytes' in kc) else None
+        valu_rate = (valu_rw * (n_rays / 64.0) / (march_ms * 1e-3)) if valu_rw else None
         res = {
             'metric': 'LOS rays/sec (wet+hydro slant delay) through ERA5 cube; achieved HBM GB/s',
             'value': value, 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -182,25 +233,33 @@ def main():
             'config': {'workload': f'configs[2]: Raytracing LOS, {rows}x{cols} scene per GPU ({n_rays/1e6:.1f}M rays), one slice at ht=0, '
                                    f'per-pixel ECEF look vectors, synthetic ERA5-sized {args.cube} f32 cube, zref=max(z)-1, MAX_SEGMENT_LENGTH=1000',
                        'rays_per_gpu': n_rays, 'cube': args.cube, 'levels_K': K, 'samples_per_ray_S': S,
-                       'parallelism': f'rows sharded x{world}, cube broadcast over RCCL ({t_bcast*1e3:.1f} ms), MAX all-reduce of {K} doubles per step' if world > 1 else 'single GPU',
+                       'parallelism': (f'rows sharded x{world} ({args.backend}, {ndev} device(s) visible), cube broadcast ({t_bcast*1e3:.1f} ms), '
+                                       f'MAX all-reduce of {K}+4 doubles per step') if world > 1 else 'single GPU',
+                       'ranks': world, 'backend': args.backend if world > 1 else None,
                        'mean_hydro_m': mean_h, 'mean_wet_m': mean_w, 'nan_fraction': nan_frac},
-            'roofline': {'bound': 'hbm', 'kernel': 'march_kernel<float2,false,true>', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': PMC_TRAFFIC_BYTES.get((rows, cols, args.cube)) if world == 1 else None,
-                         'traffic_unit': 'bytes per march_kernel launch (PMC, profiles/r01_v12_hbm_traffic_pmc.txt)',
-                         'traffic_GBps': (PMC_TRAFFIC_BYTES[(rows, cols, args.cube)] / (march_ms * 1e-3) / 1e9) if (world == 1 and (rows, cols, args.cube) in PMC_TRAFFIC_BYTES) else None,
-                         'algorithmic_bytes_per_ray': bytes_per_ray, 'compulsory_bytes_per_ray': 64 + (ny * nx * nz * 8) / n_rays,
+            # The limiter the SQ counters show is fp64 vector-ALU issue, so THAT is the roofline (frac <= 1 by construction:
+            # instructions actually issued / issue slots of the chip).  The SURVEY 8(d) gather-model byte rate and the
+            # PMC-measured DRAM rate are reported beside it under "hbm".
+            'roofline': {'bound': 'valu_fp64_issue', 'kernel': 'march_kernel<float2,false,true>',
+                         'achieved': valu_rate / 1e9 if valu_rate else None, 'peak': VALU_ISSUE_PEAK / 1e9, 'unit': 'G wave64-instr/s',
+                         'frac': valu_rate / VALU_ISSUE_PEAK if valu_rate else None,
+                         'traffic': traffic, 'traffic_unit': 'HBM bytes per march_kernel launch (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE, separate passes)',
+                         'valu_instr_per_raywave': valu_rw, 'valu_busy_frac': km.get('valu_busy_frac'),
+                         'valu_per_evaluated_sample': (valu_rw / (S - (K - 1))) if valu_rw else None,
+                         'vgpr': km.get('vgpr'), 'scratch_bytes': km.get('scratch'),
+                         'crossings': {'valu_instr_per_raywave': kc.get('valu_per_raywave'), 'valu_busy_frac': kc.get('valu_busy_frac'),
+                                       'vgpr': kc.get('vgpr'), 'scratch_bytes': kc.get('scratch'),
+                                       'frac': (kc['valu_per_raywave'] * (n_rays / 64.0) / (pre_ms * 1e-3) / VALU_ISSUE_PEAK) if kc.get('valu_per_raywave') and pre_ms > 0 else None},
                          'march_ms_per_step': march_ms, 'crossings_ms_per_step': pre_ms, 'march_launches_timed': n_march,
-                         'note': 'achieved = (64*S+64) B/ray (SURVEY 8d gather model, S = reference samples/ray) x rays / march_kernel time; '
-                                 'the kernel evaluates only the S-(K-1) distinct sample points (level-boundary samples are shared by two '
-                                 'segments) and its gathers are served by L2/MALL, so this is an algorithmic-throughput figure, not DRAM traffic. '
-                                 'The limiter is the fp64 vector ALU: SQ counters (profiles/r01_v12_sq_counters_per_raywave.txt) show the VALU '
-                                 'busy 93% of a resident wave\'s time in march_kernel (12.4k VALU instructions per 64-ray wave) and 87% in crossings_kernel (3.3k); '
-                                 'see "valu" for the issue-rate roofline computed from this run\'s kernel time',
-                         'valu_busy_frac': 0.93,
-                         'valu': ({'bound': 'fp64 vector-ALU issue', 'achieved': VALU_PER_RAYWAVE[args.cube] * (n_rays / 64.0) / (march_ms * 1e-3) / 1e9,
-                                   'peak': VALU_ISSUE_PEAK / 1e9, 'unit': 'G wave64-instr/s',
-                                   'frac': VALU_PER_RAYWAVE[args.cube] * (n_rays / 64.0) / (march_ms * 1e-3) / VALU_ISSUE_PEAK,
-                                   'valu_instr_per_raywave': VALU_PER_RAYWAVE[args.cube]} if args.cube in VALU_PER_RAYWAVE else None)},
+                         'counters_source': prof_src if prof is not None else None, 'counters_note': None if prof is not None else prof_src,
+                         'hbm': {'peak_GBps': HBM_PEAK_GBS,
+                                 'gather_model_GBps': gather_GBps, 'gather_model_frac': gather_GBps / HBM_PEAK_GBS,
+                                 'gather_model_note': '(64*S+64) B/ray of SURVEY 8d x rays / march time: an algorithmic rate, the gathers are L2/MALL hits - NOT a utilisation',
+                                 'algorithmic_bytes_per_ray': bytes_per_ray, 'compulsory_bytes_per_ray': 64 + (ny * nx * nz * 8) / n_rays,
+                                 'measured_GBps': (traffic / (march_ms * 1e-3) / 1e9) if traffic is not None else None,
+                                 'hbm_measured_frac': (traffic / (march_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic is not None else None,
+                                 'step_traffic_bytes': step_traffic,
+                                 'step_measured_frac': (step_traffic / ((march_ms + pre_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS) if step_traffic is not None else None}},
         }
         if world == 1 and args.cpu_sample > 0:
             res['cpu_baseline'] = cpu_baseline(args, xpts, ypts, inc_cols, hd, nparts, zref, out_w, out_h)

@@ -97,11 +97,17 @@ int rdr_device_info(rdr_ctx* ctx, char* name, int name_len, int* compute_units, 
  * events and returns how many launches of kernel kind `which` (0 ray prepass, 1 ray march, 2 interp,
  * 3 other) were recorded and their summed duration in ms. */
 int rdr_set_profiling(rdr_ctx* ctx, int on);
-/* Ray pass 1 hands each ray's set-up (origin, look vector, origin frame) and its K+1 level-crossing parameters to
- * pass 2 through an HBM workspace of 8*(14+K) bytes per ray (712 B/ray for an 80-level cube; 11.4 GB for 16 M rays).
- * `bytes` caps it (default 48 GiB of the 288 GB, and never more than half of the free memory); larger batches are
- * integrated in chunks.  Env override at rdr_create: RAIDER_HIP_WORKSPACE_BYTES. */
+/* Ray pass 1 hands each ray's record to pass 2 through an HBM workspace of 232 B per ray (29 doubles: the degree-5 ray
+ * polynomials h(u), lat(u), lon(u), the degree-7 level-crossing polynomial, the ray-length scale and the two crossings of
+ * the first level; 3.7 GB for 16 M rays).  The few rays the static classification sends to the generic-geodesy kernels
+ * (poles, grazing incidence, the +-180 deg meridian) keep origin / look vector / origin frame in the same record and their
+ * K+1 level crossings in a compact side buffer sized for 1/32 of the batch (or for the generic-ray count last seen on this
+ * ctx); a generic ray that finds it full has its crossings recomputed by pass 2.
+ * `bytes` caps records + side buffer (default 48 GiB of the 288 GB, and never more than half of the free memory); larger
+ * batches are integrated in chunks.  Env override at rdr_create: RAIDER_HIP_WORKSPACE_BYTES. */
 int rdr_set_workspace_limit(rdr_ctx* ctx, int64_t bytes);
+/* Columns of the generic-ray side buffer: >= 0 fixes the capacity (0: always recompute), -1 restores the automatic sizing. */
+int rdr_set_side_capacity(rdr_ctx* ctx, int64_t columns);
 int rdr_profile_get(rdr_ctx* ctx, int which, int* count, float* total_ms);
 
 /* ---- weather cube ----------------------------------------------------------------------------

@@ -55,6 +55,7 @@ SYMBOLS = [
     ('rdr_device_info', C.c_int, [_VP, C.c_char_p, C.c_int, C.POINTER(C.c_int), c_lp]),
     ('rdr_set_profiling', C.c_int, [_VP, C.c_int]),
     ('rdr_set_workspace_limit', C.c_int, [_VP, C.c_int64]),
+    ('rdr_set_side_capacity', C.c_int, [_VP, C.c_int64]),
     ('rdr_profile_get', C.c_int, [_VP, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_float)]),
     ('rdr_cube_create', C.c_int, [_VP, _VP, C.c_int64, _VP, C.c_int64, _VP, C.c_int64, _VP, _VP, C.c_int,
                                   C.c_int64, C.c_int64, C.c_int64, C.c_int, C.POINTER(_VP)]),
@@ -208,6 +209,10 @@ class Context:
     def set_workspace_limit(self, nbytes):
         """Cap the HBM workspace that hands ray records from ray pass 1 to pass 2 (bigger batches run in chunks)."""
         check(self.lib.rdr_set_workspace_limit(self.handle, int(nbytes)), self.handle)
+
+    def set_side_capacity(self, columns=-1):
+        """Capacity (rays) of the side buffer holding the level crossings of generic-geodesy rays; -1 = automatic."""
+        check(self.lib.rdr_set_side_capacity(self.handle, int(columns)), self.handle)
 
     def profile_get(self, which):
         """(launch count, total ms) of kernel kind `which` since set_profiling(True)."""

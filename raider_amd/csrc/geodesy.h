@@ -95,19 +95,26 @@ RDR_HD void ecef2lla(double x, double y, double z, double& lon_deg, double& lat_
     h = geo_height(g, z);
 }
 
-// inc/heading (deg) -> local ENU unit vector (losreader.py:374-396) -> ECEF (utilFcns.py:91-121).
-RDR_HD void inc_hd_to_ecef(double inc_deg, double hd_deg, double lat_deg, double lon_deg,
-                           double& u, double& v, double& w) {
-    double si, ci, sh, ch, sla, cla, slo, clo;
+// inc/heading (deg) -> local ENU unit vector (losreader.py:374-396) -> ECEF (utilFcns.py:91-121); the caller supplies
+// sin / cos of the origin's latitude and longitude.
+RDR_HD void inc_hd_to_ecef_sc(double inc_deg, double hd_deg, double sla, double cla, double slo, double clo,
+                              double& u, double& v, double& w) {
+    double si, ci, sh, ch;
     sincos(inc_deg * DEG_TO_RAD, &si, &ci);
     sincos((hd_deg + 90.0) * DEG_TO_RAD, &sh, &ch);
     const double east = si * ch, north = si * sh, up = ci;
-    sincos(lat_deg * DEG_TO_RAD, &sla, &cla);
-    sincos(lon_deg * DEG_TO_RAD, &slo, &clo);
     const double t = cla * up - sla * north;
     w = sla * up + cla * north;
     u = clo * t - slo * east;
     v = slo * t + clo * east;
+}
+
+RDR_HD void inc_hd_to_ecef(double inc_deg, double hd_deg, double lat_deg, double lon_deg,
+                           double& u, double& v, double& w) {
+    double sla, cla, slo, clo;
+    sincos(lat_deg * DEG_TO_RAD, &sla, &cla);
+    sincos(lon_deg * DEG_TO_RAD, &slo, &clo);
+    inc_hd_to_ecef_sc(inc_deg, hd_deg, sla, cla, slo, clo, u, v, w);
 }
 
 // ---- Lambert conformal conic (PROJ `lcc`, Snyder 15-1..15-4 / 14-1..14-4 for the sphere) ---------------------------

@@ -44,7 +44,12 @@ struct rdr_ctx {
     int* d_nparts = nullptr;                  // [MAX_LEVELS]
     int* d_nslow = nullptr;                   // [1] rays sent to the generic kernels by the last pass 1
     int* d_tilectr = nullptr;                 // [4][8] per-XCD tile counters of the four ray-kernel launches of a step
-    DevBuf ws;                                // pass 1 -> pass 2 workspace (field-major ray records)
+    DevBuf ws;                                // pass 1 -> pass 2 workspace (field-major ray records, 232 B per ray)
+    DevBuf side;                              // level crossings of the generic rays (compact columns of K+1 doubles)
+    int64_t side_cap = 0;                     // columns of `side` in the current layout
+    int* d_sidectr = nullptr;                 // [1] next free column
+    int64_t side_forced = -1;                 // rdr_set_side_capacity
+    int64_t last_nslow = 0;                   // generic rays seen by the last pass 1 whose count the host happened to read back
     size_t ws_limit = (size_t)48 << 30;       // cap on that workspace; bigger batches are marched in chunks
     // which ray batch the stored records belong to (a later rdr_ray_march reuses them only for the identical batch)
     struct { const void* cube = nullptr; int64_t n = -1; double ht = 0, zref = 0; const void* a = nullptr; const void* b = nullptr; const void* c = nullptr; int K = 0; bool valid = false; } wsig;
@@ -176,6 +181,8 @@ int rdr_create(int device, rdr_ctx** out) {
     HIPCHECK(nullptr, hipMalloc((void**)&c->d_nparts, MAX_LEVELS * sizeof(int)));
     HIPCHECK(nullptr, hipMalloc((void**)&c->d_nslow, sizeof(int)));
     HIPCHECK(nullptr, hipMalloc((void**)&c->d_tilectr, 32 * sizeof(int)));
+    HIPCHECK(nullptr, hipMalloc((void**)&c->d_sidectr, sizeof(int)));
+    HIPCHECK(nullptr, hipMemset(c->d_sidectr, 0, sizeof(int)));
     HIPCHECK(nullptr, hipMemset(c->d_nslow, 0, sizeof(int)));
     if (const char* e = std::getenv("RAIDER_HIP_WORKSPACE_BYTES")) c->ws_limit = (size_t)std::strtoull(e, nullptr, 10);
     *out = c;
@@ -193,6 +200,8 @@ void rdr_destroy(rdr_ctx* c) {
     if (c->d_nslow) (void)hipFree(c->d_nslow);
     if (c->d_tilectr) (void)hipFree(c->d_tilectr);
     if (c->ws.p) (void)hipFree(c->ws.p);
+    if (c->side.p) (void)hipFree(c->side.p);
+    if (c->d_sidectr) (void)hipFree(c->d_sidectr);
     for (auto& v : c->evs) for (auto& pr : v) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
@@ -225,6 +234,13 @@ int rdr_device_info(rdr_ctx* c, char* name, int name_len, int* cus, int64_t* mem
 int rdr_set_workspace_limit(rdr_ctx* c, int64_t bytes) {
     if (!c || bytes < (int64_t)1 << 20) return fail(c, RDR_ERR_INVALID, "rdr_set_workspace_limit: need at least 1 MiB");
     c->ws_limit = (size_t)bytes;
+    c->wsig.valid = false;
+    return RDR_OK;
+}
+
+int rdr_set_side_capacity(rdr_ctx* c, int64_t columns) {
+    if (!c) return fail(nullptr, RDR_ERR_INVALID, "ctx is NULL");
+    c->side_forced = columns < 0 ? -1 : columns;
     c->wsig.valid = false;
     return RDR_OK;
 }
@@ -740,26 +756,63 @@ static int ray_grid(rdr_ctx* c, int64_t ntiles, int per_cu) {
     return (int)g;
 }
 
-static int ws_fields(int K) { return WS_T + K + 1; }
+// Workspace = ray records (WS_NFIELDS doubles per ray slot, every ray) + the side buffer (K+1 crossings per GENERIC ray).
+static size_t ws_tile_bytes() { return (size_t)WS_NFIELDS * BLOCK * sizeof(double); }
 
-// Largest number of tiles whose records fit the workspace limit / half of the free device memory.
-static int64_t ws_chunk_tiles(rdr_ctx* c, int K) {
-    const size_t per_tile = (size_t)ws_fields(K) * BLOCK * sizeof(double);
-    size_t free_b = 0, total_b = 0;
-    size_t budget = c->ws_limit;
-    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = std::min(budget, std::max(c->ws.cap, free_b / 2 + c->ws.cap));
-    return (int64_t)std::max<size_t>(1, budget / per_tile);
+// Side-buffer columns for a launch of `slots` ray slots: rays the static classification rejects are rare (none at all on most
+// scenes), so 1/32 of the batch is provisioned up front; when the host has seen a larger count on this context (dateline or polar
+// scenes: every slice of a tropo_delay call repeats it) that count is used.  Rays beyond the capacity are still integrated
+// correctly - pass 2 recomputes their crossings.
+static int64_t side_columns(rdr_ctx* c, int64_t slots, int K, size_t budget_left) {
+    if (c->side_forced >= 0) return std::min<int64_t>(c->side_forced, slots);
+    int64_t want = std::max<int64_t>(65536, slots / 32);
+    if (c->last_nslow > 0) want = std::max<int64_t>(want, c->last_nslow + c->last_nslow / 16 + 1024);
+    want = std::min<int64_t>(want, slots);
+    const size_t col = (size_t)(K + 1) * sizeof(double);
+    want = std::min<int64_t>(want, (int64_t)(budget_left / col));
+    return std::max<int64_t>(want, 0);
 }
 
-static int ws_reserve(rdr_ctx* c, int64_t tiles, int K, double** out) {
-    const size_t need = (size_t)tiles * BLOCK * ws_fields(K) * sizeof(double);
+static size_t ws_budget(rdr_ctx* c) {
+    size_t free_b = 0, total_b = 0;
+    size_t budget = c->ws_limit;
+    const size_t held = c->ws.cap + c->side.cap;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = std::min(budget, std::max(held, free_b / 2 + held));
+    return budget;
+}
+
+// Largest number of tiles whose records (plus a 1/32 side buffer) fit the workspace limit / half of the free device memory.
+static int64_t ws_chunk_tiles(rdr_ctx* c, int K) {
+    const size_t per_tile = ws_tile_bytes() + (size_t)(K + 1) * sizeof(double) * BLOCK / 32;
+    return (int64_t)std::max<size_t>(1, ws_budget(c) / per_tile);
+}
+
+// Reserve records for `tiles` tiles and point P at them (records, side buffer, side counter).
+static int ws_reserve(rdr_ctx* c, int64_t tiles, int K, RayParams& P) {
+    const size_t need = (size_t)tiles * ws_tile_bytes();
     if (c->ws.cap < need) {
         if (c->ws.p) { HIPCHECK(c, hipStreamSynchronize(c->stream)); HIPCHECK(c, hipFree(c->ws.p)); c->ws.p = nullptr; c->ws.cap = 0; }
         HIPCHECK(c, hipMalloc(&c->ws.p, need));
         c->ws.cap = need;
     }
-    *out = (double*)c->ws.p;
+    const size_t budget = ws_budget(c);
+    const int64_t cols = side_columns(c, tiles * BLOCK, K, budget > need ? budget - need : 0);
+    const size_t sneed = (size_t)cols * (K + 1) * sizeof(double);
+    if (c->side.cap < sneed) {
+        if (c->side.p) { HIPCHECK(c, hipStreamSynchronize(c->stream)); HIPCHECK(c, hipFree(c->side.p)); c->side.p = nullptr; c->side.cap = 0; }
+        HIPCHECK(c, hipMalloc(&c->side.p, sneed));
+        c->side.cap = sneed;
+    }
+    c->side_cap = cols;
+    P.ws = (double*)c->ws.p;
+    P.side = cols > 0 ? (double*)c->side.p : nullptr; P.side_cap = cols; P.side_ctr = c->d_sidectr;
     return RDR_OK;
+}
+
+// the records written by the last pass 1 (wsig_match): same layout, nothing re-reserved
+static void ws_attach(rdr_ctx* c, RayParams& P) {
+    P.ws = (double*)c->ws.p;
+    P.side = c->side_cap > 0 ? (double*)c->side.p : nullptr; P.side_cap = c->side_cap; P.side_ctr = c->d_sidectr;
 }
 
 static void wsig_set(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, double ht, double zref, int K, bool valid) {
@@ -784,19 +837,25 @@ static bool wsig_match(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, double 
 static int launch_crossings(rdr_ctx* c, const rdr_cube* q, RayParams P, int64_t tb, int64_t tc, int64_t nslots_total = 0, bool reset_nslow = true) {
     P.tile_begin = tb; P.tile_count = tc; P.nslots = nslots_total > 0 ? nslots_total : tc * BLOCK;
     const int g = ray_grid(c, tc, 8);
-    if (reset_nslow) HIPCHECK(c, hipMemsetAsync(c->d_nslow, 0, sizeof(int), c->stream));
+    if (reset_nslow) {
+        HIPCHECK(c, hipMemsetAsync(c->d_nslow, 0, sizeof(int), c->stream));
+        HIPCHECK(c, hipMemsetAsync(c->d_sidectr, 0, sizeof(int), c->stream));
+    }
     HIPCHECK(c, hipMemsetAsync(c->d_tilectr, 0, 16 * sizeof(int), c->stream));
     P.tile_ctr = c->d_tilectr;
     {
         KTimer t(c, 0);
         const bool lcc = q->proj.kind == 1;
-        if (q->dtype == RDR_F32) {
-            if (lcc) hipLaunchKernelGGL((crossings_kernel<float2, false, true>), dim3(g), dim3(BLOCK), ray_smem(q), c->stream, make_view<float2>(q), P, q->proj);
-            else hipLaunchKernelGGL((crossings_kernel<float2, false, false>), dim3(g), dim3(BLOCK), ray_smem(q), c->stream, make_view<float2>(q), P, q->proj);
-        } else {
-            if (lcc) hipLaunchKernelGGL((crossings_kernel<double2, false, true>), dim3(g), dim3(BLOCK), ray_smem(q), c->stream, make_view<double2>(q), P, q->proj);
-            else hipLaunchKernelGGL((crossings_kernel<double2, false, false>), dim3(g), dim3(BLOCK), ray_smem(q), c->stream, make_view<double2>(q), P, q->proj);
-        }
+        // input form of the batch, fixed at compile time for the two hot ones (crossings_kernel's OM parameter)
+        const int om = P.origin_mode != RDR_ORIGIN_GRID ? 0 : (P.los_mode == RDR_LOS_VEC ? 1 : 2);
+        const dim3 G(g), B(BLOCK);
+        const size_t sm = ray_smem(q);
+#define RDR_LAUNCH_X(T2, LCC_, OM_) hipLaunchKernelGGL((crossings_kernel<T2, false, LCC_, OM_>), G, B, sm, c->stream, make_view<T2>(q), P, q->proj)
+#define RDR_LAUNCH_X_OM(T2, LCC_) do { if (om == 1) RDR_LAUNCH_X(T2, LCC_, 1); else if (om == 2) RDR_LAUNCH_X(T2, LCC_, 2); else RDR_LAUNCH_X(T2, LCC_, 0); } while (0)
+        if (q->dtype == RDR_F32) { if (lcc) RDR_LAUNCH_X_OM(float2, true); else RDR_LAUNCH_X_OM(float2, false); }
+        else { if (lcc) RDR_LAUNCH_X_OM(double2, true); else RDR_LAUNCH_X_OM(double2, false); }
+#undef RDR_LAUNCH_X_OM
+#undef RDR_LAUNCH_X
     }
     // generic-geodesy mop-up of the rays the classification rejected (returns at once when there are none)
     P.tile_ctr = c->d_tilectr + 8;
@@ -839,12 +898,11 @@ static int launch_march(rdr_ctx* c, const rdr_cube* q, RayParams P, int64_t tb, 
 // pass 2 for the whole batch when no valid records are around: chunked (pass-1-store, pass-2) pairs
 static int march_chunked(rdr_ctx* c, const rdr_cube* q, const RayParams& P0, int K) {
     const int64_t chunk = std::min<int64_t>(P0.ntiles, ws_chunk_tiles(c, K));
-    double* ws;
-    int rc = ws_reserve(c, chunk, K, &ws); if (rc) return rc;
+    RayParams Pw = P0;
+    int rc = ws_reserve(c, chunk, K, Pw); if (rc) return rc;
     for (int64_t tb = 0; tb < P0.ntiles; tb += chunk) {
         const int64_t tc = std::min<int64_t>(chunk, P0.ntiles - tb);
-        RayParams P = P0;
-        P.ws = ws;
+        RayParams P = Pw;
         unsigned long long* keep = P.maxlen_bits;
         P.maxlen_bits = nullptr;                      // store only, no reduction
         rc = launch_crossings(c, q, P, tb, tc); if (rc) return rc;
@@ -862,8 +920,8 @@ static int raytrace_pipelined(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, 
                               double* wet, double* hydro) {
     const int64_t tile_rows = P.ntiles / P.tiles_x;
     const int nchunk = (int)std::min<int64_t>(8, tile_rows);
-    double* ws;
-    int rc = ws_reserve(c, P.ntiles, K, &ws); if (rc) return rc;
+    int rc = ws_reserve(c, P.ntiles, K, P); if (rc) return rc;
+    double* const ws = P.ws;
     const int64_t nslots_total = P.ntiles * BLOCK;
     if (d_los) P.los = d_los;                  // (else the look vectors come from inc / heading or zenith: nothing to upload)
     std::vector<hipEvent_t> ev(2 * nchunk, nullptr);
@@ -927,14 +985,16 @@ int rdr_ray_prepass(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, double ht,
     if (r->n > 0) {
         // keep the ray records for the rdr_ray_march that normally follows (same device arrays, whole batch fits)
         const bool keep = r->loc == RDR_DEVICE && P.ntiles <= ws_chunk_tiles(c, K);
-        if (keep) { rc = ws_reserve(c, P.ntiles, K, &P.ws); if (rc) return rc; }
+        if (keep) { rc = ws_reserve(c, P.ntiles, K, P); if (rc) return rc; }
         rc = launch_crossings(c, q, P, 0, P.ntiles); if (rc) return rc;
         if (keep) wsig_set(c, q, r, ht, zref, K, true);
     }
-    int f = 0;
+    int f = 0, nslow = 0;
     HIPCHECK(c, hipMemcpyAsync(maxlen, c->d_maxlen, (size_t)K * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHECK(c, hipMemcpyAsync(&f, c->d_flags, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(&nslow, c->d_nslow, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHECK(c, hipStreamSynchronize(c->stream));
+    c->last_nslow = nslow;
     if (flags) *flags = f;
     return RDR_OK;
 }
@@ -955,7 +1015,7 @@ int rdr_ray_prepass_device(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, dou
     c->wsig.valid = false;
     if (r->n > 0) {
         const bool keep = P.ntiles <= ws_chunk_tiles(c, K);
-        if (keep) { rc = ws_reserve(c, P.ntiles, K, &P.ws); if (rc) return rc; }
+        if (keep) { rc = ws_reserve(c, P.ntiles, K, P); if (rc) return rc; }
         rc = launch_crossings(c, q, P, 0, P.ntiles); if (rc) return rc;
         if (keep) wsig_set(c, q, r, ht, zref, K, true);
     }
@@ -982,7 +1042,7 @@ int rdr_ray_march_device(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, doubl
     P.wet = wet; P.hyd = hydro;
     hipLaunchKernelGGL(unpack_partition_kernel, dim3(1), dim3(256), 0, c->stream, partition, K, c->d_maxlen, c->d_flags);
     HIPCHECK(c, hipGetLastError());
-    if (reuse) { P.ws = (double*)c->ws.p; rc = launch_march(c, q, P, 0, P.ntiles); }
+    if (reuse) { ws_attach(c, P); rc = launch_march(c, q, P, 0, P.ntiles); }
     else rc = march_chunked(c, q, P, K);
     c->wsig.valid = false;
     return rc;
@@ -1011,7 +1071,7 @@ int rdr_ray_march(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, double ht, d
     rc = stage_out(c, SLOT_OUT0, wet, (size_t)r->n * 8, r->loc, &dw); if (rc) return rc;
     rc = stage_out(c, SLOT_OUT1, hydro, (size_t)r->n * 8, r->loc, &dh); if (rc) return rc;
     P.wet = (double*)dw; P.hyd = (double*)dh;
-    if (reuse) { P.ws = (double*)c->ws.p; rc = launch_march(c, q, P, 0, P.ntiles); }
+    if (reuse) { ws_attach(c, P); rc = launch_march(c, q, P, 0, P.ntiles); }
     else rc = march_chunked(c, q, P, K);
     c->wsig.valid = false;
     if (rc) return rc;
@@ -1061,7 +1121,7 @@ int rdr_raytrace(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, double ht, do
         rc = raytrace_pipelined(c, q, r, P, K, (double*)dl, (double*)dw, (double*)dh, wet, hydro); if (rc) return rc;
     } else if (P.ntiles <= ws_chunk_tiles(c, K)) {
         // whole batch fits: pass 1 reduces AND stores the ray records, pass 2 streams them back
-        rc = ws_reserve(c, P.ntiles, K, &P.ws); if (rc) return rc;
+        rc = ws_reserve(c, P.ntiles, K, P); if (rc) return rc;
         rc = launch_crossings(c, q, P, 0, P.ntiles); if (rc) return rc;
         rc = launch_march(c, q, P, 0, P.ntiles); if (rc) return rc;
     } else {
@@ -1077,10 +1137,12 @@ int rdr_raytrace(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, double ht, do
     const bool need_sync = r->loc == RDR_HOST || nparts_out || flags_out;
     if (need_sync) {
         std::vector<double> ml(K);
-        int f = 0;
+        int f = 0, nslow = 0;
         HIPCHECK(c, hipMemcpyAsync(ml.data(), c->d_maxlen, (size_t)K * 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHECK(c, hipMemcpyAsync(&f, c->d_flags, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHECK(c, hipMemcpyAsync(&nslow, c->d_nslow, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIPCHECK(c, hipStreamSynchronize(c->stream));
+        c->last_nslow = nslow;
         if (nparts_out) rdr_nparts(ml.data(), K, max_seg, nparts_out);
         if (flags_out) *flags_out = f;
         return flags_to_status(c, f);

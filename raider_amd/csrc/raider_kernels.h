@@ -204,15 +204,22 @@ struct PendingSample {
     double ty, tx, tz;
 };
 
-// LIGHT: called from the light march loop (index-space x / y on exact axes, two-entry z window).
-template <typename T2, bool LIGHT = false>
+// MODE 0: generic kernels (three-entry z window).  MODE 1 (light march loop, a level's TOP sample or the ray's first sample):
+// index-space x / y on exact axes, two-entry z window.  MODE 2 (light march loop, a sample strictly INSIDE model interval kz):
+// its z cell is kz itself, one table entry, no select.  Any sample whose weight leaves [0,1] takes the exact search.
+template <typename T2, int MODE = 0>
 __device__ __forceinline__ void sample_issue(const CubeView<T2>& c, const AxisTabs& m, double y, double x, double z, int kz,
                                              PendingSample<T2>& s) {
     const double2* ez = m.ez;
     int iy, ix, iz;
-    cell_xy<LIGHT>(m.ey, c.ny, y, c.y_lo, c.y_hi, c.inv_dy, c.exact_y, c.uni_y, iy, s.ty);
-    cell_xy<LIGHT>(m.ex, c.nx, x, c.x_lo, c.x_hi, c.inv_dx, c.exact_x, c.uni_x, ix, s.tx);
-    if (LIGHT) window2_cell(ez, c.nz, z, kz, c.nz >= 4, iz, s.tz);
+    cell_xy<MODE != 0>(m.ey, c.ny, y, c.y_lo, c.y_hi, c.inv_dy, c.exact_y, c.uni_y, iy, s.ty);
+    cell_xy<MODE != 0>(m.ex, c.nx, x, c.x_lo, c.x_hi, c.inv_dx, c.exact_x, c.uni_x, ix, s.tx);
+    if (MODE == 2) {
+        const double2 e0 = ez[kz];                                              // kz <= nz-2: slice-uniform address
+        iz = kz;
+        s.tz = (z - e0.x) * e0.y;
+        if (!(s.tz >= 0.0) || !(s.tz <= 1.0)) cell_exact(ez, c.nz, z, iz, s.tz);   // rare
+    } else if (MODE == 1) window2_cell(ez, c.nz, z, kz, c.nz >= 4, iz, s.tz);
     else window_cell(ez, c.nz, z, kz, c.nz >= 4, iz, s.tz);
     const T2 *p00, *p01, *p10, *p11;
     if (c.small) {              // one 32-bit element offset against four uniform row bases
@@ -235,6 +242,7 @@ __device__ __forceinline__ void sample_issue(const CubeView<T2>& c, const AxisTa
     s.v[6] = p11[0]; s.v[7] = p11[1];
 }
 
+// Generic kernels: scipy's own summation order, weight = ((1*wy)*wx)*wz over the corners in lexicographic order (_rgi.py:490-498).
 template <typename T2>
 __device__ __forceinline__ void sample_finish(const PendingSample<T2>& s, double& wet, double& hyd) {
     const double wy0 = 1.0 - s.ty, wx0 = 1.0 - s.tx, wz0 = 1.0 - s.tz;
@@ -249,6 +257,21 @@ __device__ __forceinline__ void sample_finish(const PendingSample<T2>& s, double
     k = a11 * wz0;  sw = fma((double)s.v[6].x, k, sw); sh = fma((double)s.v[6].y, k, sh);
     k = a11 * s.tz; sw = fma((double)s.v[7].x, k, sw); sh = fma((double)s.v[7].y, k, sh);
     wet = sw; hyd = sh;
+}
+
+// Light march loop: the same trilinear interpolant in nested-lerp form, a + t (b - a) along z, then x, then y: 7 lerps of
+// (sub, fma) per field = 28 instructions instead of the 31 of the weight-product form (the f32 -> f64 conversions are exact, so
+// the two forms agree to a few ulp of the interpolated value; the parity tests hold 1e-9 m on the integrated delay).
+template <typename T2>
+__device__ __forceinline__ void sample_finish_lerp(const PendingSample<T2>& s, double& wet, double& hyd) {
+    auto lerp = [](double a, double b, double t) { return fma(t, b - a, a); };
+    const double w00 = lerp((double)s.v[0].x, (double)s.v[1].x, s.tz), h00 = lerp((double)s.v[0].y, (double)s.v[1].y, s.tz);
+    const double w01 = lerp((double)s.v[2].x, (double)s.v[3].x, s.tz), h01 = lerp((double)s.v[2].y, (double)s.v[3].y, s.tz);
+    const double w10 = lerp((double)s.v[4].x, (double)s.v[5].x, s.tz), h10 = lerp((double)s.v[4].y, (double)s.v[5].y, s.tz);
+    const double w11 = lerp((double)s.v[6].x, (double)s.v[7].x, s.tz), h11 = lerp((double)s.v[6].y, (double)s.v[7].y, s.tz);
+    const double w0 = lerp(w00, w01, s.tx), h0 = lerp(h00, h01, s.tx);
+    const double w1 = lerp(w10, w11, s.tx), h1 = lerp(h10, h11, s.tx);
+    wet = lerp(w0, w1, s.ty); hyd = lerp(h0, h1, s.ty);
 }
 
 template <typename T2>
@@ -297,7 +320,6 @@ __device__ __forceinline__ double level_top_u(const double* hpoly, double hi, do
 }
 
 // N independent level crossings carried side by side (same arithmetic per level as level_top_u).
-constexpr int LEVEL_ILP = 2;
 template <int N>
 __device__ __forceinline__ void level_top_u_n(const double* hpoly, const double* hi, double su, double ou, double gain, double* u) {
 #pragma unroll
@@ -317,19 +339,62 @@ __device__ __forceinline__ void level_top_u_n(const double* hpoly, const double*
     }
 }
 
+// ---- crossing polynomial ---------------------------------------------------------------------------------------------
+// The (deliberately NOT converged) three-iteration crossing level_top_u(h) of a light ray is a composition of polynomials in
+// the level height h, i.e. a smooth function of h; its degree-7 interpolant X(v) at the 8 Chebyshev nodes of the slice's
+// level-top range, v = (h - hm) / hh in [-1, 1], reproduces it to < 1e-10 m along the ray up to 60 deg incidence, 7e-9 m at
+// 70 deg and 3e-6 m at 85 deg under an 80 km model top (a crossing shifted by d moves a delay by ~1.5e-3 d; sweep:
+// tools/ray_poly_probe.py).  Pass 1 fits it once per ray (8 x 21 FMAs + 64) and then every level crossing, in BOTH passes,
+// is 7 FMAs instead of 21 - same polynomial, same level abscissae (LDS table xv), hence identical crossings in the two passes.
+constexpr int PX = 8;
+__device__ const double XPOLY_NODES[PX] = {0.98078528040323044913, 0.83146961230254523708, 0.55557023301960222474, 0.19509032201612826785,
+                                           -0.19509032201612826785, -0.55557023301960222474, -0.83146961230254523708, -0.98078528040323044913};
+__device__ const double XPOLY_VINV[PX][PX] = {   // [node j][power n]
+    {-0.024864045922457250864, -0.025351161379823003334, 0.76980164952545230204, 0.78488295543032986324, -3.1779876260079822119, -3.2402480843731826008, 3.0614674589207181738, 3.1214451522580522856},
+    {0.083522329739912365, 0.10045145186799834205, -2.5519026177451504679, -3.0691471822744071686, 9.6723408277623460247, 11.632825402935940496, -7.391036260090294049, -8.8891237283136355959},
+    {-0.1870757203331861272, -0.33672740045197043705, 5.3803297424913405655, 9.6843376817517615307, -12.500767952508536122, -22.500787856406753567, 7.391036260090294049, 13.303513796840723793},
+    {0.62841743651573101306, 3.2211615113525685678, -3.5982287742716423996, -18.443912220177554698, 6.0064147507541723095, 30.787866300500633524, -3.0614674589207181738, -15.692564486451687186},
+    {0.62841743651573101306, -3.2211615113525685678, -3.5982287742716423996, 18.443912220177554698, 6.0064147507541723095, -30.787866300500633524, -3.0614674589207181738, 15.692564486451687186},
+    {-0.1870757203331861272, 0.33672740045197043705, 5.3803297424913405655, -9.6843376817517615307, -12.500767952508536122, 22.500787856406753567, 7.391036260090294049, -13.303513796840723793},
+    {0.083522329739912365, -0.10045145186799834205, -2.5519026177451504679, 3.0691471822744071686, 9.6723408277623460247, -11.632825402935940496, -7.391036260090294049, 8.8891237283136355959},
+    {-0.024864045922457250864, 0.025351161379823003334, 0.76980164952545230204, -0.78488295543032986324, -3.1779876260079822119, 3.2402480843731826008, 3.0614674589207181738, -3.1214451522580522856}};
+
+__device__ __forceinline__ double poly7(const double* c, double v) {
+    double r = fma(c[7], v, c[6]);
+    r = fma(r, v, c[5]);
+    r = fma(r, v, c[4]);
+    r = fma(r, v, c[3]);
+    r = fma(r, v, c[2]);
+    r = fma(r, v, c[1]);
+    return fma(r, v, c[0]);
+}
+
+// hm / hh: centre and half width of the slice's level-top range (slice-uniform, fill_tables).  Two nodes per trip: their
+// Newton chains are independent and fill each other's dependent-issue bubbles.
+__device__ __forceinline__ void fit_crossing_poly(const double* hpoly, double su, double ou, double gain, double hm, double hh, double* xc) {
+#pragma unroll
+    for (int n = 0; n < PX; ++n) xc[n] = 0.0;
+#pragma unroll 1
+    for (int j = 0; j < PX; j += 2) {
+        double hn[2], un[2];
+        hn[0] = fma(hh, XPOLY_NODES[j], hm); hn[1] = fma(hh, XPOLY_NODES[j + 1], hm);
+        level_top_u_n<2>(hpoly, hn, su, ou, gain, un);
+#pragma unroll
+        for (int n = 0; n < PX; ++n) xc[n] = fma(XPOLY_VINV[j + 1][n], un[1], fma(XPOLY_VINV[j][n], un[0], xc[n]));
+    }
+}
+
 // Workspace record handed from pass 1 (crossings_kernel) to pass 2 (march_kernel): one column per ray SLOT
 // (slot = local tile * 256 + thread), field-major so every field access is a perfectly coalesced 512 B per wave:
-//   ws[f * nslots + slot]
-//   f = 0        1.0: light ray (polynomial geodesy), 0.0: generic ray
-//   light ray:   1..6 h(u) | 7..12 lat(u) [deg] | 13..18 lon(u) [deg] monomial coefficients | 19 |l|/su (metres per unit of u)
-//                | 20 su | 21 ou (u = su t + ou) | 22 su/cos_factor | 23, 24 u at the bottom / top of the first level.
-//                Pass 2 re-derives the other level crossings from h(u) (21 FMAs per level) instead of streaming them.
-//   generic ray: 1..3 origin ECEF | 4..6 look vector | 7 lat0 | 8 lon0 | 9..12 sin/cos lat0, sin/cos lon0
-//                | 25 .. 25+K  ray parameter t of the K+1 level crossings
-constexpr int WS_FAST = 0, WS_POLY_H = 1, WS_POLY_LAT = 7, WS_POLY_LON = 13, WS_SCALE = 19, WS_SU = 20, WS_OU = 21, WS_GAIN = 22,
-              WS_U0 = 23, WS_U1 = 24;
-constexpr int WS_ORIGIN = 1, WS_LOS = 4, WS_LAT0 = 7, WS_LON0 = 8, WS_S0 = 9, WS_C0 = 10, WS_SL0 = 11, WS_CL0 = 12;
-constexpr int WS_T = 25;
+//   ws[f * nslots + slot],  WS_NFIELDS = 29 fields = 232 B per ray - for every ray, light or generic
+//   light ray:   0..5 h(u) | 6..11 lat(u) | 12..17 lon(u) monomial coefficients (index space on exact axes) | 18..25 crossing
+//                polynomial X(v) | 26 |l|/su (metres per unit of u; > 0) | 27, 28 u at the bottom / top of the first level
+//   generic ray: 0..2 origin ECEF | 3..5 look vector | 6 lat0 | 7 lon0 | 8..11 sin/cos lat0, sin/cos lon0 | 12 index of the ray's
+//                column in the SIDE buffer, -1: none | 26 = 0.0, which is what marks the ray as generic
+// Side buffer (generic rays only, usually empty): side[k * side_cap + idx] = ray parameter t of level crossing k = 0..K.  A
+// generic ray that finds the side buffer full (idx -1) has its crossings recomputed by pass 2 - slower, never wrong.
+constexpr int WS_POLY_H = 0, WS_POLY_LAT = 6, WS_POLY_LON = 12, WS_XPOLY = 18, WS_SCALE = 26, WS_U0 = 27, WS_U1 = 28, WS_NFIELDS = 29;
+constexpr int WS_ORIGIN = 0, WS_LOS = 3, WS_LAT0 = 6, WS_LON0 = 7, WS_S0 = 8, WS_C0 = 9, WS_SL0 = 10, WS_CL0 = 11, WS_SIDE = 12;
 
 struct RayParams {
     // geometry
@@ -350,6 +415,8 @@ struct RayParams {
     int* tile_ctr;                     // [8] per-XCD next-tile counters of this launch (zeroed by the host)
     // pass 1 -> pass 2 workspace (this launch covers tiles [tile_begin, tile_begin + tile_count))
     double* ws; int64_t nslots;
+    double* side; int64_t side_cap;    // crossings of the generic rays (compact columns), int* side_ctr = next free column
+    int* side_ctr;
     int64_t tile_begin, tile_count;
     // outputs
     double* wet; double* hyd;
@@ -385,6 +452,8 @@ struct RaySmem {
     double* step;           // [nz] 1/(nParts-1) (pass 2)
     double* hs;             // [nz] 0.5e-6/(nParts-1): half the trapezoid weight per unit of ray length (pass 2)
     double* trig;           // [64] (sin, cos) of the tile's 16 row latitudes, then of its 16 column longitudes (pass 1, GRID rays)
+    double* xv;             // [nz] abscissa of level k's top in the crossing polynomial: (hi[k] - xmap[0]) / xmap[1]
+    double* xmap;           // [2] centre and half width of the level-top range hi[1] .. hi[K-1]
     int* kz; int* np; int* K;
 };
 constexpr int MXCOLS = 16;
@@ -404,7 +473,9 @@ __device__ __forceinline__ RaySmem carve_smem(unsigned char* raw, int ny, int nx
     m.step = reinterpret_cast<double*>(m.mxcol + (size_t)nz * MXCOLS);
     m.hs = m.step + nz;
     m.trig = m.hs + nz;
-    m.kz = reinterpret_cast<int*>(m.trig + 64);
+    m.xv = m.trig + 64;
+    m.xmap = m.xv + nz;
+    m.kz = reinterpret_cast<int*>(m.xmap + 2);
     m.np = m.kz + nz;
     m.K = m.np + nz;
     return m;
@@ -416,6 +487,7 @@ inline size_t ray_smem_bytes(int64_t ny, int64_t nx, int64_t nz, int exact_y, in
            + (size_t)nz * 8 * 2                   // lo, hi
            + (size_t)nz * 8 * MXCOLS              // mxcol
            + (size_t)nz * 8 * 2 + 64 * 8          // step, hs, trig
+           + (size_t)nz * 8 + 16                  // xv, xmap
            + (size_t)nz * 4 * 2 + 16;             // kz, np, K
 }
 
@@ -431,9 +503,20 @@ __device__ __forceinline__ int fill_tables(const CubeView<T2>& c, const RaySmem&
     if (m.ax.ey) fill(const_cast<double2*>(m.ax.ey), c.axes, c.ny);
     if (m.ax.ex) fill(const_cast<double2*>(m.ax.ex), c.axes + c.ny, c.nx);
     fill(const_cast<double2*>(m.ax.ez), c.axes + c.ny + c.nx, c.nz);
-    if (tid == 0) *m.K = build_levels(c.axes + c.ny + c.nx, c.nz, ht, zref, m.lo, m.hi, m.kz);
+    if (tid == 0) {
+        const int K = build_levels(c.axes + c.ny + c.nx, c.nz, ht, zref, m.lo, m.hi, m.kz);
+        *m.K = K;
+        // range of the level tops the crossing polynomial has to cover (levels 1 .. K-1; level 0 has its own iteration)
+        const double a = K > 1 ? m.hi[1] : (K > 0 ? m.hi[0] : 0.0), b = K > 1 ? m.hi[K - 1] : a;
+        m.xmap[0] = 0.5 * (a + b);
+        m.xmap[1] = fmax(0.5 * (b - a), 1.0);
+    }
     __syncthreads();
-    return *m.K;
+    const int K = *m.K;
+    const double hm = m.xmap[0], ihh = 1.0 / m.xmap[1];
+    for (int k = tid; k < K; k += BLOCK) m.xv[k] = (m.hi[k] - hm) * ihh;
+    __syncthreads();
+    return K;
 }
 
 // XCD-aware tile walk: workgroup b runs on XCD b%8 -> each XCD sweeps one contiguous band of tiles (its cube slab stays in
@@ -461,9 +544,16 @@ struct TileWalk {
 // SLOW = true : generic geodesy, processes ONLY those rays, exits at once when there are none.
 // LCC (light kernel only): the cube is on a Lambert-conformal-conic grid; a separate instantiation so that the projection's
 // pow/tan/sincos code does not weigh on the register allocation of the lon/lat one.
-template <typename T2, bool SLOW, bool LCC = false>
+// OM (light kernel only): how the batch is given, fixed at compile time so that the hot instantiations carry none of the libm
+// code of the other input forms (atan / atan2 of XYZ origins, four sincos of inc/heading look vectors) - with everything in one
+// body the compiler hoisted so many of their invariants that the per-level loop spilled (220 B of scratch per lane in round 1):
+//   1: GRID origins + per-pixel look vectors;  2: GRID origins + incidence / heading (arrays or scalars) or zenith;  0: any.
+template <typename T2, bool SLOW, bool LCC = false, int OM = 0>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 : 4, SLOW ? 8 : 4))) void crossings_kernel(CubeView<T2> c, RayParams P, LccParams proj) {
+    static_assert(!SLOW || OM == 0, "the generic kernel takes every input form");
     if (SLOW && *P.nslow == 0) return;
+    const int origin_mode = OM != 0 ? 0 : P.origin_mode;
+    const int los_mode = OM == 1 ? 0 : P.los_mode;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const RaySmem m = carve_smem(smem_raw, c.ny, c.nx, c.nz, c.exact_y, c.exact_x);
     const int K = fill_tables(c, m, P.ht, P.zref);
@@ -475,14 +565,13 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
     // the workgroup's LDS table with one ds_max_u64 (non-negative doubles order like their bit patterns); the columns are
     // combined once, at the end of the kernel.  NaN lengths are left out here and reported through the flags, which is how
     // ndarray.max's NaN poisoning is reproduced on the host side.
-    unsigned long long* const mxc = m.mxcol + (tid & (MXCOLS - 1));
     int my_flags = 0;
     TileWalk walk(P.tile_count, P.tile_ctr, m.K + 2);
     int64_t lt;
     while (walk.next(P.tile_count, lt)) {
         const int64_t t = P.tile_begin + lt;
         int64_t i, row = 0, col = 0; bool active;
-        if (P.origin_mode == 0) {
+        if (origin_mode == 0) {
             const int64_t ty = t / P.tiles_x, tx = t - ty * P.tiles_x;
             row = ty * TILE + (tid >> 4); col = tx * TILE + (tid & 15);
             active = row < P.ny && col < P.nx;
@@ -494,7 +583,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
         // ---- origin: llh -> ECEF (delay.py:262-267)
         double lat = 0, lon = 0, ox = qnan(), oy = qnan(), oz = qnan();
         RayBase base;
-        if (!SLOW && P.origin_mode == 0) {
+        if (!SLOW && origin_mode == 0) {
             // a tile has 16 distinct latitudes and 16 distinct longitudes: 32 lanes take the sines / cosines for everybody
             // (the previous tile's readers are past the barriers of walk.next())
             if (tid < 32) {
@@ -518,9 +607,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
             }
         } else {
             if (active) {
-                if (P.origin_mode == 0) { lat = P.ypts[row]; lon = P.xpts[col]; }
+                if (origin_mode == 0) { lat = P.ypts[row]; lon = P.xpts[col]; }
                 else if (P.lat) { lat = P.lat[i]; lon = P.lon[i]; }
-                if (P.origin_mode == 2) {
+                if (origin_mode == 2) {
                     ox = P.xyz[3 * i]; oy = P.xyz[3 * i + 1]; oz = P.xyz[3 * i + 2];
                     if (!P.lat) { double h0_; ecef2lla(ox, oy, oz, lon, lat, h0_); }   // frame for the delta lat/lon formulas
                 } else lla2ecef(lat, lon, P.ht, ox, oy, oz);
@@ -530,9 +619,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
         // ---- look vector (delay.py:270)
         double lx = qnan(), ly = qnan(), lz = qnan();
         if (active) {
-            if (P.los_mode == 0) { lx = P.los[3 * i]; ly = P.los[3 * i + 1]; lz = P.los[3 * i + 2]; }
-            else if (P.los_mode == 1) inc_hd_to_ecef(P.inc[i], P.hd ? P.hd[i] : P.hd0, lat, lon, lx, ly, lz);
-            else if (P.los_mode == 2) inc_hd_to_ecef(P.inc0, P.hd0, lat, lon, lx, ly, lz);
+            // (inc / heading: the origin's own sines / cosines are the ones inc_hd_to_ecef would compute again)
+            if (los_mode == 0) { lx = P.los[3 * i]; ly = P.los[3 * i + 1]; lz = P.los[3 * i + 2]; }
+            else if (los_mode == 1) inc_hd_to_ecef_sc(P.inc[i], P.hd ? P.hd[i] : P.hd0, base.s0, base.c0, base.sl0, base.cl0, lx, ly, lz);
+            else if (los_mode == 2) inc_hd_to_ecef_sc(P.inc0, P.hd0, base.s0, base.c0, base.sl0, base.cl0, lx, ly, lz);
             else { lx = base.c0 * base.cl0; ly = base.c0 * base.sl0; lz = base.s0; }   // zenith (losreader.py:302-316)
         }
         // |l| (1 for unit look vectors): ray length between two crossings = (t_hi - t_lo) * |l|   (losreader.py:821)
@@ -558,16 +648,35 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
         const bool mine = SLOW ? !fast_ok : fast_ok;      // lanes this instantiation is responsible for
         if (SLOW && !__any(mine)) continue;               // (wave-uniform) nothing to mop up in this wave
         const bool cnt = active && mine;
+        // this lane's column of the per-level maxima; derived afresh per tile (an address kept live across the polynomial fit,
+        // the register-hungriest stretch of the kernel, is the one value the allocator had to spill)
+        int mxcol_idx = tid & (MXCOLS - 1);
+        asm volatile("" : "+v"(mxcol_idx));
+        unsigned long long* const mxc = m.mxcol + mxcol_idx;
         double* const w = P.ws ? P.ws + slot : nullptr;
         const int64_t ns = P.nslots;
         if constexpr (SLOW) {
+            // a column of the side buffer for this ray's K+1 crossings: one device atomic per wave, columns handed out in lane
+            // order; -1 when the buffer is full (pass 2 then recomputes the crossings)
+            int64_t sidx = -1;
+            if (w) {
+                const unsigned long long mm = __ballot(mine);
+                const int lane = tid & 63;
+                int base = 0;
+                if (lane == 0) base = atomicAdd(P.side_ctr, (int)__popcll(mm));
+                base = __shfl(base, 0, 64);
+                const int64_t cand = (int64_t)base + __popcll(mm & ((1ULL << lane) - 1ULL));
+                if (mine && cand < P.side_cap) sidx = cand;
+            }
+            double* const sd = (sidx >= 0) ? P.side + sidx : nullptr;
             if (w && mine) {
-                w[(int64_t)WS_FAST * ns] = 0.0;
+                w[(int64_t)WS_SCALE * ns] = 0.0;
                 w[(int64_t)(WS_ORIGIN + 0) * ns] = ox; w[(int64_t)(WS_ORIGIN + 1) * ns] = oy; w[(int64_t)(WS_ORIGIN + 2) * ns] = oz;
                 w[(int64_t)(WS_LOS + 0) * ns] = lx; w[(int64_t)(WS_LOS + 1) * ns] = ly; w[(int64_t)(WS_LOS + 2) * ns] = lz;
                 w[(int64_t)WS_LAT0 * ns] = lat; w[(int64_t)WS_LON0 * ns] = lon;
                 w[(int64_t)WS_S0 * ns] = base.s0; w[(int64_t)WS_C0 * ns] = base.c0;
                 w[(int64_t)WS_SL0 * ns] = base.sl0; w[(int64_t)WS_CL0 * ns] = base.cl0;
+                w[(int64_t)WS_SIDE * ns] = (double)sidx;
             }
             double t_hi = 0.0, inv_cosf = 1.0;
 #pragma unroll 1
@@ -580,9 +689,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
                 t_hi = toa_newton_t(ox, oy, oz, lx, ly, lz, hi, k == 0 ? 10 : 3, inv_cosf);
                 const double L = (t_hi - t_lo) * nl;
                 if (k == 0) inv_cosf = L / (hi - lo);                                       // 1/cos_factor, losreader.py:824-825
-                if (w && mine) {
-                    if (k == 0) w[(int64_t)WS_T * ns] = t_lo;
-                    w[(int64_t)(WS_T + k + 1) * ns] = t_hi;
+                if (sd) {
+                    if (k == 0) sd[0] = t_lo;
+                    sd[(int64_t)(k + 1) * P.side_cap] = t_hi;
                 }
                 if (reduce) {
                     if (cnt) my_flags |= (L != L) ? 1 : 2;
@@ -620,21 +729,18 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
 #pragma unroll
                     for (int n = 1; n < PN; ++n) q.lon[n] *= c.inv_dx;
                 }
-                w[(int64_t)WS_FAST * ns] = 1.0;
 #pragma unroll
                 for (int n = 0; n < PN; ++n) {
                     w[(int64_t)(WS_POLY_H + n) * ns] = q.h[n];
                     w[(int64_t)(WS_POLY_LAT + n) * ns] = q.lat[n];
                     w[(int64_t)(WS_POLY_LON + n) * ns] = q.lon[n];
                 }
-                w[(int64_t)WS_SCALE * ns] = scale; w[(int64_t)WS_SU * ns] = su; w[(int64_t)WS_OU * ns] = ou;
+                w[(int64_t)WS_SCALE * ns] = scale;
             }
             // getTopOfAtmosphere carried on u: u0 = u(h); u += (h - H(u)) * su / factor   (losreader.py:724-731)
-            double u_hi = 0.0, gain = su, inv_cosf = 1.0;
-            double last_len = 0.0;      // a light ray's lengths are NaN for every level or for none (they all stem from one polynomial)
-            // The level heights are read from LDS ONE LEVEL AHEAD: LDS operations complete in order, so a read issued after
-            // level k's ds_max would have to wait for that atomic; issued before it, it only waits for itself.
             // Level 0 (ten plain Newton steps per end, losreader.py:770-777) sets the gain of every later level.
+            double u_hi = 0.0, gain = su;
+            double last_len = 0.0;      // a light ray's lengths are NaN for every level or for none (they all stem from one polynomial)
             if (K > 0) {
                 const double lo = m.lo[0], hi = m.hi[0];
                 double u_lo = fma(lo, su, ou);
@@ -646,35 +752,36 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
                 }
                 const double L = (u_hi - u_lo) * scale;
                 last_len = L;
-                inv_cosf = L / (hi - lo); gain = su * inv_cosf;                                // 1/cos_factor, losreader.py:824-825
-                if (w && mine) { w[(int64_t)WS_GAIN * ns] = gain; w[(int64_t)WS_U0 * ns] = u_lo; w[(int64_t)WS_U1 * ns] = u_hi; }
+                gain = su * (L / (hi - lo));                                                   // su / cos_factor, losreader.py:824-825
+                if (w && mine) { w[(int64_t)WS_U0 * ns] = u_lo; w[(int64_t)WS_U1 * ns] = u_hi; }
                 if (reduce) {
                     atomicMax(&mxc[0], (unsigned long long)__double_as_longlong((cnt && L > 0.0) ? L : 0.0));
                     if (cnt && !(poly5(q.h, u_lo) < c.z_lo)) my_flags |= 4;                    // first sample of the ray
                 }
             }
-            // Later levels: their Newton chains are independent of one another (each starts from its own level height), so
-            // LEVEL_ILP of them are carried side by side to fill the FMA pipeline's dependent-issue bubbles.
+            // Later levels: the three-iteration crossing as a polynomial of the level height (fit_crossing_poly)
+            double xc[PX];
+            fit_crossing_poly(q.h, su, ou, gain, m.xmap[0], m.xmap[1], xc);
+            if (w && mine) {
+#pragma unroll
+                for (int n = 0; n < PX; ++n) w[(int64_t)(WS_XPOLY + n) * ns] = xc[n];
+            }
             if (reduce) {
+                // The level abscissae are read from LDS ahead of the ds_max of the previous pair: LDS operations complete in
+                // order, so a read issued after an atomic would wait for it.
                 int k = 1;
-                for (; k + LEVEL_ILP <= K; k += LEVEL_ILP) {
-                    double hk[LEVEL_ILP], uk[LEVEL_ILP];
-#pragma unroll
-                    for (int j = 0; j < LEVEL_ILP; ++j) hk[j] = m.hi[k + j];
-                    level_top_u_n<LEVEL_ILP>(q.h, hk, su, ou, gain, uk);
-#pragma unroll
-                    for (int j = 0; j < LEVEL_ILP; ++j) {
-                        const double L = (uk[j] - u_hi) * scale;
-                        u_hi = uk[j];
-                        last_len = L;
-                        atomicMax(&mxc[(k + j) * MXCOLS], (unsigned long long)__double_as_longlong((cnt && L > 0.0) ? L : 0.0));
-                    }
+                for (; k + 2 <= K; k += 2) {
+                    const double v0 = m.xv[k], v1 = m.xv[k + 1];
+                    const double ua = poly7(xc, v0), ub = poly7(xc, v1);
+                    const double La = (ua - u_hi) * scale, Lb = (ub - ua) * scale;
+                    u_hi = ub; last_len = Lb;
+                    atomicMax(&mxc[k * MXCOLS], (unsigned long long)__double_as_longlong((cnt && La > 0.0) ? La : 0.0));
+                    atomicMax(&mxc[(k + 1) * MXCOLS], (unsigned long long)__double_as_longlong((cnt && Lb > 0.0) ? Lb : 0.0));
                 }
                 for (; k < K; ++k) {
-                    const double u_top = level_top_u(q.h, m.hi[k], su, ou, gain);
+                    const double u_top = poly7(xc, m.xv[k]);
                     const double L = (u_top - u_hi) * scale;
-                    u_hi = u_top;
-                    last_len = L;
+                    u_hi = u_top; last_len = L;
                     atomicMax(&mxc[k * MXCOLS], (unsigned long long)__double_as_longlong((cnt && L > 0.0) ? L : 0.0));
                 }
                 if (K > 0 && cnt && !(poly5(q.h, u_hi) > c.z_hi)) my_flags |= 8;               // last sample of the ray
@@ -750,7 +857,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
         }
         const double* w = P.ws + (lt * BLOCK + tid);
         const int64_t ns = P.nslots;
-        const bool fast_ok = !active || w[(int64_t)WS_FAST * ns] != 0.0;
+        const double scale_rec = w[(int64_t)WS_SCALE * ns];         // light ray: ray length per unit of u (> 0 or NaN); generic ray: 0
+        const bool fast_ok = !active || scale_rec != 0.0;
         const bool mine = SLOW ? !fast_ok : fast_ok;
         if (SLOW && !__any(mine)) continue;
         double acc_w = 0.0, acc_h = 0.0;
@@ -761,28 +869,37 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
             // evaluated once and carries both trapezoid end weights; a level is its interior samples (usually none or one)
             // plus its top sample.  Latency is hidden by the four waves per SIMD, not by batching samples inside a lane.
             RayPoly q;
+            double xc[PX];
 #pragma unroll
             for (int n = 0; n < PN; ++n) {
                 q.h[n] = w[(int64_t)(WS_POLY_H + n) * ns];
                 q.lat[n] = w[(int64_t)(WS_POLY_LAT + n) * ns];
                 q.lon[n] = w[(int64_t)(WS_POLY_LON + n) * ns];
             }
-            const double scale = w[(int64_t)WS_SCALE * ns];              // ray length per unit of u
-            // The level crossings are re-derived from h(u) as the loop reaches them (no global loads inside the loop besides
-            // the gathers, so the only memory waits are on a sample's own corners).
-            const double su = w[(int64_t)WS_SU * ns], ou = w[(int64_t)WS_OU * ns], gain = w[(int64_t)WS_GAIN * ns];
-            auto issue = [&](double us, int zbase, bool floor_it, bool ceil_it, PendingSample<T2>& s) {
+            // The level crossings come from the ray's crossing polynomial as the loop reaches them (7 FMAs, no global loads
+            // inside the loop besides the gathers, so the only memory waits are on a sample's own corners).
+#pragma unroll
+            for (int n = 0; n < PX; ++n) xc[n] = w[(int64_t)(WS_XPOLY + n) * ns];
+            const double scale = scale_rec;
+            // MODE 1: a level's top sample / the ray's first sample; MODE 2: a sample strictly inside its model interval
+            auto issue_top = [&](double us, int zbase, bool floor_it, bool ceil_it, PendingSample<T2>& s) {
                 double ph = poly5(q.h, us);
                 const double plat = poly5(q.lat, us), plon = poly5(q.lon, us);       // delay.py:295 through the ray polynomials
                 // all-pixels z-clamp of the very first / very last sample (delay.py:306-311): when it applies every pixel is
-                // below (above) the cube, so "set to zmin" == max(ph, zmin)
-                if (floor_it) ph = fmax(ph, c.z_lo);
-                if (ceil_it) ph = fmin(ph, c.z_hi);
-                sample_issue<T2, true>(c, m.ax, plat, plon, ph, zbase, s);           // delay.py:298,319
+                // below (above) the cube, so "set to zmin" == max(ph, zmin).  Slice-uniform conditions: real (scalar) branches,
+                // so the two samples of a ray they can apply to are the only ones that pay for them.
+                if (floor_it) { asm volatile("" ::: "memory"); ph = fmax(ph, c.z_lo); }
+                if (ceil_it) { asm volatile("" ::: "memory"); ph = fmin(ph, c.z_hi); }
+                sample_issue<T2, 1>(c, m.ax, plat, plon, ph, zbase, s);              // delay.py:298,319
+            };
+            auto issue_mid = [&](double us, int kz_, PendingSample<T2>& s) {
+                const double ph = poly5(q.h, us);
+                const double plat = poly5(q.lat, us), plon = poly5(q.lon, us);
+                sample_issue<T2, 2>(c, m.ax, plat, plon, ph, kz_, s);
             };
             auto finish = [&](const PendingSample<T2>& s, double wv) {
                 double vw, vh;
-                sample_finish(s, vw, vh);
+                sample_finish_lerp(s, vw, vh);
                 acc_w = fma(wv, vw, acc_w); acc_h = fma(wv, vh, acc_h);              // delay.py:323
             };
             int np = __builtin_amdgcn_readfirstlane(m.np[0]);                        // >= 2 (fill above)
@@ -795,7 +912,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
             // two-entry z window must start one interval lower
             if (K > 0) {
                 PendingSample<T2> s;
-                issue(fma(0.0 * step, du, u_k), window2_base(c.nz, kz - ((m.lo[0] <= m.ax.ez[kz].x) ? 1 : 0)), clamp_lo, false, s);
+                issue_top(fma(0.0 * step, du, u_k), window2_base(c.nz, kz - ((m.lo[0] <= m.ax.ez[kz].x) ? 1 : 0)), clamp_lo, false, s);
                 finish(s, hs * du);
             }
 #pragma unroll 1
@@ -807,17 +924,17 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
 #pragma unroll 1
                 for (int j = 1; j < np - 1; ++j) {                                   // low + frac * (high - low), delay.py:292
                     PendingSample<T2> s;
-                    issue(fma((double)j * step, du, u_k), zbase, false, false, s);
+                    issue_mid(fma((double)j * step, du, u_k), kz, s);
                     finish(s, w_mid);
                 }
-                // top sample: its gathers are issued first, the next level's crossing (21 dependent FMAs that need no memory) is
-                // computed while they are in flight, then the sample is finished with the weight of both its segments
+                // top sample: its gathers are issued first, the next level's crossing (7 FMAs that need no memory) is computed
+                // while they are in flight, then the sample is finished with the weight of both its segments
                 PendingSample<T2> top;
-                issue(fma((double)(np - 1) * step, du, u_k), zbase, false, clamp_hi && !more, top);
+                issue_top(fma((double)(np - 1) * step, du, u_k), zbase, false, clamp_hi && !more, top);
                 double du1 = 0.0, hs1 = 0.0;
                 double w_top = hs * du;
                 if (more) {
-                    const double t2 = level_top_u(q.h, m.hi[k + 1], su, ou, gain);
+                    const double t2 = poly7(xc, m.xv[k + 1]);
                     du1 = t2 - u_last; u_last = t2; hs1 = m.hs[k + 1];
                     w_top = fma(hs1, du1, w_top);
                 }
@@ -837,13 +954,23 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
             const double lx = w[(int64_t)(WS_LOS + 0) * ns], ly = w[(int64_t)(WS_LOS + 1) * ns], lz = w[(int64_t)(WS_LOS + 2) * ns];
             const double nl2 = fma(lx, lx, fma(ly, ly, lz * lz));
             const double scale = nl2 * rsq_nr<2>(nl2);                  // |l|: ray length per unit of t
-            double t_hi = w[(int64_t)WS_T * ns];
-            double t_next = w[(int64_t)(WS_T + 1) * ns];             // crossings are streamed one level ahead of their use
+            // level crossings: streamed from the ray's side-buffer column one level ahead of their use, or - when pass 1 found the
+            // side buffer full - recomputed with the very same iteration (same inputs, same instruction sequence)
+            const int64_t sidx = mine ? (int64_t)w[(int64_t)WS_SIDE * ns] : -1;
+            const double* const sd = (sidx >= 0 && P.side) ? P.side + sidx : nullptr;
+            double t_hi = 0.0, t_next = 0.0, inv_cosf = 1.0;
+            if (sd) { t_hi = sd[0]; t_next = sd[P.side_cap]; }
+            else if (mine && K > 0) t_hi = toa_newton_t(ox, oy, oz, lx, ly, lz, m.lo[0], 10, 1.0);
     #pragma unroll 1
             for (int k = 0; k < K; ++k) {
                 const double t_lo = t_hi;
-                t_hi = t_next;
-                if (k + 2 <= K) t_next = w[(int64_t)(WS_T + k + 2) * ns];
+                if (sd) {
+                    t_hi = t_next;
+                    if (k + 2 <= K) t_next = sd[(int64_t)(k + 2) * P.side_cap];
+                } else if (mine) {
+                    t_hi = toa_newton_t(ox, oy, oz, lx, ly, lz, m.hi[k], k == 0 ? 10 : 3, inv_cosf);
+                    if (k == 0) inv_cosf = ((t_hi - t_lo) * scale) / (m.hi[0] - m.lo[0]);      // losreader.py:824-825, as in pass 1
+                }
                 const double dt = t_hi - t_lo;
                 const int np = m.np[k];
                 const double step = m.step[k];

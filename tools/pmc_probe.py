@@ -20,7 +20,8 @@ a = torch.zeros(1 << 27, dtype=torch.float64, device=dev)
 b = torch.empty_like(a)
 b.copy_(a)
 torch.cuda.synchronize()
-c = synthetic_cube(300, 300, 80, seed=0)
+ny_, nx_, nz_ = (int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else '300x300x80').split('x'))
+c = synthetic_cube(ny_, nx_, nz_, seed=0)
 cube = R.Cube(c['ys'], c['xs'], c['zs'], torch.from_numpy(c['wet']).to(dev), torch.from_numpy(c['hydro']).to(dev), order='zyx')
 rows = cols = 4000
 xpts, ypts, inc_cols, hd = scene_grid(rows, cols)
