@@ -418,7 +418,9 @@ def test_host_buffer_pipeline_matches_device_path(R):
     xx, yy = np.meshgrid(xp, yp)
     pw, ph, pn, pf = cube.raytrace(R.Rays.points(lat=yy.ravel(), lon=xx.ravel(), los=los.reshape(-1, 3)), 120.0, zref)
     assert np.array_equal(pn, dn)
-    np.testing.assert_array_equal(pw.reshape(ny, nx), hw); np.testing.assert_array_equal(ph.reshape(ny, nx), hh)
+    # (same arithmetic, but a different instantiation of pass 1 - crossings_kernel is specialised by input form, and the compiler
+    # contracts a*b+c differently in each: a few ulp in the ray origin, 1e-13 m in the delay)
+    np.testing.assert_allclose(pw.reshape(ny, nx), hw, rtol=0, atol=1e-12); np.testing.assert_allclose(ph.reshape(ny, nx), hh, rtol=0, atol=1e-12)
 
 
 def test_two_contexts_in_two_threads(R):
