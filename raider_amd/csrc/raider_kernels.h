@@ -176,13 +176,17 @@ __device__ __forceinline__ void cell_xy(const double2* e, int n, double v, doubl
     if (exact) {
         i = (int)tf;                                                            // = floor for the tf >= 0 this path accepts
         t = __builtin_amdgcn_fract(tf);
-        ok = (tf >= 0.0) & (tf < (double)(n - 1));
+        const double nm1 = (double)(n - 1);
+        ok = (tf >= 0.0) & (tf < nm1);
         if (__builtin_expect(!ok, 0)) {                                         // rare: the last node, outside the axis, NaN
             asm volatile("" ::: "memory");                                      // keep this a skipped branch, not if-converted selects
-            const double vr = IDX ? fma(tf, 1.0 / inv_d, g0) : v;               // (back to the axis's own units)
-            const bool inside = (vr >= g0) & (vr <= g_last);
-            i = inside ? n - 2 : 0;
-            t = inside ? tf - (double)(n - 2) : qnan();
+            // inside the axis after all?  In axis units when v is one (scipy's own test, _rgi.py:437-442); an index-space
+            // coordinate (IDX) is inside only ON the last node.  The cell follows from which end tf fell off: a coordinate a
+            // rounding error below the first node belongs to cell 0, not to the last cell.
+            const bool inside = IDX ? (tf == nm1) : ((v >= g0) & (v <= g_last));
+            const bool low_end = tf < 1.0;
+            i = (inside && !low_end) ? n - 2 : 0;
+            t = inside ? (low_end ? tf : (tf - nm1) + 1.0) : qnan();
         }
         return;
     } else {
@@ -930,7 +934,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
                 // top sample: its gathers are issued first, the next level's crossing (7 FMAs that need no memory) is computed
                 // while they are in flight, then the sample is finished with the weight of both its segments
                 PendingSample<T2> top;
-                issue_top(fma((double)(np - 1) * step, du, u_k), zbase, false, clamp_hi && !more, top);
+                issue_top(u_k + du, zbase, false, clamp_hi && !more, top);                // fraction exactly 1.0, as np.linspace returns it
                 double du1 = 0.0, hs1 = 0.0;
                 double w_top = hs * du;
                 if (more) {
