@@ -200,6 +200,18 @@ int rdr_ray_march(rdr_ctx* ctx, const rdr_cube* cube, const rdr_rays* rays, doub
 int rdr_raytrace(rdr_ctx* ctx, const rdr_cube* cube, const rdr_rays* rays, double ht, double zref,
                  double max_seg, double* wet, double* hydro, int32_t* nparts_out, int32_t* flags_out);
 
+/* The height loop of _build_cube_ray (delay.py:256-323) in one call: `nslices` slices at heights hts[] (host array) of the SAME
+ * origins - GRID or LLH - each integrated exactly as rdr_raytrace would (its own level table, per-level slice maxima, nParts and
+ * z-clamp decision), but in one pass-1 / pass-2 launch pair, so that production-sized jobs (20 heights x 1e4-1e5 rays,
+ * aria/prepFromGUNW.py:173,180) fill the GPU.  los_per_slice != 0: rays->los / inc / hd hold nslices consecutive blocks of
+ * rays->n entries (look vectors that depend on the target height, losreader.py:219-255); 0: one block serves every slice.
+ * wet / hydro: [nslices][n].  Host outputs, filled after a synchronisation when given: K_out[nslices] contributing model
+ * intervals per slice (0: build_ray -> None, the slice's delays are 0), nparts_out[nslices][ld] (ld >= nz-1),
+ * flags_out[nslices] RDR_FLAG_* bits - the caller raises what delay.py:276-283 raises, slice by slice. */
+int rdr_raytrace_slices(rdr_ctx* ctx, const rdr_cube* cube, const rdr_rays* rays, const double* hts, int32_t nslices,
+                        int32_t los_per_slice, double zref, double max_seg, double* wet, double* hydro, int32_t* K_out,
+                        int32_t* nparts_out, int32_t ld, int32_t* flags_out);
+
 /* Materialising variants for API parity on small inputs:
  * getTopOfAtmosphere (losreader.py:706-733): factor==NULL -> 10 iterations with factor 1, else 3 */
 int rdr_top_of_atmosphere(rdr_ctx* ctx, const double* xyz, const double* los, int64_t n, double toaheight,

@@ -74,6 +74,7 @@ SYMBOLS = [
     ('rdr_nparts', C.c_int, [_VP, C.c_int32, C.c_double, _VP]),
     ('rdr_ray_march', C.c_int, [_VP, _VP, C.POINTER(RdrRays), C.c_double, C.c_double, _VP, C.c_int32, _VP, _VP]),
     ('rdr_raytrace', C.c_int, [_VP, _VP, C.POINTER(RdrRays), C.c_double, C.c_double, C.c_double, _VP, _VP, _VP, c_ip]),
+    ('rdr_raytrace_slices', C.c_int, [_VP, _VP, C.POINTER(RdrRays), _VP, C.c_int32, C.c_int32, C.c_double, C.c_double, _VP, _VP, _VP, _VP, C.c_int32, _VP]),
     ('rdr_top_of_atmosphere', C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_double, _VP, _VP, C.c_int]),
     ('rdr_build_ray', C.c_int, [_VP, _VP, C.c_int64, C.c_double, _VP, _VP, C.c_int64, C.c_double, c_ip, _VP, _VP, _VP, C.c_int]),
     ('rdr_lla2ecef', C.c_int, [_VP, _VP, _VP, _VP, C.c_int64, _VP, C.c_int]),

@@ -25,6 +25,8 @@ struct DevBuf {
     size_t cap = 0;
 };
 
+constexpr int MAX_SLICES = 512;   // height slices per rdr_raytrace_slices call
+
 enum { SLOT_IN0 = 0, SLOT_IN1, SLOT_IN2, SLOT_IN3, SLOT_IN4, SLOT_IN5, SLOT_OUT0, SLOT_OUT1, SLOT_OUT2, SLOT_AUX, NSLOT };
 
 struct rdr_ctx {
@@ -39,9 +41,9 @@ struct rdr_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> evs[4];   // HIP event pairs around every launch, per kernel kind
     size_t ev_used[4] = {0, 0, 0, 0};
     DevBuf slot[NSLOT];
-    unsigned long long* d_maxlen = nullptr;   // [MAX_LEVELS]
-    int* d_flags = nullptr;                   // [1]
-    int* d_nparts = nullptr;                  // [MAX_LEVELS]
+    unsigned long long* d_maxlen = nullptr;   // [MAX_SLICES][MAX_LEVELS]
+    int* d_flags = nullptr;                   // [MAX_SLICES]
+    int* d_nparts = nullptr;                  // [MAX_LEVELS] (rdr_ray_march's host-given partition)
     int* d_nslow = nullptr;                   // [1] rays sent to the generic kernels by the last pass 1
     int* d_tilectr = nullptr;                 // [4][8] per-XCD tile counters of the four ray-kernel launches of a step
     DevBuf ws;                                // pass 1 -> pass 2 workspace (field-major ray records, 232 B per ray)
@@ -176,8 +178,8 @@ int rdr_create(int device, rdr_ctx** out) {
     HIPCHECK(nullptr, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     HIPCHECK(nullptr, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
-    HIPCHECK(nullptr, hipMalloc((void**)&c->d_maxlen, MAX_LEVELS * sizeof(unsigned long long)));
-    HIPCHECK(nullptr, hipMalloc((void**)&c->d_flags, sizeof(int)));
+    HIPCHECK(nullptr, hipMalloc((void**)&c->d_maxlen, (size_t)MAX_SLICES * MAX_LEVELS * sizeof(unsigned long long)));
+    HIPCHECK(nullptr, hipMalloc((void**)&c->d_flags, MAX_SLICES * sizeof(int)));
     HIPCHECK(nullptr, hipMalloc((void**)&c->d_nparts, MAX_LEVELS * sizeof(int)));
     HIPCHECK(nullptr, hipMalloc((void**)&c->d_nslow, sizeof(int)));
     HIPCHECK(nullptr, hipMalloc((void**)&c->d_tilectr, 32 * sizeof(int)));
@@ -706,8 +708,9 @@ static int check_rays(rdr_ctx* c, const rdr_rays* r) {
     return RDR_OK;
 }
 
-// stage every ray array the mode needs; fills P
-static int stage_rays(rdr_ctx* c, const rdr_rays* r, RayParams& P) {
+// stage every ray array the mode needs; fills P (one slice; los_mult > 1: the look-vector / incidence / heading arrays hold
+// los_mult consecutive blocks of n rays, one per height slice)
+static int stage_rays(rdr_ctx* c, const rdr_rays* r, RayParams& P, int64_t los_mult = 1) {
     std::memset(&P, 0, sizeof(P));
     P.n = r->n; P.origin_mode = r->origin_mode; P.los_mode = r->los_mode; P.nx = r->nx; P.ny = r->ny;
     P.inc0 = r->inc0; P.hd0 = r->hd0;
@@ -722,10 +725,11 @@ static int stage_rays(rdr_ctx* c, const rdr_rays* r, RayParams& P) {
         rc = stage_in(c, SLOT_IN1, r->lon, (size_t)r->n * 8, loc, &d); if (rc) return rc; P.lon = (const double*)d;
         if (r->origin_mode == RDR_ORIGIN_XYZ) { rc = stage_in(c, SLOT_IN2, r->xyz, (size_t)r->n * 24, loc, &d); if (rc) return rc; P.xyz = (const double*)d; }
     }
-    if (r->los_mode == RDR_LOS_VEC) { rc = stage_in(c, SLOT_IN3, r->los, (size_t)r->n * 24, loc, &d); if (rc) return rc; P.los = (const double*)d; }
+    const size_t nl = (size_t)r->n * (size_t)los_mult;
+    if (r->los_mode == RDR_LOS_VEC) { rc = stage_in(c, SLOT_IN3, r->los, nl * 24, loc, &d); if (rc) return rc; P.los = (const double*)d; }
     else if (r->los_mode == RDR_LOS_INC_HD) {
-        rc = stage_in(c, SLOT_IN4, r->inc, (size_t)r->n * 8, loc, &d); if (rc) return rc; P.inc = (const double*)d;
-        if (r->hd) { rc = stage_in(c, SLOT_IN5, r->hd, (size_t)r->n * 8, loc, &d); if (rc) return rc; P.hd = (const double*)d; }   // NULL: hd0 for every ray
+        rc = stage_in(c, SLOT_IN4, r->inc, nl * 8, loc, &d); if (rc) return rc; P.inc = (const double*)d;
+        if (r->hd) { rc = stage_in(c, SLOT_IN5, r->hd, nl * 8, loc, &d); if (rc) return rc; P.hd = (const double*)d; }   // NULL: hd0 for every ray
     }
     if (r->origin_mode == RDR_ORIGIN_GRID) {
         P.tiles_x = (int)((r->nx + TILE - 1) / TILE);
@@ -734,6 +738,7 @@ static int stage_rays(rdr_ctx* c, const rdr_rays* r, RayParams& P) {
         P.tiles_x = 1;
         P.ntiles = (r->n + BLOCK - 1) / BLOCK;
     }
+    P.nslices = 1; P.tiles_per_slice = std::max<int64_t>(P.ntiles, 1); P.hts = nullptr; P.los_stride = 0;
     P.maxlen_bits = c->d_maxlen; P.flags = c->d_flags;
     P.ws = nullptr; P.nslots = 0; P.tile_begin = 0; P.tile_count = P.ntiles; P.nslow = c->d_nslow;
     return RDR_OK;
@@ -1146,6 +1151,96 @@ int rdr_raytrace(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, double ht, do
         if (nparts_out) rdr_nparts(ml.data(), K, max_seg, nparts_out);
         if (flags_out) *flags_out = f;
         return flags_to_status(c, f);
+    }
+    return RDR_OK;
+}
+
+// Several height slices of _build_cube_ray in ONE pass-1 / pass-2 launch pair (delay.py:256-323 loops over them): a production
+// job is ~20 heights x 1e4-1e5 rays (aria/prepFromGUNW.py:173,180), and one such slice fills a fraction of the chip.  Tiles are
+// numbered slice-major; per-level maxima / flags / nParts stay per slice (RayParams), so the result is what slice-by-slice
+// calls give, bit for bit.
+int rdr_raytrace_slices(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, const double* hts, int32_t nslices, int32_t los_per_slice,
+                        double zref, double max_seg, double* wet, double* hydro, int32_t* K_out, int32_t* nparts_out, int32_t ld,
+                        int32_t* flags_out) {
+    if (!c || !q || !hts || !wet || !hydro) return fail(c, RDR_ERR_INVALID, "rdr_raytrace_slices: NULL argument");
+    if (nslices < 1 || nslices > MAX_SLICES) return fail(c, RDR_ERR_INVALID, "rdr_raytrace_slices: 1..512 slices per call");
+    if (!(max_seg > 0)) return fail(c, RDR_ERR_INVALID, "rdr_raytrace_slices: MAX_SEGMENT_LENGTH must be positive");
+    if (nparts_out && ld < (int32_t)q->nz - 1) return fail(c, RDR_ERR_INVALID, "rdr_raytrace_slices: nparts_out needs a row length of at least nz-1");
+    int rc = check_rays(c, r); if (rc) return rc;
+    if (r->origin_mode == RDR_ORIGIN_XYZ && nslices > 1) return fail(c, RDR_ERR_INVALID, "rdr_raytrace_slices: XYZ origins belong to one height; use GRID or LLH origins");
+    std::vector<int> Ks(nslices);
+    int Kmax = 0;
+    for (int s = 0; s < nslices; ++s) {
+        std::vector<double> lo, hi; std::vector<int> kz;
+        Ks[s] = levels_host(q->zs, hts[s], zref, lo, hi, kz);
+        Kmax = std::max(Kmax, Ks[s]);
+        if (K_out) K_out[s] = Ks[s];
+    }
+    if (r->n == 0) return RDR_OK;
+    HIPCHECK(c, hipSetDevice(c->device));
+    RayParams P;
+    rc = stage_rays(c, r, P, los_per_slice ? nslices : 1); if (rc) return rc;
+    const int64_t per = P.ntiles;                                   // tiles of one slice
+    const size_t nout = (size_t)r->n * nslices;
+    void *dw, *dh;
+    rc = stage_out(c, SLOT_OUT0, wet, nout * 8, r->loc, &dw); if (rc) return rc;
+    rc = stage_out(c, SLOT_OUT1, hydro, nout * 8, r->loc, &dh); if (rc) return rc;
+    const void* dht;
+    rc = stage_in(c, SLOT_AUX, hts, (size_t)nslices * 8, RDR_HOST, &dht); if (rc) return rc;
+    HIPCHECK(c, hipStreamSynchronize(c->stream));                   // (hts is the caller's memory)
+    P.nslices = nslices; P.tiles_per_slice = per; P.hts = (const double*)dht; P.los_stride = los_per_slice ? r->n : 0;
+    P.ntiles = per * nslices;
+    P.ht = hts[0]; P.zref = zref; P.max_seg = max_seg;
+    P.wet = (double*)dw; P.hyd = (double*)dh;
+    HIPCHECK(c, hipMemsetAsync(c->d_maxlen, 0, (size_t)nslices * MAX_LEVELS * sizeof(unsigned long long), c->stream));
+    HIPCHECK(c, hipMemsetAsync(c->d_flags, 0, (size_t)nslices * sizeof(int), c->stream));
+    c->wsig.valid = false;
+    const int64_t fit = ws_chunk_tiles(c, std::max(Kmax, 1));
+    if (per <= fit) {
+        // groups of whole slices whose records fit the workspace: one launch pair per group (usually one group)
+        const int64_t g = std::max<int64_t>(1, fit / per);
+        for (int64_t s0 = 0; s0 < nslices; s0 += g) {
+            const int64_t ns = std::min<int64_t>(g, nslices - s0);
+            RayParams Pg = P;
+            rc = ws_reserve(c, ns * per, std::max(Kmax, 1), Pg); if (rc) return rc;
+            rc = launch_crossings(c, q, Pg, s0 * per, ns * per); if (rc) return rc;
+            rc = launch_march(c, q, Pg, s0 * per, ns * per); if (rc) return rc;
+        }
+    } else {
+        // a single slice exceeds the workspace: per slice, pass 1 (reduction only) then chunked (store, march) pairs
+        for (int s = 0; s < nslices; ++s) {
+            RayParams Ps = P;
+            Ps.ws = nullptr;
+            rc = launch_crossings(c, q, Ps, (int64_t)s * per, per); if (rc) return rc;
+            const int64_t chunk = std::min<int64_t>(per, fit);
+            RayParams Pw = P;
+            rc = ws_reserve(c, chunk, std::max(Kmax, 1), Pw); if (rc) return rc;
+            for (int64_t tb = 0; tb < per; tb += chunk) {
+                const int64_t tc = std::min<int64_t>(chunk, per - tb);
+                RayParams Pc = Pw;
+                Pc.maxlen_bits = nullptr;
+                rc = launch_crossings(c, q, Pc, (int64_t)s * per + tb, tc); if (rc) return rc;
+                Pc.maxlen_bits = P.maxlen_bits;
+                rc = launch_march(c, q, Pc, (int64_t)s * per + tb, tc); if (rc) return rc;
+            }
+        }
+    }
+    rc = finish_out(c, wet, dw, nout * 8, r->loc); if (rc) return rc;
+    rc = finish_out(c, hydro, dh, nout * 8, r->loc); if (rc) return rc;
+    const bool need_sync = r->loc == RDR_HOST || nparts_out || flags_out;
+    if (need_sync) {
+        std::vector<double> ml((size_t)nslices * MAX_LEVELS);
+        std::vector<int> f(nslices);
+        int nslow = 0;
+        HIPCHECK(c, hipMemcpyAsync(ml.data(), c->d_maxlen, ml.size() * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHECK(c, hipMemcpyAsync(f.data(), c->d_flags, (size_t)nslices * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHECK(c, hipMemcpyAsync(&nslow, c->d_nslow, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHECK(c, hipStreamSynchronize(c->stream));
+        c->last_nslow = nslow;
+        for (int s = 0; s < nslices; ++s) {
+            if (nparts_out) rdr_nparts(ml.data() + (size_t)s * MAX_LEVELS, Ks[s], max_seg, nparts_out + (size_t)s * ld);
+            if (flags_out) flags_out[s] = f[s];
+        }
     }
     return RDR_OK;
 }

@@ -409,12 +409,17 @@ struct RayParams {
     const double* lat; const double* lon; const double* xyz;
     const double* los; const double* inc; const double* hd;
     double inc0, hd0;
-    // slice
+    // slices: a batch is nslices >= 1 height slices of the SAME origins (delay.py:256: one slice per output height).  Tiles are
+    // numbered slice-major (tile t belongs to slice t / tiles_per_slice); everything the reference reduces over a slice -
+    // per-level maxima, flags, nParts - is kept per slice, so a batched launch gives exactly what slice-by-slice launches give.
+    int nslices; int64_t tiles_per_slice;
+    const double* hts;                 // [nslices] slice heights, or nullptr: one slice at `ht`
+    int64_t los_stride;                // rays between consecutive slices in los / inc / hd (0: the same arrays for every slice)
     double ht, zref, max_seg;
     // batch-global state
-    unsigned long long* maxlen_bits;   // [MAX_LEVELS] per-level max ray length (bit pattern of a non-negative double); nullptr: no reduction
-    int* flags;                        // RDR_FLAG_* bits (OR-reduced)
-    const int* nparts_override;        // [K] or nullptr -> ceil(maxlen/max_seg)+1
+    unsigned long long* maxlen_bits;   // [nslices][MAX_LEVELS] per-level max ray length (bit pattern of a non-negative double); nullptr: no reduction
+    int* flags;                        // [nslices] RDR_FLAG_* bits (OR-reduced)
+    const int* nparts_override;        // [nslices][MAX_LEVELS] or nullptr -> ceil(maxlen/max_seg)+1
     int* nslow;                        // number of rays the static classification sent to the generic (slow) kernels
     int* tile_ctr;                     // [8] per-XCD next-tile counters of this launch (zeroed by the host)
     // pass 1 -> pass 2 workspace (this launch covers tiles [tile_begin, tile_begin + tile_count))
@@ -428,12 +433,12 @@ struct RayParams {
     int64_t ntiles; int tiles_x;
 };
 
-// The slice-uniform level table of build_ray (losreader.py:785-808), computed by one thread into LDS.
-__device__ inline int build_levels(const double* zs, int nz, double ht, double zref, double* s_lo, double* s_hi, int* s_kz) {
+// The slice-uniform level table of build_ray (losreader.py:785-808), computed by one thread into LDS from the LDS z table.
+__device__ inline int build_levels(const double2* ez, int nz, double ht, double zref, double* s_lo, double* s_hi, int* s_kz) {
     int K = 0;
-    const double ztop = zs[nz - 1];
+    const double ztop = ez[nz - 1].x;
     for (int zz = 0; zz < nz - 1; ++zz) {
-        double lo = zs[zz], hi = zs[zz + 1];
+        double lo = ez[zz].x, hi = ez[zz + 1].x;
         if (hi == ztop) hi -= 0.01;
         if (hi < ht || lo >= zref) continue;
         if (lo < ht) lo = ht;
@@ -495,8 +500,9 @@ inline size_t ray_smem_bytes(int64_t ny, int64_t nx, int64_t nz, int exact_y, in
            + (size_t)nz * 4 * 2 + 16;             // kz, np, K
 }
 
+// Axis tables: once per workgroup.
 template <typename T2>
-__device__ __forceinline__ int fill_tables(const CubeView<T2>& c, const RaySmem& m, double ht, double zref) {
+__device__ __forceinline__ void fill_axes(const CubeView<T2>& c, const RaySmem& m) {
     const int tid = threadIdx.x;
     auto fill = [&](double2* dst, const double* g, int n) {
         for (int i = tid; i < n; i += BLOCK) {
@@ -507,8 +513,15 @@ __device__ __forceinline__ int fill_tables(const CubeView<T2>& c, const RaySmem&
     if (m.ax.ey) fill(const_cast<double2*>(m.ax.ey), c.axes, c.ny);
     if (m.ax.ex) fill(const_cast<double2*>(m.ax.ex), c.axes + c.ny, c.nx);
     fill(const_cast<double2*>(m.ax.ez), c.axes + c.ny + c.nx, c.nz);
+    __syncthreads();
+}
+
+// Level table of one slice (height ht): whenever a workgroup moves on to a tile of another slice.  Called by every thread.
+__device__ __forceinline__ int fill_levels(int nz, const RaySmem& m, double ht, double zref) {
+    const int tid = threadIdx.x;
+    __syncthreads();                                   // the previous slice's readers are done with the tables
     if (tid == 0) {
-        const int K = build_levels(c.axes + c.ny + c.nx, c.nz, ht, zref, m.lo, m.hi, m.kz);
+        const int K = build_levels(m.ax.ez, nz, ht, zref, m.lo, m.hi, m.kz);
         *m.K = K;
         // range of the level tops the crossing polynomial has to cover (levels 1 .. K-1; level 0 has its own iteration)
         const double a = K > 1 ? m.hi[1] : (K > 0 ? m.hi[0] : 0.0), b = K > 1 ? m.hi[K - 1] : a;
@@ -560,20 +573,45 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
     const int los_mode = OM == 1 ? 0 : P.los_mode;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const RaySmem m = carve_smem(smem_raw, c.ny, c.nx, c.nz, c.exact_y, c.exact_x);
-    const int K = fill_tables(c, m, P.ht, P.zref);
+    fill_axes(c, m);
     const int tid = threadIdx.x;
     const bool reduce = P.maxlen_bits != nullptr;
-    if (reduce) for (int k = tid; k < K * MXCOLS; k += BLOCK) m.mxcol[k] = 0ULL;
-    __syncthreads();
-    // per-level maximum of the ray length over the batch (delay.py:283): every lane folds its length into column lane%16 of
+    // per-level maximum of the ray length over a slice (delay.py:283): every lane folds its length into column lane%16 of
     // the workgroup's LDS table with one ds_max_u64 (non-negative doubles order like their bit patterns); the columns are
-    // combined once, at the end of the kernel.  NaN lengths are left out here and reported through the flags, which is how
-    // ndarray.max's NaN poisoning is reproduced on the host side.
+    // combined when the workgroup leaves the slice (flush).  NaN lengths are left out here and reported through the flags,
+    // which is how ndarray.max's NaN poisoning is reproduced on the host side.
     int my_flags = 0;
+    int K = 0, slice = -1;
+    double ht = P.ht;
+    auto flush = [&]() {                                   // called by every thread of the workgroup
+        if (!reduce || slice < 0) return;
+        __syncthreads();
+        for (int k = tid; k < K; k += BLOCK) {
+            unsigned long long v = 0ULL;
+#pragma unroll
+            for (int cc = 0; cc < MXCOLS; ++cc) v = max(v, m.mxcol[k * MXCOLS + cc]);
+            atomicMax(&P.maxlen_bits[(int64_t)slice * MAX_LEVELS + k], v);
+        }
+        int f = my_flags;
+        for (int off = 32; off > 0; off >>= 1) f |= __shfl_xor(f, off, 64);
+        if ((tid & 63) == 0 && f) atomicOr(P.flags + slice, f);
+        my_flags = 0;
+    };
     TileWalk walk(P.tile_count, P.tile_ctr, m.K + 2);
     int64_t lt;
     while (walk.next(P.tile_count, lt)) {
-        const int64_t t = P.tile_begin + lt;
+        const int64_t tg = P.tile_begin + lt;              // tile of the batch; t: tile within its slice
+        const int sl = (int)(tg / P.tiles_per_slice);
+        const int64_t t = tg - (int64_t)sl * P.tiles_per_slice;
+        if (sl != slice) {                                 // (workgroup-uniform) first tile, or the walk has reached the next slice
+            flush();
+            slice = sl;
+            ht = P.hts ? P.hts[sl] : P.ht;
+            K = fill_levels(c.nz, m, ht, P.zref);
+            if (reduce) for (int k = tid; k < K * MXCOLS; k += BLOCK) m.mxcol[k] = 0ULL;
+            __syncthreads();
+        }
+        const int64_t lbase = (int64_t)sl * P.los_stride;  // this slice's block of the look-vector / incidence arrays
         int64_t i, row = 0, col = 0; bool active;
         if (origin_mode == 0) {
             const int64_t ty = t / P.tiles_x, tx = t - ty * P.tiles_x;
@@ -605,9 +643,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
             base.sl0 = active ? m.trig[32 + 2 * (tid & 15)] : 0.0; base.cl0 = active ? m.trig[33 + 2 * (tid & 15)] : 1.0;
             if (active) {                                          // lla2ecef (geodesy.h) with the shared sines / cosines
                 const double N = WGS84_A / sqrt(1.0 - WGS84_ES * base.s0 * base.s0);
-                ox = (N + P.ht) * base.c0 * base.cl0;
-                oy = (N + P.ht) * base.c0 * base.sl0;
-                oz = (N * (1.0 - WGS84_ES) + P.ht) * base.s0;
+                ox = (N + ht) * base.c0 * base.cl0;
+                oy = (N + ht) * base.c0 * base.sl0;
+                oz = (N * (1.0 - WGS84_ES) + ht) * base.s0;
             }
         } else {
             if (active) {
@@ -616,7 +654,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
                 if (origin_mode == 2) {
                     ox = P.xyz[3 * i]; oy = P.xyz[3 * i + 1]; oz = P.xyz[3 * i + 2];
                     if (!P.lat) { double h0_; ecef2lla(ox, oy, oz, lon, lat, h0_); }   // frame for the delta lat/lon formulas
-                } else lla2ecef(lat, lon, P.ht, ox, oy, oz);
+                } else lla2ecef(lat, lon, ht, ox, oy, oz);
             }
             base = make_base(lat, lon);
         }
@@ -624,8 +662,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
         double lx = qnan(), ly = qnan(), lz = qnan();
         if (active) {
             // (inc / heading: the origin's own sines / cosines are the ones inc_hd_to_ecef would compute again)
-            if (los_mode == 0) { lx = P.los[3 * i]; ly = P.los[3 * i + 1]; lz = P.los[3 * i + 2]; }
-            else if (los_mode == 1) inc_hd_to_ecef_sc(P.inc[i], P.hd ? P.hd[i] : P.hd0, base.s0, base.c0, base.sl0, base.cl0, lx, ly, lz);
+            if (los_mode == 0) { const double* lp = P.los + 3 * (lbase + i); lx = lp[0]; ly = lp[1]; lz = lp[2]; }
+            else if (los_mode == 1) inc_hd_to_ecef_sc(P.inc[lbase + i], P.hd ? P.hd[lbase + i] : P.hd0, base.s0, base.c0, base.sl0, base.cl0, lx, ly, lz);
             else if (los_mode == 2) inc_hd_to_ecef_sc(P.inc0, P.hd0, base.s0, base.c0, base.sl0, base.cl0, lx, ly, lz);
             else { lx = base.c0 * base.cl0; ly = base.c0 * base.sl0; lz = base.s0; }   // zenith (losreader.py:302-316)
         }
@@ -639,7 +677,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
         // on the ground (tools/ray_poly_probe.py), which moves delays by < 1e-10 m - and must not reach the +-180 meridian
         // (the light path does not wrap longitudes).
         const double cosi = (lx * base.c0 * base.cl0 + ly * base.c0 * base.sl0 + lz * base.s0) / nl;
-        const double gam = (P.zref - P.ht) / (cosi * 6.3e6);
+        const double gam = (P.zref - ht) / (cosi * 6.3e6);
         // LCC cubes: spherical cones only (HRRR), and the node projections use short series in log(t/t_origin) <= gam / cos(lat)
         // (geodesy_fast.h); an ellipsoidal cone goes to the generic kernels (lcc_forward) ray by ray.
         const bool fast_ok = !active || ((cosi > 0.05) && (base.c0 > gam + 0.02) && (gam < 0.2 * (base.c0 - gam)) && (gam < 0.035) &&
@@ -714,8 +752,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
             // ---- light rays: fit h(u), lat(u), lon(u) once, then everything is polynomial arithmetic.
             // Range of the ray parameter any Newton iterate / sample can take: iterates start at t0 = level height
             // (>= ht) and move monotonically to the crossing, which lies in [0, (zref - ht)/cos(inc)].
-            const double t_a = fmin(0.0, P.ht) - 1.0;
-            const double t_b = fmax(P.zref, (P.zref - P.ht) / (cosi * nl)) + 1.0;
+            const double t_a = fmin(0.0, ht) - 1.0;
+            const double t_b = fmax(P.zref, (P.zref - ht) / (cosi * nl)) + 1.0;
             const double half = 0.5 * (t_b - t_a), mid = 0.5 * (t_b + t_a);
             const double su = 1.0 / half, ou = -mid * su;
             RayPoly q;
@@ -793,18 +831,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
             if (reduce && cnt && K > 0) my_flags |= (last_len != last_len) ? 1 : 2;
         }
     }
-    if (reduce) {
-        __syncthreads();
-        for (int k = tid; k < K; k += BLOCK) {
-            unsigned long long v = 0ULL;
-#pragma unroll
-            for (int cc = 0; cc < MXCOLS; ++cc) v = max(v, m.mxcol[k * MXCOLS + cc]);
-            atomicMax(&P.maxlen_bits[k], v);
-        }
-        int f = my_flags;
-        for (int off = 32; off > 0; off >>= 1) f |= __shfl_xor(f, off, 64);
-        if ((tid & 63) == 0 && f) atomicOr(P.flags, f);
-    }
+    flush();
 }
 
 // ---- pass 2: trapezoid integration of both fields along every ray (delay.py:285-323) -------------------------------
@@ -819,36 +846,45 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
     if (REGULAR) { c.exact_y = 1; c.exact_x = 1; c.small = 1; }
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const RaySmem m = carve_smem(smem_raw, c.ny, c.nx, c.nz, c.exact_y, c.exact_x);
-    const int K = fill_tables(c, m, P.ht, P.zref);
+    fill_axes(c, m);
     const int tid = threadIdx.x;
-    if (tid == 0) m.K[1] = 0;
-    __syncthreads();
-    for (int k = tid; k < K; k += BLOCK) {
-        int np;
-        if (P.nparts_override) np = P.nparts_override[k];
-        else {
-            const double parts = ceil(__longlong_as_double((long long)P.maxlen_bits[k]) / P.max_seg) + 1.0;   // delay.py:283
-            np = (parts >= 1.0 && parts <= (double)MAX_NPARTS) ? (int)parts : -1;
-        }
-        if (np < 2 || np > MAX_NPARTS) {      // diverged lengths (e.g. look vectors far from unit length): refuse to loop over them
-            np = 2;
-            if (tid < BLOCK) atomicOr(P.flags, 16);    // RDR_FLAG_DIVERGED
-            m.K[1] = 1;
-        }
-        m.np[k] = np;
-        m.step[k] = 1.0 / ((double)np - 1.0);                    // np.linspace(0,1,np) (delay.py:287)
-        m.hs[k] = 0.5e-6 * m.step[k];                            // delay.py:314-315: end points get half of L*1e-6/(np-1)
-    }
-    __syncthreads();
-    const double poison = m.K[1] ? qnan() : 0.0;   // diverged slice: every output is NaN
-    const int flags_in = *P.flags;
-    const bool clamp_lo = !(flags_in & 4);   // ALL first samples below zmin  (delay.py:306-307)
-    const bool clamp_hi = !(flags_in & 8);   // ALL last samples above zmax   (delay.py:310-311)
-    const bool clamp_any = clamp_lo | clamp_hi;
+    int K = 0, slice = -1;
+    double poison = 0.0;
+    bool clamp_lo = false, clamp_hi = false, clamp_any = false;
     TileWalk walk(P.tile_count, P.tile_ctr, m.K + 2);
     int64_t lt;
     while (walk.next(P.tile_count, lt)) {
-        const int64_t t = P.tile_begin + lt;
+        const int64_t tg = P.tile_begin + lt;              // tile of the batch; t: tile within its slice
+        const int sl = (int)(tg / P.tiles_per_slice);
+        const int64_t t = tg - (int64_t)sl * P.tiles_per_slice;
+        if (sl != slice) {                                 // (workgroup-uniform) the slice's level table and integration partition
+            slice = sl;
+            K = fill_levels(c.nz, m, P.hts ? P.hts[sl] : P.ht, P.zref);
+            if (tid == 0) m.K[1] = 0;
+            __syncthreads();
+            for (int k = tid; k < K; k += BLOCK) {
+                int np;
+                if (P.nparts_override) np = P.nparts_override[(int64_t)sl * MAX_LEVELS + k];
+                else {
+                    const double parts = ceil(__longlong_as_double((long long)P.maxlen_bits[(int64_t)sl * MAX_LEVELS + k]) / P.max_seg) + 1.0;   // delay.py:283
+                    np = (parts >= 1.0 && parts <= (double)MAX_NPARTS) ? (int)parts : -1;
+                }
+                if (np < 2 || np > MAX_NPARTS) {      // diverged lengths (e.g. look vectors far from unit length): refuse to loop over them
+                    np = 2;
+                    atomicOr(P.flags + sl, 16);       // RDR_FLAG_DIVERGED
+                    m.K[1] = 1;
+                }
+                m.np[k] = np;
+                m.step[k] = 1.0 / ((double)np - 1.0);                    // np.linspace(0,1,np) (delay.py:287)
+                m.hs[k] = 0.5e-6 * m.step[k];                            // delay.py:314-315: end points get half of L*1e-6/(np-1)
+            }
+            __syncthreads();
+            poison = m.K[1] ? qnan() : 0.0;           // diverged slice: every output is NaN
+            const int flags_in = P.flags[sl];
+            clamp_lo = !(flags_in & 4);               // ALL first samples below zmin  (delay.py:306-307)
+            clamp_hi = !(flags_in & 8);               // ALL last samples above zmax   (delay.py:310-311)
+            clamp_any = clamp_lo | clamp_hi;
+        }
         int64_t i; bool active;
         if (P.origin_mode == 0) {
             const int64_t ty = t / P.tiles_x, tx = t - ty * P.tiles_x;
@@ -1006,7 +1042,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
                 }
             }
         }
-        if (active && mine) { P.wet[i] = acc_w + poison; P.hyd[i] = acc_h + poison; }
+        if (active && mine) { const int64_t o = (int64_t)sl * P.n + i; P.wet[o] = acc_w + poison; P.hyd[o] = acc_h + poison; }
     }
 }
 

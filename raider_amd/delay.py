@@ -388,6 +388,29 @@ def _build_cube_ray(xpts, ypts, zpts, los, model_crs, pts_crs, interpolators, ou
     direct = output_created_here and list(fields) == [0, 1]
 
     grid_is_ll = _is_4326(pts_crs)
+    if direct and grid_is_ll and hasattr(los, 'ray_batch_slices') and zpts.size > 0:
+        # the whole height loop as one batched launch pair per <= 512 slices (Cube.raytrace_slices): bit-identical to the slice
+        # loop below, but a production job (20 heights x 1e4-1e5 rays) fills the GPU instead of a tenth of it
+        from ._lib import FLAG_ANY_FINITE, FLAG_ANY_NAN
+        for s0 in range(0, zpts.size, 512):
+            zz = np.ascontiguousarray(zpts[s0:s0 + 512], dtype=np.float64)
+            logger.info(f'Processing slices {s0 + 1}-{s0 + zz.size} / {len(zpts)}')
+            rays = los.ray_batch_slices(xpts, ypts, zz)
+            _, _, K, _nparts, flags = cube.raytrace_slices(rays, zz, MAX_TROPO_HEIGHT, MAX_SEGMENT_LENGTH,
+                                                           out=(outputArrs[0][s0:s0 + zz.size], outputArrs[1][s0:s0 + zz.size]))
+            for hh, ht in enumerate(zz):                                   # the reference's failure modes, in slice order
+                if K[hh] == 0:
+                    if ht == zpts[-1]:                                     # delay.py:276-277: the slice stays zero (the kernels wrote 0)
+                        continue
+                    raise TypeError("ufunc 'isnan' not supported for the input types (build_ray returned None)")   # delay.py:279
+                if not (flags[hh] & FLAG_ANY_FINITE):
+                    raise ValueError('geo2rdr did not converge. Check orbit coverage')            # delay.py:279-280
+                if flags[hh] & FLAG_ANY_NAN:
+                    raise ValueError('some ray lengths are NaN: the number of integration parts (delay.py:283) is undefined')
+                if flags[hh] & 16:
+                    raise ValueError('ray lengths diverged: a model level asks for fewer than 2 or more than 65536 integration parts '
+                                     '(are the look vectors unit vectors?)')
+        return outputArrs
     for hh, ht in enumerate(zpts):
         logger.info(f'Processing slice {hh + 1} / {len(zpts)}: {ht}')
         if grid_is_ll and hasattr(los, 'ray_batch'):

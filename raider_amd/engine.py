@@ -177,6 +177,7 @@ class Cube:
         """Pass 2 driven by a device-resident (all-reduced) partition.  Asynchronous."""
         rays.adopt_stream(self.ctx)
         wet, hyd = out if out is not None else rays.empty_outputs()
+        rays.check_outputs(wet, hyd)
         check(self.ctx.lib.rdr_ray_march_device(self.ctx.handle, self.handle, C.byref(rays.struct), float(ht), float(zref), float(max_seg),
                                                 ptr(partition), ptr(wet), ptr(hyd)), self.ctx.handle)
         return wet, hyd
@@ -185,6 +186,7 @@ class Cube:
         rays.adopt_stream(self.ctx)
         nparts = np.ascontiguousarray(nparts, dtype=np.int32)
         wet, hyd = out if out is not None else rays.empty_outputs()
+        rays.check_outputs(wet, hyd)
         check(self.ctx.lib.rdr_ray_march(self.ctx.handle, self.handle, C.byref(rays.struct), float(ht), float(zref), ptr(nparts),
                                          int(flags), ptr(wet), ptr(hyd)), self.ctx.handle)
         return wet, hyd
@@ -194,6 +196,7 @@ class Cube:
         nparts/flags are None when want_nparts is False (fully asynchronous for device arrays)."""
         rays.adopt_stream(self.ctx)
         wet, hyd = out if out is not None else rays.empty_outputs()
+        rays.check_outputs(wet, hyd)
         if want_nparts:
             K = len(self.ray_levels(ht, zref)[0])
             nparts = np.zeros(K, dtype=np.int32)
@@ -204,6 +207,36 @@ class Cube:
         check(self.ctx.lib.rdr_raytrace(self.ctx.handle, self.handle, C.byref(rays.struct), float(ht), float(zref), float(max_seg),
                                         ptr(wet), ptr(hyd), None, None), self.ctx.handle)
         return wet, hyd, None, None
+
+    def raytrace_slices(self, rays, hts, zref, max_seg=1000.0, out=None, want_partition=True):
+        """The height loop of _build_cube_ray (delay.py:256-323) in one launch pair: every slice hts[s] of the same origins is
+        integrated exactly as raytrace() would integrate it alone (own level table, slice maxima, nParts, z-clamp decision).
+        `rays`: a GRID / LLH batch; when built with slices=S its look-vector / incidence arrays hold one block per slice.
+        Returns (wet[S,...], hydro[S,...], K[S], nparts[S, nz-1], flags[S]); the last three are None when want_partition is
+        False (fully asynchronous for device arrays).  K[s] == 0: build_ray -> None for that slice (its delays are 0)."""
+        rays.adopt_stream(self.ctx)
+        hts = f64(np.atleast_1d(hts)).ravel()
+        S = hts.size
+        if rays.slices not in (0, S):
+            raise ValueError(f'the ray batch carries look vectors for {rays.slices} slices, {S} heights were given')
+        if out is not None:
+            wet, hyd = out
+        elif rays._torch_device is not None:
+            import torch
+            wet = torch.empty((S,) + tuple(rays.shape), dtype=torch.float64, device=rays._torch_device)
+            hyd = torch.empty_like(wet)
+        else:
+            wet = np.empty((S,) + tuple(rays.shape)); hyd = np.empty_like(wet)
+        rays.check_outputs(wet, hyd)
+        ld = self.shape[2] - 1
+        if want_partition:
+            K = np.zeros(S, dtype=np.int32); nparts = np.zeros((S, ld), dtype=np.int32); flags = np.zeros(S, dtype=np.int32)
+            check(self.ctx.lib.rdr_raytrace_slices(self.ctx.handle, self.handle, C.byref(rays.struct), ptr(hts), S, int(rays.slices > 0), float(zref),
+                                                   float(max_seg), ptr(wet), ptr(hyd), ptr(K), ptr(nparts), ld, ptr(flags)), self.ctx.handle)
+            return wet, hyd, K, nparts, flags
+        check(self.ctx.lib.rdr_raytrace_slices(self.ctx.handle, self.handle, C.byref(rays.struct), ptr(hts), S, int(rays.slices > 0), float(zref),
+                                               float(max_seg), ptr(wet), ptr(hyd), None, None, ld, None), self.ctx.handle)
+        return wet, hyd, None, None, None
 
     def __del__(self):
         try:
@@ -224,26 +257,79 @@ class Rays:
         self.shape = ()
         self._torch_device = None
         self._keep_tensor = None
+        self._has_host = False
+        self.slices = 0          # > 0: the look-vector / incidence / heading arrays hold one block of n rays per height slice
 
     def _set(self, field, arr):
+        """Every array of a batch lives in ONE place (the C struct has a single `loc`): all NumPy, or all tensors on one GPU.
+        A mixed batch gets its NumPy arrays uploaded to the tensors' device."""
         if arr is None:
             return
         if _is_dev(arr):
-            self._torch_device = arr.device
-            self._keep_tensor = arr
-            assert arr.is_contiguous()
-            self._keep.append(arr)
-            setattr(self.struct, field, arr.data_ptr())
-        else:
-            a = f64(arr)
-            self._keep.append(a)
-            setattr(self.struct, field, a.ctypes.data)
+            import torch
+            if arr.dtype != torch.float64:
+                raise TypeError(f'ray arrays must be float64 (got {arr.dtype} for {field})')
+            if self._torch_device is not None and arr.device != self._torch_device:
+                raise ValueError(f'ray arrays live on different devices ({self._torch_device} and {arr.device})')
+            if not arr.is_cuda:
+                arr = arr.numpy()                      # a CPU tensor is a host array
+            else:
+                if self._has_host:
+                    self._upload_host_fields(arr.device)
+                self._torch_device = arr.device
+                self._keep_tensor = arr
+                if not arr.is_contiguous():
+                    arr = arr.contiguous()
+                self._keep.append(arr)
+                setattr(self.struct, field, arr.data_ptr())
+                return
+        a = f64(arr)
+        if self._torch_device is not None:
+            import torch
+            t = torch.from_numpy(a).to(self._torch_device)
+            self._keep.append(t)
+            setattr(self.struct, field, t.data_ptr())
+            return
+        self._has_host = True
+        self._keep.append((field, a))
+        setattr(self.struct, field, a.ctypes.data)
+
+    def _upload_host_fields(self, device):
+        import torch
+        kept = []
+        for item in self._keep:
+            if isinstance(item, tuple):
+                field, a = item
+                t = torch.from_numpy(a).to(device)
+                setattr(self.struct, field, t.data_ptr())
+                kept.append(t)
+            else:
+                kept.append(item)
+        self._keep = kept
+        self._has_host = False
+
+    def check_outputs(self, *outs):
+        """Output arrays must live where the batch lives (a NumPy output handed to a device batch would be written through a
+        host pointer by the kernels)."""
+        for o in outs:
+            if o is None:
+                continue
+            dev = _is_dev(o) and getattr(o, 'is_cuda', False)
+            if dev != (self._torch_device is not None):
+                raise ValueError('output arrays must be ' + ('tensors on ' + str(self._torch_device) if self._torch_device is not None else 'NumPy arrays') +
+                                 ' for this ray batch')
+            if dev and (o.device != self._torch_device or not o.is_contiguous()):
+                raise ValueError('output tensors must be contiguous and on the device of the ray batch')
+            if not dev and not (isinstance(o, np.ndarray) and o.dtype == np.float64 and o.flags.c_contiguous):
+                raise ValueError('output arrays must be C-contiguous float64 NumPy arrays')
 
     @classmethod
-    def grid(cls, xpts, ypts, los=None, inc=None, hd=None, zenith=False):
+    def grid(cls, xpts, ypts, los=None, inc=None, hd=None, zenith=False, slices=0):
         """Origins on meshgrid(xpts, ypts) (delay.py:242).  LOS: `los` (ny,nx,3) ECEF unit vectors, or
-        inc/hd (scalars or (ny,nx) arrays, degrees), or zenith."""
+        inc/hd (scalars or (ny,nx) arrays, degrees), or zenith.  slices=S: los / inc / hd carry a leading slice axis of
+        length S (look vectors that depend on the slice height; Cube.raytrace_slices)."""
         r = cls()
+        r.slices = int(slices)
         nx = xpts.numel() if _is_dev(xpts) else np.size(xpts)
         ny = ypts.numel() if _is_dev(ypts) else np.size(ypts)
         r.struct.origin_mode = L.ORIGIN_GRID
@@ -274,10 +360,11 @@ class Rays:
 
     def _set_los(self, los, inc, hd, zenith):
         n = self.struct.n
+        mult = max(self.slices, 1)
         if los is not None:
             cnt = los.numel() if _is_dev(los) else np.size(los)
-            if cnt != 3 * n:
-                raise ValueError(f'look vectors must have shape {self.shape + (3,)}')
+            if cnt != 3 * n * mult:
+                raise ValueError(f'look vectors must have shape {((mult,) if self.slices else ()) + tuple(self.shape) + (3,)}')
             self.struct.los_mode = L.LOS_VEC
             self._set('los', los)
         elif zenith:
@@ -290,10 +377,11 @@ class Rays:
                 self.struct.inc0, self.struct.hd0 = float(inc), float(hd)
             else:
                 one_heading = np.ndim(hd) == 0 and not _is_dev(hd)          # incidence raster + one heading: no heading array
+                full = ((mult,) if self.slices else ()) + tuple(self.shape)
                 if not _is_dev(inc):
-                    inc = np.broadcast_to(np.asarray(inc, dtype=np.float64), self.shape)
-                    if not one_heading:
-                        hd = np.broadcast_to(np.asarray(hd, dtype=np.float64), self.shape)
+                    inc = np.broadcast_to(np.asarray(inc, dtype=np.float64), full)
+                    if not one_heading and not _is_dev(hd):
+                        hd = np.broadcast_to(np.asarray(hd, dtype=np.float64), full)
                     if inc.min() < 0:
                         raise ValueError('inc_hd_to_enu: Incidence angle cannot be less than 0')
                 self.struct.los_mode = L.LOS_INC_HD
@@ -304,6 +392,8 @@ class Rays:
                     self._set('hd', hd)
         else:
             raise ValueError('a ray batch needs look vectors, inc/heading, or zenith=True')
+        if self._torch_device is not None and self._has_host:
+            self._upload_host_fields(self._torch_device)
         self.struct.loc = L.RDR_DEVICE if self._torch_device is not None else L.RDR_HOST
 
     def adopt_stream(self, ctx):

@@ -95,16 +95,29 @@ class Conventional(LOS):
             return inc_hd_to_enu(self._inc, hd)
         if self._file is None:
             raise ValueError('LOS file not set')
+        # losreader.py:116-121: try the file as a 2-band LOS raster first; anything rasterio cannot open (OSError / TypeError,
+        # exactly what the reference catches) is taken for an orbit / state-vector file.  Without rasterio the raster route
+        # does not exist: say so if the orbit parsers then reject the file, instead of blaming its format.
         try:
             import rasterio
-            with rasterio.open(self._file) as src:
-                data = src.read()
-            return inc_hd_to_enu(*data)
-        except (ImportError, OSError, TypeError):
-            pass
+        except ImportError:
+            rasterio = None
+        if rasterio is not None:
+            try:
+                with rasterio.open(self._file) as src:
+                    data = src.read()
+                return inc_hd_to_enu(*data)
+            except (OSError, TypeError):
+                pass
         # otherwise treat it as an orbit / state-vector file (losreader.py:122-128)
         from .orbits import get_sv
-        svs = np.stack(get_sv(self._file, self._time, self._pad), axis=-1)
+        try:
+            svs = np.stack(get_sv(self._file, self._time, self._pad), axis=-1)
+        except ValueError as e:
+            if rasterio is None:
+                raise ImportError(f'{self._file} is not an orbit / state-vector file ({e}); reading it as an ISCE line-of-sight '
+                                  'raster needs rasterio, which is not installed') from e
+            raise
         return state_to_los(svs, [self._lats, self._lons, self._heights])
 
     def __call__(self, delays):
@@ -176,6 +189,23 @@ class Raytracing(LOS):
             xx, yy = np.meshgrid(xpts, ypts)
             xyz = np.stack(lla2ecef(yy, xx, np.full(yy.shape, float(ht))), axis=-1)
             return Rays.grid(xpts, ypts, los=self._orbit.look_vectors(xyz))
+        if self._lv is not None:
+            return Rays.grid(xpts, ypts, los=self._lv)
+        return Rays.grid(xpts, ypts, inc=self._inc, hd=self._hd)
+
+    def ray_batch_slices(self, xpts, ypts, hts):
+        """Engine fast path for the whole height loop of _build_cube_ray: ONE `Rays` batch covering every slice.  Look vectors
+        given as arrays / incidence + heading are the same for every height (as in getLookVectors); orbit-based ones depend on
+        the target height (losreader.py:219-255) and are solved for all slices in one zero-Doppler launch."""
+        from .engine import Rays
+        hts = np.atleast_1d(np.asarray(hts, dtype=np.float64))
+        if self._lv is None and self._inc is None:
+            if self._orbit is None:
+                raise ValueError('The orbit has not been set (call setTime)')
+            from .utilFcns import lla2ecef
+            xx, yy = np.meshgrid(xpts, ypts)
+            xyz = np.stack([np.stack(lla2ecef(yy, xx, np.full(yy.shape, float(h))), axis=-1) for h in hts], axis=0)
+            return Rays.grid(xpts, ypts, los=self._orbit.look_vectors(xyz), slices=hts.size)
         if self._lv is not None:
             return Rays.grid(xpts, ypts, los=self._lv)
         return Rays.grid(xpts, ypts, inc=self._inc, hd=self._hd)
