@@ -83,6 +83,7 @@ def main():
     ap.add_argument('--coll-device', action='store_true', help='keep collective tensors on the GPU even with --backend gloo (dry run of the async path)')
     ap.add_argument('--backend', type=str, default='auto', help='torch.distributed backend for N>1: nccl (= RCCL), gloo, or auto = nccl when every rank has '
                                                                 'its own GPU, else gloo with device-resident collective tensors (ranks sharing a GPU: RCCL refuses duplicates)')
+    ap.add_argument('--dump', type=str, default='', help='write this rank\'s slab of the hydrostatic / wet delays to <dump>.rank<r>.npz (tests)')
     ap.add_argument('--cpu-sample', type=int, default=640, help='edge of the square ray block timed on the CPU oracle (0 = skip)')
     args = ap.parse_args()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -204,6 +205,8 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
+    if args.dump:
+        np.savez(f'{args.dump}.rank{rank}.npz', wet=out_w.cpu().numpy(), hydro=out_h.cpu().numpy(), nparts=np.asarray(nparts))
     nan_frac = float(torch.isnan(out_h).double().mean().item())
     mean_h = float(torch.nanmean(out_h).item()); mean_w = float(torch.nanmean(out_w).item())
 

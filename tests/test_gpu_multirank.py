@@ -1,0 +1,39 @@
+"""GPU: the N > 1 path of bench.py, launched exactly as the driver launches N = 1 (`python bench.py --gpus N ...`): bench.py
+re-executes itself through torch.distributed.run.  On a 1-GPU box the two ranks share the device (RCCL refuses two ranks on one
+GPU, so the collectives go through gloo on device-resident tensors - the same code path, rdr_ray_prepass_device ->
+all_reduce(MAX) -> rdr_ray_march_device, as with nccl on an 8-GPU node)."""
+import json
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _bench(tmp_path, tag, *args):
+    out = subprocess.run([sys.executable, str(ROOT / 'bench.py'), '--steps', '2', '--warmup', '1', '--cpu-sample', '0', '--cols', '1200',
+                          '--dump', str(tmp_path / tag)] + list(args), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-4000:])
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_self_launches_two_ranks_and_matches_one_rank(tmp_path):
+    """`python bench.py --gpus 2` (no torchrun): two ranks trace the two halves of a 1400x1200 scene with ONE MAX all-reduce of
+    the K+4-element partition per step; the concatenated slabs equal the single-rank result of the whole scene bit for bit
+    (delay.py:283 semantics across ranks), which shard-local nParts would not give (golden g5b)."""
+    one = _bench(tmp_path, 'one', '--gpus', '1', '--rows', '1400')
+    two = _bench(tmp_path, 'two', '--gpus', '2', '--rows', '700')
+    assert one['n_gpus'] == 1 and two['n_gpus'] == 2 and two['config']['ranks'] == 2
+    assert two['config']['rays_per_gpu'] == 700 * 1200 and two['value'] > 0 and two['scaling'] == 'weak'
+    assert two['config']['backend'] in ('nccl', 'gloo')
+    a = np.load(tmp_path / 'one.rank0.npz')
+    b0, b1 = np.load(tmp_path / 'two.rank0.npz'), np.load(tmp_path / 'two.rank1.npz')
+    assert np.array_equal(a['nparts'], b0['nparts']) and np.array_equal(a['nparts'], b1['nparts'])
+    assert np.array_equal(a['hydro'], np.concatenate([b0['hydro'], b1['hydro']])) and np.array_equal(a['wet'], np.concatenate([b0['wet'], b1['wet']]))
+    assert np.isfinite(a['hydro']).all()

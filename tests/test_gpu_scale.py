@@ -118,27 +118,89 @@ def test_config2_conventional_1000(R, era5):
     np.testing.assert_allclose(conv(hyd[0]), hyd[0] / np.cos(np.radians(39.0)), rtol=1e-15)
 
 
-def test_config5_blend_and_stations(R):
-    """configs[4]-like: HRRR-sized 1000x1000x50 f32 cubes, two-epoch blend, 5 M station points (sampled check):
-    gather(blend) == the oracle RGI on the f32-blended cube; and == w1*gather(a)+w2*gather(b) to f32 rounding."""
+def test_config4_full_size_one_gpu(R, era5):
+    """configs[3]: the 10000x10000 scene (1e8 rays) BASELINE shards over 8 GPUs, here on ONE (23 GB of ray records fit the
+    default workspace): finite everywhere, the reference's nParts, four blocks against the oracle driven with the whole-slice
+    partition, and an 8 GiB workspace (the slice integrated in 3 chunks) == the unchunked result bit for bit."""
+    import torch
+    dev = torch.device('cuda')
+    ctx = R.Context.default()
+    rows = cols = 10000
+    xpts, ypts, inc_cols = _scene(rows, cols)
+    hd = -167.9
+    zref = float(era5['zs'].max() - 1)
+    cube = R.Cube(era5['ys'], era5['xs'], era5['zs'], era5['wet'], era5['hydro'], order='zyx')
+    xt, yt = torch.from_numpy(xpts).to(dev), torch.from_numpy(ypts).to(dev)
+    inc = torch.from_numpy(np.ascontiguousarray(np.broadcast_to(inc_cols, (rows, cols)))).to(dev)
+    rays = R.Rays.grid(xt, yt, inc=inc, hd=hd)
+    wet = torch.empty((rows, cols), dtype=torch.float64, device=dev); hyd = torch.empty_like(wet)
+    _, _, nparts, flags = cube.raytrace(rays, 0.0, zref, out=(wet, hyd))
+    assert int(nparts.sum()) == 178 and len(nparts) == 76
+    assert bool(torch.isfinite(wet).all()) and bool(torch.isfinite(hyd).all())
+    for r0, c0 in ((0, 0), (rows - 20, cols - 20), (6321, 2777), (9000, 16)):
+        ow, oh = _oracle_block(era5, xpts[c0:c0 + 20], ypts[r0:r0 + 20], np.broadcast_to(inc_cols[c0:c0 + 20], (20, 20)), hd, zref, nparts)
+        np.testing.assert_allclose(wet[r0:r0 + 20, c0:c0 + 20].cpu().numpy(), ow, rtol=0, atol=TIGHT)
+        np.testing.assert_allclose(hyd[r0:r0 + 20, c0:c0 + 20].cpu().numpy(), oh, rtol=0, atol=TIGHT)
+    w2 = torch.empty_like(wet); h2 = torch.empty_like(wet)
+    ctx.set_workspace_limit(8 << 30)
+    try:
+        _, _, np2, _ = cube.raytrace(rays, 0.0, zref, out=(w2, h2))
+    finally:
+        ctx.set_workspace_limit(48 << 30)
+    assert np.array_equal(np2, nparts) and torch.equal(w2, wet) and torch.equal(h2, hyd)
+
+
+HRRR = dict(lat_1=38.5, lat_2=38.5, lat_0=38.5, lon_0=262.5 - 360.0, a=6371229.0, es=0.0)       # models/hrrr.py:248-259
+
+
+def test_config5_lcc_blend_stations_and_rays(R):
+    """configs[4] as SURVEY 8(d) specifies it: HRRR-like 1000x1000x50 f32 cubes on the 3-km Lambert-conformal-conic grid
+    (x = -1.5e6 + 3000 i, y = -1.5e6 + 3000 j, 50 quadratic levels to 26 km), two epochs blended (0.25, 0.75), 5 M station
+    points given in lon/lat (projected on the device), and a ray-traced 2000x2000 scene through the same blended cube.
+    gather(blend) == the oracle RGI on the f32-blended cube at the oracle's own LCC coordinates; ray blocks == the oracle with
+    the cube's projection (delay.py:253,295) driven with the whole-slice partition."""
     rng = np.random.default_rng(3)
-    ys = np.linspace(30, 45, 1000); xs = np.linspace(-125, -100, 1000); zs = np.round(-100 + 26100 * np.linspace(0, 1, 50) ** 2, 3)
-    base = 300 * np.exp(-zs / 8000)[:, None, None]
-    e = [(base * (1 + 0.05 * rng.standard_normal((50, 1000, 1000)))).astype(np.float32) for _ in range(4)]
-    a = R.Cube(ys, xs, zs, e[0], e[1], order='zyx'); b = R.Cube(ys, xs, zs, e[2], e[3], order='zyx')
-    w1, w2 = O.time_weights(2700.0, 0.0, 3600.0)
+    xs = -1.5e6 + 3000.0 * np.arange(1000); ys = -1.5e6 + 3000.0 * np.arange(1000)
+    zs = np.round(-100 + 26100 * np.linspace(0, 1, 50) ** 2, 3)
+    hyd0 = 270 * np.exp(-zs / 8000)[:, None, None]; wet0 = 60 * np.exp(-zs / 2000)[:, None, None]
+    e = [(hyd0 * (1 + 0.01 * rng.standard_normal((1, 1000, 1000)))).astype(np.float32) if k % 2 else
+         (wet0 * (1 + 0.1 * rng.standard_normal((1, 1000, 1000)))).astype(np.float32) for k in range(4)]      # wet_a, hydro_a, wet_b, hydro_b
+    a = R.Cube(ys, xs, zs, e[0], e[1], order='zyx').set_projection_lcc(**HRRR)
+    b = R.Cube(ys, xs, zs, e[2], e[3], order='zyx').set_projection_lcc(**HRRR)
+    w1, w2 = 0.25, 0.75
     m = a.blend(w1, b, w2)
-    n = 5_000_000
-    pts = np.stack([rng.uniform(30.5, 44.5, n), rng.uniform(-124, -101, n), rng.uniform(0, 4000, n)], -1)
-    gw, gh = m.interp(pts)
-    assert np.isfinite(gw).all()
-    idx = rng.choice(n, 20000, replace=False)
+    assert m.projection == a.projection
     bw = O.blend_cubes(w1, e[0], w2, e[2]); bh = O.blend_cubes(w1, e[1], w2, e[3])
+    # ---- 5 M stations in lon/lat, inside the grid
+    n = 5_000_000
+    lat = rng.uniform(28.0, 49.0, n); lon = rng.uniform(-110.0, -85.0, n); hgt = rng.uniform(0, 4000, n)
+    py, px = m.project(lat, lon)
+    assert px.min() > xs[0] and px.max() < xs[-1] and py.min() > ys[0] and py.max() < ys[-1]
+    gw, gh = m.interp(np.stack([py, px, hgt], -1))
+    assert np.isfinite(gw).all() and np.isfinite(gh).all()
+    idx = rng.choice(n, 20000, replace=False)
+    ox, oy = O.lcc_forward(lat[idx], lon[idx], **HRRR)
+    np.testing.assert_allclose(px[idx], ox, rtol=0, atol=2e-6); np.testing.assert_allclose(py[idx], oy, rtol=0, atol=2e-6)
     iw, ih = O.getInterpolators(xs, ys, zs, bw, bh)
-    np.testing.assert_allclose(gw[idx], iw(pts[idx]), rtol=0, atol=1e-11)
-    np.testing.assert_allclose(gh[idx], ih(pts[idx]), rtol=0, atol=1e-11)
-    aw, _ = a.interp(pts[idx]); cw, _ = b.interp(pts[idx])
-    np.testing.assert_allclose(gw[idx], w1 * aw + w2 * cw, rtol=3e-7)
+    q = np.stack([oy, ox, hgt[idx]], -1)
+    np.testing.assert_allclose(gw[idx], iw(q), rtol=0, atol=1e-8)          # (2e-6 m of projection difference x the field's gradient)
+    np.testing.assert_allclose(gh[idx], ih(q), rtol=0, atol=1e-8)
+    # ---- 2000 x 2000 rays through the blended LCC cube
+    rows = cols = 2000
+    lonp = np.linspace(-104.0, -92.0, cols); latp = np.linspace(44.0, 33.0, rows)
+    inc_cols = 30.0 + 16.0 * (np.arange(cols) / float(cols)); hd = -167.9
+    zref = float(zs.max() - 1)
+    inc = np.ascontiguousarray(np.broadcast_to(inc_cols, (rows, cols)))
+    wet, hyd, nparts, _ = m.raytrace(R.Rays.grid(lonp, latp, inc=inc, hd=hd), 0.0, zref)
+    assert np.isfinite(wet).all() and np.isfinite(hyd).all()
+    ip = list(O.getInterpolators(xs, ys, zs, bw, bh))
+    for r0, c0 in ((0, 0), (rows - 12, cols - 12), (777, 1234)):
+        incb = np.broadcast_to(inc_cols[c0:c0 + 12], (12, 12))
+        look = lambda ht_, llh, xyz, yy: O.look_vectors_from_inc_hd(incb, np.full(yy.shape, hd), llh[1], llh[0], llh[2])
+        ow, oh = O.build_cube_ray(lonp[c0:c0 + 12], latp[r0:r0 + 12], np.array([0.0]), look, ip, MAX_TROPO_HEIGHT=zref,
+                                  nParts_override=[nparts], model_proj=HRRR)
+        np.testing.assert_allclose(wet[r0:r0 + 12, c0:c0 + 12], ow[0], rtol=0, atol=TIGHT)
+        np.testing.assert_allclose(hyd[r0:r0 + 12, c0:c0 + 12], oh[0], rtol=0, atol=TIGHT)
 
 
 # ---- edge cases -----------------------------------------------------------------------------------------------
