@@ -438,16 +438,17 @@ int rdr_cube_blend(rdr_ctx* c, const rdr_cube* a, double w1, const rdr_cube* b, 
     q->ys = a->ys; q->xs = a->xs; q->zs = a->zs; q->proj = a->proj;
     int rc = cube_alloc(c, q);
     if (rc) { rdr_cube_destroy(q); return rc; }
-    const int64_t total = a->ny * a->nx * a->nz;
-    const int g = grid_for(total, 256, c->num_cus * 8);
+    const int64_t nscal = 2 * a->ny * a->nx * a->nz;                  // (wet, hydro) pairs as one flat array
+    const int vec = a->dtype == RDR_F32 ? 4 : 2;
+    const int g = grid_for((nscal / vec + 3) / 4, 256, c->num_cus * 16);
     {
         KTimer t(c, 3);
         if (a->dtype == RDR_F32)
-            hipLaunchKernelGGL((blend_kernel<float, float2>), dim3(g), dim3(256), 0, c->stream, (const float2*)a->d_vals, (float)w1,
-                               (const float2*)b->d_vals, (float)w2, (float2*)q->d_vals, total);
+            hipLaunchKernelGGL((blend_kernel<float>), dim3(g), dim3(256), 0, c->stream, (const float*)a->d_vals, (float)w1,
+                               (const float*)b->d_vals, (float)w2, (float*)q->d_vals, nscal);
         else
-            hipLaunchKernelGGL((blend_kernel<double, double2>), dim3(g), dim3(256), 0, c->stream, (const double2*)a->d_vals, w1,
-                               (const double2*)b->d_vals, w2, (double2*)q->d_vals, total);
+            hipLaunchKernelGGL((blend_kernel<double>), dim3(g), dim3(256), 0, c->stream, (const double*)a->d_vals, w1,
+                               (const double*)b->d_vals, w2, (double*)q->d_vals, nscal);
     }
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);

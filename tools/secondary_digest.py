@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""gpurun_out/secondary (tools/profile_secondary.sh) -> profiles/r02_secondary.json + r02_secondary_kernel_stats.txt: per secondary
+kernel the rocprofv3 average duration, the SURVEY 8(d) algorithmic bytes and the resulting rate against the 8 TB/s HBM peak."""
+import csv
+import glob
+import json
+import subprocess
+import sys
+from pathlib import Path
+
+REPO = Path(__file__).resolve().parent.parent
+src = REPO / 'gpurun_out' / 'secondary'
+line = [ln for ln in (src / 'bench.json').read_text().splitlines() if ln.startswith('{')][-1]
+res = json.loads(line)
+stats = glob.glob(str(src / 'kt') + '/**/*kernel_stats.csv', recursive=True)[0]
+subprocess.run([sys.executable, str(REPO / 'tools' / 'rocprof_summary.py'), stats, str(REPO / 'profiles' / 'r02_secondary_kernel_stats.txt'),
+                'tools/secondary_bench.py: configs 2 / 5 sizes, producer, orbit look vectors'], check=True, stdout=subprocess.DEVNULL)
+rows = list(csv.DictReader(open(stats)))
+for k, d in res.items():
+    cand = [r for r in rows if k in r['Name']]
+    if not cand:
+        continue
+    r = max(cand, key=lambda r: float(r['TotalDurationNs']))
+    avg = float(r['AverageNs']) * 1e-9
+    d['rocprof_kernel'] = r['Name'][:120]; d['rocprof_calls'] = int(r['Calls']); d['rocprof_avg_us'] = avg * 1e6
+    d['units_per_s'] = d['units'] / avg
+    d['algorithmic_GBps'] = d['units'] * d['bytes_per_unit'] / avg / 1e9
+    d['frac_of_hbm_peak_8TBps'] = d['algorithmic_GBps'] / 8000.0
+(REPO / 'profiles' / 'r02_secondary.json').write_text(json.dumps(res, indent=1) + '\n')
+for k, d in res.items():
+    print(f"{k:24s} {d.get('rocprof_avg_us', float('nan')):10.1f} us  {d.get('units_per_s', 0)/1e9:8.2f} G {d['unit']}/s  {d.get('algorithmic_GBps', 0):9.1f} GB/s  = {d.get('frac_of_hbm_peak_8TBps', 0):.3f} of 8 TB/s")
