@@ -132,6 +132,7 @@ int rdr_cube_axes(const rdr_cube* cube, double* ys, double* xs, double* zs);
  * HRRR's sphere (a = 6371229).  rdr_interp3 keeps taking points already in cube coordinates (scipy semantics). */
 #define RDR_PROJ_LONLAT 0
 #define RDR_PROJ_LCC 1
+#define RDR_PROJ_STERE 2   /* POLAR stereographic: params = {a, es, lat_0 (+-90), lat_ts (NaN: use k_0), k_0, lon_0, x_0, y_0} (HRRR-AK, models/hrrr.py:22-25) */
 int rdr_cube_set_projection(rdr_cube* cube, int kind, const double* params, int nparams);
 /* transformPoints (delay.py:404-436) for EPSG:4326 -> the cube's CRS: (lat, lon) deg -> (y, x) model coordinates */
 int rdr_project_points(rdr_ctx* ctx, const rdr_cube* cube, const double* lat, const double* lon, int64_t n, double* y, double* x, int loc);

@@ -390,6 +390,45 @@ def orbit_look_vectors(st, sp, sv, xyz, threshold=1.0e-7, maxiter=30):
 # ----------------------------------------------------------------------------------------------
 # cube builders
 # ----------------------------------------------------------------------------------------------
+def stere_forward(lat, lon, lat_0=90.0, lat_ts=None, k_0=1.0, lon_0=0.0, x_0=0.0, y_0=0.0, a=6371229.0, es=0.0):
+    """Geodetic -> POLAR stereographic (lat_0 = +-90), what pyproj does for a model on `+proj=stere` (HRRR-AK:
+    models/hrrr.py:22-25,359 `+proj=stere +lat_0=90 +lon_0=225 +lat_ts=60` on the sphere a = b = 6371229; call sites
+    delay.py:207-209,253,295).  Restates PROJ's published `stere` polar branch = Snyder (USGS PP 1395) 21-33 / 21-34 with
+    21-39 (true scale at lat_ts) or 21-33 (scale k_0 at the pole); the southern aspect mirrors latitude, as PROJ does.
+    PARITY WITH PROJ ITSELF IS UNPINNED (pyproj is not installed here); pinned on Snyder's numerical example (p. 315:
+    International ellipsoid, lat_ts = -71, lon_0 = -100, point (-75, 150) -> x = -1 540 033.6 m, y = -560 526.4 m).
+    Returns (x, y)."""
+    if abs(abs(lat_0) - 90.0) > 1e-9:
+        raise NotImplementedError('only the polar aspect of the stereographic projection (lat_0 = +-90)')
+    e = np.sqrt(es)
+    south = lat_0 < 0
+    sg = -1.0 if south else 1.0
+
+    def tsfn(phi):
+        s_ = np.sin(phi)
+        t_ = np.tan(0.5 * (np.pi / 2 - phi))
+        return t_ / ((1 - e * s_) / (1 + e * s_)) ** (0.5 * e) if e != 0 else t_
+    phi = sg * np.radians(np.asarray(lat, dtype=np.float64))
+    t = tsfn(phi)
+    if lat_ts is not None and abs(abs(lat_ts) - 90.0) > 1e-9:
+        pc = abs(np.radians(lat_ts))
+        mc = np.cos(pc) / np.sqrt(1 - es * np.sin(pc) ** 2)
+        rho = a * mc * t / tsfn(pc)
+    else:
+        rho = 2 * a * k_0 * t / np.sqrt((1 + e) ** (1 + e) * (1 - e) ** (1 - e))
+    dlam = np.radians(np.asarray(lon, dtype=np.float64)) - np.radians(lon_0)
+    dlam = np.where(dlam > np.pi, dlam - 2 * np.pi, np.where(dlam < -np.pi, dlam + 2 * np.pi, dlam))
+    return x_0 + rho * np.sin(dlam), y_0 - sg * rho * np.cos(dlam)
+
+
+def project_forward(lat, lon, model_proj):
+    """(x, y) of geodetic points in the model CRS given as a dict: {'proj': 'stere', ...stere_forward keywords} or
+    lcc_forward keywords (optionally with 'proj': 'lcc')."""
+    kw = dict(model_proj)
+    kind = kw.pop('proj', 'lcc')
+    return stere_forward(lat, lon, **kw) if kind == 'stere' else lcc_forward(lat, lon, **kw)
+
+
 def build_cube(xpts, ypts, zpts, interpolators, model_proj=None):
     """delay.py:196-216.  model_proj=None: model_crs == pts_crs (EPSG:4326 cube); else a dict of lcc_forward keyword
     arguments = the `transformPoints(yy, xx, ht, pts_crs, model_crs)` branch (delay.py:207-209) for an LCC model."""
@@ -397,7 +436,7 @@ def build_cube(xpts, ypts, zpts, interpolators, model_proj=None):
     zpts = np.asarray(zpts)
     out = [np.zeros((zpts.size, len(ypts), len(xpts))) for _ in interpolators]
     if model_proj is not None:
-        px, py = lcc_forward(yy, xx, **model_proj)
+        px, py = project_forward(yy, xx, model_proj)
         xx, yy = px, py
     for ii, ht in enumerate(zpts):
         pts = np.stack([yy, xx, np.full(yy.shape, ht)], axis=-1)
@@ -416,7 +455,7 @@ def integrate_slice(model_zs, ray_lengths, low_xyzs, high_xyzs, nParts, interpol
             pts_xyz = low_xyzs[zz] + ff * (high_xyzs[zz] - low_xyzs[zz])
             lon, lat, h = ecef2lla(pts_xyz[..., 0], pts_xyz[..., 1], pts_xyz[..., 2])
             if model_proj is not None:      # ecef_to_model = ECEF -> geodetic -> model CRS (delay.py:253,295)
-                lon, lat = lcc_forward(lat, lon, **model_proj)
+                lon, lat = project_forward(lat, lon, model_proj)
             pts = np.stack((lat, lon, h), axis=-1)
             if (pts[..., -1] < zmin).all():
                 pts[..., -1] = zmin

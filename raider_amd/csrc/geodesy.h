@@ -153,6 +153,28 @@ inline LccParams lcc_setup(double a, double es, double lat1_deg, double lat2_deg
     return L;
 }
 
+// Polar stereographic (PROJ `stere` with lat_0 = +-90; Snyder 21-33 / 21-34 / 21-39; HRRR-AK: models/hrrr.py:22-25,359) is the
+// cone of constant n = +1 (north) or -1 (south): rho = a m_c t / t_c (true scale at lat_ts) or 2 a k_0 t / sqrt((1+e)^(1+e)
+// (1-e)^(1-e)) (scale k_0 at the pole), theta = n (lam - lam0), x = x0 + rho sin(theta), y = y0 - rho cos(theta) - i.e. exactly
+// lcc_forward with rho0 = 0.  For the southern aspect t(phi)^-1 = t(-phi) does the mirroring and a NEGATIVE a F restores the
+// signs (x = |rho| sin(dlam), y = +|rho| cos(dlam)).  So every kernel that handles LCC cubes handles these unchanged.
+// lat_ts: NaN -> use k0.
+inline LccParams stere_setup(double a, double es, double lat0_deg, double lat_ts_deg, double k0, double lon0_deg, double x0, double y0) {
+    LccParams L;
+    L.kind = 1; L.e = sqrt(es); L.x0 = x0; L.y0 = y0; L.lam0 = lon0_deg * DEG_TO_RAD; L.rho0 = 0.0;
+    const bool south = lat0_deg < 0;
+    L.n = south ? -1.0 : 1.0;
+    double scale;
+    if (lat_ts_deg == lat_ts_deg && fabs(fabs(lat_ts_deg) - 90.0) > 1e-9) {
+        const double pc = fabs(lat_ts_deg) * DEG_TO_RAD;
+        scale = cos(pc) / sqrt(1.0 - es * sin(pc) * sin(pc)) / lcc_tsfn(pc, L.e);
+    } else {
+        scale = 2.0 * k0 / sqrt(pow(1.0 + L.e, 1.0 + L.e) * pow(1.0 - L.e, 1.0 - L.e));
+    }
+    L.aF = (south ? -1.0 : 1.0) * a * scale;
+    return L;
+}
+
 RDR_HD void lcc_forward(const LccParams& L, double lat_deg, double lon_deg, double& x, double& y) {
     const double phi = lat_deg * DEG_TO_RAD;
     double dlam = lon_deg * DEG_TO_RAD - L.lam0;

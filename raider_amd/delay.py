@@ -57,13 +57,12 @@ def _is_4326(crs):
     return _epsg(crs) == 4326
 
 
-def _lcc_params(crs):
-    """Lambert-conformal-conic parameters of a model CRS, or None.  Accepts a dict ({'proj': 'lcc', 'lat_1': ...}),
-    a PROJ string ('+proj=lcc +lat_1=... +a=... +b=...', models/hrrr.py:255-259), or a pyproj CRS."""
-    d = None
+def _crs_dict(crs):
+    """PROJ parameters of a CRS given as a dict, a PROJ string ('+proj=lcc +lat_1=... +a=... +b=...', models/hrrr.py:255-259,
+    '+proj=stere +lat_0=90 ...', models/hrrr.py:22-25) or a pyproj CRS; None when it cannot be taken apart."""
     if isinstance(crs, dict):
-        d = dict(crs)
-    elif isinstance(crs, str) and '+proj=' in crs:
+        return dict(crs)
+    if isinstance(crs, str) and '+proj=' in crs:
         d = {}
         for tok in crs.split():
             if tok.startswith('+') and '=' in tok:
@@ -72,13 +71,16 @@ def _lcc_params(crs):
                     d[k] = float(v)
                 except ValueError:
                     d[k] = v
-    elif pyproj is not None and hasattr(crs, 'to_dict'):
+        return d
+    if pyproj is not None and hasattr(crs, 'to_dict'):
         try:
-            d = crs.to_dict()
+            return crs.to_dict()
         except Exception:
-            d = None
-    if not d or d.get('proj') != 'lcc':
-        return None
+            return None
+    return None
+
+
+def _ellipsoid(d):
     a = float(d.get('a', d.get('R', 6378137.0)))
     if 'b' in d:
         b = float(d['b']); es = 1.0 - (b * b) / (a * a)
@@ -90,21 +92,51 @@ def _lcc_params(crs):
         es = 0.0 if 'R' in d or 'ellps' not in d else 0.0066943799901413165
     else:
         es = 0.0066943799901413165     # WGS84 default ellipsoid
+    return a, max(es, 0.0)
+
+
+def _lcc_params(crs):
+    """Lambert-conformal-conic parameters of a model CRS, or None."""
+    d = _crs_dict(crs)
+    if not d or d.get('proj') != 'lcc':
+        return None
+    a, es = _ellipsoid(d)
     lat_1 = float(d.get('lat_1', d.get('lat_0', 0.0)))
     return dict(lat_1=lat_1, lat_2=float(d.get('lat_2', lat_1)), lat_0=float(d.get('lat_0', 0.0)), lon_0=float(d.get('lon_0', 0.0)),
-                x_0=float(d.get('x_0', 0.0)), y_0=float(d.get('y_0', 0.0)), a=a, es=max(es, 0.0))
+                x_0=float(d.get('x_0', 0.0)), y_0=float(d.get('y_0', 0.0)), a=a, es=es)
+
+
+def _stere_params(crs):
+    """Polar-stereographic parameters of a model CRS (HRRR-AK, models/hrrr.py:22-25), or None.  The oblique aspect raises."""
+    d = _crs_dict(crs)
+    if not d or d.get('proj') not in ('stere', 'ups'):
+        return None
+    a, es = _ellipsoid(d)
+    lat_0 = float(d.get('lat_0', 0.0))
+    if abs(abs(lat_0) - 90.0) > 1e-9:
+        raise NotImplementedError(f'only the polar aspect of the stereographic projection is built in (lat_0 = +-90), got lat_0 = {lat_0}')
+    lat_ts = d.get('lat_ts')
+    return dict(lat_0=lat_0, lat_ts=None if lat_ts is None else float(lat_ts), k_0=float(d.get('k_0', d.get('k', 1.0))),
+                lon_0=float(d.get('lon_0', 0.0)), x_0=float(d.get('x_0', 0.0)), y_0=float(d.get('y_0', 0.0)), a=a, es=es)
 
 
 def _apply_model_crs(cube, model_crs):
-    """Make the device cube aware of a projected model CRS; returns True when queries must stay geodetic."""
+    """Make the device cube aware of the model CRS; returns True when the model is projected (queries must stay geodetic)."""
     if _is_4326(model_crs):
+        if cube.projection is not None:
+            cube.clear_projection()             # (a cached cube that served a projected model before)
         return False
     lcc = _lcc_params(model_crs)
-    if lcc is None:
-        return False
-    if cube.projection is None or {k: cube.projection.get(k) for k in lcc} != lcc:
-        cube.set_projection_lcc(**lcc)
-    return True
+    if lcc is not None:
+        if cube.projection is None or cube.projection.get('proj') != 'lcc' or {k: cube.projection.get(k) for k in lcc} != lcc:
+            cube.set_projection_lcc(**lcc)
+        return True
+    st = _stere_params(model_crs)
+    if st is not None:
+        if cube.projection is None or cube.projection.get('proj') != 'stere' or {k: cube.projection.get(k) for k in st} != st:
+            cube.set_projection_stere(**st)
+        return True
+    return False
 
 
 # ------------------------------------------------------------------------------------------------
@@ -227,15 +259,19 @@ def _cube_of(interpolators):
         return first.cube, [i.field for i in interpolators]
     if len(interpolators) > 2:
         raise ValueError('at most two interpolators (wet, hydro) are supported')
+    # cached upload, valid only for the SAME pair of interpolators still holding the SAME value arrays (an interpolator whose
+    # `.values` were replaced, or paired with a different partner, is uploaded again)
+    last = interpolators[-1]
+    key = (id(last), id(first.values), id(last.values), np.shape(first.values))
     cached = getattr(first, '_raider_amd_cube', None)
-    if cached is not None:
-        return cached, list(range(len(interpolators)))
+    if cached is not None and cached[0] == key:
+        return cached[1], list(range(len(interpolators)))
     grid = first.grid
     a = np.asarray(first.values)
-    b = np.asarray(interpolators[-1].values)
+    b = np.asarray(last.values)
     cube = Cube(grid[0], grid[1], grid[2], a, b.astype(a.dtype, copy=False), order='yxz')
     try:
-        first._raider_amd_cube = cube
+        first._raider_amd_cube = (key, cube)
     except AttributeError:
         pass
     return cube, list(range(len(interpolators)))
@@ -352,6 +388,8 @@ def _build_cube(xpts, ypts, zpts, model_crs, pts_crs, interpolators):
     """delay.py:196-216: zenith / projected cube, one trilinear gather of both fields per node."""
     cube, fields = _cube_of(interpolators)
     zpts = np.asarray(zpts)
+    if _is_4326(model_crs) and cube.projection is not None:
+        cube.clear_projection()                            # (a cached cube that served a projected model before)
     if _same_crs(model_crs, pts_crs) and cube.projection is None:
         res = cube.build_cube(xpts, ypts, zpts)            # points generated on the fly in the kernel
         return [res[f] for f in fields]
@@ -375,8 +413,8 @@ def _build_cube_ray(xpts, ypts, zpts, los, model_crs, pts_crs, interpolators, ou
     pass 2 = Newton level intersections + ECEF->geodetic + trilinear gather + trapezoid, per ray."""
     cube, fields = _cube_of(interpolators)
     if not _is_4326(model_crs) and not _apply_model_crs(cube, model_crs):
-        raise NotImplementedError('ray tracing needs the weather cube on an EPSG:4326 lat/lon grid or on a Lambert-conformal-'
-                                  f'conic grid (HRRR); got {model_crs!r}')
+        raise NotImplementedError('ray tracing needs the weather cube on an EPSG:4326 lat/lon grid, a Lambert-conformal-conic grid '
+                                  f'(HRRR) or a polar-stereographic grid (HRRR-AK); got {model_crs!r}')
     xpts = np.asarray(xpts, dtype=np.float64)
     ypts = np.asarray(ypts, dtype=np.float64)
     zpts = np.asarray(zpts)

@@ -88,6 +88,20 @@ class Cube:
         self.projection = dict(proj='lcc', lat_1=lat_1, lat_2=lat_2, lat_0=lat_0, lon_0=lon_0, x_0=x_0, y_0=y_0, a=a, es=es)
         return self
 
+    def set_projection_stere(self, lat_0=90.0, lat_ts=None, k_0=1.0, lon_0=0.0, x_0=0.0, y_0=0.0, a=6371229.0, es=0.0):
+        """The cube's x/y axes are POLAR stereographic metres (HRRR-AK: models/hrrr.py:22-25,359 `+proj=stere +lat_0=90
+        +lon_0=225 +lat_ts=60`, sphere a=6371229).  lat_ts=None: scale k_0 at the pole."""
+        p = np.array([a, es, lat_0, np.nan if lat_ts is None else lat_ts, k_0, lon_0, x_0, y_0], dtype=np.float64)
+        check(self.ctx.lib.rdr_cube_set_projection(self.handle, 2, ptr(p), p.size), self.ctx.handle)
+        self.projection = dict(proj='stere', lat_0=lat_0, lat_ts=lat_ts, k_0=k_0, lon_0=lon_0, x_0=x_0, y_0=y_0, a=a, es=es)
+        return self
+
+    def clear_projection(self):
+        """Back to a lon/lat (EPSG:4326) cube."""
+        check(self.ctx.lib.rdr_cube_set_projection(self.handle, 0, None, 0), self.ctx.handle)
+        self.projection = None
+        return self
+
     def project(self, lats, lons):
         """EPSG:4326 (lat, lon) -> the cube's (y, x) coordinates (identity for lon/lat cubes)."""
         lats, lons = np.broadcast_arrays(np.asarray(lats, dtype=np.float64), np.asarray(lons, dtype=np.float64))

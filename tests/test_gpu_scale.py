@@ -640,3 +640,77 @@ def test_build_cube_ray_batched_equals_slice_loop(R):
     assert not a[0][-1].any() and a[0][0].min() > 0
     with pytest.raises(TypeError):
         _build_cube_ray(xpts, ypts, np.array([0.0, zref + 5.0, 100.0]), los, 4326, 4326, fi, MAX_TROPO_HEIGHT=zref)
+
+
+AK = dict(lat_0=90.0, lat_ts=60.0, lon_0=225.0, a=6371229.0, es=0.0)          # HRRR-AK: models/hrrr.py:22-25,359
+
+
+def test_polar_stereographic_projection_on_device(R):
+    """rdr_cube_set_projection(RDR_PROJ_STERE) + rdr_project_points: Snyder's worked example (south polar, ellipsoid, lat_ts),
+    HRRR-AK's spherical north-polar CRS and the k_0 variant against the oracle restatement, poles included."""
+    ys, xs, zs = np.linspace(0.0, 1.0, 4), np.linspace(0.0, 1.0, 4), np.linspace(0.0, 1.0, 4)
+    cube = R.Cube(ys, xs, zs, np.zeros((4, 4, 4), np.float32), np.zeros((4, 4, 4), np.float32), order='zyx')
+    cube.set_projection_stere(lat_0=-90.0, lat_ts=-71.0, lon_0=-100.0, a=6378388.0, es=0.00672267)
+    y, x = cube.project(np.array([-75.0]), np.array([150.0]))
+    assert abs(x[0] - (-1540033.6)) < 0.05 and abs(y[0] - (-560526.4)) < 0.05
+    rng = np.random.default_rng(0)
+    for par, lat in ((AK, rng.uniform(40, 90, 2000)), (dict(lat_0=-90.0, lat_ts=-71.0, lon_0=0.0, a=6378137.0, es=0.0066943799901413165), rng.uniform(-90, -50, 2000)),
+                     (dict(lat_0=90.0, lat_ts=None, k_0=0.994, lon_0=-45.0, a=6378137.0, es=0.0066943799901413165), rng.uniform(45, 90, 2000))):
+        lon = rng.uniform(-180, 180, lat.size)
+        lat[:2] = par['lat_0']                                   # the pole itself
+        cube.set_projection_stere(**par)
+        y, x = cube.project(lat, lon)
+        ox, oy = O.stere_forward(lat, lon, **par)
+        np.testing.assert_allclose(x, ox, rtol=0, atol=2e-6); np.testing.assert_allclose(y, oy, rtol=0, atol=2e-6)
+    with pytest.raises(ValueError):
+        cube.set_projection_stere(lat_0=45.0, lat_ts=None, lon_0=0.0)            # oblique aspect: not built in
+
+
+@pytest.mark.parametrize('case', ['hrrr_ak_sphere', 'south_ellipsoid'])
+def test_raytrace_and_zenith_through_polar_stereographic_cube(R, case):
+    """The ray tracer and the zenith gather on a weather cube whose x / y axes are polar-stereographic metres (HRRR-AK's grid:
+    ecef_to_model = 4978 -> `+proj=stere`, delay.py:252-253,295): against the oracle with the same projection, 1e-9 m.  The
+    spherical north-polar cube takes the light ray path (relative projection, the cone of constant n = 1), the ellipsoidal
+    south-polar one the generic kernels."""
+    rng = np.random.default_rng(4)
+    if case == 'hrrr_ak_sphere':
+        par = dict(AK); lat_c, lon_c = 63.0, -150.0
+    else:
+        par = dict(lat_0=-90.0, lat_ts=-71.0, lon_0=0.0, a=6378137.0, es=0.0066943799901413165); lat_c, lon_c = -72.0, 40.0
+    c = O.synthetic_cube(40, 44, 36, seed=9, ztop=26000.0)
+    # a 3-km grid around the scene
+    cx, cy = O.stere_forward(lat_c, lon_c, **par)
+    xs = cx + 3000.0 * (np.arange(44) - 22); ys = cy + 3000.0 * (np.arange(40) - 20)
+    proj = dict(par, proj='stere')
+    cube = R.Cube(ys, xs, c['zs'], c['wet'], c['hydro'], order='zyx').set_projection_stere(**par)
+    ip = list(O.getInterpolators(xs, ys, c['zs'], c['wet'], c['hydro']))
+    ny, nx = 21, 26
+    dlat = 0.45; dlon = 0.45 / np.cos(np.radians(lat_c))
+    ypts = np.linspace(lat_c + dlat, lat_c - dlat, ny); xpts = np.linspace(lon_c - dlon, lon_c + dlon, nx)
+    inc = rng.uniform(18, 48, (ny, nx)); hd = rng.uniform(-180, 180, (ny, nx))
+    zref = float(c['zs'].max() - 1)
+    for ht in (0.0, 900.0):
+        look = lambda ht_, llh, xyz, yy: O.look_vectors_from_inc_hd(inc, hd, llh[1], llh[0], llh[2])
+        (ow, oh), onp = O.build_cube_ray(xpts, ypts, np.array([ht]), look, ip, MAX_TROPO_HEIGHT=zref, return_nparts=True, model_proj=proj)
+        wet, hyd, nparts, _ = cube.raytrace(R.Rays.grid(xpts, ypts, inc=inc, hd=hd), ht, zref)
+        assert np.array_equal(nparts, onp[0])
+        assert np.array_equal(np.isnan(wet), np.isnan(ow[0])) and np.isfinite(ow[0]).mean() > 0.6
+        np.testing.assert_allclose(wet, ow[0], rtol=0, atol=TIGHT, equal_nan=True)
+        np.testing.assert_allclose(hyd, oh[0], rtol=0, atol=TIGHT, equal_nan=True)
+    tot = R.Cube(ys, xs, c['zs'], c['wet_total'], c['hydro_total'], order='zyx').set_projection_stere(**par)
+    it = list(O.getInterpolators(xs, ys, c['zs'], c['wet_total'], c['hydro_total']))
+    zw, zh = tot.build_cube(xpts, ypts, np.array([0.0, 1500.0]))
+    ozw, ozh = O.build_cube(xpts, ypts, np.array([0.0, 1500.0]), it, model_proj=proj)
+    np.testing.assert_allclose(zw, ozw, rtol=0, atol=1e-11, equal_nan=True); np.testing.assert_allclose(zh, ozh, rtol=0, atol=1e-11, equal_nan=True)
+    # through the public API with the CRS given as the PROJ string the HRRR-AK model carries
+    from raider_amd.delay import _build_cube_ray
+    from raider_amd.delayFcns import FieldInterpolator
+    from raider_amd.losreader import Raytracing
+    crs = ('+proj=stere +lat_0={lat_0} +lon_0={lon_0} +lat_ts={lat_ts} +a={a} +b={b} +units=m'
+           .format(b=par['a'] * np.sqrt(1 - par['es']), **par))
+    cube2 = R.Cube(ys, xs, c['zs'], c['wet'], c['hydro'], order='zyx')
+    res = _build_cube_ray(xpts, ypts, np.array([0.0]), Raytracing(inc=inc, heading=hd), crs, 4326,
+                          [FieldInterpolator(cube2, 0), FieldInterpolator(cube2, 1)], MAX_TROPO_HEIGHT=zref)
+    (ow, oh) = O.build_cube_ray(xpts, ypts, np.array([0.0]), look, ip, MAX_TROPO_HEIGHT=zref, model_proj=proj)
+    np.testing.assert_allclose(res[0][0], ow[0], rtol=0, atol=TIGHT, equal_nan=True)
+    np.testing.assert_allclose(res[1][0], oh[0], rtol=0, atol=TIGHT, equal_nan=True)

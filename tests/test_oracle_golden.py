@@ -341,3 +341,32 @@ def test_wgs84_conversion_against_the_epsg_guidance_note_example():
     assert abs(x[0] - 3771793.968) < 1e-3 and abs(y[0] - 140253.342) < 1e-3 and abs(z[0] - 5124304.349) < 1e-3
     lo, la, hh = O.ecef2lla(np.array([3771793.968]), np.array([140253.342]), np.array([5124304.349]))
     assert abs(la[0] - lat) < 1e-8 and abs(lo[0] - lon) < 1e-8 and abs(hh[0] - h) < 1e-3
+
+
+def test_polar_stereographic_against_snyders_worked_example():
+    """Polar stereographic forward: J. P. Snyder, Map Projections - A Working Manual (USGS PP 1395, 1987), numerical example for
+    the ellipsoidal polar aspect with a latitude of true scale (p. 315): International ellipsoid (a = 6 378 388.0 m, e^2 =
+    0.00672267), lat_ts = -71, lon_0 = -100, point (75 S, 150 E) -> t = 0.1325120, t_c = 0.1684118, x = -1 540 033.6 m,
+    y = -560 526.4 m.  An authority independent of PROJ (which is absent here); plus the closed-form properties the
+    projection must have (pole -> origin, true scale on lat_ts, the meridian lon_0 maps to x = 0, north = mirrored south)."""
+    x, y = O.stere_forward(-75.0, 150.0, lat_0=-90.0, lat_ts=-71.0, lon_0=-100.0, a=6378388.0, es=0.00672267)
+    assert abs(x - (-1540033.6)) < 0.05 and abs(y - (-560526.4)) < 0.05
+    # HRRR-AK's own CRS (models/hrrr.py:22-25): sphere, lat_ts 60, lon_0 225
+    ak = dict(lat_0=90.0, lat_ts=60.0, lon_0=225.0, a=6371229.0, es=0.0)
+    x, y = O.stere_forward(90.0, 17.0, **ak)
+    assert abs(x) < 1e-6 and abs(y) < 1e-6
+    x, y = O.stere_forward(np.array([55.0, 70.0]), np.array([-135.0, -135.0]), **ak)                  # lon_0 = 225 = -135: on the central meridian
+    assert np.all(np.abs(x) < 1e-6) and np.all(y < 0) and y[0] < y[1]
+    # true scale on lat_ts: a small meridional step has the length R dphi, a small step along the parallel R cos(phi) dlam
+    d = 1e-6
+    x0, y0 = O.stere_forward(60.0, -150.0, **ak); x1, y1 = O.stere_forward(60.0 + d, -150.0, **ak); x2, y2 = O.stere_forward(60.0, -150.0 + d, **ak)
+    R0 = 6371229.0
+    assert abs(np.hypot(x1 - x0, y1 - y0) / (R0 * np.radians(d)) - 1) < 1e-6
+    assert abs(np.hypot(x2 - x0, y2 - y0) / (R0 * np.cos(np.radians(60.0)) * np.radians(d)) - 1) < 1e-6
+    # scale k_0 at the pole (variant A) on the sphere: rho = 2 R k0 tan(pi/4 - phi/2)
+    x, y = O.stere_forward(80.0, 90.0, lat_0=90.0, lat_ts=None, k_0=0.994, lon_0=0.0, a=R0, es=0.0)
+    assert abs(x - 2 * R0 * 0.994 * np.tan(np.radians(5.0))) < 1e-6 and abs(y) < 1e-6
+    # the southern aspect is the mirrored northern one
+    xn, yn = O.stere_forward(72.0, 33.0, lat_0=90.0, lat_ts=70.0, lon_0=-45.0, a=6378137.0, es=0.0066943799901413165)
+    xs_, ys_ = O.stere_forward(-72.0, 33.0, lat_0=-90.0, lat_ts=-70.0, lon_0=-45.0, a=6378137.0, es=0.0066943799901413165)
+    assert abs(xn - xs_) < 1e-6 and abs(yn + ys_) < 1e-6
