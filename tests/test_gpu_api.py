@@ -407,3 +407,37 @@ def test_wgs84_conversion_against_the_epsg_guidance_note_example():
     assert abs(x[0] - 3771793.968) < 1e-3 and abs(y[0] - 140253.342) < 1e-3 and abs(z[0] - 5124304.349) < 1e-3
     lo, la, hh = ecef2lla(np.array([3771793.968]), np.array([140253.342]), np.array([5124304.349]))
     assert abs(la[0] - lat) < 1e-8 and abs(lo[0] - lon) < 1e-8 and abs(hh[0] - h) < 1e-3
+
+
+def test_orbit_kernel_on_a_circular_orbit_closed_form_and_reference_state_vectors():
+    """orbit_los_kernel against anchors the builder did not write (tests/orbit_anchor.py): (a) a circular equatorial orbit, for
+    which the zero-Doppler azimuth time of ANY target is exactly lon / w, the range follows from the law of cosines and the
+    look vector in closed form (what stays is the Hermite error of a circle sampled every 10 s, 2e-4 m); (b) the Sentinel-1
+    state vectors of the reference's own fixture (test/test_losreader.py:20-92): with every other vector as the orbit, the
+    sensor position the kernel reports at zero Doppler (target + range x look vector) lies on the TRUE orbit through the
+    skipped vectors.  isce3's own interpolation order / solver tolerances stay unpinned."""
+    import datetime as dt
+    from tests import orbit_anchor as A
+    from raider_amd.orbits import Orbit
+    epoch = dt.datetime(2018, 11, 12, 23, 0, 2)
+    st, sp, sv = A.circular_orbit()
+    orb = Orbit([epoch + dt.timedelta(seconds=float(x)) for x in st], sp, sv)
+    T, t0, rg0, los0 = A.targets(np.random.default_rng(1), n=4000)
+    los, az, rg = orb.look_vectors(T, return_geometry=True)
+    assert np.isfinite(az).all()
+    az_rel = az - orb.time[0] if np.abs(az).max() > 1e4 else az                    # seconds on the orbit's own clock
+    assert np.abs(az_rel - t0).max() < 1e-6 and np.abs(rg - rg0).max() < 1e-3 and np.abs(los - los0).max() < 1e-8
+    # (b) real state vectors, every other one; targets placed at zero Doppler of the SKIPPED vectors
+    orb2 = Orbit([epoch + dt.timedelta(seconds=float(x)) for x in A.S1_T[::2]], A.S1_POS[::2], A.S1_VEL[::2])
+    for k in (1, 3, 5):
+        S, V = A.S1_POS[k], A.S1_VEL[k]
+        # a ground-ish target in the plane through S perpendicular to V (zero Doppler of that state vector), 35 deg off nadir
+        down = -S / np.linalg.norm(S)
+        side = np.cross(V, down); side /= np.linalg.norm(side)
+        dirn = np.cos(np.radians(35.0)) * down + np.sin(np.radians(35.0)) * side
+        dirn -= V * (dirn @ V) / (V @ V); dirn /= np.linalg.norm(dirn)
+        Tk = S + 850000.0 * dirn
+        l2, a2, r2 = orb2.look_vectors(Tk[None, :], return_geometry=True)
+        a2_rel = a2[0] - orb2.time[0] if abs(a2[0]) > 1e4 else a2[0]
+        assert abs(a2_rel - A.S1_T[k]) < 5e-6                                       # 2 cm of Hermite error / 7.5 km/s
+        assert np.abs(Tk + r2[0] * l2[0] - S).max() < 5e-2 and abs(r2[0] - 850000.0) < 2e-2

@@ -1,0 +1,123 @@
+"""CPU: raider_amd.h5write (HDF5 / NetCDF-4 writer) - round trip through raider_amd.h5lite and, where the image has it, validation by
+libhdf5 ITSELF (/opt/conda: h5dump + libhdf5_hl's dimension-scale API through ctypes), plus the layout of the reference's own
+processed-cube files (tests/golden/ref_files) reproduced variable for variable."""
+import ctypes as C
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from raider_amd import h5lite, h5write
+
+H5DUMP = shutil.which('h5dump') or ('/opt/conda/bin/h5dump' if os.path.exists('/opt/conda/bin/h5dump') else None)
+LIBHDF5 = '/opt/conda/lib/libhdf5.so'
+LIBHDF5_HL = '/opt/conda/lib/libhdf5_hl.so'
+
+
+def _cube_file(path, rng):
+    z = np.array([-100.0, 0.0, 250.0, 1000.0, 5000.0]); y = np.linspace(30, 31, 4); x = np.linspace(-100, -99, 3)
+    v = {'z': (('z',), z, {'axis': 'Z', 'units': 'm'}), 'y': (('y',), y, {'units': 'degrees_north'}), 'x': (('x',), x, {'units': 'degrees_east'}),
+         'wet': (('z', 'y', 'x'), rng.standard_normal((5, 4, 3)), {'units': 'm', 'description': 'wet delay', 'grid_mapping': 'crs'}),
+         'hydro': (('z', 'y', 'x'), rng.standard_normal((5, 4, 3)).astype(np.float32), {'units': 'm', 'grid_mapping': 'crs'}),
+         'latitude': (('y', 'x'), np.broadcast_to(y[:, None], (4, 3)).copy(), {}),
+         'crs': ((), np.array(-2147483647, dtype=np.int32), {'grid_mapping_name': 'latitude_longitude', 'semi_major_axis': 6378137.0,
+                                                             'crs_wkt': 'GEOGCRS["WGS 84",ID["EPSG",4326]]'})}
+    v['wet'][1][2, 1, 1] = np.nan
+    h5write.write_netcdf4(path, {'z': 5, 'y': 4, 'x': 3}, v, {'Conventions': 'CF-1.7', 'title': 'RAiDER geo cube'})
+    return v
+
+
+def test_roundtrip_through_the_reader(tmp_path):
+    rng = np.random.default_rng(0)
+    p = tmp_path / 'cube.nc'
+    v = _cube_file(p, rng)
+    assert open(p, 'rb').read(8) == b'\x89HDF\r\n\x1a\n'
+    f = h5lite.File(p)
+    assert sorted(f.keys()) == sorted(v)
+    for name, (dims, arr, attrs) in v.items():
+        d = f[name]
+        got = d.read()
+        assert got.dtype == np.asarray(arr).dtype and got.shape == np.shape(arr)
+        np.testing.assert_array_equal(got, arr)
+        a = d.attrs
+        for k, val in attrs.items():
+            if isinstance(val, str):
+                assert a[k] == val
+            else:
+                assert np.allclose(a[k], val)
+    assert f.attrs['Conventions'] == 'CF-1.7' and f.attrs['title'] == 'RAiDER geo cube' and f.attrs['_NCProperties'].startswith('version=2')
+    assert f['x'].attrs['CLASS'] == 'DIMENSION_SCALE' and f['x'].attrs['NAME'] == 'x' and int(f['x'].attrs['_Netcdf4Dimid']) == 2
+    assert list(f['wet'].attrs['_Netcdf4Coordinates']) == [0, 1, 2] and np.isnan(f['wet'].attrs['_FillValue']).all()
+
+
+def test_argument_checks(tmp_path):
+    with pytest.raises(ValueError, match='coordinate variable'):
+        h5write.write_netcdf4(tmp_path / 'a.nc', {'x': 3}, {'v': (('x',), np.zeros(3), {})})
+    with pytest.raises(ValueError, match='shape'):
+        h5write.write_netcdf4(tmp_path / 'a.nc', {'x': 3}, {'x': (('x',), np.zeros(3), {}), 'v': (('x',), np.zeros(4), {})})
+    with pytest.raises(ValueError, match='element type'):
+        h5write.write_netcdf4(tmp_path / 'a.nc', {'x': 3}, {'x': (('x',), np.array(['a', 'b', 'c']), {})})
+
+
+@pytest.mark.skipif(H5DUMP is None, reason='no h5dump in this image')
+def test_libhdf5_reads_the_file_h5dump(tmp_path):
+    """h5dump (libhdf5 1.10.6) walks the whole file - superblock, symbol table, every object header, the global heap behind
+    DIMENSION_LIST - and prints the values this writer was given."""
+    rng = np.random.default_rng(1)
+    p = tmp_path / 'cube.nc'
+    v = _cube_file(p, rng)
+    out = subprocess.run([H5DUMP, str(p)], capture_output=True, text=True)
+    assert out.returncode == 0 and 'error' not in out.stderr.lower(), out.stderr[-2000:]
+    txt = out.stdout
+    for name in v:
+        assert f'DATASET "{name}"' in txt
+    assert 'DATASPACE  SCALAR' in txt.split('DATASET "crs"')[1].split('DATA {')[0]            # the grid-mapping variable is a scalar
+    assert '(DATASET' in txt.split('ATTRIBUTE "DIMENSION_LIST"')[1][:400] and ' /z' in txt.split('ATTRIBUTE "DIMENSION_LIST"')[1][:400]
+    hdr = subprocess.run([H5DUMP, '-H', '-p', str(p)], capture_output=True, text=True).stdout
+    assert 'CONTIGUOUS' in hdr and 'H5T_IEEE_F64LE' in hdr and 'H5T_IEEE_F32LE' in hdr and 'H5D_FILL_TIME_IFSET' in hdr
+    one = subprocess.run([H5DUMP, '-d', '/hydro', '-w', '0', str(p)], capture_output=True, text=True).stdout
+    import re
+    body = re.sub(r'\([0-9,]+\):', ' ', one.split('DATA {')[1].split('}')[0])               # drop the (i,j,k): row labels
+    nums = [float(t) for t in body.replace(',', ' ').split()]
+    np.testing.assert_allclose(nums, v['hydro'][1].ravel(), rtol=1e-5)
+
+
+@pytest.mark.skipif(not (os.path.exists(LIBHDF5) and os.path.exists(LIBHDF5_HL)), reason='no libhdf5 in this image')
+def test_libhdf5_dimension_scale_api_accepts_the_netcdf4_dimensions(tmp_path):
+    """What netCDF-C does when it opens a NetCDF-4 file: H5DSis_scale on the coordinate variables, H5DSget_num_scales /
+    H5DSis_attached on the data variables (these walk DIMENSION_LIST and REFERENCE_LIST), H5Dread of the values."""
+    rng = np.random.default_rng(2)
+    p = tmp_path / 'cube.nc'
+    v = _cube_file(p, rng)
+    h5 = C.CDLL(LIBHDF5, mode=C.RTLD_GLOBAL); hl = C.CDLL(LIBHDF5_HL)
+    hid = C.c_int64
+    h5.H5open.restype = C.c_int
+    h5.H5Fopen.restype = hid; h5.H5Fopen.argtypes = [C.c_char_p, C.c_uint, hid]
+    h5.H5Dopen2.restype = hid; h5.H5Dopen2.argtypes = [hid, C.c_char_p, hid]
+    h5.H5Dread.restype = C.c_int; h5.H5Dread.argtypes = [hid, hid, hid, hid, hid, C.c_void_p]
+    h5.H5Dclose.argtypes = [hid]; h5.H5Fclose.argtypes = [hid]
+    hl.H5DSis_scale.restype = C.c_int; hl.H5DSis_scale.argtypes = [hid]
+    hl.H5DSget_num_scales.restype = C.c_int; hl.H5DSget_num_scales.argtypes = [hid, C.c_uint]
+    hl.H5DSis_attached.restype = C.c_int; hl.H5DSis_attached.argtypes = [hid, hid, C.c_uint]
+    assert h5.H5open() >= 0
+    f = h5.H5Fopen(str(p).encode(), 0, 0)
+    assert f >= 0
+    ds = {n: h5.H5Dopen2(f, n.encode(), 0) for n in v}
+    assert all(d >= 0 for d in ds.values())
+    for n in ('z', 'y', 'x'):
+        assert hl.H5DSis_scale(ds[n]) == 1
+    assert hl.H5DSis_scale(ds['wet']) == 0
+    for ax, n in enumerate(('z', 'y', 'x')):
+        assert hl.H5DSget_num_scales(ds['wet'], ax) == 1 and hl.H5DSget_num_scales(ds['hydro'], ax) == 1
+        assert hl.H5DSis_attached(ds['wet'], ds[n], ax) == 1
+        assert hl.H5DSis_attached(ds['wet'], ds[n], (ax + 1) % 3) == 0
+    assert hl.H5DSis_attached(ds['latitude'], ds['y'], 0) == 1 and hl.H5DSis_attached(ds['latitude'], ds['x'], 1) == 1
+    native_double = hid.in_dll(h5, 'H5T_NATIVE_DOUBLE_g').value
+    buf = np.empty((5, 4, 3))
+    assert h5.H5Dread(ds['wet'], native_double, 0, 0, 0, buf.ctypes.data_as(C.c_void_p)) >= 0
+    np.testing.assert_array_equal(buf, v['wet'][1])
+    for d in ds.values():
+        h5.H5Dclose(d)
+    h5.H5Fclose(f)

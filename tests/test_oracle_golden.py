@@ -370,3 +370,21 @@ def test_polar_stereographic_against_snyders_worked_example():
     xn, yn = O.stere_forward(72.0, 33.0, lat_0=90.0, lat_ts=70.0, lon_0=-45.0, a=6378137.0, es=0.0066943799901413165)
     xs_, ys_ = O.stere_forward(-72.0, 33.0, lat_0=-90.0, lat_ts=-70.0, lon_0=-45.0, a=6378137.0, es=0.0066943799901413165)
     assert abs(xn - xs_) < 1e-6 and abs(yn + ys_) < 1e-6
+
+
+def test_orbit_solver_restatement_on_a_circular_orbit_and_the_reference_state_vectors():
+    """tests/orbit_anchor.py: the oracle's zero-Doppler restatement against the closed form of a circular orbit (azimuth time
+    lon / w, law-of-cosines range, look vector), and its Hermite interpolant against the Sentinel-1 state vectors of the
+    reference's own fixture (every other vector predicts the skipped ones)."""
+    from tests import orbit_anchor as A
+    st, sp, sv = A.circular_orbit()
+    T, t0, rg0, los0 = A.targets(np.random.default_rng(0))
+    los, t, rg = O.orbit_look_vectors(st, sp, sv, T)
+    assert np.isfinite(t).all()
+    assert np.abs(t - t0).max() < 1e-6 and np.abs(rg - rg0).max() < 1e-3 and np.abs(los - los0).max() < 1e-8
+    # Hermite through vectors 0, 2, 4, 6 (20 s apart) at the times of 1, 3, 5: a 4th-order interpolant of a 7 km/s orbit
+    pos, vel = O.orbit_hermite(A.S1_T[::2], A.S1_POS[::2], A.S1_VEL[::2], A.S1_T[1:6:2])
+    assert np.abs(pos - A.S1_POS[1:6:2]).max() < 2e-2 and np.abs(vel - A.S1_VEL[1:6:2]).max() < 2e-3
+    # and through ALL of them it reproduces the nodes and stays on the orbit in between (radius / speed vary smoothly)
+    pos, vel = O.orbit_hermite(A.S1_T, A.S1_POS, A.S1_VEL, A.S1_T)
+    assert np.abs(pos - A.S1_POS).max() < 1e-6 and np.abs(vel - A.S1_VEL).max() < 1e-9
