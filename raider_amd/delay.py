@@ -204,26 +204,39 @@ class DelayCube:
         except KeyError:
             raise AttributeError(k)
 
-    def to_netcdf(self, path):
-        """The delay-cube file of delay.py:329-401 / cli/raider.py (ds.to_netcdf) as NetCDF-3 (64-bit offset) through scipy:
-        dims z, y, x; variables wet, hydro (f64, units m, grid_mapping crs), coordinate variables, the integer `crs`
-        grid-mapping variable and the global attributes.  (NetCDF-4 output needs netCDF4/h5py, which the reference gets
-        from xarray; when xarray is installed writeResultsToXarray returns a real Dataset instead of this class.)"""
-        from scipy.io import netcdf_file
+    def to_netcdf(self, path, format='NETCDF4'):
+        """The delay-cube file of delay.py:329-401 / cli/raider.py:373-398 (`ds.to_netcdf`): dims z, y, x; variables wet, hydro (f64,
+        units m, grid_mapping crs), coordinate variables, the integer `crs` grid-mapping variable and the global attributes.
+        format='NETCDF4' (what the reference writes): HDF5 through raider_amd.h5write; 'NETCDF3_64BIT': classic format through
+        scipy.  (When xarray is installed writeResultsToXarray returns a real Dataset instead of this class.)"""
         v = self.variables
+        degrees = self.attrs.get('_degrees', True)
+        desc = str(self.attrs.get('description', '')).replace('RAiDER geo cube - ', '')
+        gattrs = {k: str(val) for k, val in self.attrs.items() if not k.startswith('_')}   # (_degrees / _crs_cf steer the writer)
+        coord_attrs = {'z': dict(axis='Z', units='m', description='height above ellipsoid'),
+                       'y': dict(units='degrees_north', standard_name='latitude', long_name='latitude') if degrees else
+                            dict(axis='Y', standard_name='projection_y_coordinate', long_name='y-coordinate in projected coordinate system', units='m'),
+                       'x': dict(units='degrees_east', standard_name='longitude', long_name='longitude') if degrees else
+                            dict(axis='X', standard_name='projection_x_coordinate', long_name='x-coordinate in projected coordinate system', units='m')}
+        if format.upper().startswith('NETCDF4'):
+            from .h5write import write_netcdf4
+            variables = {d: ((d,), np.asarray(v[d], dtype=np.float64), coord_attrs[d]) for d in ('z', 'y', 'x')}
+            for name, long in (('wet', 'wet'), ('hydro', 'hydrostatic')):
+                variables[name] = (('z', 'y', 'x'), np.asarray(v[name], dtype=np.float64),
+                                   dict(units='m', description=f'{long} {desc} delay', grid_mapping='crs'))
+            variables['crs'] = ((), np.array(-2147483647, dtype=np.int64), dict(self.attrs.get('_crs_cf') or {}))
+            write_netcdf4(path, {d: int(np.size(v[d])) for d in ('z', 'y', 'x')}, variables, gattrs)
+            return str(path)
+        from scipy.io import netcdf_file
         with netcdf_file(str(path), 'w', version=2) as f:
-            for k, val in self.attrs.items():
-                if not k.startswith('_'):                      # (_degrees / _crs_cf steer the writer, they are not file attributes)
-                    setattr(f, k, str(val))
+            for k, val in gattrs.items():
+                setattr(f, k, val)
             for d in ('z', 'y', 'x'):
                 f.createDimension(d, int(np.size(v[d])))
                 cv = f.createVariable(d, 'f8', (d,))
                 cv[:] = np.asarray(v[d], dtype=np.float64)
-            f.variables['z'].axis = 'Z'; f.variables['z'].units = 'm'; f.variables['z'].description = 'height above ellipsoid'
-            degrees = self.attrs.get('_degrees', True)
-            f.variables['y'].units = 'degrees_north' if degrees else 'm'
-            f.variables['x'].units = 'degrees_east' if degrees else 'm'
-            desc = str(self.attrs.get('description', '')).replace('RAiDER geo cube - ', '')
+                for k, val in coord_attrs[d].items():
+                    setattr(cv, k, val)
             for name, long in (('wet', 'wet'), ('hydro', 'hydrostatic')):
                 dv = f.createVariable(name, 'f8', ('z', 'y', 'x'))
                 dv[:] = np.asarray(v[name], dtype=np.float64)
@@ -232,6 +245,7 @@ class DelayCube:
             crs.data[()] = -2147483647
             for k, val in (self.attrs.get('_crs_cf') or {}).items():
                 setattr(crs, k, val)
+        return str(path)
 
 
 def _is_cube_aoi(aoi):

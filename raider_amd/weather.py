@@ -53,14 +53,14 @@ class ProcessedModel:
         if k in ('wet_total', 'hydro_total'): return np.ascontiguousarray(self.total.read()[k == 'hydro_total'].transpose(2, 0, 1))
         raise KeyError(k)
 
-    def to_netcdf(self, path, time=None, model_name='ERA-5'):
+    def to_netcdf(self, path, time=None, model_name='ERA-5', format='NETCDF4'):
         """The processed weather-model file of WeatherModel.write (weatherModel.py:659-724): dims z, y, x; variables wet, hydro
         (f32), wet_total, hydro_total (f64) - and t, p, e (f32) when the model was produced with return_state=True - with the
         reference's units / standard_name / grid_mapping attributes, 2-D latitude / longitude, the `proj` grid-mapping variable
-        carrying `crs_wkt`, and the global attributes.  Written as NetCDF-3 (64-bit offset) through scipy - readable by xarray /
-        netCDF4 and by this package's own tropo_delay / getInterpolators; the reference writes NetCDF-4 through xarray."""
+        carrying `crs_wkt`, and the global attributes.  format='NETCDF4' (what the reference writes through xarray): HDF5 via
+        raider_amd.h5write, coordinate variables typed as in the reference's files (x, y f32; z f64); 'NETCDF3_64BIT': classic
+        format through scipy.  Either is read back by tropo_delay / getInterpolators, xarray and netCDF4."""
         import datetime as dt
-        from scipy.io import netcdf_file
         if not isinstance(self.proj, int) or self.proj != 4326:
             raise NotImplementedError('ProcessedModel.to_netcdf: only EPSG:4326 models carry a crs_wkt here (no pyproj in the image)')
         ys, xs, zs = self.pointwise.grid
@@ -70,17 +70,38 @@ class ProcessedModel:
                   ('wet_total', wt, 'f8', 'm', 'total_wet_refractivity'), ('hydro_total', ht, 'f8', 'm', 'total_hydrostatic_refractivity')]
         if self.t is not None:
             fields = [('t', self.t, 'f4', 'K', 'temperature'), ('p', self.p, 'f4', 'Pa', 'pressure'), ('e', self.e, 'f4', 'Pa', 'humidity')] + fields
+        gattrs = dict(Conventions='CF-1.6', title='Weather model data and delay calculations', model_name=str(model_name))
+        if time is not None:
+            gattrs['datetime'] = time.strftime('%Y_%m_%dT%H_%M_%S')
+        gattrs['date_created'] = dt.datetime.now().strftime('%Y_%m_%dT%H_%M_%S')
+        crs_wkt = ('GEOGCRS["WGS 84",DATUM["World Geodetic System 1984",ELLIPSOID["WGS 84",6378137,298.257223563,LENGTHUNIT["metre",1]]],'
+                   'PRIMEM["Greenwich",0,ANGLEUNIT["degree",0.0174532925199433]],CS[ellipsoidal,2],AXIS["geodetic latitude (Lat)",north,'
+                   'ORDER[1],ANGLEUNIT["degree",0.0174532925199433]],AXIS["geodetic longitude (Lon)",east,ORDER[2],'
+                   'ANGLEUNIT["degree",0.0174532925199433]],ID["EPSG",4326]]')
+        proj_attrs = dict(crs_wkt=crs_wkt, semi_major_axis=6378137.0, semi_minor_axis=6356752.314245179, inverse_flattening=298.257223563,
+                          reference_ellipsoid_name='WGS 84', longitude_of_prime_meridian=0.0, prime_meridian_name='Greenwich',
+                          geographic_crs_name='WGS 84', horizontal_datum_name='World Geodetic System 1984', grid_mapping_name='latitude_longitude')
+        lon2, lat2 = np.meshgrid(xs, ys)
+        if format.upper().startswith('NETCDF4'):
+            from .h5write import write_netcdf4
+            # (the reference's files carry x / y as float32 because its ERA-5 axes ARE float32; axes that are not exactly
+            # representable in float32 stay float64 - a rounded axis would move every interpolation weight)
+            f32_exact = lambda a: bool(np.array_equal(np.asarray(a, np.float32).astype(np.float64), np.asarray(a, np.float64)))
+            hdt = np.float32 if (f32_exact(xs) and f32_exact(ys)) else np.float64
+            variables = {'z': (('z',), np.asarray(zs, np.float64), {}), 'y': (('y',), np.asarray(ys, hdt), {}), 'x': (('x',), np.asarray(xs, hdt), {}),
+                         'latitude': (('y', 'x'), lat2.astype(hdt), {}), 'longitude': (('y', 'x'), lon2.astype(hdt), {})}
+            for name, arr, typ, units, std in fields:
+                variables[name] = (('z', 'y', 'x'), zyx(arr).astype(typ), dict(units=units, standard_name=std, grid_mapping='proj', coordinates='latitude longitude'))
+            variables['proj'] = ((), np.array(0, dtype=np.int64), proj_attrs)
+            write_netcdf4(path, dict(z=np.size(zs), y=np.size(ys), x=np.size(xs)), variables, gattrs)
+            return str(path)
+        from scipy.io import netcdf_file
         with netcdf_file(str(path), 'w', version=2) as f:
-            f.Conventions = 'CF-1.6'
-            f.title = 'Weather model data and delay calculations'
-            f.model_name = str(model_name)
-            if time is not None:
-                f.datetime = time.strftime('%Y_%m_%dT%H_%M_%S')
-            f.date_created = dt.datetime.now().strftime('%Y_%m_%dT%H_%M_%S')
+            for k, v in gattrs.items():
+                setattr(f, k, v)
             for d, v in (('z', zs), ('y', ys), ('x', xs)):
                 f.createDimension(d, int(np.size(v)))
                 f.createVariable(d, 'f8', (d,))[:] = np.asarray(v, dtype=np.float64)
-            lon2, lat2 = np.meshgrid(xs, ys)
             f.createVariable('latitude', 'f8', ('y', 'x'))[:] = lat2
             f.createVariable('longitude', 'f8', ('y', 'x'))[:] = lon2
             for name, arr, typ, units, std in fields:
@@ -89,13 +110,8 @@ class ProcessedModel:
                 v.units = units; v.standard_name = std; v.grid_mapping = 'proj'
             pj = f.createVariable('proj', 'i4', ())
             pj.data[()] = 0
-            pj.crs_wkt = ('GEOGCRS["WGS 84",DATUM["World Geodetic System 1984",ELLIPSOID["WGS 84",6378137,298.257223563,LENGTHUNIT["metre",1]]],'
-                          'PRIMEM["Greenwich",0,ANGLEUNIT["degree",0.0174532925199433]],CS[ellipsoidal,2],AXIS["geodetic latitude (Lat)",north,'
-                          'ORDER[1],ANGLEUNIT["degree",0.0174532925199433]],AXIS["geodetic longitude (Lon)",east,ORDER[2],'
-                          'ANGLEUNIT["degree",0.0174532925199433]],ID["EPSG",4326]]')
-            pj.grid_mapping_name = 'latitude_longitude'
-            pj.semi_major_axis = 6378137.0; pj.inverse_flattening = 298.257223563; pj.longitude_of_prime_meridian = 0.0
-            pj.reference_ellipsoid_name = 'WGS 84'
+            for k, v in proj_attrs.items():
+                setattr(pj, k, v)
         return str(path)
 
     def interpolators(self, kind='pointwise'):

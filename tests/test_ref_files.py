@@ -66,8 +66,32 @@ def test_two_epoch_blend_reproduces_the_reference_product(golden):
         assert out.dtype == g[f'interp_{v}'].dtype and np.array_equal(out, g[f'interp_{v}']), v
 
 
+def test_delay_cube_netcdf4_roundtrip(tmp_path):
+    """DelayCube.to_netcdf writes NetCDF-4 (HDF5) by default, as the reference's `ds.to_netcdf` does (delay.py:329-401 ->
+    cli/raider.py:373-398): read back through the built-in reader, and by the delay path as a cube source."""
+    from raider_amd import h5lite
+    from raider_amd.delay import writeResultsToXarray, DelayCube
+    rng = np.random.default_rng(0)
+    x, y, z = np.linspace(-118, -117, 5), np.linspace(34, 33, 4), np.array([0.0, 500.0, 1000.0])
+    wet, hyd = rng.normal(size=(3, 4, 5)), rng.normal(size=(3, 4, 5))
+    ds = writeResultsToXarray(dt.datetime(2020, 1, 1, 12), x, y, z, 4326, wet, hyd, 'ERA5_x.nc', 'slant - raytracing')
+    if not isinstance(ds, DelayCube):
+        pytest.skip('xarray is installed here: writeResultsToXarray returned a real Dataset')
+    path = tmp_path / 'delay.nc'
+    ds.to_netcdf(path)
+    assert open(path, 'rb').read(4) == b'\x89HDF'
+    f = h5lite.File(path)
+    assert np.array_equal(f['wet'].read(), wet) and np.array_equal(f['hydro'].read(), hyd) and np.array_equal(f['y'].read(), y)
+    assert f['wet'].attrs['grid_mapping'] == 'crs' and f['wet'].attrs['units'] == 'm' and f['hydro'].attrs['description'] == 'hydrostatic slant - raytracing delay'
+    assert f.attrs['description'] == 'RAiDER geo cube - slant - raytracing' and f['crs'].attrs['grid_mapping_name'] == 'latitude_longitude'
+    assert f['z'].attrs['CLASS'] == 'DIMENSION_SCALE' and f['y'].attrs['units'] == 'degrees_north' and int(f['crs'].read()) == -2147483647
+    from raider_amd.delayFcns import _load_fields
+    var, get = _load_fields(str(path))
+    assert np.array_equal(get('hydro'), hyd)
+
+
 def test_delay_cube_netcdf3_roundtrip(tmp_path):
-    """DelayCube.to_netcdf (the shim's delay-cube writer, delay.py:329-401 layout) -> scipy reads it back"""
+    """DelayCube.to_netcdf(format='NETCDF3_64BIT') (the classic-format variant of the delay-cube writer) -> scipy reads it back"""
     from scipy.io import netcdf_file
     from raider_amd.delay import writeResultsToXarray, DelayCube
     rng = np.random.default_rng(0)
@@ -77,7 +101,7 @@ def test_delay_cube_netcdf3_roundtrip(tmp_path):
     if not isinstance(ds, DelayCube):
         pytest.skip('xarray is installed here: writeResultsToXarray returned a real Dataset')
     path = tmp_path / 'delay.nc'
-    ds.to_netcdf(path)
+    ds.to_netcdf(path, format='NETCDF3_64BIT')
     with netcdf_file(str(path), 'r', mmap=False) as f:
         assert f.variables['wet'].dimensions == ('z', 'y', 'x')
         assert np.array_equal(f.variables['wet'][:], wet) and np.array_equal(f.variables['hydro'][:], hyd)
@@ -310,16 +334,34 @@ def test_gpu_producer_chain_from_raw_era5_file(raw, proc):
 
 @pytest.mark.gpu
 def test_processed_model_file_roundtrip(tmp_path):
-    """ProcessedModel.to_netcdf writes the processed-cube layout of WeatherModel.write (as NetCDF-3): read back by path it gives the
-    same delays as the device-resident model, and its variables / attributes are the reference's."""
+    """ProcessedModel.to_netcdf writes the processed-cube file of WeatherModel.write - NetCDF-4 by default, NetCDF-3 on request: read
+    back by path either gives the same delays as the device-resident model; the NetCDF-4 file has the reference's own file
+    (tests/golden/ref_files, written by the real RAiDER through xarray) as its template: same variables, element types, shapes,
+    per-variable attribute names and values."""
     from scipy.io import netcdf_file
+    from raider_amd import h5lite
     from raider_amd.delay import GridAOI, tropo_delay
     from raider_amd.losreader import Raytracing, Zenith
     from raider_amd.weather import load_ecmwf_model_levels
     d = Path(__file__).parent / 'golden' / 'ref_files'
     model = load_ecmwf_model_levels(d / 'ERA-5_2019_11_17_T20_51_58.nc', return_state=True)
     when = dt.datetime(2019, 11, 17, 20, 51, 58)
-    path = model.to_netcdf(tmp_path / 'ERA-5_2019_11_17_T20_51_58_5S_2S_41W_37W.nc', time=when)
+    path4 = model.to_netcdf(tmp_path / 'ERA-5_2019_11_17_T20_51_58_5S_2S_41W_37W.nc', time=when)
+    mine, ref = h5lite.File(path4), h5lite.File(d / 'ERA-5_2019_11_17_T20_51_58_5S_2S_41W_37W.nc')
+    assert set(mine.keys()) == set(ref.keys()) - {'datetime'}                      # (the scalar time coordinate xarray adds is not written)
+    for k in mine.keys():
+        a, b = mine[k], ref[k]
+        assert a.shape == b.shape and a.dtype == b.dtype, k
+        drop = {'_Netcdf4Dimid', 'coordinates', 'grid_mapping'} if k in ('proj',) else {'_Netcdf4Dimid'}
+        assert set(a.attrs) - {'_Netcdf4Dimid'} >= set(b.attrs) - drop - {'REFERENCE_LIST', 'DIMENSION_LIST'}, (k, set(a.attrs), set(b.attrs))
+        for an in ('units', 'standard_name', 'grid_mapping', 'CLASS', 'NAME', 'grid_mapping_name', 'crs_wkt', 'semi_major_axis', 'inverse_flattening'):
+            if an in b.attrs:
+                va, vb = a.attrs[an], b.attrs[an]
+                assert (va == vb) if isinstance(vb, str) else np.allclose(va, vb), (k, an, va, vb)
+    for k in ('x', 'y', 'z', 'latitude', 'longitude'):
+        assert np.array_equal(mine[k].read(), ref[k].read()), k
+    assert {'Conventions', 'title', 'datetime', 'date_created', '_NCProperties'} <= set(mine.attrs) and mine.attrs['datetime'] == ref.attrs['datetime']
+    path = model.to_netcdf(tmp_path / 'classic.nc', time=when, format='NETCDF3_64BIT')
     with netcdf_file(path, 'r', mmap=False) as f:
         assert set(f.variables) >= {'x', 'y', 'z', 't', 'p', 'e', 'wet', 'hydro', 'wet_total', 'hydro_total', 'latitude', 'longitude', 'proj'}
         assert f.variables['wet'].dimensions == ('z', 'y', 'x') and f.variables['wet'].data.dtype.itemsize == 4 and f.variables['wet_total'].data.dtype.itemsize == 8
@@ -329,6 +371,7 @@ def test_processed_model_file_roundtrip(tmp_path):
     aoi = GridAOI(x[2:-2], y[2:-2][::-1])
     for los in (Zenith(), Raytracing(inc=35.0, heading=-167.9)):
         a, _ = tropo_delay(when, model, aoi, los, [0.0, 1200.0], 4326, None)
-        b, _ = tropo_delay(when, path, aoi, los, [0.0, 1200.0], 4326, None)
-        assert np.array_equal(np.asarray(a['hydro'][:]), np.asarray(b['hydro'][:]), equal_nan=True)
-        assert np.array_equal(np.asarray(a['wet'][:]), np.asarray(b['wet'][:]), equal_nan=True) and np.isfinite(np.asarray(a['hydro'][:])).any()
+        for pth in (path, path4):
+            b, _ = tropo_delay(when, pth, aoi, los, [0.0, 1200.0], 4326, None)
+            assert np.array_equal(np.asarray(a['hydro'][:]), np.asarray(b['hydro'][:]), equal_nan=True)
+            assert np.array_equal(np.asarray(a['wet'][:]), np.asarray(b['wet'][:]), equal_nan=True) and np.isfinite(np.asarray(a['hydro'][:])).any()
