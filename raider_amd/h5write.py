@@ -296,6 +296,7 @@ def write_netcdf4(path, dims, variables, global_attrs=None, fill_floats=True):
             at += [('CLASS', 'DIMENSION_SCALE'), ('NAME', name)]
             if users[name]:
                 at.append(('REFERENCE_LIST', ReferenceList(users[name])))
+            at.append(('_Netcdf4Coordinates', np.array([dimid[name]], dtype=np.int32)))
             at.append(('_Netcdf4Dimid', np.int32(dimid[name])))
         elif vd:
             at.append(('DIMENSION_LIST', DimensionList(vd)))

@@ -74,13 +74,18 @@ class ProcessedModel:
         if time is not None:
             gattrs['datetime'] = time.strftime('%Y_%m_%dT%H_%M_%S')
         gattrs['date_created'] = dt.datetime.now().strftime('%Y_%m_%dT%H_%M_%S')
-        crs_wkt = ('GEOGCRS["WGS 84",DATUM["World Geodetic System 1984",ELLIPSOID["WGS 84",6378137,298.257223563,LENGTHUNIT["metre",1]]],'
-                   'PRIMEM["Greenwich",0,ANGLEUNIT["degree",0.0174532925199433]],CS[ellipsoidal,2],AXIS["geodetic latitude (Lat)",north,'
-                   'ORDER[1],ANGLEUNIT["degree",0.0174532925199433]],AXIS["geodetic longitude (Lon)",east,ORDER[2],'
-                   'ANGLEUNIT["degree",0.0174532925199433]],ID["EPSG",4326]]')
+        # EPSG:4326 as current PROJ releases spell it in WKT2:2019 (what pyproj's CRS.to_cf() puts into the reference's files)
+        crs_wkt = ('GEOGCRS["WGS 84",ENSEMBLE["World Geodetic System 1984 ensemble",MEMBER["World Geodetic System 1984 (Transit)"],'
+                   'MEMBER["World Geodetic System 1984 (G730)"],MEMBER["World Geodetic System 1984 (G873)"],MEMBER["World Geodetic System 1984 (G1150)"],'
+                   'MEMBER["World Geodetic System 1984 (G1674)"],MEMBER["World Geodetic System 1984 (G1762)"],MEMBER["World Geodetic System 1984 (G2139)"],'
+                   'ELLIPSOID["WGS 84",6378137,298.257223563,LENGTHUNIT["metre",1]],ENSEMBLEACCURACY[2.0]],PRIMEM["Greenwich",0,'
+                   'ANGLEUNIT["degree",0.0174532925199433]],CS[ellipsoidal,2],AXIS["geodetic latitude (Lat)",north,ORDER[1],'
+                   'ANGLEUNIT["degree",0.0174532925199433]],AXIS["geodetic longitude (Lon)",east,ORDER[2],ANGLEUNIT["degree",0.0174532925199433]],'
+                   'USAGE[SCOPE["Horizontal component of 3D system."],AREA["World."],BBOX[-90,-180,90,180]],ID["EPSG",4326]]')
         proj_attrs = dict(crs_wkt=crs_wkt, semi_major_axis=6378137.0, semi_minor_axis=6356752.314245179, inverse_flattening=298.257223563,
                           reference_ellipsoid_name='WGS 84', longitude_of_prime_meridian=0.0, prime_meridian_name='Greenwich',
-                          geographic_crs_name='WGS 84', horizontal_datum_name='World Geodetic System 1984', grid_mapping_name='latitude_longitude')
+                          geographic_crs_name='WGS 84', horizontal_datum_name='World Geodetic System 1984 ensemble', grid_mapping_name='latitude_longitude',
+                          grid_mapping='proj')      # (weatherModel.py:716-717 tags every data variable, `proj` included)
         lon2, lat2 = np.meshgrid(xs, ys)
         if format.upper().startswith('NETCDF4'):
             from .h5write import write_netcdf4

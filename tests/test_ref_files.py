@@ -352,7 +352,7 @@ def test_processed_model_file_roundtrip(tmp_path):
     for k in mine.keys():
         a, b = mine[k], ref[k]
         assert a.shape == b.shape and a.dtype == b.dtype, k
-        drop = {'_Netcdf4Dimid', 'coordinates', 'grid_mapping'} if k in ('proj',) else {'_Netcdf4Dimid'}
+        drop = {'_Netcdf4Dimid', 'coordinates'} if k in ('proj',) else {'_Netcdf4Dimid'}
         assert set(a.attrs) - {'_Netcdf4Dimid'} >= set(b.attrs) - drop - {'REFERENCE_LIST', 'DIMENSION_LIST'}, (k, set(a.attrs), set(b.attrs))
         for an in ('units', 'standard_name', 'grid_mapping', 'CLASS', 'NAME', 'grid_mapping_name', 'crs_wkt', 'semi_major_axis', 'inverse_flattening'):
             if an in b.attrs:
