@@ -195,20 +195,26 @@ __device__ const double RAY_POLY_VINV[PN][PN] = {   // [node j][power n]
 
 // proj.kind == 1: the cube lives on a Lambert-conformal-conic grid (HRRR) - the "lat" / "lon" polynomials are then fitted to
 // the projected northing / easting of the node points (ecef_to_model, delay.py:253,295), which are just as smooth along a ray.
+// Projection of a ray origin onto a spherical cone: rho = aF t^n with t = cos(phi) / (1 + sin(phi)) from the origin's own sine /
+// cosine - one log and one exp per LATITUDE - and sin / cos of theta = n (lam - lam0) - one sincos per LONGITUDE.  On a GRID batch
+// a tile has 16 of each: crossings_kernel computes them once per tile and shares them through LDS (lcc_rho / lcc_theta).
+__device__ __forceinline__ double lcc_rho(const LccParams& proj, double s0, double c0) { return proj.aF * exp(proj.n * log(c0 / (1.0 + s0))); }
+__device__ __forceinline__ void lcc_theta(const LccParams& proj, double lon_deg, double& st, double& ct) {
+    double dlam = lon_deg * DEG_TO_RAD - proj.lam0;
+    if (dlam > 3.141592653589793) dlam -= 6.283185307179586;
+    else if (dlam < -3.141592653589793) dlam += 6.283185307179586;
+    sincos(proj.n * dlam, &st, &ct);
+}
+
 template <bool LCC>
 __device__ __forceinline__ void fit_ray_poly(const RayBase& b, double ox, double oy, double oz, double lx, double ly, double lz,
-                                             double mid, double half, const LccParams& proj, RayPoly& q) {
+                                             double mid, double half, const LccParams& proj, const LccOrigin* shared_org, RayPoly& q) {
     double x0 = b.lon0, y0 = b.lat0;
     LccOrigin org = {0.0, 0.0, 0.0};
     if (LCC) {
-        // Spherical cone (the static classification sends every ray of an ELLIPSOIDAL LCC cube to the generic kernels):
-        // rho = aF t^n with t = cos(phi) / (1 + sin(phi)) from the base's own sine / cosine - one log, one exp and one sincos
-        // per ray instead of lcc_forward's sin, tan, pow and sincos.
-        double dlam = b.lon0 * DEG_TO_RAD - proj.lam0;
-        if (dlam > 3.141592653589793) dlam -= 6.283185307179586;
-        else if (dlam < -3.141592653589793) dlam += 6.283185307179586;
-        org.rho = proj.aF * exp(proj.n * log(b.c0 / (1.0 + b.s0)));
-        sincos(proj.n * dlam, &org.st, &org.ct);
+        // Spherical cone (the static classification sends every ray of an ELLIPSOIDAL LCC cube to the generic kernels)
+        if (shared_org) org = *shared_org;
+        else { org.rho = lcc_rho(proj, b.s0, b.c0); lcc_theta(proj, b.lon0, org.st, org.ct); }
         x0 = fma(org.rho, org.st, proj.x0);
         y0 = proj.y0 + proj.rho0 - org.rho * org.ct;
     }

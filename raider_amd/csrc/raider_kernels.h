@@ -460,7 +460,8 @@ struct RaySmem {
     unsigned long long* mxcol; // [nz][MXCOLS] per-level running maxima of the workgroup, one column per lane%MXCOLS (pass 1)
     double* step;           // [nz] 1/(nParts-1) (pass 2)
     double* hs;             // [nz] 0.5e-6/(nParts-1): half the trapezoid weight per unit of ray length (pass 2)
-    double* trig;           // [64] (sin, cos) of the tile's 16 row latitudes, then of its 16 column longitudes (pass 1, GRID rays)
+    double* trig;           // [64] (sin, cos) of the tile's 16 row latitudes, then of its 16 column longitudes (pass 1, GRID rays);
+                            // [64..112) LCC cubes: rho of the 16 rows, then (sin, cos) theta of the 16 columns
     double* xv;             // [nz] abscissa of level k's top in the crossing polynomial: (hi[k] - xmap[0]) / xmap[1]
     double* xmap;           // [2] centre and half width of the level-top range hi[1] .. hi[K-1]
     int* kz; int* np; int* K;
@@ -482,7 +483,7 @@ __device__ __forceinline__ RaySmem carve_smem(unsigned char* raw, int ny, int nx
     m.step = reinterpret_cast<double*>(m.mxcol + (size_t)nz * MXCOLS);
     m.hs = m.step + nz;
     m.trig = m.hs + nz;
-    m.xv = m.trig + 64;
+    m.xv = m.trig + 112;
     m.xmap = m.xv + nz;
     m.kz = reinterpret_cast<int*>(m.xmap + 2);
     m.np = m.kz + nz;
@@ -495,7 +496,7 @@ inline size_t ray_smem_bytes(int64_t ny, int64_t nx, int64_t nz, int exact_y, in
     return (size_t)table_nodes(ny, nx, nz, exact_y, exact_x) * 16     // axis tables
            + (size_t)nz * 8 * 2                   // lo, hi
            + (size_t)nz * 8 * MXCOLS              // mxcol
-           + (size_t)nz * 8 * 2 + 64 * 8          // step, hs, trig
+           + (size_t)nz * 8 * 2 + 112 * 8         // step, hs, trig
            + (size_t)nz * 8 + 16                  // xv, xmap
            + (size_t)nz * 4 * 2 + 16;             // kz, np, K
 }
@@ -518,7 +519,8 @@ __device__ __forceinline__ void fill_axes(const CubeView<T2>& c, const RaySmem& 
 
 // Level table of one slice (height ht): whenever a workgroup moves on to a tile of another slice.  Called by every thread.
 __device__ __forceinline__ int fill_levels(int nz, const RaySmem& m, double ht, double zref) {
-    const int tid = threadIdx.x;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
     __syncthreads();                                   // the previous slice's readers are done with the tables
     if (tid == 0) {
         const int K = build_levels(m.ax.ez, nz, ht, zref, m.lo, m.hi, m.kz);
@@ -554,6 +556,20 @@ struct TileWalk {
     }
 };
 
+// Sines / cosines (and, on a conic cube, the origin projection terms) of one of a tile's 16 row latitudes (lane < 16) or 16
+// column longitudes, into the tile's LDS table.  (Inlined on purpose: as a real call - tried to keep the libm constants from being
+// hoisted and spilled - the kernel returned corrupted slice flags on LCC cubes.)
+template <bool LCC>
+__device__ __forceinline__ void tile_trig(double v, int lane, const LccParams& proj, double* trig) {
+    double sv, cv;
+    sincos(v * DEG_TO_RAD, &sv, &cv);
+    trig[2 * lane] = sv; trig[2 * lane + 1] = cv;
+    if (LCC) {                                             // the origin's projection: per row / per column as well
+        if (lane < 16) trig[64 + lane] = lcc_rho(proj, sv, cv);
+        else { double st, ct; lcc_theta(proj, v, st, ct); trig[80 + 2 * (lane - 16)] = st; trig[81 + 2 * (lane - 16)] = ct; }
+    }
+}
+
 // ---- pass 1: per-ray set-up + level crossings (build_ray, losreader.py:772-835) ------------------------------------
 // Optional outputs (both may be on): the per-level batch maximum of the ray length + flags (what delay.py:283,306-311
 // reduce over the slice) and the workspace record for pass 2.
@@ -586,7 +602,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
     auto flush = [&]() {                                   // called by every thread of the workgroup
         if (!reduce || slice < 0) return;
         __syncthreads();
-        for (int k = tid; k < K; k += BLOCK) {
+        int tf = threadIdx.x;
+        asm volatile("" : "+v"(tf));                       // (opaque: no address derived from it is kept live across the tile loop)
+        for (int k = tf; k < K; k += BLOCK) {
             unsigned long long v = 0ULL;
 #pragma unroll
             for (int cc = 0; cc < MXCOLS; ++cc) v = max(v, m.mxcol[k * MXCOLS + cc]);
@@ -594,7 +612,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
         }
         int f = my_flags;
         for (int off = 32; off > 0; off >>= 1) f |= __shfl_xor(f, off, 64);
-        if ((tid & 63) == 0 && f) atomicOr(P.flags + slice, f);
+        if ((tf & 63) == 0 && f) atomicOr(P.flags + slice, f);
         my_flags = 0;
     };
     TileWalk walk(P.tile_count, P.tile_ctr, m.K + 2);
@@ -608,18 +626,24 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
             slice = sl;
             ht = P.hts ? P.hts[sl] : P.ht;
             K = fill_levels(c.nz, m, ht, P.zref);
-            if (reduce) for (int k = tid; k < K * MXCOLS; k += BLOCK) m.mxcol[k] = 0ULL;
+            int tz = threadIdx.x;
+            asm volatile("" : "+v"(tz));
+            if (reduce) for (int k = tz; k < K * MXCOLS; k += BLOCK) m.mxcol[k] = 0ULL;
             __syncthreads();
         }
+        // The thread index as the tile body sees it: an opaque per-tile copy, so that nothing derived from it (LDS addresses, record
+        // pointers, row / column offsets) is hoisted out of the tile loop and kept live - or spilled - across the polynomial fit.
+        int tl = threadIdx.x;
+        asm volatile("" : "+v"(tl));
         const int64_t lbase = (int64_t)sl * P.los_stride;  // this slice's block of the look-vector / incidence arrays
         int64_t i, row = 0, col = 0; bool active;
         if (origin_mode == 0) {
             const int64_t ty = t / P.tiles_x, tx = t - ty * P.tiles_x;
-            row = ty * TILE + (tid >> 4); col = tx * TILE + (tid & 15);
+            row = ty * TILE + (tl >> 4); col = tx * TILE + (tl & 15);
             active = row < P.ny && col < P.nx;
             i = row * P.nx + col;
         } else {
-            i = t * BLOCK + tid;
+            i = t * BLOCK + tl;
             active = i < P.n;
         }
         // ---- origin: llh -> ECEF (delay.py:262-267)
@@ -628,19 +652,17 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
         if (!SLOW && origin_mode == 0) {
             // a tile has 16 distinct latitudes and 16 distinct longitudes: 32 lanes take the sines / cosines for everybody
             // (the previous tile's readers are past the barriers of walk.next())
-            if (tid < 32) {
+            if (tl < 32) {
                 const int64_t ty = t / P.tiles_x, tx = t - ty * P.tiles_x;
-                const int64_t r = ty * TILE + (tid & 15), cc = tx * TILE + (tid & 15);
-                const double v = tid < 16 ? (r < P.ny ? P.ypts[r] : 0.0) : (cc < P.nx ? P.xpts[cc] : 0.0);
-                double sv, cv;
-                sincos(v * DEG_TO_RAD, &sv, &cv);
-                m.trig[2 * tid] = sv; m.trig[2 * tid + 1] = cv;
+                const int64_t r = ty * TILE + (tl & 15), cc = tx * TILE + (tl & 15);
+                const double v = tl < 16 ? (r < P.ny ? P.ypts[r] : 0.0) : (cc < P.nx ? P.xpts[cc] : 0.0);
+                tile_trig<LCC>(v, tl, proj, m.trig);
             }
             __syncthreads();
             if (active) { lat = P.ypts[row]; lon = P.xpts[col]; }
             base.lat0 = lat; base.lon0 = lon;
-            base.s0 = active ? m.trig[2 * (tid >> 4)] : 0.0; base.c0 = active ? m.trig[2 * (tid >> 4) + 1] : 1.0;
-            base.sl0 = active ? m.trig[32 + 2 * (tid & 15)] : 0.0; base.cl0 = active ? m.trig[33 + 2 * (tid & 15)] : 1.0;
+            base.s0 = active ? m.trig[2 * (tl >> 4)] : 0.0; base.c0 = active ? m.trig[2 * (tl >> 4) + 1] : 1.0;
+            base.sl0 = active ? m.trig[32 + 2 * (tl & 15)] : 0.0; base.cl0 = active ? m.trig[33 + 2 * (tl & 15)] : 1.0;
             if (active) {                                          // lla2ecef (geodesy.h) with the shared sines / cosines
                 const double N = WGS84_A / sqrt(1.0 - WGS84_ES * base.s0 * base.s0);
                 ox = (N + ht) * base.c0 * base.cl0;
@@ -682,17 +704,17 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
         // (geodesy_fast.h); an ellipsoidal cone goes to the generic kernels (lcc_forward) ray by ray.
         const bool fast_ok = !active || ((cosi > 0.05) && (base.c0 > gam + 0.02) && (gam < 0.2 * (base.c0 - gam)) && (gam < 0.035) &&
                                          (fabs(lon) + 5.0 < 180.0) && (proj.kind != 1 || (proj.e == 0.0 && gam < 0.09 * base.c0)));   // (run-time test: the generic kernels must classify identically)
-        const int64_t slot = lt * BLOCK + tid;
+        const int64_t slot = lt * BLOCK + tl;
         if (!SLOW) {
             const unsigned long long slow_mask = __ballot(!fast_ok);
-            if (slow_mask && (tid & 63) == 0) atomicAdd(P.nslow, (int)__popcll(slow_mask));
+            if (slow_mask && (tl & 63) == 0) atomicAdd(P.nslow, (int)__popcll(slow_mask));
         }
         const bool mine = SLOW ? !fast_ok : fast_ok;      // lanes this instantiation is responsible for
         if (SLOW && !__any(mine)) continue;               // (wave-uniform) nothing to mop up in this wave
         const bool cnt = active && mine;
         // this lane's column of the per-level maxima; derived afresh per tile (an address kept live across the polynomial fit,
         // the register-hungriest stretch of the kernel, is the one value the allocator had to spill)
-        int mxcol_idx = tid & (MXCOLS - 1);
+        int mxcol_idx = tl & (MXCOLS - 1);
         asm volatile("" : "+v"(mxcol_idx));
         unsigned long long* const mxc = m.mxcol + mxcol_idx;
         double* const w = P.ws ? P.ws + slot : nullptr;
@@ -703,7 +725,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
             int64_t sidx = -1;
             if (w) {
                 const unsigned long long mm = __ballot(mine);
-                const int lane = tid & 63;
+                const int lane = tl & 63;
                 int base = 0;
                 if (lane == 0) base = atomicAdd(P.side_ctr, (int)__popcll(mm));
                 base = __shfl(base, 0, 64);
@@ -757,7 +779,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
             const double half = 0.5 * (t_b - t_a), mid = 0.5 * (t_b + t_a);
             const double su = 1.0 / half, ou = -mid * su;
             RayPoly q;
-            fit_ray_poly<LCC>(base, ox, oy, oz, lx, ly, lz, mid, half, proj, q);
+            LccOrigin lorg = {0.0, 0.0, 0.0};
+            const bool shared_lcc = LCC && !SLOW && origin_mode == 0;
+            if (shared_lcc) { lorg.rho = m.trig[64 + (tl >> 4)]; lorg.st = m.trig[80 + 2 * (tl & 15)]; lorg.ct = m.trig[81 + 2 * (tl & 15)]; }
+            fit_ray_poly<LCC>(base, ox, oy, oz, lx, ly, lz, mid, half, proj, shared_lcc ? &lorg : nullptr, q);
             const double scale = nl * half;                           // ray length per unit of u
             if (w && mine) {
                 // exact-uniform axes: hand pass 2 the INDEX-space coordinate (v - g0) * (n-1)/(g[n-1]-g0) directly (cell_xy<true>)
@@ -879,8 +904,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
                 m.hs[k] = 0.5e-6 * m.step[k];                            // delay.py:314-315: end points get half of L*1e-6/(np-1)
             }
             __syncthreads();
-            poison = m.K[1] ? qnan() : 0.0;           // diverged slice: every output is NaN
             const int flags_in = P.flags[sl];
+            // Every output of the slice is NaN when its partition is undefined: diverged lengths, or a NaN ray length anywhere in
+            // the slice - ndarray.max poisons nParts and the reference raises (delay.py:283).  The synchronous entry points raise
+            // the same error; a caller of the asynchronous ones (device arrays, no host round trip) gets NaN, never a finite
+            // delay computed with a partition the reference does not define.
+            poison = (m.K[1] || (flags_in & 1)) ? qnan() : 0.0;
             clamp_lo = !(flags_in & 4);               // ALL first samples below zmin  (delay.py:306-307)
             clamp_hi = !(flags_in & 8);               // ALL last samples above zmax   (delay.py:310-311)
             clamp_any = clamp_lo | clamp_hi;
