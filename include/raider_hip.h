@@ -136,6 +136,11 @@ int rdr_cube_axes(const rdr_cube* cube, double* ys, double* xs, double* zs);
 int rdr_cube_set_projection(rdr_cube* cube, int kind, const double* params, int nparams);
 /* transformPoints (delay.py:404-436) for EPSG:4326 -> the cube's CRS: (lat, lon) deg -> (y, x) model coordinates */
 int rdr_project_points(rdr_ctx* ctx, const rdr_cube* cube, const double* lat, const double* lon, int64_t n, double* y, double* x, int loc);
+/* transformPoints (delay.py:404-436) between EPSG:4326 and a TRANSVERSE-MERCATOR CRS (every UTM zone, EPSG:326xx / 327xx; national
+ * TM grids) - the pyproj call behind output grids that are not lon/lat (delay.py:207-209,259-263).  params = {a, es, lat_0, lon_0,
+ * k_0, x_0, y_0} (m, -, deg, deg, -, m, m).  direction 0: in = (lat, lon) deg -> out = (y, x) m; 1: in = (y, x) m -> out = (lat, lon) deg. */
+int rdr_transform_tm(rdr_ctx* ctx, const double* params, int nparams, int direction, const double* in_a, const double* in_b, int64_t n,
+                     double* out_a, double* out_b, int loc);
 /* temporal blend, cli/raider.py:817-819: out = w1*a + w2*b (f32 cubes blend in f32, f64 in f64) */
 int rdr_cube_blend(rdr_ctx* ctx, const rdr_cube* a, double w1, const rdr_cube* b, double w2, rdr_cube** out);
 /* Azimuth-time-grid temporal interpolation.

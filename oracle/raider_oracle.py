@@ -421,6 +421,67 @@ def stere_forward(lat, lon, lat_0=90.0, lat_ts=None, k_0=1.0, lon_0=0.0, x_0=0.0
     return x_0 + rho * np.sin(dlam), y_0 - sg * rho * np.cos(dlam)
 
 
+def _tm_setup(a, es, lat_0, lon_0, k_0):
+    f = 1 - np.sqrt(1 - es); n = f / (2 - f)
+    A = a / (1 + n) * (1 + n ** 2 / 4 + n ** 4 / 64 + n ** 6 / 256)
+    al = [n / 2 - 2 * n ** 2 / 3 + 5 * n ** 3 / 16 + 41 * n ** 4 / 180 - 127 * n ** 5 / 288 + 7891 * n ** 6 / 37800,
+          13 * n ** 2 / 48 - 3 * n ** 3 / 5 + 557 * n ** 4 / 1440 + 281 * n ** 5 / 630 - 1983433 * n ** 6 / 1935360,
+          61 * n ** 3 / 240 - 103 * n ** 4 / 140 + 15061 * n ** 5 / 26880 + 167603 * n ** 6 / 181440,
+          49561 * n ** 4 / 161280 - 179 * n ** 5 / 168 + 6601661 * n ** 6 / 7257600,
+          34729 * n ** 5 / 80640 - 3418889 * n ** 6 / 1995840, 212378941 * n ** 6 / 319334400]
+    be = [n / 2 - 2 * n ** 2 / 3 + 37 * n ** 3 / 96 - n ** 4 / 360 - 81 * n ** 5 / 512 + 96199 * n ** 6 / 604800,
+          n ** 2 / 48 + n ** 3 / 15 - 437 * n ** 4 / 1440 + 46 * n ** 5 / 105 - 1118711 * n ** 6 / 3870720,
+          17 * n ** 3 / 480 - 37 * n ** 4 / 840 - 209 * n ** 5 / 4480 + 5569 * n ** 6 / 90720,
+          4397 * n ** 4 / 161280 - 11 * n ** 5 / 504 - 830251 * n ** 6 / 7257600,
+          4583 * n ** 5 / 161280 - 108847 * n ** 6 / 3991680, 20648693 * n ** 6 / 638668800]
+    return np.sqrt(es), k_0 * A, al, be
+
+
+def _tm_conformal(e, phi, lam):
+    tau = np.tan(phi)
+    sig = np.sinh(e * np.arctanh(e * tau / np.sqrt(1 + tau ** 2)))
+    taup = tau * np.sqrt(1 + sig ** 2) - sig * np.sqrt(1 + tau ** 2)
+    return np.arctan2(taup, np.cos(lam)), np.arcsinh(np.sin(lam) / np.sqrt(taup ** 2 + np.cos(lam) ** 2))
+
+
+def tm_forward(lat, lon, lat_0=0.0, lon_0=0.0, k_0=0.9996, x_0=500000.0, y_0=0.0, a=6378137.0, es=0.0066943799901413165):
+    """Geodetic -> transverse Mercator (UTM: lat_0 = 0, k_0 = 0.9996, x_0 = 500 000, y_0 = 0 / 10 000 000, lon_0 = 6 zone - 183):
+    what pyproj does in transformPoints (delay.py:404-436) for a UTM output grid.  Krueger's series in the third flattening to
+    n^6 (Karney 2011, eqs. 7-11, 35) = the formulation of PROJ's `etmerc` / `utm`; PARITY WITH PROJ ITSELF IS UNPINNED (pyproj is
+    absent), pinned instead on Snyder's UTM example (PP 1395 p. 269: Clarke 1866, (40.5 N, 73.5 W), lon_0 = 75 W -> x = 127 106.5 m,
+    y = 4 484 124.4 m) and the OSGB example of IOGP Guidance Note 7-2 (E 577 274.99, N 69 740.50).  Returns (x, y)."""
+    e, kA, al, _ = _tm_setup(a, es, lat_0, lon_0, k_0)
+    xi0p, eta0p = _tm_conformal(e, np.radians(lat_0), 0.0)
+    xi0 = xi0p + sum(al[j] * np.sin(2 * (j + 1) * xi0p) * np.cosh(2 * (j + 1) * eta0p) for j in range(6))
+    lam = np.radians(np.asarray(lon, dtype=np.float64) - lon_0)
+    lam = np.where(lam > np.pi, lam - 2 * np.pi, np.where(lam < -np.pi, lam + 2 * np.pi, lam))
+    xip, etap = _tm_conformal(e, np.radians(np.asarray(lat, dtype=np.float64)), lam)
+    xi = xip + sum(al[j] * np.sin(2 * (j + 1) * xip) * np.cosh(2 * (j + 1) * etap) for j in range(6))
+    eta = etap + sum(al[j] * np.cos(2 * (j + 1) * xip) * np.sinh(2 * (j + 1) * etap) for j in range(6))
+    return x_0 + kA * eta, y_0 + kA * (xi - xi0)
+
+
+def tm_inverse(x, y, lat_0=0.0, lon_0=0.0, k_0=0.9996, x_0=500000.0, y_0=0.0, a=6378137.0, es=0.0066943799901413165):
+    """Transverse Mercator -> geodetic (Karney 2011 eqs. 11, 36 and the Newton step 19-21).  Returns (lat, lon) in degrees."""
+    e, kA, al, be = _tm_setup(a, es, lat_0, lon_0, k_0)
+    xi0p, eta0p = _tm_conformal(e, np.radians(lat_0), 0.0)
+    xi0 = xi0p + sum(al[j] * np.sin(2 * (j + 1) * xi0p) * np.cosh(2 * (j + 1) * eta0p) for j in range(6))
+    xi = (np.asarray(y, dtype=np.float64) - y_0) / kA + xi0; eta = (np.asarray(x, dtype=np.float64) - x_0) / kA
+    xip = xi - sum(be[j] * np.sin(2 * (j + 1) * xi) * np.cosh(2 * (j + 1) * eta) for j in range(6))
+    etap = eta - sum(be[j] * np.cos(2 * (j + 1) * xi) * np.sinh(2 * (j + 1) * eta) for j in range(6))
+    taup = np.sin(xip) / np.sqrt(np.sinh(etap) ** 2 + np.cos(xip) ** 2)
+    lam = np.arctan2(np.sinh(etap), np.cos(xip))
+    tau = taup.copy() if isinstance(taup, np.ndarray) else np.float64(taup)
+    for _ in range(6):
+        t1 = np.sqrt(1 + tau ** 2)
+        sig = np.sinh(e * np.arctanh(e * tau / t1))
+        tpi = tau * np.sqrt(1 + sig ** 2) - sig * t1
+        tau = tau + (taup - tpi) / np.sqrt(1 + tpi ** 2) * (1 + (1 - es) * tau ** 2) / ((1 - es) * t1)
+    lon = np.degrees(lam) + lon_0
+    lon = np.where(lon > 180, lon - 360, np.where(lon < -180, lon + 360, lon))
+    return np.degrees(np.arctan(tau)), lon
+
+
 def project_forward(lat, lon, model_proj):
     """(x, y) of geodetic points in the model CRS given as a dict: {'proj': 'stere', ...stere_forward keywords} or
     lcc_forward keywords (optionally with 'proj': 'lcc')."""

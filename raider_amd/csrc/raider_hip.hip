@@ -146,6 +146,7 @@ static inline int grid_for(int64_t n, int block, int max_blocks) {
 #include "producer_kernels.h"
 #include "orbit_kernels.h"
 #include "native_kernels.h"
+#include "proj_kernels.h"
 
 // ------------------------------------------------------------------------------------------------
 // C ABI
@@ -431,6 +432,28 @@ int rdr_project_points(rdr_ctx* c, const rdr_cube* q, const double* lat, const d
     HIPCHECK(c, hipGetLastError());
     rc = finish_out(c, y, oy, (size_t)n * 8, loc); if (rc) return rc;
     rc = finish_out(c, x, ox, (size_t)n * 8, loc); if (rc) return rc;
+    if (loc == RDR_HOST) HIPCHECK(c, hipStreamSynchronize(c->stream));
+    return RDR_OK;
+}
+
+int rdr_transform_tm(rdr_ctx* c, const double* p, int np, int direction, const double* in_a, const double* in_b, int64_t n, double* out_a,
+                     double* out_b, int loc) {
+    if (!c || !p || np < 7 || (n > 0 && (!in_a || !in_b || !out_a || !out_b))) return fail(c, RDR_ERR_INVALID, "rdr_transform_tm: NULL argument / 7 parameters (a, es, lat_0, lon_0, k_0, x_0, y_0)");
+    if (!(p[0] > 0) || p[1] < 0 || p[1] >= 1 || std::fabs(p[2]) > 90 || !(p[4] > 0)) return fail(c, RDR_ERR_INVALID, "rdr_transform_tm: invalid transverse-Mercator parameters");
+    if (direction != 0 && direction != 1) return fail(c, RDR_ERR_INVALID, "rdr_transform_tm: direction is 0 (forward) or 1 (inverse)");
+    if (n == 0) return RDR_OK;
+    HIPCHECK(c, hipSetDevice(c->device));
+    const TmParams T = tm_setup(p[0], p[1], p[2], p[3], p[4], p[5], p[6]);
+    const void *da, *db; void *oa, *ob;
+    int rc = stage_in(c, SLOT_IN0, in_a, (size_t)n * 8, loc, &da); if (rc) return rc;
+    rc = stage_in(c, SLOT_IN1, in_b, (size_t)n * 8, loc, &db); if (rc) return rc;
+    rc = stage_out(c, SLOT_OUT0, out_a, (size_t)n * 8, loc, &oa); if (rc) return rc;
+    rc = stage_out(c, SLOT_OUT1, out_b, (size_t)n * 8, loc, &ob); if (rc) return rc;
+    hipLaunchKernelGGL(tm_kernel, dim3(grid_for(n, 256, c->num_cus * 8)), dim3(256), 0, c->stream, T, direction, (const double*)da, (const double*)db, n,
+                       (double*)oa, (double*)ob);
+    HIPCHECK(c, hipGetLastError());
+    rc = finish_out(c, out_a, oa, (size_t)n * 8, loc); if (rc) return rc;
+    rc = finish_out(c, out_b, ob, (size_t)n * 8, loc); if (rc) return rc;
     if (loc == RDR_HOST) HIPCHECK(c, hipStreamSynchronize(c->stream));
     return RDR_OK;
 }

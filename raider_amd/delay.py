@@ -71,6 +71,8 @@ def _crs_dict(crs):
                     d[k] = float(v)
                 except ValueError:
                     d[k] = v
+            elif tok.startswith('+') and len(tok) > 1:
+                d[tok[1:]] = True                                  # flags: +south, +no_defs
         return d
     if pyproj is not None and hasattr(crs, 'to_dict'):
         try:
@@ -118,6 +120,23 @@ def _stere_params(crs):
     lat_ts = d.get('lat_ts')
     return dict(lat_0=lat_0, lat_ts=None if lat_ts is None else float(lat_ts), k_0=float(d.get('k_0', d.get('k', 1.0))),
                 lon_0=float(d.get('lon_0', 0.0)), x_0=float(d.get('x_0', 0.0)), y_0=float(d.get('y_0', 0.0)), a=a, es=es)
+
+
+def _tm_params(crs):
+    """Transverse-Mercator parameters of a CRS: a WGS 84 / UTM EPSG code, or a `+proj=tmerc` / `+proj=utm` PROJ string / dict; else None."""
+    from .utilFcns import utm_params
+    e = _epsg(crs)
+    if e is not None:
+        return utm_params(e)
+    d = _crs_dict(crs)
+    if not d or d.get('proj') not in ('tmerc', 'etmerc', 'utm'):
+        return None
+    a, es = _ellipsoid(d)
+    if d.get('proj') == 'utm':
+        zone = int(d['zone'])
+        return dict(a=a, es=es, lat_0=0.0, lon_0=6.0 * zone - 183.0, k_0=0.9996, x_0=500000.0, y_0=10000000.0 if ('south' in d) else 0.0)
+    return dict(a=a, es=es, lat_0=float(d.get('lat_0', 0.0)), lon_0=float(d.get('lon_0', 0.0)), k_0=float(d.get('k_0', d.get('k', 1.0))),
+                x_0=float(d.get('x_0', 0.0)), y_0=float(d.get('y_0', 0.0)))
 
 
 def _apply_model_crs(cube, model_crs):
@@ -518,6 +537,14 @@ def writeResultsToXarray(datetime, xpts, ypts, zpts, crs, wetDelay, hydroDelay, 
         if degrees:
             attrs['_crs_cf'] = dict(grid_mapping_name='latitude_longitude', semi_major_axis=6378137.0, inverse_flattening=298.257223563,
                                     longitude_of_prime_meridian=0.0, geographic_crs_name='WGS 84')
+        else:
+            tm = _tm_params(crs)
+            if tm is not None:                                     # CF-1.7 grid mapping of a transverse-Mercator / UTM output grid
+                attrs['_crs_cf'] = dict(grid_mapping_name='transverse_mercator', semi_major_axis=tm['a'],
+                                        inverse_flattening=1.0 / (1.0 - np.sqrt(1.0 - tm['es'])) if tm['es'] > 0 else 0.0,
+                                        longitude_of_prime_meridian=0.0, latitude_of_projection_origin=tm['lat_0'],
+                                        longitude_of_central_meridian=tm['lon_0'], scale_factor_at_central_meridian=tm['k_0'],
+                                        false_easting=tm['x_0'], false_northing=tm['y_0'])
         return DelayCube(dict(wet=np.asarray(wetDelay), hydro=np.asarray(hydroDelay), x=np.asarray(xpts), y=np.asarray(ypts),
                               z=np.asarray(zpts), crs=np.array(-2147483647)), attrs)
     ds = xr.Dataset(
@@ -553,8 +580,24 @@ def transformPoints(lats, lons, hgts, old_proj, new_proj):
     if eo == 4978 and en == 4326:
         lon, lat, h = ecef2lla(lons, lats, hgts)          # always_xy: x = "lons" argument, y = "lats" argument
         return np.stack([lat, lon, h], axis=-1)
+    # transverse-Mercator CRSs (every UTM zone; national TM grids given as a PROJ string / dict) against EPSG:4326, on the GPU
+    tm_o, tm_n = _tm_params(old_proj), _tm_params(new_proj)
+    if tm_n is not None and eo == 4326:
+        from .utilFcns import transverse_mercator
+        y, x = transverse_mercator(lats, lons, tm_n)
+        return np.stack([y, x, hgts], axis=-1)
+    if tm_o is not None and en == 4326:
+        from .utilFcns import transverse_mercator
+        lat, lon = transverse_mercator(lats, lons, tm_o, inverse=True)        # (y, x) travel in the (lats, lons) slots
+        return np.stack([lat, lon, hgts], axis=-1)
+    if tm_o is not None and en == 4978:
+        from .utilFcns import transverse_mercator
+        lat, lon = transverse_mercator(lats, lons, tm_o, inverse=True)
+        x, y, z = lla2ecef(lat, lon, hgts)
+        return np.stack([y, x, z], axis=-1)
     if pyproj is None:
-        raise NotImplementedError(f'transformPoints {old_proj} -> {new_proj} needs pyproj (only EPSG:4326 <-> EPSG:4978 are built in)')
+        raise NotImplementedError(f'transformPoints {old_proj} -> {new_proj} needs pyproj (built in: EPSG:4326 <-> EPSG:4978 and EPSG:4326 <-> '
+                                  'transverse Mercator / UTM)')
     t = pyproj.Transformer.from_crs(old_proj, new_proj, always_xy=True)
     res = t.transform(lons, lats, hgts)
     return np.stack([res[1], res[0], res[2]], axis=-1)

@@ -70,3 +70,29 @@ def ecef2enu(xyz, lat, lon, height):
     n = -slat * t + clat * z
     u = clat * t + slat * z
     return np.stack((e, n, u), axis=-1)
+
+
+def utm_params(epsg):
+    """Transverse-Mercator parameters of a WGS 84 / UTM zone EPSG code (326zz north, 327zz south), or None."""
+    epsg = int(epsg)
+    if 32601 <= epsg <= 32660 or 32701 <= epsg <= 32760:
+        zone = epsg % 100
+        return dict(a=6378137.0, es=0.0066943799901413165, lat_0=0.0, lon_0=6.0 * zone - 183.0, k_0=0.9996, x_0=500000.0,
+                    y_0=10000000.0 if epsg >= 32701 else 0.0)
+    return None
+
+
+def transverse_mercator(a_in, b_in, params, inverse=False):
+    """Forward: (lat, lon) deg -> (y, x) m; inverse: (y, x) m -> (lat, lon) deg, on the GPU (rdr_transform_tm: Krueger series to n^6,
+    the formulation of PROJ's etmerc / utm).  params: dict(a, es, lat_0, lon_0, k_0, x_0, y_0)."""
+    import ctypes as C
+    from . import _lib as L
+    from ._lib import Context, check, f64, ptr
+    a_in, b_in = np.broadcast_arrays(np.asarray(a_in, dtype=np.float64), np.asarray(b_in, dtype=np.float64))
+    shp = a_in.shape
+    ua, ub = f64(a_in).ravel(), f64(b_in).ravel()
+    oa, ob = np.empty(ua.size), np.empty(ua.size)
+    p = np.array([params[k] for k in ('a', 'es', 'lat_0', 'lon_0', 'k_0', 'x_0', 'y_0')], dtype=np.float64)
+    ctx = Context.default()
+    check(ctx.lib.rdr_transform_tm(ctx.handle, ptr(p), p.size, int(bool(inverse)), ptr(ua), ptr(ub), ua.size, ptr(oa), ptr(ob), L.RDR_HOST), ctx.handle)
+    return oa.reshape(shp), ob.reshape(shp)

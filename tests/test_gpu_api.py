@@ -441,3 +441,44 @@ def test_orbit_kernel_on_a_circular_orbit_closed_form_and_reference_state_vector
         a2_rel = a2[0] - orb2.time[0] if abs(a2[0]) > 1e4 else a2[0]
         assert abs(a2_rel - A.S1_T[k]) < 5e-6                                       # 2 cm of Hermite error / 7.5 km/s
         assert np.abs(Tk + r2[0] * l2[0] - S).max() < 5e-2 and abs(r2[0] - 850000.0) < 2e-2
+
+
+def test_utm_output_grid_through_transformPoints_and_tropo_delay(c1):
+    """A UTM output grid (`out_proj` = EPSG:32611; reference: delay.py:207-209 for the zenith cube, :259-263 for ray tracing,
+    transformPoints :404-436 through pyproj): the transverse-Mercator kernel against the oracle's Krueger series, and the delays
+    of a UTM-gridded cube equal to those of the same points queried in lon/lat."""
+    import raider_amd as R
+    from raider_amd.delay import transformPoints, _build_cube, _build_cube_ray, writeResultsToXarray
+    from raider_amd.delayFcns import FieldInterpolator
+    from raider_amd.losreader import Raytracing
+    rng = np.random.default_rng(0)
+    la = rng.uniform(-80, 84, 5000); lo = rng.uniform(-123, -111, 5000); h = rng.uniform(0, 3000, 5000)
+    p = transformPoints(la, lo, h, 4326, 32611)
+    ox, oy = O.tm_forward(la, lo, lat_0=0.0, lon_0=-117.0, k_0=0.9996, x_0=500000.0, y_0=0.0)
+    np.testing.assert_allclose(p[:, 1], ox, rtol=0, atol=1e-6); np.testing.assert_allclose(p[:, 0], oy, rtol=0, atol=1e-6)
+    back = transformPoints(p[:, 0], p[:, 1], p[:, 2], 32611, 4326)
+    np.testing.assert_allclose(back[:, 0], la, rtol=0, atol=1e-11); np.testing.assert_allclose(back[:, 1], lo, rtol=0, atol=1e-11)
+    ps = transformPoints(-30.0, 25.0, 0.0, 4326, 'EPSG:32735')                  # southern zone 35: false northing 10 000 000
+    sx, sy = O.tm_forward(-30.0, 25.0, lat_0=0.0, lon_0=27.0, k_0=0.9996, x_0=500000.0, y_0=10000000.0)
+    assert abs(ps[1] - sx) < 1e-6 and abs(ps[0] - sy) < 1e-6
+    # a cube on a UTM grid over the c1 weather cube (-121..-113, 30..36): zone 11
+    cube = R.Cube(c1['ys'], c1['xs'], c1['zs'], c1['wet'], c1['hydro'], order='zyx')
+    tot = R.Cube(c1['ys'], c1['xs'], c1['zs'], c1['wet_total'], c1['hydro_total'], order='zyx')
+    xg = 300000.0 + 20000.0 * np.arange(12); yg = 3800000.0 - 20000.0 * np.arange(9)
+    zpts = np.array([0.0, 800.0])
+    xx, yy = np.meshgrid(xg, yg)
+    ll = transformPoints(yy, xx, np.zeros_like(xx), 32611, 4326)
+    zw, zh = _build_cube(xg, yg, zpts, 4326, 32611, [FieldInterpolator(tot, 0), FieldInterpolator(tot, 1)])
+    for k, ht in enumerate(zpts):
+        rw, rh = tot.interp(np.stack([ll[..., 0], ll[..., 1], np.full(xx.shape, ht)], -1))
+        assert np.array_equal(zw[k], rw, equal_nan=True) and np.array_equal(zh[k], rh, equal_nan=True) and np.isfinite(rw).all()
+    los = Raytracing(inc=np.full(xx.shape, 36.0), heading=-167.9)
+    zref = float(c1['zs'].max() - 1)
+    rw_, rh_ = _build_cube_ray(xg, yg, zpts, los, 4326, 32611, [FieldInterpolator(cube, 0), FieldInterpolator(cube, 1)], MAX_TROPO_HEIGHT=zref)
+    for k, ht in enumerate(zpts):
+        w, h_, _, _ = cube.raytrace(R.Rays.points(lat=ll[..., 0].ravel().copy(), lon=ll[..., 1].ravel().copy(), inc=np.full(xx.size, 36.0), hd=np.full(xx.size, -167.9)), float(ht), zref)
+        np.testing.assert_allclose(rw_[k].ravel(), w, rtol=0, atol=1e-12); np.testing.assert_allclose(rh_[k].ravel(), h_, rtol=0, atol=1e-12)
+        assert np.isfinite(w).all()
+    ds = writeResultsToXarray(__import__('datetime').datetime(2020, 1, 1), xg, yg, zpts, 32611, rw_, rh_, 'x.nc', 'slant - raytracing')
+    if hasattr(ds, 'attrs') and '_crs_cf' in getattr(ds, 'attrs', {}):
+        assert ds.attrs['_crs_cf']['grid_mapping_name'] == 'transverse_mercator' and ds.attrs['_crs_cf']['longitude_of_central_meridian'] == -117.0

@@ -388,3 +388,29 @@ def test_orbit_solver_restatement_on_a_circular_orbit_and_the_reference_state_ve
     # and through ALL of them it reproduces the nodes and stays on the orbit in between (radius / speed vary smoothly)
     pos, vel = O.orbit_hermite(A.S1_T, A.S1_POS, A.S1_VEL, A.S1_T)
     assert np.abs(pos - A.S1_POS).max() < 1e-6 and np.abs(vel - A.S1_VEL).max() < 1e-9
+
+
+def test_transverse_mercator_against_published_examples():
+    """Transverse Mercator (the transformPoints step of a UTM output grid): Snyder's UTM example (USGS PP 1395 p. 269: Clarke 1866,
+    (40 30' N, 73 30' W), central meridian 75 W, k_0 = 0.9996 -> x = 127 106.5 m, y = 4 484 124.4 m) and the Transverse-Mercator
+    example of IOGP Guidance Note 7-2 (OSGB 1936 / British National Grid: Airy 1830, lat_0 49 N, lon_0 2 W, k_0 = 0.9996012717,
+    FE 400 000, FN -100 000; (50 30' N, 0 30' E) -> E 577 274.99 m, N 69 740.50 m - computed there with the truncated USGS series,
+    hence centimetres).  Plus forward / inverse closure and the defining properties (scale k_0 on the central meridian)."""
+    x, y = O.tm_forward(40.5, -73.5, lat_0=0.0, lon_0=-75.0, k_0=0.9996, x_0=0.0, y_0=0.0, a=6378206.4, es=0.00676866)
+    assert abs(x - 127106.5) < 0.05 and abs(y - 4484124.4) < 0.05
+    f = 1 / 299.32496
+    osgb = dict(lat_0=49.0, lon_0=-2.0, k_0=0.9996012717, x_0=400000.0, y_0=-100000.0, a=6377563.396, es=2 * f - f * f)
+    x, y = O.tm_forward(50.5, 0.5, **osgb)
+    assert abs(x - 577274.99) < 0.02 and abs(y - 69740.50) < 0.02
+    lat, lon = O.tm_inverse(577274.99, 69740.50, **osgb)
+    assert abs(lat - 50.5) < 2e-7 and abs(lon - 0.5) < 2e-7
+    rng = np.random.default_rng(0)
+    utm11 = dict(lat_0=0.0, lon_0=-117.0, k_0=0.9996, x_0=500000.0, y_0=0.0)
+    la = rng.uniform(-80, 84, 2000); lo = rng.uniform(-123, -111, 2000)
+    x, y = O.tm_forward(la, lo, **utm11)
+    la2, lo2 = O.tm_inverse(x, y, **utm11)
+    assert np.abs(la2 - la).max() < 1e-11 and np.abs(lo2 - lo).max() < 1e-11
+    # on the central meridian x = x_0 and dy/dlat = k_0 * meridional radius of curvature
+    x0, y0 = O.tm_forward(35.0, -117.0, **utm11); x1, y1 = O.tm_forward(35.0 + 1e-6, -117.0, **utm11)
+    es = 0.0066943799901413165; M = 6378137.0 * (1 - es) / (1 - es * np.sin(np.radians(35.0)) ** 2) ** 1.5
+    assert abs(x0 - 500000.0) < 1e-6 and abs((y1 - y0) / np.radians(1e-6) / (0.9996 * M) - 1) < 1e-6
