@@ -55,6 +55,9 @@ def load_counters(cube, rows, cols):
         if d.get('source_hash') != want:
             why = f'{f.name}: source hash {d.get("source_hash")} != current {want} (stale profile)'
             continue
+        if d.get('cube') != cube:
+            why = f'{f.name}: profiled on cube {d.get("cube")}, this run uses {cube}'
+            continue
         return d, str(f.relative_to(REPO))
     return None, why
 
