@@ -352,6 +352,11 @@ def test_integration_md_stub_runs_as_printed(c1):
         zref = float(c['zs'].max() - 1)
         w, h = raytrace_slice(pw, xp, yp, 0.0, LOS, zref)
         assert raytrace_slice(pw, xp, yp, zref + 10.0, LOS, zref) is None
+        hts = np.array([0.0, 750.0, zref + 10.0])
+        cw, ch = raytrace_cube(pw, c['zs'].size, xp, yp, hts, np.stack([LOS, LOS, LOS]), zref)
+        assert np.array_equal(cw[0], w) and np.array_equal(ch[0], h) and not cw[2].any()
+        w1, h1 = raytrace_slice(pw, xp, yp, 750.0, LOS, zref)
+        assert np.array_equal(cw[1], w1) and np.array_equal(ch[1], h1)
         np.savez(OUT, zw=zw, zh=zh, w=w, h=h, LOS=LOS)
     ''')
     import tempfile
