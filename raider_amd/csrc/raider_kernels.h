@@ -25,6 +25,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "geodesy.h"
 #include "geodesy_fast.h"
@@ -155,9 +156,12 @@ __device__ __forceinline__ int window2_base(int n, int guess) { return min(max(g
 
 __device__ __forceinline__ void window2_cell(const double2* e, int n, double v, int i0, bool trust, int& i, double& t) {
     const double2 e0 = e[i0], e1 = e[i0 + 1];                                 // i0 = window2_base(n, guess), slice-uniform
-    const bool up = v >= e1.x;
+    // measured from the MIDDLE node g[i0+1] (where a level top sits, within the Newton residual): above it the weight is d r1,
+    // below it 1 + d r0 - one subtraction, one 64-bit select (the reciprocal), one 32-bit select (the high word of 0.0 / 1.0)
+    const double d = v - e1.x;
+    const bool up = d >= 0.0;
     i = i0 + (int)up;
-    t = (v - (up ? e1.x : e0.x)) * (up ? e1.y : e0.y);
+    t = fma(d, up ? e1.y : e0.y, up ? 0.0 : 1.0);
     if (!trust || !(t >= 0.0) || !(t <= 1.0)) cell_exact(e, n, v, i, t);      // rare
 }
 
@@ -168,7 +172,9 @@ __device__ __forceinline__ void window2_cell(const double2* e, int n, double v, 
 // Anything else (last node, outside, NaN, irregular axis) takes the exact search.
 // IDX (light rays on an exact axis): v already IS the index-space coordinate (v_real - g0) * inv_d - pass 1 folds that map
 // into the ray polynomial's coefficients.
-template <bool IDX = false>
+// NOCHECK (light march loop, exact axes only): the caller has PROVEN from the ray's polynomial coefficients that every sample of
+// every ray of the wave lies inside [0, n-1) - the bounds test and its rare path are compiled out.
+template <bool IDX = false, bool NOCHECK = false>
 __device__ __forceinline__ void cell_xy(const double2* e, int n, double v, double g0, double g_last, double inv_d, bool exact, bool trust,
                                         int& i, double& t) {
     bool ok;
@@ -176,6 +182,7 @@ __device__ __forceinline__ void cell_xy(const double2* e, int n, double v, doubl
     if (exact) {
         i = (int)tf;                                                            // = floor for the tf >= 0 this path accepts
         t = __builtin_amdgcn_fract(tf);
+        if (NOCHECK) return;
         const double nm1 = (double)(n - 1);
         ok = (tf >= 0.0) & (tf < nm1);
         if (__builtin_expect(!ok, 0)) {                                         // rare: the last node, outside the axis, NaN
@@ -211,13 +218,13 @@ struct PendingSample {
 // MODE 0: generic kernels (three-entry z window).  MODE 1 (light march loop, a level's TOP sample or the ray's first sample):
 // index-space x / y on exact axes, two-entry z window.  MODE 2 (light march loop, a sample strictly INSIDE model interval kz):
 // its z cell is kz itself, one table entry, no select.  Any sample whose weight leaves [0,1] takes the exact search.
-template <typename T2, int MODE = 0>
+template <typename T2, int MODE = 0, bool NOCHECK = false>
 __device__ __forceinline__ void sample_issue(const CubeView<T2>& c, const AxisTabs& m, double y, double x, double z, int kz,
                                              PendingSample<T2>& s) {
     const double2* ez = m.ez;
     int iy, ix, iz;
-    cell_xy<MODE != 0>(m.ey, c.ny, y, c.y_lo, c.y_hi, c.inv_dy, c.exact_y, c.uni_y, iy, s.ty);
-    cell_xy<MODE != 0>(m.ex, c.nx, x, c.x_lo, c.x_hi, c.inv_dx, c.exact_x, c.uni_x, ix, s.tx);
+    cell_xy<MODE != 0, NOCHECK>(m.ey, c.ny, y, c.y_lo, c.y_hi, c.inv_dy, c.exact_y, c.uni_y, iy, s.ty);
+    cell_xy<MODE != 0, NOCHECK>(m.ex, c.nx, x, c.x_lo, c.x_hi, c.inv_dx, c.exact_x, c.uni_x, ix, s.tx);
     if (MODE == 2) {
         const double2 e0 = ez[kz];                                              // kz <= nz-2: slice-uniform address
         iz = kz;
@@ -885,9 +892,11 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
         if (sl != slice) {                                 // (workgroup-uniform) the slice's level table and integration partition
             slice = sl;
             K = fill_levels(c.nz, m, P.hts ? P.hts[sl] : P.ht, P.zref);
-            if (tid == 0) m.K[1] = 0;
+            int tz = threadIdx.x;
+            asm volatile("" : "+v"(tz));                   // (opaque: nothing derived from it is hoisted out of the tile loop and spilled)
+            if (tz == 0) m.K[1] = 0;
             __syncthreads();
-            for (int k = tid; k < K; k += BLOCK) {
+            for (int k = tz; k < K; k += BLOCK) {
                 int np;
                 if (P.nparts_override) np = P.nparts_override[(int64_t)sl * MAX_LEVELS + k];
                 else {
@@ -914,17 +923,19 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
             clamp_hi = !(flags_in & 8);               // ALL last samples above zmax   (delay.py:310-311)
             clamp_any = clamp_lo | clamp_hi;
         }
+        int tl = threadIdx.x;
+        asm volatile("" : "+v"(tl));                       // per-tile opaque copy of the thread index (see crossings_kernel)
         int64_t i; bool active;
         if (P.origin_mode == 0) {
             const int64_t ty = t / P.tiles_x, tx = t - ty * P.tiles_x;
-            const int64_t row = ty * TILE + (tid >> 4), col = tx * TILE + (tid & 15);
+            const int64_t row = ty * TILE + (tl >> 4), col = tx * TILE + (tl & 15);
             active = row < P.ny && col < P.nx;
             i = row * P.nx + col;
         } else {
-            i = t * BLOCK + tid;
+            i = t * BLOCK + tl;
             active = i < P.n;
         }
-        const double* w = P.ws + (lt * BLOCK + tid);
+        const double* w = P.ws + (lt * BLOCK + tl);
         const int64_t ns = P.nslots;
         const double scale_rec = w[(int64_t)WS_SCALE * ns];         // light ray: ray length per unit of u (> 0 or NaN); generic ray: 0
         const bool fast_ok = !active || scale_rec != 0.0;
@@ -951,6 +962,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
             for (int n = 0; n < PX; ++n) xc[n] = w[(int64_t)(WS_XPOLY + n) * ns];
             const double scale = scale_rec;
             // MODE 1: a level's top sample / the ray's first sample; MODE 2: a sample strictly inside its model interval
+            auto run = [&](auto nochk) {
+            constexpr bool NC = decltype(nochk)::value;
             auto issue_top = [&](double us, int zbase, bool floor_it, bool ceil_it, PendingSample<T2>& s) {
                 double ph = poly5(q.h, us);
                 const double plat = poly5(q.lat, us), plon = poly5(q.lon, us);       // delay.py:295 through the ray polynomials
@@ -959,12 +972,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
                 // so the two samples of a ray they can apply to are the only ones that pay for them.
                 if (floor_it) { asm volatile("" ::: "memory"); ph = fmax(ph, c.z_lo); }
                 if (ceil_it) { asm volatile("" ::: "memory"); ph = fmin(ph, c.z_hi); }
-                sample_issue<T2, 1>(c, m.ax, plat, plon, ph, zbase, s);              // delay.py:298,319
+                sample_issue<T2, 1, NC>(c, m.ax, plat, plon, ph, zbase, s);              // delay.py:298,319
             };
             auto issue_mid = [&](double us, int kz_, PendingSample<T2>& s) {
                 const double ph = poly5(q.h, us);
                 const double plat = poly5(q.lat, us), plon = poly5(q.lon, us);
-                sample_issue<T2, 2>(c, m.ax, plat, plon, ph, kz_, s);
+                sample_issue<T2, 2, NC>(c, m.ax, plat, plon, ph, kz_, s);
             };
             auto finish = [&](const PendingSample<T2>& s, double wv) {
                 double vw, vh;
@@ -1015,6 +1028,38 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
                     step = m.step[k + 1];
                 }
             }
+            };
+            // Bounds of the horizontal cell search, decided ONCE per wave from the polynomial coefficients.  Every sample's ray
+            // parameter lies between the ray's crossings: the two of the first level (u0, u1 of the record) and X(v_k), |v_k| <= 1,
+            // whose magnitude is at most sum |x_k|.  So when |u0|, |u1| and sum |x_k| are all <= 1.001 (the crossings sit inside
+            // the fit range [-1, 1] by construction; diverged or non-finite rays fail this), every sample has |u| <= 1.001 and
+            // p(u) lies within c0 +- 1.006 sum_{k>=1} |c_k| (1.001^5 < 1.006).  When that interval is inside [0, n-1) for the
+            // index-space lat AND lon polynomials of every ray of the wave, no gather can leave the cube and the per-sample bounds
+            // tests (4 compares + the rare-path plumbing) are compiled out of the loop.  Lanes of tile padding get a harmless
+            // in-range polynomial; a wave holding a generic ray (whose record is not a polynomial), a diverged ray or a ray near
+            // the cube's edge keeps the checked loop.
+            bool lane_safe = false;
+            if (REGULAR) {
+                double u0r = w[(int64_t)WS_U0 * ns], u1r = w[(int64_t)WS_U1 * ns];
+                if (!active) {
+#pragma unroll
+                    for (int n = 0; n < PN; ++n) { q.lat[n] = 0.0; q.lon[n] = 0.0; }
+                    q.lat[0] = 0.5; q.lon[0] = 0.5;
+#pragma unroll
+                    for (int n = 0; n < PX; ++n) xc[n] = 0.0;
+                    u0r = 0.0; u1r = 0.0;
+                }
+                auto inside = [&](const double* cf, int n) {
+                    const double r = 1.006 * (fabs(cf[1]) + fabs(cf[2]) + fabs(cf[3]) + fabs(cf[4]) + fabs(cf[5]));
+                    return (cf[0] - r >= 0.0) & (cf[0] + r < (double)(n - 1));
+                };
+                double xs = 0.0;
+#pragma unroll
+                for (int n = 0; n < PX; ++n) xs += fabs(xc[n]);
+                lane_safe = (mine || !active) && (fabs(u0r) <= 1.001) && (fabs(u1r) <= 1.001) && (xs <= 1.001) && inside(q.lat, c.ny) && inside(q.lon, c.nx);
+            }
+            if (REGULAR && __all(lane_safe)) run(std::integral_constant<bool, true>{});
+            else run(std::integral_constant<bool, false>{});
             acc_w *= scale; acc_h *= scale;
         } else {
             double vw_top = 0.0, vh_top = 0.0;    // sample values at the top of the previous segment (= bottom of this one)
