@@ -843,22 +843,35 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
             if (reduce) {
                 // The level abscissae are read from LDS ahead of the ds_max of the previous pair: LDS operations complete in
                 // order, so a read issued after an atomic would wait for it.
+                // A lane that does not count (tile padding, a ray left to the generic kernel) contributes length 0 to every
+                // level: its scale is zeroed once, here, instead of a select per level; v_max_f64(L, 0) then also maps a NaN
+                // length (0 x NaN of such a lane, or a genuinely NaN ray - reported through the flags) to 0, so that the u64
+                // maximum never sees a negative or non-finite bit pattern.
+                // The metres-per-unit-u scale is folded into the polynomial once (8 multiplications), so a level costs 7 FMAs, one
+                // subtraction and the v_max.
+                const double mscale = cnt ? scale : 0.0;
+                const double u_end = K > 1 ? poly7(xc, m.xv[K - 1]) : u_hi;                    // the ray's last crossing (flags below)
+                double xm[PX];
+#pragma unroll
+                for (int n = 0; n < PX; ++n) xm[n] = xc[n] * mscale;
+                double s_hi = u_hi * mscale;                                                   // scaled crossing of the previous level
                 int k = 1;
                 for (; k + 2 <= K; k += 2) {
                     const double v0 = m.xv[k], v1 = m.xv[k + 1];
-                    const double ua = poly7(xc, v0), ub = poly7(xc, v1);
-                    const double La = (ua - u_hi) * scale, Lb = (ub - ua) * scale;
-                    u_hi = ub; last_len = Lb;
-                    atomicMax(&mxc[k * MXCOLS], (unsigned long long)__double_as_longlong((cnt && La > 0.0) ? La : 0.0));
-                    atomicMax(&mxc[(k + 1) * MXCOLS], (unsigned long long)__double_as_longlong((cnt && Lb > 0.0) ? Lb : 0.0));
+                    const double sa = poly7(xm, v0), sb = poly7(xm, v1);
+                    const double La = sa - s_hi, Lb = sb - sa;
+                    s_hi = sb;
+                    atomicMax(&mxc[k * MXCOLS], (unsigned long long)__double_as_longlong(fmax(La, 0.0)));
+                    atomicMax(&mxc[(k + 1) * MXCOLS], (unsigned long long)__double_as_longlong(fmax(Lb, 0.0)));
                 }
                 for (; k < K; ++k) {
-                    const double u_top = poly7(xc, m.xv[k]);
-                    const double L = (u_top - u_hi) * scale;
-                    u_hi = u_top; last_len = L;
-                    atomicMax(&mxc[k * MXCOLS], (unsigned long long)__double_as_longlong((cnt && L > 0.0) ? L : 0.0));
+                    const double st = poly7(xm, m.xv[k]);
+                    const double L = st - s_hi;
+                    s_hi = st;
+                    atomicMax(&mxc[k * MXCOLS], (unsigned long long)__double_as_longlong(fmax(L, 0.0)));
                 }
-                if (K > 0 && cnt && !(poly5(q.h, u_hi) > c.z_hi)) my_flags |= 8;               // last sample of the ray
+                if (K > 1) last_len = u_end * scale;                                          // (only its NaN-ness is used)
+                if (K > 0 && cnt && !(poly5(q.h, u_end) > c.z_hi)) my_flags |= 8;              // last sample of the ray
             }
             if (reduce && cnt && K > 0) my_flags |= (last_len != last_len) ? 1 : 2;
         }
