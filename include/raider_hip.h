@@ -109,6 +109,9 @@ int rdr_set_workspace_limit(rdr_ctx* ctx, int64_t bytes);
 /* Columns of the generic-ray side buffer: >= 0 fixes the capacity (0: always recompute), -1 restores the automatic sizing. */
 int rdr_set_side_capacity(rdr_ctx* ctx, int64_t columns);
 int rdr_profile_get(rdr_ctx* ctx, int which, int* count, float* total_ms);
+/* diagnostics: rays the static classification sent to the generic-geodesy kernels in the last ray pass 1 whose result this ctx read
+ * back (rdr_ray_prepass, and rdr_raytrace / rdr_raytrace_slices when they synchronise); -1 for a NULL ctx */
+int64_t rdr_generic_ray_count(rdr_ctx* ctx);
 
 /* ---- weather cube ----------------------------------------------------------------------------
  * Replaces getInterpolators (tools/RAiDER/delayFcns.py:23-58): the two fields of one processed weather

@@ -56,6 +56,7 @@ SYMBOLS = [
     ('rdr_set_profiling', C.c_int, [_VP, C.c_int]),
     ('rdr_set_workspace_limit', C.c_int, [_VP, C.c_int64]),
     ('rdr_set_side_capacity', C.c_int, [_VP, C.c_int64]),
+    ('rdr_generic_ray_count', C.c_int64, [_VP]),
     ('rdr_profile_get', C.c_int, [_VP, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_float)]),
     ('rdr_cube_create', C.c_int, [_VP, _VP, C.c_int64, _VP, C.c_int64, _VP, C.c_int64, _VP, _VP, C.c_int,
                                   C.c_int64, C.c_int64, C.c_int64, C.c_int, C.POINTER(_VP)]),
@@ -215,6 +216,10 @@ class Context:
     def set_side_capacity(self, columns=-1):
         """Capacity (rays) of the side buffer holding the level crossings of generic-geodesy rays; -1 = automatic."""
         check(self.lib.rdr_set_side_capacity(self.handle, int(columns)), self.handle)
+
+    def generic_ray_count(self):
+        """Rays the last synchronising ray pass 1 left to the generic-geodesy kernels (diagnostics)."""
+        return int(self.lib.rdr_generic_ray_count(self.handle))
 
     def profile_get(self, which):
         """(launch count, total ms) of kernel kind `which` since set_profiling(True)."""

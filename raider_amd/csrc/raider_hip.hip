@@ -248,6 +248,8 @@ int rdr_set_side_capacity(rdr_ctx* c, int64_t columns) {
     return RDR_OK;
 }
 
+int64_t rdr_generic_ray_count(rdr_ctx* c) { return c ? c->last_nslow : -1; }
+
 int rdr_set_profiling(rdr_ctx* c, int on) {
     if (!c) return fail(nullptr, RDR_ERR_INVALID, "ctx is NULL");
     c->profiling = on != 0;

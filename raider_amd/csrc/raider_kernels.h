@@ -709,8 +709,25 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
         const double gam = (P.zref - ht) / (cosi * 6.3e6);
         // LCC cubes: spherical cones only (HRRR), and the node projections use short series in log(t/t_origin) <= gam / cos(lat)
         // (geodesy_fast.h); an ellipsoidal cone goes to the generic kernels (lcc_forward) ray by ray.
+        // The +-180 deg meridian: the light path carries longitude UNWRAPPED (origin + small delta), the reference wraps every
+        // sample into (-180, 180] (atan2).  The two agree whenever no sample crosses the meridian (origin more than 5 deg away from
+        // it - a ray travels < 0.2 rad = 11.5 deg only at high latitude, where the other clauses bite first... kept as before), and
+        // ALSO when a crossing sample is outside the cube either way: a lon/lat cube whose x axis ends at or before +180 and starts
+        // more than 12 deg after -180 (wrap_pos) gives NaN for an unwrapped 180.x (beyond the axis) and for the reference's
+        // wrapped -179.x (before it) alike; mirrored for origins near -180 (wrap_neg).  Dateline scenes (Fiji, Chukotka, the
+        // Aleutians) then stay on the light path.  On a conic / polar-stereographic cube only the cone's own cut meridian
+        // lam0 +- 180 matters (theta = n (lam - lam0) is wrapped there); geographic +-180 is an ordinary meridian.
+        bool lon_ok;
+        if (proj.kind == 1) {
+            double dl = lon - proj.lam0 * RAD_TO_DEG;
+            dl -= 360.0 * rint(dl * (1.0 / 360.0));
+            lon_ok = fabs(dl) + 12.0 < 180.0;
+        } else {
+            const bool wrap_pos = (c.x_hi <= 180.0) & (c.x_lo > -168.0), wrap_neg = (c.x_lo >= -180.0) & (c.x_hi < 168.0);
+            lon_ok = (fabs(lon) + 5.0 < 180.0) || ((fabs(lon) <= 180.0) && (lon > 0.0 ? wrap_pos : wrap_neg));
+        }
         const bool fast_ok = !active || ((cosi > 0.05) && (base.c0 > gam + 0.02) && (gam < 0.2 * (base.c0 - gam)) && (gam < 0.035) &&
-                                         (fabs(lon) + 5.0 < 180.0) && (proj.kind != 1 || (proj.e == 0.0 && gam < 0.09 * base.c0)));   // (run-time test: the generic kernels must classify identically)
+                                         lon_ok && (proj.kind != 1 || (proj.e == 0.0 && gam < 0.09 * base.c0)));   // (run-time test: the generic kernels must classify identically)
         const int64_t slot = lt * BLOCK + tl;
         if (!SLOW) {
             const unsigned long long slow_mask = __ballot(!fast_ok);

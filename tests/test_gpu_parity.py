@@ -336,3 +336,50 @@ def test_survey_sanity_numbers_slant_to_zenith_ratio(R):
     zz = np.concatenate([[0.0], zs[zs > 0]]); zz[-1] = zref
     prof = np.interp(zz, zs, f.astype(np.float32).astype(np.float64))
     assert abs(hz.mean() - 1e-6 * np.sum(0.5 * (prof[1:] + prof[:-1]) * np.diff(zz))) < 1e-9
+
+
+@pytest.mark.parametrize('case', ['east_of_cube_end', 'west_side', 'global_axis', 'stere_across_dateline'])
+def test_dateline_scenes(R, case):
+    """Scenes at the +-180 deg meridian.  The light ray path carries longitude unwrapped, the reference wraps every sample
+    (atan2): they agree when a crossing sample is outside the cube either way (a regional lon/lat cube ending at the meridian:
+    NaN in both), which is what lets such scenes stay on the light path; a cube whose axis spans both ends (global model) keeps
+    the generic kernels, where rays really do re-enter at the other end; on a polar-stereographic (HRRR-AK) grid the geographic
+    dateline is an ordinary meridian and rays cross it with finite delays.  All against the oracle, NaN patterns included."""
+    rng = np.random.default_rng(8)
+    ny, nx = 14, 40
+    proj = None
+    if case == 'east_of_cube_end':
+        c = O.synthetic_cube(30, 60, 30, seed=5, y0=50.0, y1=58.0, x0=172.0, x1=179.99)
+        ypts = np.linspace(56.0, 52.0, ny); xpts = np.linspace(178.6, 179.97, nx)
+    elif case == 'west_side':
+        c = O.synthetic_cube(30, 60, 30, seed=5, y0=-20.0, y1=-12.0, x0=-179.99, x1=-172.0)
+        ypts = np.linspace(-14.0, -18.0, ny); xpts = np.linspace(-179.97, -178.6, nx)
+    elif case == 'global_axis':
+        c = O.synthetic_cube(24, 361, 24, seed=5, y0=50.0, y1=58.0, x0=-180.0, x1=180.0)
+        ypts = np.linspace(56.0, 52.0, ny); xpts = np.linspace(178.6, 179.97, nx)
+    else:
+        par = dict(lat_0=90.0, lat_ts=60.0, lon_0=225.0, a=6371229.0, es=0.0)
+        c = O.synthetic_cube(50, 50, 30, seed=5, ztop=26000.0)
+        cx, cy = O.stere_forward(52.0, 180.0, **par)
+        c['xs'] = cx + 6000.0 * (np.arange(50) - 25); c['ys'] = cy + 6000.0 * (np.arange(50) - 25)
+        proj = dict(par, proj='stere')
+        ypts = np.linspace(52.8, 51.2, ny); xpts = np.concatenate([np.linspace(178.9, 179.98, nx // 2), np.linspace(-179.98, -178.9, nx // 2)])
+    cube = R.Cube(c['ys'], c['xs'], c['zs'], c['wet'], c['hydro'], order='zyx')
+    if proj is not None:
+        cube.set_projection_stere(**par)
+    ip = list(O.getInterpolators(c['xs'], c['ys'], c['zs'], c['wet'], c['hydro']))
+    inc = rng.uniform(25, 50, (ny, nx)); hd = rng.choice([-167.9, -12.1, 90.0, -90.0], (ny, nx))       # incl. due east / west looks
+    zref = c['zs'].max() - 1
+    look = lambda ht_, llh, xyz, yy: O.look_vectors_from_inc_hd(inc, hd, llh[1], llh[0], llh[2])
+    (ow, oh), onp = O.build_cube_ray(xpts, ypts, np.array([0.0]), look, ip, MAX_TROPO_HEIGHT=zref, return_nparts=True, model_proj=proj)
+    wet, hyd, nparts, _ = cube.raytrace(R.Rays.grid(xpts, ypts, inc=inc, hd=hd), 0.0, zref)
+    assert np.array_equal(nparts, onp[0])
+    assert np.array_equal(np.isnan(wet), np.isnan(ow[0])) and np.array_equal(np.isnan(hyd), np.isnan(oh[0]))
+    generic = cube.ctx.generic_ray_count()
+    assert (generic == ny * nx) if case == 'global_axis' else (generic == 0), generic          # which kernels did the work
+    if case in ('east_of_cube_end', 'west_side'):
+        assert 0.02 < np.isnan(oh[0]).mean() < 0.9            # some rays leave through the meridian, most do not
+    else:
+        assert np.isfinite(oh[0]).mean() > 0.95               # rays crossing the dateline keep finite delays
+    np.testing.assert_allclose(wet, ow[0], rtol=0, atol=5 * TIGHT, equal_nan=True)
+    np.testing.assert_allclose(hyd, oh[0], rtol=0, atol=5 * TIGHT, equal_nan=True)

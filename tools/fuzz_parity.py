@@ -18,22 +18,33 @@ seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 rng = np.random.default_rng(seed)
 worst = dict(wet=0.0, hydro=0.0)
 bad = []
-stats = dict(trials=0, lcc_trials=0, all_nan_slices=0, no_level_slices=0, nan_rays=0, rays=0)
+stats = dict(trials=0, lcc_trials=0, stere_trials=0, dateline_trials=0, all_nan_slices=0, no_level_slices=0, nan_rays=0, rays=0)
 for trial in range(ntrials):
     ny, nx, nz = int(rng.integers(6, 50)), int(rng.integers(6, 50)), int(rng.integers(5, 48))
-    lat_c = rng.uniform(-80, 80); lon_c = rng.uniform(-160, 160)
+    lat_c = rng.uniform(-80, 80); lon_c = rng.uniform(-160, 160) if rng.random() < 0.85 else rng.choice([-1.0, 1.0]) * rng.uniform(170.0, 179.5)   # incl. the date line
     dlat = rng.uniform(1.5, 8.0); dlon = min(rng.uniform(1.5, 8.0) / max(np.cos(np.radians(lat_c)), 0.2), 30.0)
+    dlon = min(dlon, 180.0 - abs(lon_c) - 1e-3)                 # a lon/lat cube's axis stays inside [-180, 180]
     ztop = float(rng.choice([15000.0, 26000.0, 41000.0, 80000.0]))
     c = O.synthetic_cube(ny, nx, nz, seed=int(rng.integers(1 << 30)), ztop=ztop, y0=lat_c - dlat, y1=lat_c + dlat, x0=lon_c - dlon, x1=lon_c + dlon)
     axes_kind = rng.choice(['exact', 'jitter', 'stretch'])
     proj = None
     u = rng.random()
+    if u >= 0.3 and u < 0.38 and abs(lat_c) > 40:      # polar-stereographic model grid (HRRR-AK's spherical one, or an ellipsoidal one), either pole
+        south = lat_c < 0
+        proj = dict(proj='stere', lat_0=-90.0 if south else 90.0, lat_ts=(-1 if south else 1) * float(rng.choice([60.0, 70.0, 71.0])) if rng.random() < 0.8 else None,
+                    k_0=0.994, lon_0=float(rng.uniform(-180, 180)), x_0=0.0, y_0=0.0, a=6371229.0 if u < 0.35 else 6378137.0, es=0.0 if u < 0.35 else 0.0066943799901413165)
+        kw = {k: v for k, v in proj.items() if k != 'proj'}
+        la, lo = np.meshgrid(np.linspace(lat_c - dlat, lat_c + dlat, 9), np.linspace(lon_c - dlon, lon_c + dlon, 9), indexing='ij')
+        px, py = O.stere_forward(la, lo, **kw)
+        c['xs'] = np.linspace(px.min(), px.max(), nx); c['ys'] = np.linspace(py.min(), py.max(), ny)
+        axes_kind = 'exact'
     if u < 0.3 and abs(lat_c) < 70:      # Lambert-conformal-conic model grid (spherical cone as HRRR's, or an ellipsoidal one)
         lat1 = float(np.clip(lat_c + rng.uniform(-6, 6), -75, 75)); lat2 = lat1 if rng.random() < 0.5 else float(np.clip(lat1 + rng.uniform(2, 12) * np.sign(lat1 or 1.0), -80, 80))
         proj = dict(lat_1=lat1, lat_2=lat2, lat_0=float(lat_c + rng.uniform(-3, 3)), lon_0=float(lon_c + rng.uniform(-15, 15)), x_0=float(rng.choice([0.0, 5.0e5])), y_0=0.0,
                     a=6371229.0 if u < 0.22 else 6378137.0, es=0.0 if u < 0.22 else 0.0066943799901413165)
         la, lo = np.meshgrid(np.linspace(lat_c - dlat, lat_c + dlat, 9), np.linspace(lon_c - dlon, lon_c + dlon, 9), indexing='ij')
         px, py = O.lcc_forward(la, lo, **proj)
+        proj = dict(proj, proj='lcc')
         c['xs'] = np.linspace(px.min(), px.max(), nx); c['ys'] = np.linspace(py.min(), py.max(), ny)
         axes_kind = 'exact'
     if proj is not None:
@@ -66,10 +77,13 @@ for trial in range(ntrials):
     look2 = lambda ht_, llh, xyz, yy_: los
     ip = list(O.getInterpolators(c['xs'], c['ys'], c['zs'], c['wet'], c['hydro']))
     cube = R.Cube(c['ys'], c['xs'], c['zs'], c['wet'], c['hydro'], order='zyx')
-    if proj is not None:
-        cube.set_projection_lcc(**proj)
-    tag = dict(trial=trial, proj=(None if proj is None else ('sphere' if proj['es'] == 0 else 'ellipsoid')), cube=[ny, nx, nz], ztop=ztop, axes=str(axes_kind), lat=round(lat_c, 2), lon=round(lon_c, 2), ht=ht, zref=zref, max_seg=max_seg, scene=[gy, gx])
-    stats['trials'] += 1; stats['lcc_trials'] += int(proj is not None)
+    if proj is not None and proj['proj'] == 'stere':
+        cube.set_projection_stere(**{k: v for k, v in proj.items() if k != 'proj'})
+    elif proj is not None:
+        cube.set_projection_lcc(**{k: v for k, v in proj.items() if k != 'proj'})
+    tag = dict(trial=trial, proj=(None if proj is None else proj['proj'] + ('/sphere' if proj['es'] == 0 else '/ellipsoid')), cube=[ny, nx, nz], ztop=ztop, axes=str(axes_kind), lat=round(lat_c, 2), lon=round(lon_c, 2), ht=ht, zref=zref, max_seg=max_seg, scene=[gy, gx])
+    stats['trials'] += 1; stats['lcc_trials'] += int(proj is not None and proj['proj'] == 'lcc'); stats['stere_trials'] += int(proj is not None and proj['proj'] == 'stere')
+    stats['dateline_trials'] += int(abs(lon_c) > 169)
     try:
         o_err = None
         (ow, oh), onp = O.build_cube_ray(xpts, ypts, np.array([ht]), look2, ip, MAX_SEGMENT_LENGTH=max_seg, MAX_TROPO_HEIGHT=zref, return_nparts=True, model_proj=proj)
