@@ -17,28 +17,31 @@ from .utilFcns import cosd, enu2ecef, sind
 
 
 class LOS(ABC):
-    """losreader.py:32-72."""
+    """The duck-typed line-of-sight protocol of the delay path (losreader.py:32-72): query flags (`is_Zenith`, `is_Projected`,
+    `ray_trace`), target points (`setPoints`) and acquisition time (`setTime`).  The target points are kept as one
+    (lats, lons, heights) triple; `_lats` / `_lons` / `_heights` are views of it for the subclasses."""
 
-    def __init__(self):
-        self._lats, self._lons, self._heights = None, None, None
+    _KINDS = dict(zenith=(True, False, False), projected=(False, True, False), raytrace=(False, False, True))
+
+    def __init__(self, kind=None):
+        self._points = (None, None, None)
         self._look_vecs = None
-        self._ray_trace = False
-        self._is_zenith = False
-        self._is_projected = False
         self._time = None
+        self._is_zenith, self._is_projected, self._ray_trace = self._KINDS.get(kind, (False, False, False))
+
+    _lats = property(lambda self: self._points[0])
+    _lons = property(lambda self: self._points[1])
+    _heights = property(lambda self: self._points[2])
 
     def setPoints(self, lats, lons=None, heights=None):
-        """losreader.py:42-60."""
-        if (lats is None) and (self._lats is None):
+        """Accepts (lats, lons, heights), (lats, lons) - heights then default to zero - or one stacked [..., 3] array."""
+        if lats is None and self._points[0] is None:
             raise RuntimeError("You haven't given any point locations yet")
-        if lons is None:
-            llh = lats
-            self._lats, self._lons, self._heights = llh[..., 0], llh[..., 1], llh[..., 2]
-        elif heights is None:
-            self._lats, self._lons = lats, lons
-            self._heights = np.zeros((len(lats), 1))
+        if lons is None:                                  # stacked llh
+            stacked = lats
+            self._points = tuple(stacked[..., k] for k in range(3))
         else:
-            self._lats, self._lons, self._heights = lats, lons, heights
+            self._points = (lats, lons, np.zeros((len(lats), 1)) if heights is None else heights)
 
     def setTime(self, datetime):
         self._time = datetime
@@ -54,17 +57,16 @@ class LOS(ABC):
 
 
 class Zenith(LOS):
-    """losreader.py:75-91."""
+    """Zenith delays are returned as they are (losreader.py:75-91)."""
 
     def __init__(self):
-        super().__init__()
-        self._is_zenith = True
+        super().__init__('zenith')
 
     def setLookVectors(self):
-        if self._lats is None:
+        if self._points[0] is None:
             raise ValueError('Target points not set')
         if self._look_vecs is None:
-            self._look_vecs = getZenithLookVecs(self._lats, self._lons, self._heights)
+            self._look_vecs = getZenithLookVecs(*self._points)
 
     def __call__(self, delays):
         return delays
@@ -78,11 +80,10 @@ class Conventional(LOS):
     the GPU instead of through isce3), or - array-backed extension - `inc`/`heading` rasters given directly."""
 
     def __init__(self, filename=None, los_convention='isce', time=None, pad=600, inc=None, heading=None):
-        super().__init__()
+        super().__init__('projected')
         self._file = filename
         self._time = time
         self._pad = pad
-        self._is_projected = True
         self._convention = los_convention
         self._inc = None if inc is None else np.asarray(inc, dtype=np.float64)
         self._hd = None if heading is None else np.asarray(heading, dtype=np.float64)
@@ -144,8 +145,7 @@ class Raytracing(LOS):
 
     def __init__(self, filename=None, los_convention='isce', time=None, look_dir='right', pad=600,
                  look_vectors=None, inc=None, heading=None):
-        super().__init__()
-        self._ray_trace = True
+        super().__init__('raytrace')
         self._file = filename
         self._time = time
         self._pad = pad
