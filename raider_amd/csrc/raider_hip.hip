@@ -1498,8 +1498,15 @@ int rdr_orbit_look_vectors(rdr_ctx* c, const double* sv_t, const double* sv_pos,
     rc = stage_out(c, SLOT_OUT0, los, (size_t)n * 24, loc, &dl); if (rc) return rc;
     if (aztime) { rc = stage_out(c, SLOT_OUT1, aztime, (size_t)n * 8, loc, &da); if (rc) return rc; }
     if (srange) { rc = stage_out(c, SLOT_OUT2, srange, (size_t)n * 8, loc, &dr); if (rc) return rc; }
-    hipLaunchKernelGGL(orbit_los_kernel, dim3(grid_for(n, 256, c->num_cus * 8)), dim3(256), 0, c->stream, dt_, dp_, dv_, (int)nsv,
-                       (const double*)dx, n, threshold, maxiter, (double*)dl, (double*)da, (double*)dr);
+    if (nsv <= ORBIT_LDS_MAX_SV) {
+        // state vectors + per-segment reciprocals in LDS, division-free Hermite evaluation (orbit_los_fast_kernel)
+        const size_t smem = ((size_t)nsv * 7 + (size_t)(nsv - 3) * 16) * sizeof(double);
+        hipLaunchKernelGGL(orbit_los_fast_kernel, dim3(grid_for(n, 256, c->num_cus * 8)), dim3(256), smem, c->stream, dt_, dp_, dv_, (int)nsv,
+                           (const double*)dx, n, threshold, maxiter, (double*)dl, (double*)da, (double*)dr);
+    } else {
+        hipLaunchKernelGGL(orbit_los_kernel, dim3(grid_for(n, 256, c->num_cus * 8)), dim3(256), 0, c->stream, dt_, dp_, dv_, (int)nsv,
+                           (const double*)dx, n, threshold, maxiter, (double*)dl, (double*)da, (double*)dr);
+    }
     HIPCHECK(c, hipGetLastError());
     rc = finish_out(c, los, dl, (size_t)n * 24, loc); if (rc) return rc;
     if (aztime) { rc = finish_out(c, aztime, da, (size_t)n * 8, loc); if (rc) return rc; }

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The secondary kernels of SURVEY 8(a) on the sizes of BASELINE configs 2 and 5, device-resident, each priced with the byte model
 of SURVEY 8(d): build_cube_kernel / interp_points_kernel (168 B per point on the f64 totals cube, 104 B on an f32 cube),
-blend_kernel (24 B per f32 cell), producer_kernel (32 B per model level + 24 B per output level, per column), orbit_los_kernel
+blend_kernel (24 B per f32 cell), producer_kernel (32 B per model level + 24 B per output level, per column), orbit_los_fast_kernel
 (48 B per target).  Run under `rocprofv3 --kernel-trace --stats` (tools/profile_secondary.sh) - tools/secondary_digest.py joins the
 per-kernel durations with these byte counts into profiles/r02_secondary.json.  Prints ONE JSON line."""
 import datetime as dt
@@ -87,5 +87,5 @@ nn = 4000
 xx, yy = np.meshgrid(np.linspace(-119.5, -115.5, nn), np.linspace(34.5, 31.5, nn))
 xyz = torch.from_numpy(np.stack(lla2ecef(yy, xx, np.zeros_like(yy)), -1)).to(dev)
 t = timed(lambda: orb.look_vectors(xyz))
-res['orbit_los_kernel'] = dict(what='zero-Doppler look vectors of a 4000x4000 scene, 25 state vectors', units=nn * nn, unit='targets', bytes_per_unit=48, wall_ms=t * 1e3, reps=REPS + 1)
+res['orbit_los_fast_kernel'] = dict(what='zero-Doppler look vectors of a 4000x4000 scene, 25 state vectors', units=nn * nn, unit='targets', bytes_per_unit=48, wall_ms=t * 1e3, reps=REPS + 1)
 print(json.dumps(res))
