@@ -165,11 +165,15 @@ __global__ __launch_bounds__(256) void interp_points_kernel(CubeView<T2> c, cons
     }
 }
 
-// _build_cube (delay.py:196-216): points generated on the fly from (xpts, ypts, zpts)
+// _build_cube (delay.py:196-216): points generated on the fly from (xpts, ypts, zpts).  One thread per output NODE (iy, ix) and
+// z chunk: the model-CRS projection of the node (LCC / polar stereographic cubes), its x / y cells and the four horizontal
+// weight products are computed once and reused for every height of the chunk; the arithmetic per point is that of trilinear<>
+// (scipy's weight order, _rgi.py:490-498), so the values are the same bit for bit.  Output (nz, ny, nx): consecutive lanes write
+// consecutive addresses at every height.
 template <typename T2>
 __global__ __launch_bounds__(256) void build_cube_kernel(CubeView<T2> c, LccParams proj, const double* __restrict__ xpts, int64_t nx,
                                                          const double* __restrict__ ypts, int64_t ny,
-                                                         const double* __restrict__ zpts, int64_t nz,
+                                                         const double* __restrict__ zpts, int64_t nz, int64_t zchunk,
                                                          double* __restrict__ wet, double* __restrict__ hyd, int axes_in_lds) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const double* s_y = c.axes;                       // very long axes stay in global memory (L1 / L2 hits)
@@ -181,15 +185,70 @@ __global__ __launch_bounds__(256) void build_cube_kernel(CubeView<T2> c, LccPara
     }
     const double* s_x = s_y + c.ny;
     const double* s_z = s_x + c.nx;
-    const int64_t n = nx * ny * nz;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t ix = i % nx, r = i / nx, iy = r % ny, iz = r / ny;
-        double w, h, qy = ypts[iy], qx = xpts[ix];
+    const int64_t nodes = nx * ny;
+    const int64_t z0 = (int64_t)blockIdx.y * zchunk, z1 = min(z0 + zchunk, nz);
+    // the heights are the same for every node: their z cells and weights once per workgroup (zchunk <= BUILD_ZCHUNK_MAX)
+    double* s_tz = reinterpret_cast<double*>(smem_raw) + (axes_in_lds ? c.ny + c.nx + c.nz : 0);
+    int* s_cz = reinterpret_cast<int*>(s_tz + zchunk);
+    for (int k = threadIdx.x; k < (int)(z1 - z0); k += blockDim.x) {
+        const double z = zpts[z0 + k];
+        int cz = -1; double tz = 0.0;
+        if ((z >= c.z_lo) && (z <= c.z_hi)) {
+            cz = find_cell(s_z, c.nz, z, c.z_lo, c.inv_dz, c.uni_z);
+            tz = (z - s_z[cz]) / (s_z[cz + 1] - s_z[cz]);
+        }
+        s_tz[k] = tz; s_cz[k] = cz;                   // cz < 0: outside the axis (or NaN) -> fill value
+    }
+    __syncthreads();
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nodes; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t ix = i % nx, iy = i / nx;
+        double qy = ypts[iy], qx = xpts[ix];
         if (proj.kind == 1) { double px_, py_; lcc_forward(proj, qy, qx, px_, py_); qx = px_; qy = py_; }   // transformPoints, delay.py:207-209
-        trilinear(c, s_y, s_x, s_z, qy, qx, zpts[iz], w, h);
-        wet[i] = w; hyd[i] = h;
+        const bool in_xy = (qy >= c.y_lo) && (qy <= c.y_hi) && (qx >= c.x_lo) && (qx <= c.x_hi);
+        int cy = 0, cx = 0;
+        double a00 = 0, a01 = 0, a10 = 0, a11 = 0;
+        if (in_xy) {
+            cy = find_cell(s_y, c.ny, qy, c.y_lo, c.inv_dy, c.uni_y);
+            cx = find_cell(s_x, c.nx, qx, c.x_lo, c.inv_dx, c.uni_x);
+            const double ty = (qy - s_y[cy]) / (s_y[cy + 1] - s_y[cy]);
+            const double tx = (qx - s_x[cx]) / (s_x[cx + 1] - s_x[cx]);
+            const double wy0 = 1.0 - ty, wx0 = 1.0 - tx;
+            a00 = wy0 * wx0; a01 = wy0 * tx; a10 = ty * wx0; a11 = ty * tx;
+        }
+        const T2* col00 = c.v + ((int64_t)cy * c.nx + cx) * c.nz;            // column (y0, x0); the others follow at fixed strides
+        const T2* col01 = col00 + c.nz;
+        const T2* col10 = col00 + (int64_t)c.nx * c.nz;
+        const T2* col11 = col10 + c.nz;
+        for (int64_t iz = z0; iz < z1; ++iz) {
+            const int cz = s_cz[iz - z0];
+            double sw = qnan(), sh = qnan();
+            if (in_xy && cz >= 0) {
+                const double tz = s_tz[iz - z0];
+                const double wz0 = 1.0 - tz;
+                double w[8], h[8];
+                ld2(col00 + cz, w[0], h[0]); ld2(col00 + cz + 1, w[1], h[1]);
+                ld2(col01 + cz, w[2], h[2]); ld2(col01 + cz + 1, w[3], h[3]);
+                ld2(col10 + cz, w[4], h[4]); ld2(col10 + cz + 1, w[5], h[5]);
+                ld2(col11 + cz, w[6], h[6]); ld2(col11 + cz + 1, w[7], h[7]);
+                const double k0 = a00 * wz0, k1 = a00 * tz, k2 = a01 * wz0, k3 = a01 * tz;
+                const double k4 = a10 * wz0, k5 = a10 * tz, k6 = a11 * wz0, k7 = a11 * tz;
+                sw = 0.0; sh = 0.0;
+                sw += w[0] * k0; sh += h[0] * k0;
+                sw += w[1] * k1; sh += h[1] * k1;
+                sw += w[2] * k2; sh += h[2] * k2;
+                sw += w[3] * k3; sh += h[3] * k3;
+                sw += w[4] * k4; sh += h[4] * k4;
+                sw += w[5] * k5; sh += h[5] * k5;
+                sw += w[6] * k6; sh += h[6] * k6;
+                sw += w[7] * k7; sh += h[7] * k7;
+            }
+            const int64_t o = iz * nodes + i;
+            wet[o] = sw; hyd[o] = sh;
+        }
     }
 }
+
+constexpr int BUILD_ZCHUNK_MAX = 1024;
 
 __global__ void project_kernel(double* wet, double* hyd, const double* __restrict__ inc, int64_t n) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {

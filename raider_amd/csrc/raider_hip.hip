@@ -655,15 +655,25 @@ int rdr_build_cube(rdr_ctx* c, const rdr_cube* q, const double* xpts, int64_t nx
     rc = stage_in(c, SLOT_IN2, zpts, (size_t)nz * 8, loc, &dz); if (rc) return rc;
     rc = stage_out(c, SLOT_OUT0, wet, (size_t)n * 8, loc, &dw); if (rc) return rc;
     rc = stage_out(c, SLOT_OUT1, hydro, (size_t)n * 8, loc, &dh); if (rc) return rc;
-    const int g = grid_for(n, 256, c->num_cus * 8);
+    // one thread per (node, z chunk): enough chunks that a small grid still fills the chip, as few as possible otherwise (the
+    // horizontal work of a node is redone per chunk)
+    const int64_t nodes = nx * ny;
+    const int64_t want_threads = (int64_t)c->num_cus * 256 * 8;
+    int64_t nchunks = std::min<int64_t>(nz, std::max<int64_t>(1, (want_threads + nodes - 1) / nodes));
+    nchunks = std::max<int64_t>(nchunks, (nz + BUILD_ZCHUNK_MAX - 1) / BUILD_ZCHUNK_MAX);      // the per-height table of a chunk lives in LDS
+    if (nchunks > 65535) return fail(c, RDR_ERR_INVALID, "rdr_build_cube: more than 65535 x 1024 heights");
+    const int64_t zchunk = (nz + nchunks - 1) / nchunks;
+    nchunks = (nz + zchunk - 1) / zchunk;
+    const dim3 g(grid_for(nodes, 256, c->num_cus * 8), (unsigned)nchunks);
+    const size_t sm = axes_smem(q) + (size_t)zchunk * 12 + 8;
     {
         KTimer t(c, 2);
         if (q->dtype == RDR_F32)
-            hipLaunchKernelGGL((build_cube_kernel<float2>), dim3(g), dim3(256), axes_smem(q), c->stream, make_view<float2>(q), q->proj,
-                               (const double*)dx, nx, (const double*)dy, ny, (const double*)dz, nz, (double*)dw, (double*)dh, (int)axes_fit_lds(q));
+            hipLaunchKernelGGL((build_cube_kernel<float2>), g, dim3(256), sm, c->stream, make_view<float2>(q), q->proj,
+                               (const double*)dx, nx, (const double*)dy, ny, (const double*)dz, nz, zchunk, (double*)dw, (double*)dh, (int)axes_fit_lds(q));
         else
-            hipLaunchKernelGGL((build_cube_kernel<double2>), dim3(g), dim3(256), axes_smem(q), c->stream, make_view<double2>(q), q->proj,
-                               (const double*)dx, nx, (const double*)dy, ny, (const double*)dz, nz, (double*)dw, (double*)dh, (int)axes_fit_lds(q));
+            hipLaunchKernelGGL((build_cube_kernel<double2>), g, dim3(256), sm, c->stream, make_view<double2>(q), q->proj,
+                               (const double*)dx, nx, (const double*)dy, ny, (const double*)dz, nz, zchunk, (double*)dw, (double*)dh, (int)axes_fit_lds(q));
     }
     HIPCHECK(c, hipGetLastError());
     rc = finish_out(c, wet, dw, (size_t)n * 8, loc); if (rc) return rc;

@@ -106,7 +106,7 @@ def main():
             lines.append(f'{k}: launches {len(f)}  read {e["hbm_read_bytes"]/1e9:.3f} GB  write {e["hbm_write_bytes"]/1e9:.3f} GB per launch')
     (prof / f'{rnd}_{tag}_hbm_traffic_pmc.txt').write_text('\n'.join(lines) + '\n')
 
-    stats = glob.glob(str(src / 'kt') + '/**/*kernel_stats.csv', recursive=True)
+    stats = sorted(glob.glob(str(src / 'kt') + '/**/*kernel_stats.csv', recursive=True), key=lambda f: Path(f).stat().st_mtime, reverse=True)
     if stats:
         subprocess.run([sys.executable, str(REPO / 'tools' / 'rocprof_summary.py'), stats[0], str(prof / f'{rnd}_{tag}_kernel_stats.txt'), tag], check=True,
                        stdout=subprocess.DEVNULL)

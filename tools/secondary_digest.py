@@ -12,7 +12,7 @@ REPO = Path(__file__).resolve().parent.parent
 src = REPO / 'gpurun_out' / 'secondary'
 line = [ln for ln in (src / 'bench.json').read_text().splitlines() if ln.startswith('{')][-1]
 res = json.loads(line)
-stats = glob.glob(str(src / 'kt') + '/**/*kernel_stats.csv', recursive=True)[0]
+stats = max(glob.glob(str(src / 'kt') + '/**/*kernel_stats.csv', recursive=True), key=lambda f: Path(f).stat().st_mtime)   # (gpurun merges runs: newest)
 subprocess.run([sys.executable, str(REPO / 'tools' / 'rocprof_summary.py'), stats, str(REPO / 'profiles' / 'r02_secondary_kernel_stats.txt'),
                 'tools/secondary_bench.py: configs 2 / 5 sizes, producer, orbit look vectors'], check=True, stdout=subprocess.DEVNULL)
 rows = list(csv.DictReader(open(stats)))
