@@ -144,6 +144,11 @@ int rdr_project_points(rdr_ctx* ctx, const rdr_cube* cube, const double* lat, co
  * k_0, x_0, y_0} (m, -, deg, deg, -, m, m).  direction 0: in = (lat, lon) deg -> out = (y, x) m; 1: in = (y, x) m -> out = (lat, lon) deg. */
 int rdr_transform_tm(rdr_ctx* ctx, const double* params, int nparams, int direction, const double* in_a, const double* in_b, int64_t n,
                      double* out_a, double* out_b, int loc);
+/* The same between EPSG:4326 and a CONIC model CRS (kind RDR_PROJ_LCC / RDR_PROJ_STERE, params as rdr_cube_set_projection): the
+ * pyproj call of transformPoints(lats, lons, hgts, EPSG:4326, hrrr_proj) and back (test/test_delayFcns.py:67-84 round-trips it).
+ * direction 0: in = (lat, lon) deg -> out = (y, x) m; 1: in = (y, x) m -> out = (lat, lon) deg. */
+int rdr_transform_cone(rdr_ctx* ctx, int kind, const double* params, int nparams, int direction, const double* in_a, const double* in_b,
+                       int64_t n, double* out_a, double* out_b, int loc);
 /* temporal blend, cli/raider.py:817-819: out = w1*a + w2*b (f32 cubes blend in f32, f64 in f64) */
 int rdr_cube_blend(rdr_ctx* ctx, const rdr_cube* a, double w1, const rdr_cube* b, double w2, rdr_cube** out);
 /* Azimuth-time-grid temporal interpolation.

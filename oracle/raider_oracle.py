@@ -482,6 +482,73 @@ def tm_inverse(x, y, lat_0=0.0, lon_0=0.0, k_0=0.9996, x_0=500000.0, y_0=0.0, a=
     return np.degrees(np.arctan(tau)), lon
 
 
+def _phi_from_t(t, e):
+    """Latitude from the conformal quantity t (Snyder 7-9 / 15-9; PROJ pj_phi2): closed form on the sphere, fixed-point on the ellipsoid."""
+    phi = np.pi / 2 - 2 * np.arctan(t)
+    if e != 0:
+        for _ in range(15):
+            es_ = e * np.sin(phi)
+            phi = np.pi / 2 - 2 * np.arctan(t * ((1 - es_) / (1 + es_)) ** (0.5 * e))
+    return phi
+
+
+def lcc_inverse(x, y, lat_1, lat_2, lat_0, lon_0, x_0=0.0, y_0=0.0, a=6371229.0, es=0.0):
+    """Lambert conformal conic -> geodetic (Snyder 15-10, 15-11, 14-9, 15-9; PROJ `lcc` inverse) - the way back of
+    transformPoints(..., hrrr_proj, 4326) (test/test_delayFcns.py:67-84 round-trips it).  Pinned on Snyder's inverse examples
+    (pp. 296-298).  Returns (lat, lon) in degrees."""
+    e = np.sqrt(es)
+
+    def tsfn(phi):
+        s_ = np.sin(phi)
+        t_ = np.tan(0.5 * (np.pi / 2 - phi))
+        return t_ / ((1 - e * s_) / (1 + e * s_)) ** (0.5 * e) if e != 0 else t_
+
+    def msfn(phi):
+        return np.cos(phi) / np.sqrt(1 - es * np.sin(phi) ** 2)
+    p1, p2, p0 = np.radians(lat_1), np.radians(lat_2), np.radians(lat_0)
+    n = np.log(msfn(p1) / msfn(p2)) / np.log(tsfn(p1) / tsfn(p2)) if abs(p1 - p2) >= 1e-10 else np.sin(p1)
+    F = msfn(p1) * tsfn(p1) ** (-n) / n
+    rho0 = a * F * tsfn(p0) ** n
+    sg = np.sign(n)                                              # Snyder: rho takes the sign of n (and so do x, rho0 - y in 14-11)
+    xp = sg * (np.asarray(x, dtype=np.float64) - x_0); yp = sg * (rho0 - (np.asarray(y, dtype=np.float64) - y_0))
+    rho = sg * np.hypot(xp, yp)
+    with np.errstate(divide='ignore', invalid='ignore'):
+        t = (rho / (a * F)) ** (1.0 / n)
+    lat = np.degrees(_phi_from_t(t, e))
+    lon = np.degrees(np.radians(lon_0) + np.arctan2(xp, yp) / n)
+    lat = np.where(rho == 0, 90.0 * sg, lat); lon = np.where(rho == 0, lon_0, lon)
+    lon = np.where(lon > 180, lon - 360, np.where(lon < -180, lon + 360, lon))
+    return lat, lon
+
+
+def stere_inverse(x, y, lat_0=90.0, lat_ts=None, k_0=1.0, lon_0=0.0, x_0=0.0, y_0=0.0, a=6371229.0, es=0.0):
+    """POLAR stereographic -> geodetic (Snyder 20-18, 21-39 / 21-40, 7-9; PROJ `stere` polar inverse).  Pinned on Snyder's inverse
+    example (p. 317).  Returns (lat, lon) in degrees."""
+    if abs(abs(lat_0) - 90.0) > 1e-9:
+        raise NotImplementedError('only the polar aspect of the stereographic projection (lat_0 = +-90)')
+    e = np.sqrt(es)
+    sg = -1.0 if lat_0 < 0 else 1.0
+    xp = np.asarray(x, dtype=np.float64) - x_0; yp = np.asarray(y, dtype=np.float64) - y_0
+    rho = np.hypot(xp, yp)
+    if lat_ts is not None and abs(abs(lat_ts) - 90.0) > 1e-9:
+        pc = abs(np.radians(lat_ts)); s_ = np.sin(pc)
+        tc = np.tan(0.5 * (np.pi / 2 - pc)) / (((1 - e * s_) / (1 + e * s_)) ** (0.5 * e) if e != 0 else 1.0)
+        t = rho * tc / (a * np.cos(pc) / np.sqrt(1 - es * s_ ** 2))
+    else:
+        t = rho * np.sqrt((1 + e) ** (1 + e) * (1 - e) ** (1 - e)) / (2 * a * k_0)
+    lat = sg * np.degrees(_phi_from_t(t, e))
+    lon = lon_0 + np.degrees(np.arctan2(xp, -sg * yp))           # north: atan2(x, -y); south: atan2(x, y)
+    lon = np.where(rho == 0, lon_0, lon)
+    lon = np.where(lon > 180, lon - 360, np.where(lon < -180, lon + 360, lon))
+    return lat, lon
+
+
+def project_inverse(x, y, model_proj):
+    kw = dict(model_proj)
+    kind = kw.pop('proj', 'lcc')
+    return stere_inverse(x, y, **kw) if kind == 'stere' else lcc_inverse(x, y, **kw)
+
+
 def project_forward(lat, lon, model_proj):
     """(x, y) of geodetic points in the model CRS given as a dict: {'proj': 'stere', ...stere_forward keywords} or
     lcc_forward keywords (optionally with 'proj': 'lcc')."""

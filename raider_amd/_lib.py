@@ -66,6 +66,7 @@ SYMBOLS = [
     ('rdr_cube_set_projection', C.c_int, [_VP, C.c_int, _VP, C.c_int]),
     ('rdr_project_points', C.c_int, [_VP, _VP, _VP, _VP, C.c_int64, _VP, _VP, C.c_int]),
     ('rdr_transform_tm', C.c_int, [_VP, _VP, C.c_int, C.c_int, _VP, _VP, C.c_int64, _VP, _VP, C.c_int]),
+    ('rdr_transform_cone', C.c_int, [_VP, C.c_int, _VP, C.c_int, C.c_int, _VP, _VP, C.c_int64, _VP, _VP, C.c_int]),
     ('rdr_cube_blend', C.c_int, [_VP, _VP, C.c_double, _VP, C.c_double, C.POINTER(_VP)]),
     ('rdr_cube_read', C.c_int, [_VP, _VP, _VP, _VP]),
     ('rdr_interp3', C.c_int, [_VP, _VP, _VP, C.c_int64, _VP, _VP, C.c_int]),

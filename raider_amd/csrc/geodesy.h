@@ -191,4 +191,31 @@ RDR_HD void lcc_forward(const LccParams& L, double lat_deg, double lon_deg, doub
     y = L.y0 + L.rho0 - rho * ct;
 }
 
+// Inverse of lcc_forward for both cones (Snyder 15-10, 15-11, 14-9 / 15-9 with the 7-9 iteration for the ellipsoid; PROJ's
+// `lcc` / polar `stere` inverse): rho carries the sign of a F (southern cones and the southern stereographic aspect have a
+// negative one), theta = atan2(+-x', +-y''), t = (rho / a F)^(1/n), lam = lam0 + theta / n, phi from t.
+RDR_HD void lcc_inverse(const LccParams& L, double x, double y, double& lat_deg, double& lon_deg) {
+    const double sg = L.aF < 0.0 ? -1.0 : 1.0;
+    const double xp = sg * (x - L.x0), yp = sg * (L.rho0 - (y - L.y0));
+    const double rho = sg * sqrt(xp * xp + yp * yp);
+    if (rho == 0.0) { lat_deg = L.n > 0.0 ? 90.0 : -90.0; lon_deg = L.lam0 * 57.295779513082321; }
+    else {
+        const double t = pow(rho / L.aF, 1.0 / L.n);
+        double phi = 1.5707963267948966 - 2.0 * atan(t);
+        if (L.e != 0.0) {
+            for (int it = 0; it < 15; ++it) {                    // contracts by ~e^2 per step
+                const double es_ = L.e * sin(phi);
+                const double nphi = 1.5707963267948966 - 2.0 * atan(t * pow((1.0 - es_) / (1.0 + es_), 0.5 * L.e));
+                const double d = nphi - phi;
+                phi = nphi;
+                if (fabs(d) < 1e-15) break;
+            }
+        }
+        lat_deg = phi * 57.295779513082321;
+        lon_deg = (L.lam0 + atan2(xp, yp) / L.n) * 57.295779513082321;
+    }
+    if (lon_deg > 180.0) lon_deg -= 360.0;
+    else if (lon_deg < -180.0) lon_deg += 360.0;
+}
+
 }  // namespace rdr

@@ -113,4 +113,14 @@ __global__ __launch_bounds__(256) void tm_kernel(TmParams T, int dir, const doub
     }
 }
 
+// The same for the two cones (LCC, polar stereographic): dir 0: (lat, lon) deg -> (y, x) m;  dir 1: (y, x) m -> (lat, lon) deg.
+__global__ __launch_bounds__(256) void cone_kernel(LccParams L, int dir, const double* __restrict__ a, const double* __restrict__ b, int64_t n,
+                                                   double* __restrict__ oa, double* __restrict__ ob) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        double u, v;
+        if (dir == 0) { lcc_forward(L, a[i], b[i], v, u); oa[i] = u; ob[i] = v; }      // u = y, v = x
+        else { lcc_inverse(L, b[i], a[i], u, v); oa[i] = u; ob[i] = v; }                // u = lat, v = lon
+    }
+}
+
 }  // namespace rdr

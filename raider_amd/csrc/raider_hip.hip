@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/raider_hip.h"
@@ -35,6 +36,7 @@ struct rdr_ctx {
     hipStream_t copy_stream = nullptr;      // host<->device transfers of the pipelined host-buffer ray tracing
     hipStream_t stream = nullptr;
     int num_cus = 256;
+    size_t lds_max = 64u << 10;             // largest dynamic LDS allocation of one workgroup
     size_t total_mem = 0;
     std::string name;
     bool profiling = false;
@@ -141,6 +143,19 @@ static inline int grid_for(int64_t n, int block, int max_blocks) {
     return (int)std::max<int64_t>(1, std::min<int64_t>(g, max_blocks));
 }
 
+
+// Launch with `sm` bytes of dynamic LDS; allocations beyond the 64 KB default need the kernel's limit raised first (long
+// non-uniform axes: their (node, 1/spacing) tables live in LDS, 16 B per node).
+template <typename... KArgs, typename... Args>
+static hipError_t launch_lds(void (*kern)(KArgs...), dim3 g, dim3 b, size_t sm, hipStream_t s, Args&&... args) {
+    if (sm > (size_t)(48u << 10)) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, g, b, sm, s, std::forward<Args>(args)...);
+    return hipGetLastError();
+}
+
 // ---- kernels other than the two ray passes (raider_kernels.h) ---------------------------------------------------------
 #include "cube_kernels.h"
 #include "producer_kernels.h"
@@ -169,24 +184,29 @@ int rdr_create(int device, rdr_ctx** out) {
     if (device >= count) return fail(nullptr, RDR_ERR_INVALID, "rdr_create: device index out of range");
     rdr_ctx* c = new rdr_ctx();
     c->device = device;
-    HIPCHECK(nullptr, hipSetDevice(device));
-    hipDeviceProp_t prop;
-    HIPCHECK(nullptr, hipGetDeviceProperties(&prop, device));
-    c->num_cus = prop.multiProcessorCount;
-    c->total_mem = prop.totalGlobalMem;
-    c->name = prop.name;
-    if (c->name.empty()) c->name = std::string("AMD ") + prop.gcnArchName;   // amdgpu.ids may be absent on the box
-    HIPCHECK(nullptr, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
-    HIPCHECK(nullptr, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
-    c->stream = c->own_stream;
-    HIPCHECK(nullptr, hipMalloc((void**)&c->d_maxlen, (size_t)MAX_SLICES * MAX_LEVELS * sizeof(unsigned long long)));
-    HIPCHECK(nullptr, hipMalloc((void**)&c->d_flags, MAX_SLICES * sizeof(int)));
-    HIPCHECK(nullptr, hipMalloc((void**)&c->d_nparts, MAX_LEVELS * sizeof(int)));
-    HIPCHECK(nullptr, hipMalloc((void**)&c->d_nslow, sizeof(int)));
-    HIPCHECK(nullptr, hipMalloc((void**)&c->d_tilectr, 32 * sizeof(int)));
-    HIPCHECK(nullptr, hipMalloc((void**)&c->d_sidectr, sizeof(int)));
-    HIPCHECK(nullptr, hipMemset(c->d_sidectr, 0, sizeof(int)));
-    HIPCHECK(nullptr, hipMemset(c->d_nslow, 0, sizeof(int)));
+    const int rc = [&]() -> int {
+        HIPCHECK(nullptr, hipSetDevice(device));
+        hipDeviceProp_t prop;
+        HIPCHECK(nullptr, hipGetDeviceProperties(&prop, device));
+        c->num_cus = prop.multiProcessorCount;
+        c->total_mem = prop.totalGlobalMem;
+        c->lds_max = std::max<size_t>(prop.sharedMemPerBlock, prop.maxSharedMemoryPerMultiProcessor);
+        c->name = prop.name;
+        if (c->name.empty()) c->name = std::string("AMD ") + prop.gcnArchName;   // amdgpu.ids may be absent on the box
+        HIPCHECK(nullptr, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+        HIPCHECK(nullptr, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        c->stream = c->own_stream;
+        HIPCHECK(nullptr, hipMalloc((void**)&c->d_maxlen, (size_t)MAX_SLICES * MAX_LEVELS * sizeof(unsigned long long)));
+        HIPCHECK(nullptr, hipMalloc((void**)&c->d_flags, MAX_SLICES * sizeof(int)));
+        HIPCHECK(nullptr, hipMalloc((void**)&c->d_nparts, MAX_LEVELS * sizeof(int)));
+        HIPCHECK(nullptr, hipMalloc((void**)&c->d_nslow, sizeof(int)));
+        HIPCHECK(nullptr, hipMalloc((void**)&c->d_tilectr, 32 * sizeof(int)));
+        HIPCHECK(nullptr, hipMalloc((void**)&c->d_sidectr, sizeof(int)));
+        HIPCHECK(nullptr, hipMemset(c->d_sidectr, 0, sizeof(int)));
+        HIPCHECK(nullptr, hipMemset(c->d_nslow, 0, sizeof(int)));
+        return RDR_OK;
+    }();
+    if (rc) { rdr_destroy(c); return rc; }
     if (const char* e = std::getenv("RAIDER_HIP_WORKSPACE_BYTES")) c->ws_limit = (size_t)std::strtoull(e, nullptr, 10);
     *out = c;
     return RDR_OK;
@@ -195,7 +215,7 @@ int rdr_create(int device, rdr_ctx** out) {
 void rdr_destroy(rdr_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto& b : c->slot) if (b.p) (void)hipFree(b.p);
     if (c->d_maxlen) (void)hipFree(c->d_maxlen);
     if (c->d_flags) (void)hipFree(c->d_flags);
@@ -396,20 +416,52 @@ int rdr_cube_axes(const rdr_cube* q, double* ys, double* xs, double* zs) {
     return RDR_OK;
 }
 
+// LccParams of a conic model CRS from the C ABI's parameter array (shared by rdr_cube_set_projection / rdr_transform_cone)
+static int cone_params(rdr_ctx* c, const char* who, int kind, const double* p, int np, LccParams& out) {
+    const std::string w(who);
+    if (kind == RDR_PROJ_STERE) {
+        if (!p || np < 8) return fail(c, RDR_ERR_INVALID, w + ": STERE needs 8 parameters (a, es, lat_0, lat_ts, k_0, lon_0, x_0, y_0)");
+        if (!(p[0] > 0) || p[1] < 0 || p[1] >= 1 || std::fabs(std::fabs(p[2]) - 90.0) > 1e-9 || (p[3] == p[3] && (std::fabs(p[3]) > 90 || p[3] * p[2] < 0)) || !(p[4] > 0))
+            return fail(c, RDR_ERR_INVALID, w + ": only the POLAR stereographic aspect is supported (lat_0 = +-90, lat_ts in the same hemisphere, k_0 > 0)");
+        out = stere_setup(p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7]);
+        return RDR_OK;
+    }
+    if (kind != RDR_PROJ_LCC || !p || np < 8) return fail(c, RDR_ERR_INVALID, w + ": LCC needs 8 parameters (a, es, lat_1, lat_2, lat_0, lon_0, x_0, y_0)");
+    if (!(p[0] > 0) || p[1] < 0 || p[1] >= 1 || std::fabs(p[2]) >= 90 || std::fabs(p[3]) >= 90 || std::fabs(p[2] + p[3]) < 1e-10)
+        return fail(c, RDR_ERR_INVALID, w + ": invalid LCC parameters");
+    out = lcc_setup(p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7]);
+    return RDR_OK;
+}
+
 int rdr_cube_set_projection(rdr_cube* q, int kind, const double* p, int np) {
     if (!q) return fail(nullptr, RDR_ERR_INVALID, "cube is NULL");
     if (kind == RDR_PROJ_LONLAT) { q->proj = LccParams{0, 0, 0, 0, 0, 0, 0, 0}; return RDR_OK; }
-    if (kind == RDR_PROJ_STERE) {
-        if (!p || np < 8) return fail(q->ctx, RDR_ERR_INVALID, "rdr_cube_set_projection: STERE needs 8 parameters (a, es, lat_0, lat_ts, k_0, lon_0, x_0, y_0)");
-        if (!(p[0] > 0) || p[1] < 0 || p[1] >= 1 || std::fabs(std::fabs(p[2]) - 90.0) > 1e-9 || (p[3] == p[3] && (std::fabs(p[3]) > 90 || p[3] * p[2] < 0)) || !(p[4] > 0))
-            return fail(q->ctx, RDR_ERR_INVALID, "rdr_cube_set_projection: only the POLAR stereographic aspect is supported (lat_0 = +-90, lat_ts in the same hemisphere, k_0 > 0)");
-        q->proj = stere_setup(p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7]);
-        return RDR_OK;
-    }
-    if (kind != RDR_PROJ_LCC || !p || np < 8) return fail(q->ctx, RDR_ERR_INVALID, "rdr_cube_set_projection: LCC needs 8 parameters (a, es, lat_1, lat_2, lat_0, lon_0, x_0, y_0)");
-    if (!(p[0] > 0) || p[1] < 0 || p[1] >= 1 || std::fabs(p[2]) >= 90 || std::fabs(p[3]) >= 90 || std::fabs(p[2] + p[3]) < 1e-10)
-        return fail(q->ctx, RDR_ERR_INVALID, "rdr_cube_set_projection: invalid LCC parameters");
-    q->proj = lcc_setup(p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7]);
+    LccParams L;
+    const int rc = cone_params(q->ctx, "rdr_cube_set_projection", kind, p, np, L);
+    if (rc) return rc;
+    q->proj = L;
+    return RDR_OK;
+}
+
+int rdr_transform_cone(rdr_ctx* c, int kind, const double* p, int np, int direction, const double* in_a, const double* in_b, int64_t n,
+                       double* out_a, double* out_b, int loc) {
+    if (!c || (n > 0 && (!in_a || !in_b || !out_a || !out_b))) return fail(c, RDR_ERR_INVALID, "rdr_transform_cone: NULL argument");
+    if (direction != 0 && direction != 1) return fail(c, RDR_ERR_INVALID, "rdr_transform_cone: direction is 0 (forward) or 1 (inverse)");
+    LccParams L;
+    int rc = cone_params(c, "rdr_transform_cone", kind, p, np, L); if (rc) return rc;
+    if (n == 0) return RDR_OK;
+    HIPCHECK(c, hipSetDevice(c->device));
+    const void *da, *db; void *oa, *ob;
+    rc = stage_in(c, SLOT_IN0, in_a, (size_t)n * 8, loc, &da); if (rc) return rc;
+    rc = stage_in(c, SLOT_IN1, in_b, (size_t)n * 8, loc, &db); if (rc) return rc;
+    rc = stage_out(c, SLOT_OUT0, out_a, (size_t)n * 8, loc, &oa); if (rc) return rc;
+    rc = stage_out(c, SLOT_OUT1, out_b, (size_t)n * 8, loc, &ob); if (rc) return rc;
+    hipLaunchKernelGGL(cone_kernel, dim3(grid_for(n, 256, c->num_cus * 8)), dim3(256), 0, c->stream, L, direction, (const double*)da, (const double*)db, n,
+                       (double*)oa, (double*)ob);
+    HIPCHECK(c, hipGetLastError());
+    rc = finish_out(c, out_a, oa, (size_t)n * 8, loc); if (rc) return rc;
+    rc = finish_out(c, out_b, ob, (size_t)n * 8, loc); if (rc) return rc;
+    if (loc == RDR_HOST) HIPCHECK(c, hipStreamSynchronize(c->stream));
     return RDR_OK;
 }
 
@@ -887,33 +939,35 @@ static bool wsig_match(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, double 
 static int launch_crossings(rdr_ctx* c, const rdr_cube* q, RayParams P, int64_t tb, int64_t tc, int64_t nslots_total = 0, bool reset_nslow = true) {
     P.tile_begin = tb; P.tile_count = tc; P.nslots = nslots_total > 0 ? nslots_total : tc * BLOCK;
     const int g = ray_grid(c, tc, 8);
+    if (ray_smem(q) > c->lds_max)
+        return fail(c, RDR_ERR_INVALID, "ray tracing: the cube's non-uniform horizontal axes and level tables need " + std::to_string(ray_smem(q)) +
+                    " B of LDS per workgroup, the device offers " + std::to_string(c->lds_max) + " (resample the cube to uniform axes or crop it)");
     if (reset_nslow) {
         HIPCHECK(c, hipMemsetAsync(c->d_nslow, 0, sizeof(int), c->stream));
         HIPCHECK(c, hipMemsetAsync(c->d_sidectr, 0, sizeof(int), c->stream));
     }
     HIPCHECK(c, hipMemsetAsync(c->d_tilectr, 0, 16 * sizeof(int), c->stream));
     P.tile_ctr = c->d_tilectr;
+    const size_t sm = ray_smem(q);
+    hipError_t e = hipSuccess;
     {
         KTimer t(c, 0);
         const bool lcc = q->proj.kind == 1;
         // input form of the batch, fixed at compile time for the two hot ones (crossings_kernel's OM parameter)
         const int om = P.origin_mode != RDR_ORIGIN_GRID ? 0 : (P.los_mode == RDR_LOS_VEC ? 1 : 2);
         const dim3 G(g), B(BLOCK);
-        const size_t sm = ray_smem(q);
-#define RDR_LAUNCH_X(T2, LCC_, OM_) hipLaunchKernelGGL((crossings_kernel<T2, false, LCC_, OM_>), G, B, sm, c->stream, make_view<T2>(q), P, q->proj)
+#define RDR_LAUNCH_X(T2, LCC_, OM_) e = launch_lds(crossings_kernel<T2, false, LCC_, OM_>, G, B, sm, c->stream, make_view<T2>(q), P, q->proj)
 #define RDR_LAUNCH_X_OM(T2, LCC_) do { if (om == 1) RDR_LAUNCH_X(T2, LCC_, 1); else if (om == 2) RDR_LAUNCH_X(T2, LCC_, 2); else RDR_LAUNCH_X(T2, LCC_, 0); } while (0)
         if (q->dtype == RDR_F32) { if (lcc) RDR_LAUNCH_X_OM(float2, true); else RDR_LAUNCH_X_OM(float2, false); }
         else { if (lcc) RDR_LAUNCH_X_OM(double2, true); else RDR_LAUNCH_X_OM(double2, false); }
 #undef RDR_LAUNCH_X_OM
 #undef RDR_LAUNCH_X
     }
+    if (e != hipSuccess) return fail(c, RDR_ERR_HIP, std::string("crossings_kernel launch: ") + hipGetErrorString(e));
     // generic-geodesy mop-up of the rays the classification rejected (returns at once when there are none)
     P.tile_ctr = c->d_tilectr + 8;
-    if (q->dtype == RDR_F32)
-        hipLaunchKernelGGL((crossings_kernel<float2, true>), dim3(g), dim3(BLOCK), ray_smem(q), c->stream, make_view<float2>(q), P, q->proj);
-    else
-        hipLaunchKernelGGL((crossings_kernel<double2, true>), dim3(g), dim3(BLOCK), ray_smem(q), c->stream, make_view<double2>(q), P, q->proj);
-    hipError_t e = hipGetLastError();
+    if (q->dtype == RDR_F32) e = launch_lds(crossings_kernel<float2, true>, dim3(g), dim3(BLOCK), sm, c->stream, make_view<float2>(q), P, q->proj);
+    else e = launch_lds(crossings_kernel<double2, true>, dim3(g), dim3(BLOCK), sm, c->stream, make_view<double2>(q), P, q->proj);
     if (e != hipSuccess) return fail(c, RDR_ERR_HIP, std::string("crossings_kernel launch: ") + hipGetErrorString(e));
     return RDR_OK;
 }
@@ -923,24 +977,25 @@ static int launch_march(rdr_ctx* c, const rdr_cube* q, RayParams P, int64_t tb, 
     const int g = ray_grid(c, tc, 8);
     HIPCHECK(c, hipMemsetAsync(c->d_tilectr + 16, 0, 16 * sizeof(int), c->stream));
     P.tile_ctr = c->d_tilectr + 16;
+    const size_t sm = ray_smem(q);
+    const dim3 G(g), B(BLOCK);
+    hipError_t e = hipSuccess;
     {
         KTimer t(c, 1);
         const auto v32 = make_view<float2>(q);
         const bool regular = q->exact[0] && q->exact[1] && v32.small && (q->dtype == RDR_F32 || make_view<double2>(q).small);
         if (q->dtype == RDR_F32) {
-            if (regular) hipLaunchKernelGGL((march_kernel<float2, false, true>), dim3(g), dim3(BLOCK), ray_smem(q), c->stream, v32, P, q->proj);
-            else hipLaunchKernelGGL((march_kernel<float2, false, false>), dim3(g), dim3(BLOCK), ray_smem(q), c->stream, v32, P, q->proj);
+            if (regular) e = launch_lds(march_kernel<float2, false, true>, G, B, sm, c->stream, v32, P, q->proj);
+            else e = launch_lds(march_kernel<float2, false, false>, G, B, sm, c->stream, v32, P, q->proj);
         } else {
-            if (regular) hipLaunchKernelGGL((march_kernel<double2, false, true>), dim3(g), dim3(BLOCK), ray_smem(q), c->stream, make_view<double2>(q), P, q->proj);
-            else hipLaunchKernelGGL((march_kernel<double2, false, false>), dim3(g), dim3(BLOCK), ray_smem(q), c->stream, make_view<double2>(q), P, q->proj);
+            if (regular) e = launch_lds(march_kernel<double2, false, true>, G, B, sm, c->stream, make_view<double2>(q), P, q->proj);
+            else e = launch_lds(march_kernel<double2, false, false>, G, B, sm, c->stream, make_view<double2>(q), P, q->proj);
         }
     }
+    if (e != hipSuccess) return fail(c, RDR_ERR_HIP, std::string("march_kernel launch: ") + hipGetErrorString(e));
     P.tile_ctr = c->d_tilectr + 24;
-    if (q->dtype == RDR_F32)
-        hipLaunchKernelGGL((march_kernel<float2, true>), dim3(g), dim3(BLOCK), ray_smem(q), c->stream, make_view<float2>(q), P, q->proj);
-    else
-        hipLaunchKernelGGL((march_kernel<double2, true>), dim3(g), dim3(BLOCK), ray_smem(q), c->stream, make_view<double2>(q), P, q->proj);
-    hipError_t e = hipGetLastError();
+    if (q->dtype == RDR_F32) e = launch_lds(march_kernel<float2, true>, G, B, sm, c->stream, make_view<float2>(q), P, q->proj);
+    else e = launch_lds(march_kernel<double2, true>, G, B, sm, c->stream, make_view<double2>(q), P, q->proj);
     if (e != hipSuccess) return fail(c, RDR_ERR_HIP, std::string("march_kernel launch: ") + hipGetErrorString(e));
     return RDR_OK;
 }
@@ -975,7 +1030,6 @@ static int raytrace_pipelined(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, 
     const int64_t nslots_total = P.ntiles * BLOCK;
     if (d_los) P.los = d_los;                  // (else the look vectors come from inc / heading or zenith: nothing to upload)
     std::vector<hipEvent_t> ev(2 * nchunk, nullptr);
-    for (auto& e : ev) HIPCHECK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     auto range = [&](int k, int64_t& tb, int64_t& tc, int64_t& r0, int64_t& cnt) {
         const int64_t t0 = tile_rows * k / nchunk, t1 = tile_rows * (k + 1) / nchunk;
         tb = t0 * P.tiles_x; tc = (t1 - t0) * P.tiles_x;
@@ -984,6 +1038,8 @@ static int raytrace_pipelined(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, 
     };
     int status = RDR_OK;
     auto cleanup = [&]() { for (auto& e : ev) if (e) (void)hipEventDestroy(e); };
+    for (auto& e : ev)
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { cleanup(); return fail(c, RDR_ERR_HIP, "pipelined ray tracing: event creation failed"); }
     for (int k = 0; k < nchunk && status == RDR_OK; ++k) {
         int64_t tb, tc, r0, cnt; range(k, tb, tc, r0, cnt);
         if (d_los && (hipMemcpyAsync(d_los + 3 * r0, r->los + 3 * r0, (size_t)cnt * 24, hipMemcpyHostToDevice, c->copy_stream) != hipSuccess ||

@@ -566,38 +566,61 @@ def writeResultsToXarray(datetime, xpts, ypts, zpts, crs, wetDelay, hydroDelay, 
     return ds
 
 
+def _builtin_crs(crs):
+    """('geodetic' | 'ecef' | 'tm' | 'cone', parameters) for the CRSs handled on the GPU, or None."""
+    e = _epsg(crs)
+    if e == 4326:
+        return 'geodetic', None
+    if e == 4978:
+        return 'ecef', None
+    tm = _tm_params(crs)
+    if tm is not None:
+        return 'tm', tm
+    lcc = _lcc_params(crs)
+    if lcc is not None:
+        return 'cone', dict(lcc, proj='lcc')
+    st = _stere_params(crs)
+    if st is not None:
+        return 'cone', dict(st, proj='stere')
+    return None
+
+
 def transformPoints(lats, lons, hgts, old_proj, new_proj):
-    """delay.py:404-436: (lat, lon, h) in `old_proj` -> stacked (y, x, z) in `new_proj`.
-    EPSG:4326 <-> EPSG:4978 run on the GPU; anything else needs pyproj (as in the reference)."""
+    """delay.py:404-436: (lat, lon, h) in `old_proj` -> stacked (y, x, z) in `new_proj` (`lats` carries y, `lons` carries x).
+    EPSG:4326, EPSG:4978, transverse-Mercator CRSs (every UTM zone; national TM grids as a PROJ string / dict) and the conic model
+    CRSs (Lambert conformal conic: HRRR; polar stereographic: HRRR-AK) are converted on the GPU in any combination, through
+    geodetic coordinates; anything else needs pyproj (as in the reference)."""
     eo, en = _epsg(old_proj), _epsg(new_proj)
     lats, lons, hgts = np.broadcast_arrays(np.asarray(lats, dtype=np.float64), np.asarray(lons, dtype=np.float64),
                                            np.asarray(hgts, dtype=np.float64))
-    if eo is not None and eo == en:
+    if (eo is not None and eo == en) or (eo is None and en is None and old_proj == new_proj):
         return np.stack([lats, lons, hgts], axis=-1)
-    if eo == 4326 and en == 4978:
-        x, y, z = lla2ecef(lats, lons, hgts)
-        return np.stack([y, x, z], axis=-1)
-    if eo == 4978 and en == 4326:
-        lon, lat, h = ecef2lla(lons, lats, hgts)          # always_xy: x = "lons" argument, y = "lats" argument
+    src, dst = _builtin_crs(old_proj), _builtin_crs(new_proj)
+    if src is not None and dst is not None:
+        from .utilFcns import conic, transverse_mercator
+        # to geodetic (lat, lon, h)
+        if src[0] == 'ecef':
+            lon, lat, h = ecef2lla(lons, lats, hgts)      # always_xy: x = "lons" argument, y = "lats" argument
+        elif src[0] == 'tm':
+            lat, lon = transverse_mercator(lats, lons, src[1], inverse=True); h = hgts
+        elif src[0] == 'cone':
+            lat, lon = conic(lats, lons, src[1], inverse=True); h = hgts
+        else:
+            lat, lon, h = lats, lons, hgts
+        # from geodetic
+        if dst[0] == 'ecef':
+            x, y, z = lla2ecef(lat, lon, h)
+            return np.stack([y, x, z], axis=-1)
+        if dst[0] == 'tm':
+            y, x = transverse_mercator(lat, lon, dst[1])
+            return np.stack([y, x, h], axis=-1)
+        if dst[0] == 'cone':
+            y, x = conic(lat, lon, dst[1])
+            return np.stack([y, x, h], axis=-1)
         return np.stack([lat, lon, h], axis=-1)
-    # transverse-Mercator CRSs (every UTM zone; national TM grids given as a PROJ string / dict) against EPSG:4326, on the GPU
-    tm_o, tm_n = _tm_params(old_proj), _tm_params(new_proj)
-    if tm_n is not None and eo == 4326:
-        from .utilFcns import transverse_mercator
-        y, x = transverse_mercator(lats, lons, tm_n)
-        return np.stack([y, x, hgts], axis=-1)
-    if tm_o is not None and en == 4326:
-        from .utilFcns import transverse_mercator
-        lat, lon = transverse_mercator(lats, lons, tm_o, inverse=True)        # (y, x) travel in the (lats, lons) slots
-        return np.stack([lat, lon, hgts], axis=-1)
-    if tm_o is not None and en == 4978:
-        from .utilFcns import transverse_mercator
-        lat, lon = transverse_mercator(lats, lons, tm_o, inverse=True)
-        x, y, z = lla2ecef(lat, lon, hgts)
-        return np.stack([y, x, z], axis=-1)
     if pyproj is None:
-        raise NotImplementedError(f'transformPoints {old_proj} -> {new_proj} needs pyproj (built in: EPSG:4326 <-> EPSG:4978 and EPSG:4326 <-> '
-                                  'transverse Mercator / UTM)')
+        raise NotImplementedError(f'transformPoints {old_proj} -> {new_proj} needs pyproj (built in: EPSG:4326, EPSG:4978, transverse Mercator / '
+                                  'UTM, Lambert conformal conic and polar stereographic, in any combination)')
     t = pyproj.Transformer.from_crs(old_proj, new_proj, always_xy=True)
     res = t.transform(lons, lats, hgts)
     return np.stack([res[1], res[0], res[2]], axis=-1)

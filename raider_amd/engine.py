@@ -16,6 +16,16 @@ def _is_dev(a):
     return hasattr(a, 'data_ptr')
 
 
+def _dev_f64(t, what, numel=None):
+    """A device array the kernels read or write through its raw pointer: float64, contiguous, on a GPU, of the expected size."""
+    import torch
+    if t.dtype != torch.float64 or not t.is_cuda or not t.is_contiguous():
+        raise TypeError(f'{what} must be a contiguous float64 tensor on the GPU (got {t.dtype} on {t.device}, contiguous={t.is_contiguous()})')
+    if numel is not None and t.numel() != numel:
+        raise ValueError(f'{what} has {t.numel()} elements, {numel} expected')
+    return t
+
+
 class Cube:
     """Both fields of one processed weather model on the GPU, with scipy-RGI semantics.
 
@@ -40,9 +50,12 @@ class Cube:
             shape = wet.shape
         else:
             import torch
+            if wet.dtype not in (torch.float32, torch.float64) or hydro.dtype != wet.dtype:
+                raise TypeError(f'device cubes must be float32 or float64 tensors of one dtype (got {wet.dtype} / {hydro.dtype})')
+            if not (wet.is_cuda and hydro.is_cuda and wet.is_contiguous() and hydro.is_contiguous()):
+                raise ValueError('device cubes must be contiguous tensors on the GPU')
             dt = L.RDR_F32 if wet.dtype == torch.float32 else L.RDR_F64
             shape = tuple(wet.shape)
-            assert wet.is_contiguous() and hydro.is_contiguous()
             self.ctx.adopt_torch_stream(wet)
         ny, nx, nz = ys.size, xs.size, zs.size
         if order == 'yxz':
@@ -129,6 +142,10 @@ class Cube:
         """scipy RGI __call__ on both fields; pts[...,3] = (y,x,z).  Returns (wet, hydro) f64."""
         if _is_dev(pts):
             import torch
+            if pts.shape[-1] != 3:
+                raise ValueError(f'The requested sample points xi have dimension {pts.shape[-1]} but this '
+                                 'RegularGridInterpolator has dimension 3')
+            _dev_f64(pts, 'pts')
             self.ctx.adopt_torch_stream(pts)
             n = pts.numel() // 3
             wet = torch.empty(pts.shape[:-1], dtype=torch.float64, device=pts.device)
@@ -150,8 +167,11 @@ class Cube:
             import torch
             self.ctx.adopt_torch_stream(xpts)
             nx, ny, nz = xpts.numel(), ypts.numel(), zpts.numel()
+            for t, what in ((xpts, 'xpts'), (ypts, 'ypts'), (zpts, 'zpts')):
+                _dev_f64(t, what)
             wet, hyd = out if out is not None else (torch.empty((nz, ny, nx), dtype=torch.float64, device=xpts.device),
                                                     torch.empty((nz, ny, nx), dtype=torch.float64, device=xpts.device))
+            _dev_f64(wet, 'out[0]', nx * ny * nz); _dev_f64(hyd, 'out[1]', nx * ny * nz)
             check(self.ctx.lib.rdr_build_cube(self.ctx.handle, self.handle, ptr(xpts), nx, ptr(ypts), ny, ptr(zpts), nz,
                                               ptr(wet), ptr(hyd), L.RDR_DEVICE), self.ctx.handle)
             return wet, hyd
@@ -179,10 +199,17 @@ class Cube:
                                            C.byref(flags)), self.ctx.handle)
         return maxlen, flags.value
 
+    def _check_partition(self, partition, ht, zref):
+        K = len(self.ray_levels(ht, zref)[0])
+        _dev_f64(partition, 'partition')
+        if partition.numel() < K + 4:
+            raise ValueError(f'partition needs K + 4 = {K + 4} elements (got {partition.numel()})')
+
     def ray_prepass_device(self, rays, ht, zref, partition):
         """Pass 1 with its result left on the device: `partition` = torch float64 tensor of K+4 elements (per-level maxima,
         then the 4 flag bits as 0/1) - ready for an element-wise MAX all-reduce.  Asynchronous."""
         rays.adopt_stream(self.ctx)
+        self._check_partition(partition, ht, zref)
         check(self.ctx.lib.rdr_ray_prepass_device(self.ctx.handle, self.handle, C.byref(rays.struct), float(ht), float(zref), ptr(partition)),
               self.ctx.handle)
         return partition
@@ -192,6 +219,7 @@ class Cube:
         rays.adopt_stream(self.ctx)
         wet, hyd = out if out is not None else rays.empty_outputs()
         rays.check_outputs(wet, hyd)
+        self._check_partition(partition, ht, zref)
         check(self.ctx.lib.rdr_ray_march_device(self.ctx.handle, self.handle, C.byref(rays.struct), float(ht), float(zref), float(max_seg),
                                                 ptr(partition), ptr(wet), ptr(hyd)), self.ctx.handle)
         return wet, hyd
@@ -241,7 +269,7 @@ class Cube:
             hyd = torch.empty_like(wet)
         else:
             wet = np.empty((S,) + tuple(rays.shape)); hyd = np.empty_like(wet)
-        rays.check_outputs(wet, hyd)
+        rays.check_outputs(wet, hyd, slices=S)
         ld = self.shape[2] - 1
         if want_partition:
             K = np.zeros(S, dtype=np.int32); nparts = np.zeros((S, ld), dtype=np.int32); flags = np.zeros(S, dtype=np.int32)
@@ -322,18 +350,22 @@ class Rays:
         self._keep = kept
         self._has_host = False
 
-    def check_outputs(self, *outs):
+    def check_outputs(self, *outs, slices=1):
         """Output arrays must live where the batch lives (a NumPy output handed to a device batch would be written through a
-        host pointer by the kernels)."""
+        host pointer by the kernels) and hold one float64 per ray (and slice)."""
+        want = int(self.struct.n) * int(slices)
         for o in outs:
             if o is None:
                 continue
+            have = o.numel() if _is_dev(o) else np.size(o)
+            if have != want:
+                raise ValueError(f'output arrays must hold {want} values for this ray batch (got {have})')
             dev = _is_dev(o) and getattr(o, 'is_cuda', False)
             if dev != (self._torch_device is not None):
                 raise ValueError('output arrays must be ' + ('tensors on ' + str(self._torch_device) if self._torch_device is not None else 'NumPy arrays') +
                                  ' for this ray batch')
-            if dev and (o.device != self._torch_device or not o.is_contiguous()):
-                raise ValueError('output tensors must be contiguous and on the device of the ray batch')
+            if dev and (o.device != self._torch_device or not o.is_contiguous() or str(o.dtype) != 'torch.float64'):
+                raise ValueError('output tensors must be contiguous float64 and on the device of the ray batch')
             if not dev and not (isinstance(o, np.ndarray) and o.dtype == np.float64 and o.flags.c_contiguous):
                 raise ValueError('output arrays must be C-contiguous float64 NumPy arrays')
 

@@ -82,6 +82,31 @@ def utm_params(epsg):
     return None
 
 
+def conic(a_in, b_in, params, inverse=False):
+    """Forward: (lat, lon) deg -> (y, x) m; inverse: (y, x) m -> (lat, lon) deg for a conic model CRS, on the GPU (rdr_transform_cone).
+    params: dict(proj='lcc', a, es, lat_1, lat_2, lat_0, lon_0, x_0, y_0) (HRRR, models/hrrr.py:248-259) or
+    dict(proj='stere', a, es, lat_0, lat_ts, k_0, lon_0, x_0, y_0) (HRRR-AK, models/hrrr.py:22-25; polar aspect only)."""
+    from . import _lib as L
+    from ._lib import Context, check, f64, ptr
+    a_in, b_in = np.broadcast_arrays(np.asarray(a_in, dtype=np.float64), np.asarray(b_in, dtype=np.float64))
+    shp = a_in.shape
+    ua, ub = f64(a_in).ravel(), f64(b_in).ravel()
+    oa, ob = np.empty(ua.size), np.empty(ua.size)
+    if params.get('proj', 'lcc') == 'stere':
+        kind = 2
+        lat_ts = params.get('lat_ts')
+        p = np.array([params['a'], params['es'], params['lat_0'], np.nan if lat_ts is None else lat_ts, params.get('k_0', 1.0), params['lon_0'],
+                      params.get('x_0', 0.0), params.get('y_0', 0.0)], dtype=np.float64)
+    else:
+        kind = 1
+        p = np.array([params['a'], params['es'], params['lat_1'], params['lat_2'], params['lat_0'], params['lon_0'], params.get('x_0', 0.0),
+                      params.get('y_0', 0.0)], dtype=np.float64)
+    ctx = Context.default()
+    check(ctx.lib.rdr_transform_cone(ctx.handle, kind, ptr(p), p.size, int(bool(inverse)), ptr(ua), ptr(ub), ua.size, ptr(oa), ptr(ob), L.RDR_HOST),
+          ctx.handle)
+    return oa.reshape(shp), ob.reshape(shp)
+
+
 def transverse_mercator(a_in, b_in, params, inverse=False):
     """Forward: (lat, lon) deg -> (y, x) m; inverse: (y, x) m -> (lat, lon) deg, on the GPU (rdr_transform_tm: Krueger series to n^6,
     the formulation of PROJ's etmerc / utm).  params: dict(a, es, lat_0, lon_0, k_0, x_0, y_0)."""

@@ -487,3 +487,83 @@ def test_utm_output_grid_through_transformPoints_and_tropo_delay(c1):
     ds = writeResultsToXarray(__import__('datetime').datetime(2020, 1, 1), xg, yg, zpts, 32611, rw_, rh_, 'x.nc', 'slant - raytracing')
     if hasattr(ds, 'attrs') and '_crs_cf' in getattr(ds, 'attrs', {}):
         assert ds.attrs['_crs_cf']['grid_mapping_name'] == 'transverse_mercator' and ds.attrs['_crs_cf']['longitude_of_central_meridian'] == -117.0
+
+
+def test_transformPoints_to_and_from_the_conic_model_crs():
+    """transformPoints(lats, lons, hts, EPSG:4326, hrrr_proj) and back - the reference's own round trip (test/test_delayFcns.py:67-84
+    through pyproj) - on the device, against the oracle's Snyder formulas; HRRR-AK's polar stereographic CRS; and a combination
+    that goes through geodetic coordinates (UTM -> LCC, LCC -> ECEF)."""
+    from raider_amd.delay import transformPoints
+    hrrr = '+proj=lcc +lat_1=38.5 +lat_2=38.5 +lat_0=38.5 +lon_0=262.5 +x_0=0 +y_0=0 +a=6371229 +b=6371229 +units=m +no_defs'     # models/hrrr.py:248-259
+    H = dict(lat_1=38.5, lat_2=38.5, lat_0=38.5, lon_0=262.5, a=6371229.0, es=0.0)
+    lats = np.array([40.0, 45.0, 55.0]); lons = np.array([-90.0, -90.0, -90.0]); hts = np.zeros(3)
+    out = transformPoints(lats, lons, hts, 4326, hrrr)                           # test_transformPoints_2
+    ox, oy = O.lcc_forward(lats, lons, **H)
+    np.testing.assert_allclose(out[:, 1], ox, rtol=0, atol=1e-6); np.testing.assert_allclose(out[:, 0], oy, rtol=0, atol=1e-6)
+    back = transformPoints(out[:, 0], out[:, 1], out[:, 2], hrrr, 4326)
+    assert np.allclose(back[:, 0], lats, rtol=0, atol=1e-11) and np.allclose(back[:, 1], lons, rtol=0, atol=1e-11) and np.allclose(back[:, 2], hts)
+    rng = np.random.default_rng(4)
+    la = rng.uniform(15, 65, 4000); lo = rng.uniform(-150, -50, 4000); h = rng.uniform(0, 9000, 4000)
+    p = transformPoints(la, lo, h, 4326, hrrr)
+    ox, oy = O.lcc_forward(la, lo, **H)
+    np.testing.assert_allclose(p[:, 1], ox, rtol=0, atol=2e-6); np.testing.assert_allclose(p[:, 0], oy, rtol=0, atol=2e-6)
+    b = transformPoints(p[:, 0], p[:, 1], p[:, 2], hrrr, 4326)
+    ola, olo = O.lcc_inverse(p[:, 1], p[:, 0], **H)
+    np.testing.assert_allclose(b[:, 0], ola, rtol=0, atol=1e-12); np.testing.assert_allclose(b[:, 1], olo, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(b[:, 0], la, rtol=0, atol=1e-11); np.testing.assert_allclose(b[:, 1], lo, rtol=0, atol=1e-11)
+    assert np.array_equal(b[:, 2], h)
+    # an ellipsoidal cone of the southern hemisphere (negative cone constant) and Snyder's ellipsoidal example, inverted
+    S = dict(proj='lcc', lat_1=-30.0, lat_2=-60.0, lat_0=-45.0, lon_0=20.0, x_0=1.0e6, y_0=2.0e6, a=6378137.0, es=0.0066943799901413165)
+    la = rng.uniform(-80, -10, 2000); lo = rng.uniform(-40, 80, 2000)
+    p = transformPoints(la, lo, 0.0, 4326, S)
+    ox, oy = O.lcc_forward(la, lo, **{k: v for k, v in S.items() if k != 'proj'})
+    np.testing.assert_allclose(p[:, 1], ox, rtol=0, atol=2e-6); np.testing.assert_allclose(p[:, 0], oy, rtol=0, atol=2e-6)
+    b = transformPoints(p[:, 0], p[:, 1], 0.0, S, 4326)
+    np.testing.assert_allclose(b[:, 0], la, rtol=0, atol=1e-11); np.testing.assert_allclose(b[:, 1], lo, rtol=0, atol=1e-11)
+    sny = dict(proj='lcc', lat_1=33.0, lat_2=45.0, lat_0=23.0, lon_0=-96.0, a=6378206.4, es=0.00676866)
+    b = transformPoints(1564649.5, 1894410.9, 0.0, sny, 4326)                     # USGS PP 1395 p. 297-298
+    assert abs(b[0] - 35.0) < 5e-7 and abs(b[1] + 75.0) < 5e-7
+    # HRRR-AK (models/hrrr.py:22-25) and a southern polar-stereographic grid
+    ak = '+proj=stere +lat_0=90 +lon_0=225 +lat_ts=60 +a=6371229 +b=6371229'
+    AK = dict(lat_0=90.0, lat_ts=60.0, lon_0=225.0, a=6371229.0, es=0.0)
+    la = rng.uniform(40, 89.9, 3000); lo = rng.uniform(-180, 180, 3000)
+    p = transformPoints(la, lo, 0.0, 4326, ak)
+    ox, oy = O.stere_forward(la, lo, **AK)
+    np.testing.assert_allclose(p[:, 1], ox, rtol=0, atol=2e-6); np.testing.assert_allclose(p[:, 0], oy, rtol=0, atol=2e-6)
+    b = transformPoints(p[:, 0], p[:, 1], 0.0, ak, 4326)
+    np.testing.assert_allclose(b[:, 0], la, rtol=0, atol=1e-11); assert np.abs((b[:, 1] - lo + 180) % 360 - 180).max() < 1e-10
+    assert np.allclose(transformPoints(0.0, 0.0, 0.0, ak, 4326)[:2], [90.0, 225.0 - 360.0])           # the pole itself
+    sp = dict(proj='stere', lat_0=-90.0, lat_ts=-71.0, lon_0=-100.0, a=6378388.0, es=0.00672267)
+    b = transformPoints(-560526.4, -1540033.6, 0.0, sp, 4326)                    # USGS PP 1395 p. 315-317
+    assert abs(b[0] + 75.0) < 5e-7 and abs(b[1] - 150.0) < 5e-7
+    # combinations through geodetic coordinates
+    la = rng.uniform(30, 36, 500); lo = rng.uniform(-121, -113, 500); h = rng.uniform(0, 3000, 500)
+    utm = transformPoints(la, lo, h, 4326, 32611)
+    via = transformPoints(utm[:, 0], utm[:, 1], utm[:, 2], 32611, hrrr)
+    direct = transformPoints(la, lo, h, 4326, hrrr)
+    np.testing.assert_allclose(via, direct, rtol=0, atol=2e-5)                   # 1e-11 deg of the UTM inverse = 1e-6 m
+    ecef = transformPoints(direct[:, 0], direct[:, 1], direct[:, 2], hrrr, 4978)
+    np.testing.assert_allclose(ecef, transformPoints(la, lo, h, 4326, 4978), rtol=0, atol=2e-5)
+
+
+def test_zenith_cube_on_a_utm_grid_over_a_projected_model():
+    """_build_cube with pts_crs = UTM and model_crs = LCC (delay.py:207-209: transformPoints(yy, xx, ht, pts_crs, model_crs)): the two
+    built-in projections chained on the device give what querying the same nodes in lon/lat gives."""
+    import raider_amd as R
+    from raider_amd.delay import transformPoints, _build_cube
+    from raider_amd.delayFcns import FieldInterpolator
+    H = dict(lat_1=38.5, lat_2=38.5, lat_0=38.5, lon_0=262.5 - 360.0, a=6371229.0, es=0.0)
+    hrrr = dict(H, proj='lcc')
+    c = O.synthetic_cube(60, 70, 20, seed=6, y0=-9.0e5, y1=1.0e5, x0=-2.2e6, x1=-1.3e6)          # model coordinates in metres: the US south-west
+    tot = R.Cube(c['ys'], c['xs'], c['zs'], c['wet_total'], c['hydro_total'], order='zyx')
+    xg = 300000.0 + 20000.0 * np.arange(12); yg = 3800000.0 - 20000.0 * np.arange(9)
+    zpts = np.array([100.0, 1500.0])
+    zw, zh = _build_cube(xg, yg, zpts, hrrr, 32611, [FieldInterpolator(tot, 0), FieldInterpolator(tot, 1)])
+    xx, yy = np.meshgrid(xg, yg)
+    ll = transformPoints(yy, xx, np.zeros_like(xx), 32611, 4326)
+    px, py = O.lcc_forward(ll[..., 0], ll[..., 1], **H)
+    ip = list(O.getInterpolators(c['xs'], c['ys'], c['zs'], c['wet_total'], c['hydro_total']))
+    for k, ht in enumerate(zpts):
+        pts = np.stack([py, px, np.full(px.shape, ht)], -1)
+        np.testing.assert_allclose(zw[k], ip[0](pts), rtol=0, atol=1e-12); np.testing.assert_allclose(zh[k], ip[1](pts), rtol=0, atol=1e-12)
+        assert np.isfinite(zw[k]).all()

@@ -244,6 +244,31 @@ def test_tiny_and_nonuniform_axes(R):
     assert np.array_equal(w0, w1) and np.array_equal(h0, h1)
 
 
+def test_long_nonuniform_axes_use_large_lds_tables(R):
+    """A wide cube whose lat / lon axes are only NEARLY uniform (f32-rounded 0.1-degree nodes, as global analyses are distributed):
+    their (node, 1/spacing) tables are 16 B per node of LDS, here 83 KB - past the 64 KB default allocation, inside the 160 KB a
+    gfx950 workgroup may have.  Still exact against the oracle; axes that cannot fit at all are refused with a clear message."""
+    n = 2600
+    rng = np.random.default_rng(5)
+    ys = np.linspace(-60.0, 60.0, n).astype(np.float32).astype(np.float64)
+    xs = np.linspace(-130.0, 130.0, n).astype(np.float32).astype(np.float64)
+    zs = np.array([-100.0, 900.0, 2500.0, 5500.0, 11000.0, 21000.0])
+    prof_h = 270.0 * np.exp(-zs / 8000.0); prof_w = 60.0 * np.exp(-zs / 2000.0)
+    g = (1.0 + 0.02 * rng.standard_normal((n, n))).astype(np.float32)
+    c = dict(ys=ys, xs=xs, zs=zs, wet=(prof_w[:, None, None] * g[None]).astype(np.float32), hydro=(prof_h[:, None, None] * g[None]).astype(np.float32))
+    assert np.ptp(np.diff(ys)) > 1e-7                                     # not exactly uniform: the table path
+    _check_against_oracle(R, c, np.linspace(-118.5, -116.5, 9), np.linspace(33.9, 32.1, 8), 38.0, -167.9, 0.0, zs.max() - 1)
+    del c, g
+    n = 6000                                                              # 192 KB of tables: more LDS than a workgroup can have
+    ys = np.linspace(-60.0, 60.0, n).astype(np.float32).astype(np.float64)
+    xs = np.linspace(-130.0, 130.0, n).astype(np.float32).astype(np.float64)
+    import torch
+    v = torch.ones((2, n, n), dtype=torch.float32, device='cuda:0')
+    big = R.Cube(ys, xs, np.array([0.0, 30000.0]), v, v, order='zyx')
+    with pytest.raises(Exception, match='LDS'):
+        big.raytrace(R.Rays.grid(np.linspace(-118.5, -116.5, 9), np.linspace(33.9, 32.1, 8), inc=30.0, hd=-167.9), 0.0, 29000.0)
+
+
 def test_f64_cube_and_other_maxseg(R):
     c = _small_cube(nz=30)
     c64 = dict(c); c64['wet'] = c['wet'].astype(np.float64) * 1.000000123; c64['hydro'] = c['hydro'].astype(np.float64) * 0.999999877

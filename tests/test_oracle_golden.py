@@ -414,3 +414,30 @@ def test_transverse_mercator_against_published_examples():
     x0, y0 = O.tm_forward(35.0, -117.0, **utm11); x1, y1 = O.tm_forward(35.0 + 1e-6, -117.0, **utm11)
     es = 0.0066943799901413165; M = 6378137.0 * (1 - es) / (1 - es * np.sin(np.radians(35.0)) ** 2) ** 1.5
     assert abs(x0 - 500000.0) < 1e-6 and abs((y1 - y0) / np.radians(1e-6) / (0.9996 * M) - 1) < 1e-6
+
+
+def test_conic_inverses_against_snyders_worked_examples():
+    """The way back of transformPoints for the conic model CRSs (test/test_delayFcns.py:67-84 round-trips it through pyproj): Snyder's
+    inverse numerical examples (USGS PP 1395: LCC pp. 296-298 on the unit sphere and the Clarke 1866 ellipsoid; polar stereographic
+    p. 317) and forward / inverse closure over both hemispheres and both cones."""
+    par = dict(lat_1=33.0, lat_2=45.0, lat_0=23.0, lon_0=-96.0)
+    la, lo = O.lcc_inverse(0.2966785, 0.2462112, a=1.0, es=0.0, **par)
+    assert abs(la - 35.0) < 5e-6 and abs(lo + 75.0) < 5e-6                          # (7 printed digits on the unit sphere)
+    la, lo = O.lcc_inverse(1894410.9, 1564649.5, a=6378206.4, es=0.00676866, **par)
+    assert abs(la - 35.0) < 5e-7 and abs(lo + 75.0) < 5e-7
+    la, lo = O.stere_inverse(-1540033.6, -560526.4, lat_0=-90.0, lat_ts=-71.0, lon_0=-100.0, a=6378388.0, es=0.00672267)
+    assert abs(la + 75.0) < 5e-7 and abs(lo - 150.0) < 5e-7
+    rng = np.random.default_rng(0)
+    lo = rng.uniform(-180, 180, 2000)
+    for kw, la in ((dict(lat_1=38.5, lat_2=38.5, lat_0=38.5, lon_0=262.5, a=6371229.0, es=0.0), rng.uniform(10, 70, 2000)),
+                   (dict(lat_1=-30.0, lat_2=-60.0, lat_0=-45.0, lon_0=20.0, x_0=1e6, y_0=2e6, a=6378137.0, es=0.0066943799901413165), rng.uniform(-80, -5, 2000))):
+        lon = kw['lon_0'] + 0.9 * lo                                                  # (stay off the cone's cut meridian)
+        x, y = O.lcc_forward(la, lon, **kw)
+        la2, lo2 = O.lcc_inverse(x, y, **kw)
+        assert np.abs(la2 - la).max() < 1e-12 and np.abs((lo2 - lon + 180) % 360 - 180).max() < 1e-12
+    for kw, la in ((dict(lat_0=90.0, lat_ts=60.0, lon_0=225.0, a=6371229.0, es=0.0), rng.uniform(30, 89.9, 2000)),
+                   (dict(lat_0=-90.0, lat_ts=-71.0, lon_0=0.0, a=6378137.0, es=0.0066943799901413165), rng.uniform(-89.9, -40, 2000)),
+                   (dict(lat_0=90.0, lat_ts=None, k_0=0.994, lon_0=-45.0, a=6378137.0, es=0.0066943799901413165), rng.uniform(40, 89.9, 2000))):
+        x, y = O.stere_forward(la, lo, **kw)
+        la2, lo2 = O.stere_inverse(x, y, **kw)
+        assert np.abs(la2 - la).max() < 1e-12 and np.abs((lo2 - lo + 180) % 360 - 180).max() < 1e-11
