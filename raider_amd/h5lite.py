@@ -20,8 +20,9 @@ Anything else (compound / reference types, version-4 chunk indices, external sto
 Test status: exercised on the NetCDF-4 files the reference's test suite holds (written by netCDF4 4.9 / libhdf5 1.12-1.14:
 superblock v2, v2 object headers, dense links and attributes, contiguous datasets, variable-length string attributes) -
 tests/test_ref_files.py checks what is read against physics identities and against the reference's own results.  The
-version-0/1 superblock, symbol-table groups and chunked / deflate / shuffle branches follow the specification but no file
-in this environment exercises them (there is no HDF5 writer here to make one).
+version-0 superblock and symbol-table groups are exercised by the files of raider_amd.h5write (tests/test_h5write.py), the
+chunked / deflate / shuffle / fletcher32 branches by libhdf5's own re-layouts of those files and of a reference cube (h5repack
+1.10.6 of the build image, same test): arrays come back bit for bit.
 """
 import zlib
 

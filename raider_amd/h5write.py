@@ -294,8 +294,6 @@ def write_netcdf4(path, dims, variables, global_attrs=None, fill_floats=True):
         fill = None
         if name in dims:
             at += [('CLASS', 'DIMENSION_SCALE'), ('NAME', name)]
-            if users[name]:
-                at.append(('REFERENCE_LIST', ReferenceList(users[name])))
             at.append(('_Netcdf4Coordinates', np.array([dimid[name]], dtype=np.int32)))
             at.append(('_Netcdf4Dimid', np.int32(dimid[name])))
         elif vd:
@@ -311,6 +309,10 @@ def write_netcdf4(path, dims, variables, global_attrs=None, fill_floats=True):
             elif not isinstance(v, str) and np.ndim(v) == 0:
                 v = np.atleast_1d(np.asarray(v))             # a NetCDF numeric attribute is a 1-D array, even of one element
             at.append((k, v))
+        if name in dims and users[name]:
+            # last, where netCDF-C puts it (it attaches the scales when the file is closed) - and where h5repack 1.10 needs it: its
+            # reference pass takes every attribute stored AFTER a compound-with-reference one for a reference attribute as well
+            at.append(('REFERENCE_LIST', ReferenceList(users[name])))
         dsets.append((name, arr, at, fill))
     root = [('_NCProperties', 'version=2,raider_amd_h5write=1')] + [(k, v if isinstance(v, str) or np.ndim(v) else np.atleast_1d(np.asarray(v))) for k, v in (global_attrs or {}).items()]
     return write_hdf5(path, dsets, root)

@@ -13,6 +13,8 @@ import numpy as np
 from . import _lib as L
 from ._lib import Context, check, f64, ptr
 from .constants import _ZREF
+from .orbits import (cut_times, filter_ESA_orbit_file, get_sv, pick_ESA_orbit_file, read_ESA_Orbit_file,   # noqa: F401  (the reference keeps
+                     read_txt_file)                                                                        # the orbit readers in this module)
 from .utilFcns import cosd, enu2ecef, sind
 
 
@@ -209,6 +211,24 @@ class Raytracing(LOS):
         if self._lv is not None:
             return Rays.grid(xpts, ypts, los=self._lv)
         return Rays.grid(xpts, ypts, inc=self._inc, hd=self._hd)
+
+    def getIntersectionWithHeight(self, height):
+        """losreader.py:257-263: where the rays from `self._xyz` along `self._look_vecs` reach `height` (getTopOfAtmosphere)."""
+        return getTopOfAtmosphere(self._xyz, self._look_vecs, height)
+
+    def getIntersectionWithLevels(self, levels):
+        """losreader.py:265-288: (self._lats.shape, len(levels), 3) ray points at the level transitions; NaN where the target
+        is above the level."""
+        rays = np.zeros(list(np.shape(self._lats)) + [len(levels), 3])
+        for ind, z in enumerate(levels):
+            value = self.getIntersectionWithHeight(z)
+            value[np.asarray(self._heights) > z, :] = np.nan
+            rays[..., ind, :] = value
+        return rays
+
+    def calculateDelays(self, delays):
+        """losreader.py:290-299."""
+        raise NotImplementedError
 
     def getLookVectors(self, ht, llh, xyz, yy):
         """delay.py:270 protocol: (ny,nx,3) unit ECEF vectors."""

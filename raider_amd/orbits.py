@@ -58,6 +58,14 @@ def filter_ESA_orbit_file(orbit_xml, ref_time):
     return t0 < ref_time < t1
 
 
+def pick_ESA_orbit_file(list_files, ref_time):
+    """losreader.py:521-534: the first .EOF file of the list whose validity window (in its NAME) contains ref_time."""
+    for path in list_files:
+        if filter_ESA_orbit_file(path, ref_time):
+            return path
+    raise AssertionError('Given orbit files did not match given date/time')
+
+
 def cut_times(times, ref_time, pad):
     """losreader.py:617-634."""
     diff = np.array([(x - ref_time).total_seconds() for x in times])

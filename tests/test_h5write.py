@@ -3,6 +3,7 @@ libhdf5 ITSELF (/opt/conda: h5dump + libhdf5_hl's dimension-scale API through ct
 processed-cube files (tests/golden/ref_files) reproduced variable for variable."""
 import ctypes as C
 import os
+from pathlib import Path
 import shutil
 import subprocess
 
@@ -121,3 +122,45 @@ def test_libhdf5_dimension_scale_api_accepts_the_netcdf4_dimensions(tmp_path):
     for d in ds.values():
         h5.H5Dclose(d)
     h5.H5Fclose(f)
+
+
+H5REPACK = shutil.which('h5repack') or ('/opt/conda/bin/h5repack' if os.path.exists('/opt/conda/bin/h5repack') else None)
+
+
+@pytest.mark.skipif(H5REPACK is None, reason='no h5repack in this image')
+def test_h5repack_rewrites_the_file_and_h5lite_reads_libhdf5s_chunked_layouts(tmp_path):
+    """h5repack (libhdf5 1.10.6) copies every object and reference attribute of a file of this writer (it needs REFERENCE_LIST
+    to be the LAST attribute of a dimension scale, where netCDF-C puts it too) - and its chunked / deflate / shuffle / fletcher32
+    outputs are what pins the chunked branch of raider_amd.h5lite on files libhdf5 itself laid out: the arrays come back
+    bit for bit, from this writer's cube and from one of the reference's own processed cubes (tests/golden/ref_files)."""
+    from raider_amd import h5lite
+    rng = np.random.default_rng(3)
+    p = tmp_path / 'cube.nc'
+    v = _cube_file(p, rng)
+    ref = Path(__file__).parent / 'golden' / 'ref_files' / 'ERA-5_2020_01_30_T13_52_45_32N_35N_120W_115W.nc'
+    rf = h5lite.File(ref)
+    ref_vars = {k: rf[k].read() for k in ('wet', 'hydro', 'wet_total', 'hydro_total', 't', 'z')}
+    big = 'wet,hydro'
+    # chunk shapes per file (own cube: 5 x 4 x 3, reference cube: 145 x 12 x 17); edge chunks are partial in both
+    variants = {'plain': ([], []), 'deflate': (['-f', f'{big}:GZIP=4'], ['2x3x2', '40x5x6']),
+                'shuffle_deflate': (['-f', f'{big}:SHUF', '-f', f'{big}:GZIP=6'], ['5x2x3', '16x12x17']),
+                'fletcher': (['-f', f'{big}:FLET'], ['3x3x3', '64x4x4']), 'chunked_only': ([], ['1x3x3', '7x7x7'])}
+    for tag, (filt, chunks) in variants.items():
+        for k, (src, want) in enumerate(((p, {n: t[1] for n, t in v.items()}), (ref, ref_vars))):
+            out = tmp_path / f'{tag}_{src.name}'
+            args = filt + (['-l', f'{big}:CHUNK={chunks[k]}'] if chunks else [])
+            r = subprocess.run([H5REPACK] + args + [str(src), str(out)], capture_output=True, text=True)
+            assert r.returncode == 0, (tag, src.name, r.stderr[-1500:])
+            f = h5lite.File(out)
+            for name, arr in want.items():
+                got = f[name].read()
+                assert got.dtype == np.asarray(arr).dtype and np.array_equal(got, arr, equal_nan=True), (tag, src.name, name)
+            if tag != 'plain':
+                hdr = subprocess.run([H5DUMP, '-H', '-p', '-d', '/wet', str(out)], capture_output=True, text=True).stdout
+                assert 'CHUNKED' in hdr, hdr[:600]
+    # the version-4 chunk indices (libver latest) are refused by name, not misread
+    out = tmp_path / 'latest.nc'
+    r = subprocess.run([H5REPACK, '--latest', '-f', f'{big}:GZIP=1', '-l', f'{big}:CHUNK=2x3x2', str(p), str(out)], capture_output=True, text=True)
+    assert r.returncode == 0
+    with pytest.raises(h5lite.UnsupportedHDF5Feature):
+        h5lite.File(out)['wet'].read()
