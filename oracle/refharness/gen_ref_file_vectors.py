@@ -10,6 +10,8 @@
       a 145 x 5 x 6 block of the three GMAO cubes of /root/reference/test/gunw_test_data/weather_files/ (12:00, 15:00 and
       the reference's own `timeInterp` product for 13:52:44): pins the two-epoch temporal blend (cli/raider.py:817-819,
       877-888) on a file the reference itself produced.
+  tests/golden/ref_files/HRRR_tropo_20200101T120000_ztd.nc (scenario_1/golden_data: a delay cube written by the reference)
+  tests/golden/ref_files/scenario_4/{lat,lon}.rdr (+ .vrt, .hdr): radar-geometry rasters of the reference's test/scenario_4
   tests/golden/ref_files/ERA-5_2019_11_17_T20_51_58.nc, ERA-5_2022_08_29_T17_00_01.nc (+ the latter's processed cube
       ERA-5_2022_08_29_T17_00_01_69N_73N_159W_152W.nc)
       RAW ERA-5 model-level files (NetCDF-3, packed int16 z / t / q / lnsp on 137 levels) whose processed counterparts sit
@@ -41,6 +43,12 @@ def main():
     src2 = REF_TEST / 'weather_files' / 'ERA-5_2020_01_30_T13_52_45_32N_35N_120W_115W.nc'
     shutil.copyfile(src2, OUT / 'ref_files' / src2.name)
     shutil.copyfile(REF_TEST / 'scenario_6' / 'stations.csv', OUT / 'ref_files' / 'scenario_6_stations.csv')
+    # radar-geometry rasters (flat binary + GDAL .vrt with the statistics GDAL recorded + ENVI .hdr): pins raider_amd.rawraster
+    (OUT / 'ref_files' / 'scenario_4').mkdir(parents=True, exist_ok=True)
+    for fn in ('lat.rdr', 'lat.rdr.vrt', 'lat.hdr', 'lon.rdr', 'lon.rdr.vrt', 'lon.hdr'):
+        shutil.copyfile(REF_TEST / 'scenario_4' / fn, OUT / 'ref_files' / 'scenario_4' / fn)
+    # the delay-cube product the reference's tests load as `wmdata` (test/test_delayFcns.py:30-45)
+    shutil.copyfile(REF_TEST / 'scenario_1' / 'golden_data' / 'HRRR_tropo_20200101T120000_ztd.nc', OUT / 'ref_files' / 'HRRR_tropo_20200101T120000_ztd.nc')
     d = REF_TEST / 'gunw_test_data' / 'weather_files'
     names = dict(t12='GMAO_2020_01_30_T12_00_00_32N_36N_121W_114W.nc', t15='GMAO_2020_01_30_T15_00_00_32N_36N_121W_114W.nc',
                  interp='GMAO_2020_01_30T13_52_44_timeInterp_32N_36N_121W_114W.nc')

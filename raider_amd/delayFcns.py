@@ -71,7 +71,10 @@ class _Var:
         return self._data
 
     def __getitem__(self, k):
-        return self.data[k]
+        d = self.data
+        if np.ndim(d) == 0 and (k is Ellipsis or k == slice(None)):
+            return d                                  # a scalar variable (crs, proj): var[:] / var[...] as netCDF4 / xarray give it
+        return d[k]
 
     def __array__(self, dtype=None, copy=None):
         return np.asarray(self.data, dtype=dtype)

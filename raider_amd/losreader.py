@@ -77,7 +77,7 @@ class Zenith(LOS):
 class Conventional(LOS):
     """Zenith delay projected with 1/cos(inc) (losreader.py:94-133).
 
-    `filename` may be an ISCE-style 2-band LOS raster path (needs rasterio, like the reference), an orbit /
+    `filename` may be an ISCE-style 2-band LOS raster path (rasterio when installed, else raider_amd.rawraster), an orbit /
     state-vector file (losreader.py:122-128: the factor is then cos(look angle) from the zero-Doppler geometry, solved on
     the GPU instead of through isce3), or - array-backed extension - `inc`/`heading` rasters given directly."""
 
@@ -98,29 +98,21 @@ class Conventional(LOS):
             return inc_hd_to_enu(self._inc, hd)
         if self._file is None:
             raise ValueError('LOS file not set')
-        # losreader.py:116-121: try the file as a 2-band LOS raster first; anything rasterio cannot open (OSError / TypeError,
-        # exactly what the reference catches) is taken for an orbit / state-vector file.  Without rasterio the raster route
-        # does not exist: say so if the orbit parsers then reject the file, instead of blaming its format.
+        # losreader.py:116-121: try the file as a 2-band LOS raster first (rasterio when installed, else the built-in reader of
+        # flat-binary rasters with a .vrt / ENVI .hdr side-car: ISCE's los.rdr); anything that cannot be opened that way
+        # (OSError / TypeError, exactly what the reference catches) is taken for an orbit / state-vector file.
+        from .rawraster import rio_open
+        raster_error = None
         try:
-            import rasterio
-        except ImportError:
-            rasterio = None
-        if rasterio is not None:
-            try:
-                with rasterio.open(self._file) as src:
-                    data = src.read()
-                return inc_hd_to_enu(*data)
-            except (OSError, TypeError):
-                pass
-        # otherwise treat it as an orbit / state-vector file (losreader.py:122-128)
+            data, _ = rio_open(self._file)
+            return inc_hd_to_enu(*data)
+        except (OSError, TypeError) as e:
+            raster_error = e
         from .orbits import get_sv
         try:
             svs = np.stack(get_sv(self._file, self._time, self._pad), axis=-1)
         except ValueError as e:
-            if rasterio is None:
-                raise ImportError(f'{self._file} is not an orbit / state-vector file ({e}); reading it as an ISCE line-of-sight '
-                                  'raster needs rasterio, which is not installed') from e
-            raise
+            raise ValueError(f'{e}; as a line-of-sight raster it could not be read either: {raster_error}') from e
         return state_to_los(svs, [self._lats, self._lons, self._heights])
 
     def __call__(self, delays):

@@ -121,3 +121,9 @@ def transverse_mercator(a_in, b_in, params, inverse=False):
     ctx = Context.default()
     check(ctx.lib.rdr_transform_tm(ctx.handle, ptr(p), p.size, int(bool(inverse)), ptr(ua), ptr(ub), ua.size, ptr(oa), ptr(ob), L.RDR_HOST), ctx.handle)
     return oa.reshape(shp), ob.reshape(shp)
+
+
+def rio_open(path, userNDV=None, band=None):
+    """utilFcns.py:164-202 (rasterio when installed, else flat-binary rasters with a .vrt / ENVI .hdr side-car)."""
+    from .rawraster import rio_open as _rio_open
+    return _rio_open(path, userNDV=userNDV, band=band)

@@ -375,3 +375,40 @@ def test_processed_model_file_roundtrip(tmp_path):
             b, _ = tropo_delay(when, pth, aoi, los, [0.0, 1200.0], 4326, None)
             assert np.array_equal(np.asarray(a['hydro'][:]), np.asarray(b['hydro'][:]), equal_nan=True)
             assert np.array_equal(np.asarray(a['wet'][:]), np.asarray(b['wet'][:]), equal_nan=True) and np.isfinite(np.asarray(a['hydro'][:])).any()
+
+
+HRRR_ZTD_CUBE = Path(__file__).parent / 'golden' / 'ref_files' / 'HRRR_tropo_20200101T120000_ztd.nc'
+
+
+@pytest.mark.gpu
+def test_getInterpolators_on_the_references_own_delay_cube(caplog):
+    """test/test_delayFcns.py:30-45 replayed: the delay-cube file the reference's tests load (scenario_1/golden_data, written by the
+    real RAiDER: f64 wet / hydro on (z, y, x), DESCENDING y, a scalar `crs` variable with the EPSG:4326 grid mapping) goes through
+    getInterpolators; the device interpolators then agree with scipy's RegularGridInterpolator on the same arrays - the second
+    stage of tropo_delay's point branch (delay.py:110-121) - and a NaN cell makes getInterpolators log 'Weather model contains NaNs!'."""
+    import logging
+    from scipy.interpolate import RegularGridInterpolator
+    from raider_amd.delayFcns import _read_cube_file, getInterpolators
+    var = _read_cube_file(HRRR_ZTD_CUBE)
+    x, y, z = (np.array(var[k][:]) for k in 'xyz')
+    wet, hyd = np.array(var['wet'][:]), np.array(var['hydro'][:])
+    assert wet.shape == (5, 102, 101) and wet.dtype == np.float64 and y[0] > y[-1] and list(z) == [0.0, 50.0, 100.0, 500.0, 1000.0]
+    assert var['wet'].attrs['grid_mapping'] == 'crs' and var['crs'].attrs['grid_mapping_name'] == 'latitude_longitude' and int(var['crs'][:]) == -2147483647
+    ifw, ifh = getInterpolators(str(HRRR_ZTD_CUBE), kind='pointwise')
+    rng = np.random.default_rng(0)
+    pts = np.stack([rng.uniform(y.min() - 0.05, y.max() + 0.05, 4000), rng.uniform(x.min() - 0.05, x.max() + 0.05, 4000), rng.uniform(-20, 1020, 4000)], -1)
+    pts[:50, 0] = y[rng.integers(0, y.size, 50)]; pts[50:100, 1] = x[rng.integers(0, x.size, 50)]; pts[100:150, 2] = z[rng.integers(0, z.size, 50)]   # exactly on nodes
+    for f, arr in ((ifw, wet), (ifh, hyd)):
+        ref = RegularGridInterpolator((y, x, z), arr.transpose(1, 2, 0), bounds_error=False, fill_value=np.nan)(pts)
+        got = f(pts)
+        assert np.array_equal(np.isnan(got), np.isnan(ref)) and np.isnan(ref).sum() > 100 and np.isfinite(ref).sum() > 2000
+        np.testing.assert_allclose(got, ref, rtol=0, atol=4e-15, equal_nan=True)
+    # the nearest node to (36.84 N, 91.84 W, 0 m): read straight from the file and through the device
+    i, j = np.abs(x + 91.84).argmin(), np.abs(y - 36.84).argmin()
+    assert ifh(np.array([y[j], x[i], 0.0])) == hyd[0, j, i] and ifw(np.array([y[j], x[i], 0.0])) == wet[0, j, i]
+    # test_getInterpolators_2: a NaN in the cube is reported, not fatal
+    ds = {k: np.array(var[k][:]) for k in ('x', 'y', 'z', 'wet', 'hydro')}
+    ds['hydro'][0, 0, 0] = np.nan
+    with caplog.at_level(logging.CRITICAL):
+        getInterpolators(ds, kind='pointwise')
+    assert 'Weather model contains NaNs!' in caplog.text
