@@ -1,0 +1,115 @@
+"""The oracle's geodesy against the EXACT mathematics of the ellipsoid, evaluated with 40 significant digits (mpmath).
+
+The reference delegates WGS 84 <-> ECEF and the model projections to pyproj / PROJ, which is absent from the image: the oracle
+restates PROJ's published formulas and is pinned on worked examples that carry millimetres (IOGP GN 7-2, Snyder).  This file
+adds what those examples cannot: the defining equations themselves, solved to 40 digits, over the whole range the delay path
+uses (heights -500 m ... 85 km, every latitude).  Findings it asserts:
+
+  * geodetic -> ECEF and the conic projections: the restatements are exact to rounding (< 5e-9 m / 2e-8 m);
+  * ECEF -> geodetic: PROJ's published inverse is ONE Bowring step, whose truncation grows with height squared - 1e-8 m at 1 km,
+    1e-6 m at 10 km, 1.6e-5 m at 40 km, 7e-5 m at 85 km in height (6e-10 degrees in latitude).  The restatement reproduces
+    that formula (it is the parity target: the reference calls PROJ); this test bounds how far formula and exact ellipsoid are
+    apart, so that ANY PROJ version within that envelope gives the same delays: integrated against the refractivity gradient
+    (270e-6/8 km, scale height 8 km) an error of 7e-5 (h / 85 km)^2 m moves a zenith delay by 3e-10 m, a slant one by < 1e-9 m."""
+import numpy as np
+import pytest
+
+from oracle import raider_oracle as O
+
+mp = pytest.importorskip('mpmath')
+
+A = mp.mpf(6378137)
+F = 1 / mp.mpf('298.257223563')
+ES = 2 * F - F * F
+
+
+def _exact_lla2ecef(lat, lon, h):
+    phi, lam = mp.radians(mp.mpf(lat)), mp.radians(mp.mpf(lon))
+    N = A / mp.sqrt(1 - ES * mp.sin(phi) ** 2)
+    return (N + h) * mp.cos(phi) * mp.cos(lam), (N + h) * mp.cos(phi) * mp.sin(lam), (N * (1 - ES) + h) * mp.sin(phi)
+
+
+def _exact_ecef2lla(x, y, z):
+    """Geodetic latitude / height of an ECEF point: Newton on the latitude equation p tan(phi) - z = e^2 N(phi) sin(phi)."""
+    x, y, z = mp.mpf(x), mp.mpf(y), mp.mpf(z)
+    p = mp.sqrt(x * x + y * y)
+    f = lambda phi: p * mp.sin(phi) - z * mp.cos(phi) - ES * A * mp.sin(phi) * mp.cos(phi) / mp.sqrt(1 - ES * mp.sin(phi) ** 2)
+    phi = mp.findroot(f, mp.atan2(z, p * (1 - ES)))
+    N = A / mp.sqrt(1 - ES * mp.sin(phi) ** 2)
+    h = p * mp.cos(phi) + z * mp.sin(phi) - A * A / N                     # = p/cos(phi) - N, stable at the poles
+    return mp.degrees(mp.atan2(y, x)), mp.degrees(phi), h
+
+
+def test_geodetic_ecef_conversions_against_40_digit_arithmetic():
+    mp.mp.dps = 40
+    rng = np.random.default_rng(0)
+    lat = np.concatenate([rng.uniform(-90, 90, 60), [0.0, 89.999, -89.999, 45.0, 1e-9]])
+    lon = np.concatenate([rng.uniform(-180, 180, 60), [0.0, 179.999, -179.999, 90.0, -90.0]])
+    h = np.concatenate([rng.uniform(-500, 85000, 60), [0.0, 85000.0, -500.0, 41000.0, 10.0]])
+    x, y, z = O.lla2ecef(lat, lon, h)
+    lo2, la2, h2 = O.ecef2lla(x, y, z)
+    worst_fwd = worst_ang = 0.0
+    worst_h = {1000.0: 0.0, 10000.0: 0.0, 40000.0: 0.0, 85000.0: 0.0}
+    for k in range(lat.size):
+        ex = _exact_lla2ecef(float(lat[k]), float(lon[k]), float(h[k]))
+        worst_fwd = max(worst_fwd, *(abs(float(mp.mpf(float(v)) - e)) for v, e in zip((x[k], y[k], z[k]), ex)))
+        elon, elat, eh = _exact_ecef2lla(float(x[k]), float(y[k]), float(z[k]))      # exact inverse OF THE DOUBLES the oracle was given
+        dh = abs(float(mp.mpf(float(h2[k])) - eh))
+        for top in worst_h:
+            if h[k] <= top:
+                worst_h[top] = max(worst_h[top], dh)
+        worst_ang = max(worst_ang, abs(float(mp.mpf(float(la2[k])) - elat)), abs(float(((mp.mpf(float(lo2[k])) - elon + 180) % 360) - 180)))
+    assert worst_fwd < 5e-9, worst_fwd                                     # forward: pure rounding (a few ulp of 6.4e6 m)
+    # inverse: the one-step Bowring formula's truncation envelope (grows ~h^2); rounding alone is ~3e-9 m
+    assert worst_h[1000.0] < 3e-8 and worst_h[10000.0] < 2e-6 and worst_h[40000.0] < 3e-5 and worst_h[85000.0] < 1e-4, worst_h
+    assert worst_ang < 1e-9, worst_ang                                     # degrees: 1e-9 deg = 1e-4 m on the ground, at 85 km
+
+
+def test_conic_projections_against_40_digit_arithmetic():
+    """lcc_forward / stere_forward and their inverses: Snyder's closed forms evaluated in 40 digits (the formulas ARE the definition
+    of the projection; PROJ implements the same ones) - bounds the double-precision rounding of the restatement, metres at 1e-8."""
+    mp.mp.dps = 40
+
+    def tsfn(phi, e):
+        s = mp.sin(phi)
+        return mp.tan((mp.pi / 2 - phi) / 2) / ((1 - e * s) / (1 + e * s)) ** (e / 2)
+
+    def msfn(phi, es):
+        return mp.cos(phi) / mp.sqrt(1 - es * mp.sin(phi) ** 2)
+
+    def lcc(lat, lon, lat_1, lat_2, lat_0, lon_0, a, es, x_0=0.0, y_0=0.0):
+        a, es = mp.mpf(a), mp.mpf(es); e = mp.sqrt(es)
+        p1, p2, p0 = (mp.radians(mp.mpf(v)) for v in (lat_1, lat_2, lat_0))
+        n = mp.log(msfn(p1, es) / msfn(p2, es)) / mp.log(tsfn(p1, e) / tsfn(p2, e)) if abs(p1 - p2) > mp.mpf('1e-10') else mp.sin(p1)
+        Fc = msfn(p1, es) * tsfn(p1, e) ** (-n) / n
+        rho0 = a * Fc * tsfn(p0, e) ** n
+        rho = a * Fc * tsfn(mp.radians(mp.mpf(lat)), e) ** n
+        th = n * mp.radians(mp.mpf(lon) - mp.mpf(lon_0))
+        return mp.mpf(x_0) + rho * mp.sin(th), mp.mpf(y_0) + rho0 - rho * mp.cos(th)
+
+    def stere_north(lat, lon, lat_ts, lon_0, a, es):
+        a, es = mp.mpf(a), mp.mpf(es); e = mp.sqrt(es)
+        pc = mp.radians(mp.mpf(lat_ts))
+        rho = a * msfn(pc, es) * tsfn(mp.radians(mp.mpf(lat)), e) / tsfn(pc, e)
+        dl = mp.radians(mp.mpf(lon) - mp.mpf(lon_0))
+        return rho * mp.sin(dl), -rho * mp.cos(dl)
+
+    rng = np.random.default_rng(1)
+    cases = [dict(lat_1=38.5, lat_2=38.5, lat_0=38.5, lon_0=-97.5, a=6371229.0, es=0.0),                       # HRRR
+             dict(lat_1=33.0, lat_2=45.0, lat_0=23.0, lon_0=-96.0, a=6378206.4, es=0.00676866)]                # Snyder's ellipsoidal case
+    for kw in cases:
+        la = rng.uniform(20, 60, 40); lo = rng.uniform(-130, -65, 40)
+        x, y = O.lcc_forward(la, lo, **kw)
+        la2, lo2 = O.lcc_inverse(x, y, **kw)
+        for k in range(la.size):
+            ex, ey = lcc(float(la[k]), float(lo[k]), **kw)
+            assert abs(float(mp.mpf(float(x[k])) - ex)) < 2e-8 and abs(float(mp.mpf(float(y[k])) - ey)) < 2e-8
+        assert np.abs(la2 - la).max() < 1e-12 and np.abs(lo2 - lo).max() < 1e-12
+    ak = dict(lat_0=90.0, lat_ts=60.0, lon_0=225.0, a=6371229.0, es=0.0)                                         # HRRR-AK
+    ell = dict(lat_0=90.0, lat_ts=70.0, lon_0=-45.0, a=6378137.0, es=0.0066943799901413165)                     # EPSG:3413's parameters
+    for kw in (ak, ell):
+        la = rng.uniform(45, 89.5, 40); lo = rng.uniform(-180, 180, 40)
+        x, y = O.stere_forward(la, lo, **kw)
+        for k in range(la.size):
+            ex, ey = stere_north(float(la[k]), float(lo[k]), kw['lat_ts'], kw['lon_0'], kw['a'], kw['es'])
+            assert abs(float(mp.mpf(float(x[k])) - ex)) < 2e-8 and abs(float(mp.mpf(float(y[k])) - ey)) < 2e-8
