@@ -259,6 +259,10 @@ def test_long_nonuniform_axes_use_large_lds_tables(R):
     assert np.ptp(np.diff(ys)) > 1e-7                                     # not exactly uniform: the table path
     _check_against_oracle(R, c, np.linspace(-118.5, -116.5, 9), np.linspace(33.9, 32.1, 8), 38.0, -167.9, 0.0, zs.max() - 1)
     del c, g
+    # 500 model levels (the library's limit is 512): the per-level tables alone are 96 KB
+    c = O.synthetic_cube(12, 14, 500, seed=3, y0=31.0, y1=35.0, x0=-120.0, x1=-115.0)
+    c['zs'] = np.linspace(-100.0, 40000.0, 500)
+    _check_against_oracle(R, c, np.linspace(-118.5, -116.5, 7), np.linspace(33.9, 32.1, 6), 33.0, -12.1, 20.0, c['zs'].max() - 1)
     n = 6000                                                              # 192 KB of tables: more LDS than a workgroup can have
     ys = np.linspace(-60.0, 60.0, n).astype(np.float32).astype(np.float64)
     xs = np.linspace(-130.0, 130.0, n).astype(np.float32).astype(np.float64)
@@ -267,6 +271,39 @@ def test_long_nonuniform_axes_use_large_lds_tables(R):
     big = R.Cube(ys, xs, np.array([0.0, 30000.0]), v, v, order='zyx')
     with pytest.raises(Exception, match='LDS'):
         big.raytrace(R.Rays.grid(np.linspace(-118.5, -116.5, 9), np.linspace(33.9, 32.1, 8), inc=30.0, hd=-167.9), 0.0, 29000.0)
+
+
+def test_cube_beyond_4_gib_uses_64_bit_offsets(R):
+    """A 1700 x 1700 x 240 f32 cube is 5.5 GB of interleaved (wet, hydro) pairs - a global 0.1-degree analysis is of that order - so
+    the 32-bit gather offsets of the usual instantiation do not reach its far end: the kernels must take their 64-bit form.  Built
+    on the device; rays, zenith nodes and station points sit in the last rows (byte offsets > 2^32) and are checked against the
+    oracle on the sub-cube around them."""
+    import torch
+    dev = torch.device('cuda:0')
+    ny = nx = 1700; nz = 240
+    ys = np.linspace(20.0, 54.0, ny); xs = np.linspace(-130.0, -96.0, nx); zs = np.linspace(-100.0, 41000.0, nz)
+    iy = torch.arange(ny, device=dev, dtype=torch.float32); ix = torch.arange(nx, device=dev, dtype=torch.float32)
+    g = 1.0 + 0.05 * torch.sin(0.37 * iy)[:, None] * torch.cos(0.21 * ix)[None, :]
+    zt = torch.from_numpy(zs).to(dev)
+    pw = (60.0 * torch.exp(-zt / 2000.0)).float(); ph = (270.0 * torch.exp(-zt / 8000.0)).float()
+    wet = (pw[:, None, None] * g[None]).contiguous(); hyd = (ph[:, None, None] * g[None]).contiguous()
+    cube = R.Cube(ys, xs, zs, wet, hyd, order='zyx')
+    j0, j1, i0, i1 = 1560, 1700, 1500, 1700                                           # rows whose offsets exceed 4 GiB
+    assert (j0 * nx * nz) * 8 > 2 ** 32
+    sub = dict(ys=ys[j0:j1], xs=xs[i0:i1], zs=zs, wet=wet[:, j0:j1, i0:i1].cpu().numpy(), hydro=hyd[:, j0:j1, i0:i1].cpu().numpy())
+    del wet, hyd, g
+    ypts = np.linspace(ys[j0 + 60], ys[j0 + 30], 9); xpts = np.linspace(xs[i0 + 60], xs[i0 + 110], 11)
+    _check_against_oracle(R, sub, xpts, ypts, 37.0, -167.9, 150.0, zs.max() - 1, cube=cube)
+    ip = list(O.getInterpolators(sub['xs'], sub['ys'], sub['zs'], sub['wet'], sub['hydro']))
+    rng = np.random.default_rng(0)
+    pts = np.stack([rng.uniform(ys[j0 + 5], ys[-1], 3000), rng.uniform(xs[i0 + 5], xs[-1], 3000), rng.uniform(-50, 30000, 3000)], -1)
+    pts[:20, 0] = ys[-1]; pts[20:40, 1] = xs[-1]                                       # the very last node of both axes
+    w, h = cube.interp(pts)
+    np.testing.assert_allclose(w, ip[0](pts), rtol=0, atol=1e-12); np.testing.assert_allclose(h, ip[1](pts), rtol=0, atol=1e-12)
+    assert np.isfinite(w).all()
+    zw, zh = cube.build_cube(xpts, ypts, np.array([0.0, 2500.0]))
+    ow, oh = O.build_cube(xpts, ypts, np.array([0.0, 2500.0]), ip)
+    np.testing.assert_allclose(zw, ow, rtol=0, atol=1e-12); np.testing.assert_allclose(zh, oh, rtol=0, atol=1e-12)
 
 
 def test_f64_cube_and_other_maxseg(R):
