@@ -1500,11 +1500,14 @@ int rdr_cubes_from_model_levels(rdr_ctx* c, const double* ys, int64_t ny, const 
     P.t_out = (float*)dt_; P.p_out = (float*)dp_; P.e_out = (float*)de_;
     const size_t per_wave = ((size_t)4 * nlev + nzo + (5 * nzo + 1) / 2 + 1) * 8;
     const int g = (int)std::max<int64_t>(1, std::min<int64_t>((ncol + 3) / 4, (int64_t)c->num_cus * 8));
+    if (per_wave * 4 > c->lds_max)
+        return bail(fail(c, RDR_ERR_INVALID, "rdr_cubes_from_model_levels: " + std::to_string(nlev) + " model levels -> " + std::to_string(nzo) +
+                         " output levels need " + std::to_string(per_wave * 4) + " B of LDS per workgroup, the device offers " + std::to_string(c->lds_max)));
+    hipError_t e;
     {
         KTimer tm(c, 3);
-        hipLaunchKernelGGL(producer_kernel, dim3(g), dim3(256), per_wave * 4, c->stream, P);
+        e = launch_lds(producer_kernel, dim3(g), dim3(256), per_wave * 4, c->stream, P);
     }
-    hipError_t e = hipGetLastError();
     if (e == hipSuccess && dt_) {
         if (finish_out(c, t_out, dt_, ob, loc) || finish_out(c, p_out, dp_, ob, loc) || finish_out(c, e_out, de_, ob, loc)) return bail(RDR_ERR_HIP);
     }

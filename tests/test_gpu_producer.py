@@ -63,6 +63,33 @@ def test_producer_vs_oracle_with_missing_data():
     np.testing.assert_allclose(wt, r['wet_total'], rtol=2 * E_RTOL, atol=1e-18)
 
 
+def test_producer_with_many_levels_needs_large_lds():
+    """500 model levels resampled to 300 heights: the per-wavefront column buffers are 98 KB per workgroup, past the 64 KB a launch
+    gets by default.  Same parity as above; a level count whose buffers exceed the device's LDS is refused by name."""
+    from oracle import raider_oracle as O
+    from raider_amd.weather import cubes_from_model_levels
+    rng = np.random.default_rng(5)
+    A, B, nl = 4, 5, 500
+    base = np.sort(rng.uniform(0, 1, (A, B, nl)), axis=2)
+    zs = -80.0 + 300.0 * rng.uniform(0, 1, (A, B, 1)) + 42000.0 * base ** 1.4
+    t = np.maximum(289.0 - 0.0063 * zs + rng.normal(0, 0.4, zs.shape), 203.0)
+    p = 101000.0 * np.exp(-zs / 7700.0)
+    q = 0.011 * np.exp(-zs / 2500.0)
+    newz = np.linspace(-100.0, 41000.0, 300)
+    r = O.cube_from_model_levels(zs, p, t, q, 'q', newz)
+    m = _run(zs, p, t, q, 'q', newz)
+    assert np.array_equal(m.zs, r['zs']) and np.array_equal(m.t, r['t']) and np.array_equal(m.p, r['p'])
+    wet, hyd = m.pointwise.read()
+    assert np.array_equal(hyd, r['hydro'])
+    np.testing.assert_allclose(wet, r['wet'], rtol=2 * E_RTOL, atol=1e-30)
+    wt, ht = m.total.read()
+    np.testing.assert_allclose(ht, r['hydro_total'], rtol=1e-13, atol=1e-18)
+    big = np.repeat(zs[..., :1], 1000, axis=2) + np.arange(1000.0) * 40.0                 # 1000 levels -> 480 heights: 171 KB
+    with pytest.raises(Exception, match='LDS'):
+        cubes_from_model_levels(np.arange(B) * 0.25 - 118.0, np.arange(A) * 0.25 + 33.0, big, 101000.0 * np.exp(-big / 7700.0), 280.0 + 0 * big, 0.001 + 0 * big, 'q',
+                                np.linspace(-100.0, 41000.0, 480))
+
+
 def test_producer_feeds_the_delay_path():
     """producer cubes -> tropo_delay-style zenith cube and a ray-traced slice, without leaving the device"""
     import torch
