@@ -103,6 +103,7 @@ def _lcc_params(crs):
     if not d or d.get('proj') != 'lcc':
         return None
     a, es = _ellipsoid(d)
+    a *= float(d.get('k_0', d.get('k', 1.0)))          # 1SP form: the scale factor multiplies every radius (rho = k_0 a F t^n), nothing else
     lat_1 = float(d.get('lat_1', d.get('lat_0', 0.0)))
     return dict(lat_1=lat_1, lat_2=float(d.get('lat_2', lat_1)), lat_0=float(d.get('lat_0', 0.0)), lon_0=float(d.get('lon_0', 0.0)),
                 x_0=float(d.get('x_0', 0.0)), y_0=float(d.get('y_0', 0.0)), a=a, es=es)
@@ -326,12 +327,10 @@ def tropo_delay(datetime, weather_model_file, aoi, los, height_levels=None, out_
     try:
         pj = var['proj']
         if isinstance(pj, (str, dict, int)):                       # mapping input: CRS given directly (EPSG / PROJ string / dict)
-            wkt = None
             wm_proj = pj
         else:
-            wkt = pj.attrs['crs_wkt']
-        if wkt is not None:
-            wm_proj = pyproj.CRS.from_wkt(wkt) if pyproj is not None else (4326 if ('WGS 84' in wkt and 'PROJCRS' not in wkt) or wkt.endswith('4326') else wkt)
+            from .crs import crs_from_proj_var
+            wm_proj = crs_from_proj_var(pj.attrs)                  # pyproj.CRS.from_wkt when installed; else CF attributes / WKT reader
     except (KeyError, AttributeError, TypeError):
         logger.warning("WARNING: I can't find a CRS in the weather model file, so I will assume you are using WGS84")
         wm_proj = 4326

@@ -61,8 +61,11 @@ class ProcessedModel:
         raider_amd.h5write, coordinate variables typed as in the reference's files (x, y f32; z f64); 'NETCDF3_64BIT': classic
         format through scipy.  Either is read back by tropo_delay / getInterpolators, xarray and netCDF4."""
         import datetime as dt
-        if not isinstance(self.proj, int) or self.proj != 4326:
-            raise NotImplementedError('ProcessedModel.to_netcdf: only EPSG:4326 models carry a crs_wkt here (no pyproj in the image)')
+        from .delay import _builtin_crs
+        kind = _builtin_crs(self.proj)
+        if kind is None or kind[0] not in ('geodetic', 'cone'):
+            raise NotImplementedError(f'ProcessedModel.to_netcdf: the model CRS {self.proj!r} has no CF description here (EPSG:4326, Lambert '
+                                      'conformal conic and polar stereographic models do)')
         ys, xs, zs = self.pointwise.grid
         wet, hyd = self.pointwise.read(); wt, ht = self.total.read()                     # (y, x, z)
         zyx = lambda v: np.ascontiguousarray(np.asarray(v).transpose(2, 0, 1))
@@ -87,6 +90,12 @@ class ProcessedModel:
                           geographic_crs_name='WGS 84', horizontal_datum_name='World Geodetic System 1984 ensemble', grid_mapping_name='latitude_longitude',
                           grid_mapping='proj')      # (weatherModel.py:716-717 tags every data variable, `proj` included)
         lon2, lat2 = np.meshgrid(xs, ys)
+        if kind[0] == 'cone':                                   # projected model (HRRR, HRRR-AK): what CRS.to_cf() writes; geodetic 2-D coordinates
+            from .crs import cf_from_crs
+            from .utilFcns import conic
+            _, cf = cf_from_crs(kind[1])
+            proj_attrs = dict(cf, grid_mapping='proj')
+            lat2, lon2 = conic(lat2, lon2, kind[1], inverse=True)          # (y, x) metres -> (lat, lon) degrees, on the device
         if format.upper().startswith('NETCDF4'):
             from .h5write import write_netcdf4
             # (the reference's files carry x / y as float32 because its ERA-5 axes ARE float32; axes that are not exactly

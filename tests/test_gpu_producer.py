@@ -167,3 +167,68 @@ def test_processed_model_is_a_weather_model_for_tropo_delay():
         assert np.array_equal(np.asarray(a['hydro'][:]), np.asarray(b['hydro'][:]))
         assert np.isfinite(np.asarray(a['hydro'][:])).all()
 
+
+
+@pytest.mark.parametrize('kind', ['hrrr', 'hrrr_ak'])
+def test_projected_model_file_roundtrip_and_crs_without_pyproj(tmp_path, kind):
+    """A processed model on HRRR's Lambert-conformal-conic grid / HRRR-AK's polar-stereographic grid written as the reference writes it
+    (weatherModel.py:659-724: `proj` carries CRS.to_cf() = crs_wkt + CF grid-mapping attributes, 2-D geodetic latitude / longitude)
+    and read back by tropo_delay by PATH: the model CRS comes from the CF attributes (or, stripped of them, from the WKT alone) -
+    no pyproj - and the zenith and ray-traced cubes equal those of the in-memory model; latitude / longitude are the inverse
+    projection of the grid nodes."""
+    import datetime as dt
+    from oracle import raider_oracle as O
+    from raider_amd import crs, h5lite
+    from raider_amd.delay import GridAOI, tropo_delay
+    from raider_amd.losreader import Raytracing, Zenith
+    from raider_amd.weather import cubes_from_model_levels, MODEL_LEVEL_HEIGHTS
+    if kind == 'hrrr':
+        P = dict(proj='lcc', lat_1=38.5, lat_2=38.5, lat_0=38.5, lon_0=262.5, x_0=0.0, y_0=0.0, a=6371229.0, b=6371229.0)
+        okw = dict(lat_1=38.5, lat_2=38.5, lat_0=38.5, lon_0=262.5, a=6371229.0, es=0.0)
+        cx, cy = O.lcc_forward(34.0, -117.0, **okw); fwd, inv = O.lcc_forward, O.lcc_inverse
+    else:
+        P = dict(proj='stere', lat_0=90.0, lat_ts=60.0, lon_0=225.0, x_0=0.0, y_0=0.0, a=6371229.0, b=6371229.0)
+        okw = dict(lat_0=90.0, lat_ts=60.0, lon_0=225.0, a=6371229.0, es=0.0)
+        cx, cy = O.stere_forward(63.0, -150.0, **okw); fwd, inv = O.stere_forward, O.stere_inverse
+    rng = np.random.default_rng(3)
+    A, B, nl = 72, 76, 40                            # 216 x 228 km: rays to the 80 km top travel 46 km sideways
+    xs = float(cx) + 3000.0 * (np.arange(B) - B / 2); ys = float(cy) + 3000.0 * (np.arange(A) - A / 2)
+    zs = -70.0 + 120.0 * rng.uniform(0, 1, (A, B, 1)) + 44000.0 * np.linspace(0, 1, nl)[None, None, :] ** 1.7
+    t = np.maximum(290.0 - 0.0064 * zs, 208.0); p = 101325.0 * np.exp(-zs / 7500.0); q = 0.013 * np.exp(-zs / 2300.0)
+    m = cubes_from_model_levels(xs, ys, zs, p, t, q, 'q', MODEL_LEVEL_HEIGHTS)
+    m.proj = P
+    path = tmp_path / f'{kind}.nc'
+    m.to_netcdf(path, time=dt.datetime(2020, 1, 1, 12), model_name='HRRR')
+    f = h5lite.File(path)
+    at = f['proj'].attrs
+    assert at['grid_mapping_name'] == ('lambert_conformal_conic' if kind == 'hrrr' else 'polar_stereographic') and at['crs_wkt'].startswith('PROJCRS[')
+    back = crs.crs_from_proj_var(at)
+    assert back['proj'] == P['proj'] and all(abs(back[k] - P[k]) < 1e-9 for k in P if k != 'proj')
+    assert crs.crs_from_wkt(at['crs_wkt']) == back
+    xx, yy = np.meshgrid(xs, ys)
+    la, lo = inv(xx, yy, **okw)
+    np.testing.assert_allclose(f['latitude'].read(), la, rtol=0, atol=1e-10); np.testing.assert_allclose(f['longitude'].read(), lo, rtol=0, atol=1e-10)
+    # output grid in lon/lat well inside the (rotated) model domain
+    clat, clon = (float(v) for v in inv(float(cx), float(cy), **okw))
+    aoi = GridAOI(np.linspace(clon - 0.3, clon + 0.3, 7), np.linspace(clat + 0.2, clat - 0.2, 6))
+    when = dt.datetime(2020, 1, 1, 12)
+    hl = [0.0, 900.0]
+    wkt_only = {k: (f[k].read() if k != 'proj' else type('V', (), dict(attrs=dict(crs_wkt=at['crs_wkt'])))()) for k in ('x', 'y', 'z', 'wet', 'hydro', 'wet_total', 'hydro_total', 'proj')}
+    for los in (Zenith(), Raytracing(inc=30.0, heading=-12.0)):
+        a, _ = tropo_delay(when, m, aoi, los, hl)
+        b, _ = tropo_delay(when, str(path), aoi, los, hl)
+        c, _ = tropo_delay(when, wkt_only, aoi, los, hl)
+        for name in ('wet', 'hydro'):
+            ref = np.asarray(a[name][:])
+            assert np.isfinite(ref).all() and ref.mean() > 0
+            assert np.array_equal(ref, np.asarray(b[name][:])) and np.array_equal(ref, np.asarray(c[name][:]))
+    # and against the oracle's own projection of the nodes: the zenith cube is the trilinear gather at the projected nodes
+    za, _ = tropo_delay(when, str(path), aoi, Zenith(), hl)
+    gx, gy = np.meshgrid(aoi.xpts, aoi.ypts)
+    px, py = fwd(gy, gx, **okw)
+    wt, ht = m.total.read()
+    ip = list(O.getInterpolators(xs, ys, np.asarray(m.zs), wt.transpose(2, 0, 1), ht.transpose(2, 0, 1)))
+    for k, h in enumerate(hl):
+        pts = np.stack([py, px, np.full(px.shape, h)], -1)
+        np.testing.assert_allclose(np.asarray(za['wet'][:])[k], ip[0](pts), rtol=0, atol=1e-12)
+        np.testing.assert_allclose(np.asarray(za['hydro'][:])[k], ip[1](pts), rtol=0, atol=1e-12)
