@@ -544,6 +544,11 @@ def writeResultsToXarray(datetime, xpts, ypts, zpts, crs, wetDelay, hydroDelay, 
                                         longitude_of_prime_meridian=0.0, latitude_of_projection_origin=tm['lat_0'],
                                         longitude_of_central_meridian=tm['lon_0'], scale_factor_at_central_meridian=tm['k_0'],
                                         false_easting=tm['x_0'], false_northing=tm['y_0'])
+            else:
+                kind = _builtin_crs(crs)
+                if kind is not None and kind[0] == 'cone':        # output grid in a conic model CRS: what CRS.to_cf() writes
+                    from .crs import cf_from_crs
+                    attrs['_crs_cf'] = cf_from_crs(kind[1])[1]
         return DelayCube(dict(wet=np.asarray(wetDelay), hydro=np.asarray(hydroDelay), x=np.asarray(xpts), y=np.asarray(ypts),
                               z=np.asarray(zpts), crs=np.array(-2147483647)), attrs)
     ds = xr.Dataset(

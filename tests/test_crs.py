@@ -89,3 +89,24 @@ def test_cf_only_grid_mappings():
     assert d['proj'] == 'tmerc' and abs(d['rf'] - 298.257223563) < 1e-6
     assert crs.crs_from_cf(dict(grid_mapping_name='latitude_longitude')) == 4326
     assert crs.crs_from_cf(dict(grid_mapping_name='rotated_latitude_longitude')) is None and crs.crs_from_cf({}) is None
+
+
+def test_delay_cube_on_a_conic_output_grid_carries_its_crs(tmp_path):
+    """writeResultsToXarray (delay.py:329-401) with out_proj = the model's own conic CRS: the `crs` grid-mapping variable of the
+    written NetCDF-4 file describes it (CF attributes + WKT), and reads back to the same parameters."""
+    import datetime
+    pytest.importorskip('scipy')
+    try:
+        import xarray  # noqa: F401
+        pytest.skip('xarray installed: the Dataset branch writes the CRS through pyproj')
+    except ImportError:
+        pass
+    from raider_amd.delay import writeResultsToXarray
+    hr = '+proj=lcc +lat_1=38.5 +lat_2=38.5 +lat_0=38.5 +lon_0=262.5 +x_0=0 +y_0=0 +a=6371229 +b=6371229 +units=m +no_defs'
+    ds = writeResultsToXarray(datetime.datetime(2020, 1, 1), np.arange(4.0) * 3000, np.arange(3.0) * 3000, np.array([0.0, 100.0]), hr, np.zeros((2, 3, 4)),
+                              np.ones((2, 3, 4)), 'x.nc', 'zenith')
+    ds.to_netcdf(tmp_path / 'out.nc')
+    f = h5lite.File(tmp_path / 'out.nc')
+    at = f['crs'].attrs
+    assert at['grid_mapping_name'] == 'lambert_conformal_conic' and f['wet'].attrs['grid_mapping'] == 'crs' and f['x'].attrs['standard_name'] == 'projection_x_coordinate'
+    assert crs.crs_from_proj_var(at) == dict(proj='lcc', lat_1=38.5, lat_2=38.5, lat_0=38.5, lon_0=262.5, x_0=0.0, y_0=0.0, a=6371229.0, b=6371229.0)
