@@ -14,6 +14,11 @@ import numpy as np
 _WGS84_A, _WGS84_RF = 6378137.0, 298.257223563
 
 
+def _is_wgs84(a, rf):
+    """WGS 84 (or GRS 80, 0.1 mm apart) within what a float32 attribute keeps (a NetCDF-3 writer may store 298.257223563 as 298.25723)."""
+    return abs(a - _WGS84_A) < 0.5 and abs(rf - _WGS84_RF) < 1e-4
+
+
 # ---- CF grid-mapping attributes ---------------------------------------------------------------------------------------------
 def _scalar(v):
     return float(np.asarray(v).ravel()[0])
@@ -53,7 +58,7 @@ def crs_from_cf(attrs):
     ell = _ellipsoid_from_cf(attrs)
     fe, fn = _scalar(attrs.get('false_easting', 0.0)), _scalar(attrs.get('false_northing', 0.0))
     if name == 'latitude_longitude':
-        if abs(ell['a'] - _WGS84_A) < 1e-3 and abs(ell['rf'] - _WGS84_RF) < 1e-6:
+        if _is_wgs84(ell['a'], ell['rf']):
             return 4326
         return _with_ellipsoid(dict(proj='longlat'), ell)
     if name == 'lambert_conformal_conic':
@@ -191,7 +196,7 @@ def crs_from_wkt(wkt):
         a *= float(lu[0][1][1])
     ellips = dict(a=a, rf=rf)
     if kind in ('GEOGCRS', 'GEOGRAPHICCRS', 'GEOGCS', 'GEODCRS', 'GEODETICCRS', 'BASEGEOGCRS'):
-        if abs(a - _WGS84_A) < 1e-3 and abs(rf - _WGS84_RF) < 1e-6:
+        if _is_wgs84(a, rf):
             return 4326
         return _with_ellipsoid(dict(proj='longlat'), ellips)
     if kind not in ('PROJCRS', 'PROJECTEDCRS', 'PROJCS'):

@@ -264,7 +264,7 @@ class DelayCube:
             crs = f.createVariable('crs', 'i4', ())
             crs.data[()] = -2147483647
             for k, val in (self.attrs.get('_crs_cf') or {}).items():
-                setattr(crs, k, val)
+                setattr(crs, k, np.float64(val) if isinstance(val, float) else val)      # (scipy narrows a bare Python float to float32)
         return str(path)
 
 

@@ -125,7 +125,7 @@ class ProcessedModel:
             pj = f.createVariable('proj', 'i4', ())
             pj.data[()] = 0
             for k, v in proj_attrs.items():
-                setattr(pj, k, v)
+                setattr(pj, k, np.float64(v) if isinstance(v, float) else v)      # (a bare Python float is narrowed to float32 by scipy's writer)
         return str(path)
 
     def interpolators(self, kind='pointwise'):
