@@ -4,3 +4,6 @@ cd /tmp && export TMPDIR=/tmp
 O=$R/gpurun_out/secondary; rm -rf $O; mkdir -p $O
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python $R/tools/secondary_bench.py > $O/bench.json 2> $O/bench.err
 tail -c 1500 $O/bench.json; tail -3 $O/bench.err
+# HBM bytes per launch (separate PMC passes, as tools/profile_round.sh does for the ray kernels)
+timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python $R/tools/secondary_bench.py > $O/fetch.log 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python $R/tools/secondary_bench.py > $O/write.log 2>&1

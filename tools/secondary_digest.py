@@ -26,6 +26,25 @@ for k, d in res.items():
     d['units_per_s'] = d['units'] / avg
     d['algorithmic_GBps'] = d['units'] * d['bytes_per_unit'] / avg / 1e9
     d['frac_of_hbm_peak_8TBps'] = d['algorithmic_GBps'] / 8000.0
+# measured HBM bytes per launch: FETCH_SIZE (KiB; gfx950: x2, checked on the calibration copy of tools/profile_round.sh) and WRITE_SIZE (x1)
+def pmc(sub, counter):
+    out = {}
+    for f in glob.glob(str(src / sub) + '/**/*counter_collection.csv', recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r['Counter_Name'] == counter:
+                out.setdefault(r['Kernel_Name'], []).append(float(r['Counter_Value']))
+    return out
+
+
+fetch, write = pmc('fetch', 'FETCH_SIZE'), pmc('write', 'WRITE_SIZE')
+for k, d in res.items():
+    fr = [v for name, vals in fetch.items() if k in name for v in vals]
+    wr = [v for name, vals in write.items() if k in name for v in vals]
+    if fr and wr and 'rocprof_avg_us' in d:
+        fr, wr = sorted(fr)[len(fr) // 2], sorted(wr)[len(wr) // 2]                 # median launch
+        d['hbm_read_bytes'] = fr * 2.0 * 1024; d['hbm_write_bytes'] = wr * 1024
+        d['hbm_measured_GBps'] = (d['hbm_read_bytes'] + d['hbm_write_bytes']) / (d['rocprof_avg_us'] * 1e-6) / 1e9
+        d['hbm_measured_frac'] = d['hbm_measured_GBps'] / 8000.0
 (REPO / 'profiles' / 'r02_secondary.json').write_text(json.dumps(res, indent=1) + '\n')
 for k, d in res.items():
-    print(f"{k:24s} {d.get('rocprof_avg_us', float('nan')):10.1f} us  {d.get('units_per_s', 0)/1e9:8.2f} G {d['unit']}/s  {d.get('algorithmic_GBps', 0):9.1f} GB/s  = {d.get('frac_of_hbm_peak_8TBps', 0):.3f} of 8 TB/s")
+    print(f"{k:24s} {d.get('rocprof_avg_us', float('nan')):10.1f} us  {d.get('units_per_s', 0)/1e9:8.2f} G {d['unit']}/s  {d.get('algorithmic_GBps', 0):9.1f} GB/s  = {d.get('frac_of_hbm_peak_8TBps', 0):.3f} of 8 TB/s;  measured HBM {d.get('hbm_measured_GBps', float('nan')):8.1f} GB/s = {d.get('hbm_measured_frac', float('nan')):.3f}")
