@@ -83,6 +83,7 @@ def main():
     ap.add_argument('--cols', type=int, default=4000)
     ap.add_argument('--cube', type=str, default='300x300x80')
     ap.add_argument('--cube-f64', action='store_true', help='experiment: upload the f32 refractivities as f64 (no cvt in the gather)')
+    ap.add_argument('--axes-f32', action='store_true', help='experiment: lat / lon axes rounded to float32 (not exactly uniform any more: the LDS-table cell search)')
     ap.add_argument('--coll-device', action='store_true', help='keep collective tensors on the GPU even with --backend gloo (dry run of the async path)')
     ap.add_argument('--backend', type=str, default='auto', help='torch.distributed backend for N>1: nccl (= RCCL), gloo, or auto = nccl when every rank has '
                                                                 'its own GPU, else gloo with device-resident collective tensors (ranks sharing a GPU: RCCL refuses duplicates)')
@@ -150,6 +151,8 @@ def main():
     ys, xs, zs = ax[:ny], ax[ny:ny + nx], ax[ny + nx:]
     if args.cube_f64:
         wet, hyd = wet.double(), hyd.double()
+    if args.axes_f32:
+        ys, xs = ys.astype(np.float32).astype(np.float64), xs.astype(np.float32).astype(np.float64)
     cube = R.Cube(ys, xs, zs, wet, hyd, order='zyx', ctx=ctx)
     zref = float(zs.max() - 1.0)                                 # delay.py:78,86-87
     ht = 0.0
@@ -246,7 +249,7 @@ def main():
             # The limiter the SQ counters show is fp64 vector-ALU issue, so THAT is the roofline (frac <= 1 by construction:
             # instructions actually issued / issue slots of the chip).  The SURVEY 8(d) gather-model byte rate and the
             # PMC-measured DRAM rate are reported beside it under "hbm".
-            'roofline': {'bound': 'valu_fp64_issue', 'kernel': 'march_kernel<float2,false,true>',
+            'roofline': {'bound': 'valu_fp64_issue', 'kernel': 'march_kernel<float2,false,1>',
                          'achieved': valu_rate / 1e9 if valu_rate else None, 'peak': VALU_ISSUE_PEAK / 1e9, 'unit': 'G wave64-instr/s',
                          'frac': valu_rate / VALU_ISSUE_PEAK if valu_rate else None,
                          'traffic': traffic, 'traffic_unit': 'HBM bytes per march_kernel launch (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE, separate passes)',

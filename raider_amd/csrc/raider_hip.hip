@@ -983,14 +983,14 @@ static int launch_march(rdr_ctx* c, const rdr_cube* q, RayParams P, int64_t tb, 
     {
         KTimer t(c, 1);
         const auto v32 = make_view<float2>(q);
-        const bool regular = q->exact[0] && q->exact[1] && v32.small && (q->dtype == RDR_F32 || make_view<double2>(q).small);
-        if (q->dtype == RDR_F32) {
-            if (regular) e = launch_lds(march_kernel<float2, false, true>, G, B, sm, c->stream, v32, P, q->proj);
-            else e = launch_lds(march_kernel<float2, false, false>, G, B, sm, c->stream, v32, P, q->proj);
-        } else {
-            if (regular) e = launch_lds(march_kernel<double2, false, true>, G, B, sm, c->stream, make_view<double2>(q), P, q->proj);
-            else e = launch_lds(march_kernel<double2, false, false>, G, B, sm, c->stream, make_view<double2>(q), P, q->proj);
-        }
+        const bool small = v32.small && (q->dtype == RDR_F32 || make_view<double2>(q).small);
+        const int grid = !small ? 0 : (q->exact[0] && q->exact[1]) ? 1 : (!q->exact[0] && !q->exact[1] && q->uni[0] && q->uni[1]) ? 2 : 0;
+#define RDR_LAUNCH_M(T2, V) (grid == 1 ? launch_lds(march_kernel<T2, false, 1>, G, B, sm, c->stream, V, P, q->proj)   \
+                             : grid == 2 ? launch_lds(march_kernel<T2, false, 2>, G, B, sm, c->stream, V, P, q->proj) \
+                                         : launch_lds(march_kernel<T2, false, 0>, G, B, sm, c->stream, V, P, q->proj))
+        if (q->dtype == RDR_F32) e = RDR_LAUNCH_M(float2, v32);
+        else e = RDR_LAUNCH_M(double2, make_view<double2>(q));
+#undef RDR_LAUNCH_M
     }
     if (e != hipSuccess) return fail(c, RDR_ERR_HIP, std::string("march_kernel launch: ") + hipGetErrorString(e));
     P.tile_ctr = c->d_tilectr + 24;

@@ -197,11 +197,13 @@ __device__ __forceinline__ void cell_xy(const double2* e, int n, double v, doubl
         }
         return;
     } else {
+        // one table entry: the weight itself says whether the guess was the cell (t in [0, 1)); anything else - the neighbour
+        // cell, the last node, outside, NaN - takes the exact search.  (A v exactly ON node i+1 may be accepted here with
+        // t = 1 - 1 ulp instead of cell i+1 with t = 0: the same value of the continuous interpolant.)
         i = min(max((int)tf, 0), n - 2);
         const double2 e0 = e[i];
-        const double g1 = e[i + 1].x;
         t = (v - e0.x) * e0.y;
-        ok = trust & (v >= e0.x) & (v < g1);
+        ok = trust & (t >= 0.0) & (t < 1.0);
     }
     if (!ok) cell_exact(e, n, v, i, t);                                         // rare
 }
@@ -899,13 +901,17 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
 // ---- pass 2: trapezoid integration of both fields along every ray (delay.py:285-323) -------------------------------
 // SLOW as in crossings_kernel: <false> integrates the classified-fast rays with the light geodesy, <true> the rest
 // with the generic one (and returns immediately when there are none).
-// REGULAR (light kernel only): both horizontal axes are exactly uniform and the cube allows 32-bit offsets (the usual
-// lat/lon or LCC model grid) - known at compile time, so the per-sample code carries no trace of the other variants.
-template <typename T2, bool SLOW, bool REGULAR = false>
+// GRID (light kernel only), known at compile time so that the per-sample code carries no trace of the other variants:
+//   1 (REGULAR): both horizontal axes are exactly uniform and the cube allows 32-bit offsets - the usual lat/lon or LCC model grid;
+//   2 (TABLES): both axes only NEARLY uniform (e.g. 0.1-degree nodes stored as float32) - guess-and-verify against the LDS tables -
+//               and 32-bit offsets;   0: whatever the run-time flags say.
+template <typename T2, bool SLOW, int GRID = 0>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 : 4, SLOW ? 8 : 4))) void march_kernel(CubeView<T2> c_in, RayParams P, LccParams proj) {
     if (SLOW && *P.nslow == 0) return;
+    constexpr bool REGULAR = GRID == 1;
     CubeView<T2> c = c_in;
     if (REGULAR) { c.exact_y = 1; c.exact_x = 1; c.small = 1; }
+    if (GRID == 2) { c.exact_y = 0; c.exact_x = 0; c.uni_y = 1; c.uni_x = 1; c.small = 1; }
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const RaySmem m = carve_smem(smem_raw, c.ny, c.nx, c.nz, c.exact_y, c.exact_x);
     fill_axes(c, m);
