@@ -103,3 +103,25 @@ def raytrace_slab(cube, rays, ht, zref, max_seg=1000.0, out=None, group=None, de
     nparts = nparts_from_maxlen(maxlen, max_seg)
     wet, hyd = cube.ray_march(rays, ht, zref, nparts, flags, out=out)
     return wet, hyd, nparts
+
+
+def raytrace_heights_sharded(cube, rays_for, hts, zref, max_seg=1000.0, world=None, rank=None):
+    """The OTHER way a ray-traced cube shards: by HEIGHT.  Every output height of _build_cube_ray is its own slice with its own
+    level table, slice maxima and nParts (delay.py:256-323), so ranks that take disjoint blocks of heights need no collective at
+    all - unlike row blocks of one slice, which share the per-level maxima (raytrace_slab*).  Rank r integrates heights
+    [h0, h0 + nh) of `hts` in one batched launch pair (Cube.raytrace_slices) and keeps / writes that slab of the (nz, ny, nx) cube.
+    `rays_for(heights)` returns the Rays batch for those heights (e.g. `los.ray_batch_slices(xpts, ypts, heights)`).
+    Returns (h0, nh, wet, hydro, K, nparts, flags); nh == 0 when there are more ranks than heights."""
+    if world is None or rank is None:
+        if is_distributed():
+            dist = _dist()
+            world, rank = dist.get_world_size(), dist.get_rank()
+        else:
+            world, rank = 1, 0
+    hts = np.atleast_1d(np.asarray(hts, dtype=np.float64))
+    h0, nh = shard_rows(hts.size, world, rank)
+    if nh == 0:
+        return h0, 0, None, None, None, None, None
+    mine = np.ascontiguousarray(hts[h0:h0 + nh])
+    wet, hyd, K, nparts, flags = cube.raytrace_slices(rays_for(mine), mine, zref, max_seg)
+    return h0, nh, wet, hyd, K, nparts, flags

@@ -776,3 +776,25 @@ def test_raytrace_and_zenith_through_polar_stereographic_cube(R, case):
     (ow, oh) = O.build_cube_ray(xpts, ypts, np.array([0.0]), look, ip, MAX_TROPO_HEIGHT=zref, model_proj=proj)
     np.testing.assert_allclose(res[0][0], ow[0], rtol=0, atol=TIGHT, equal_nan=True)
     np.testing.assert_allclose(res[1][0], oh[0], rtol=0, atol=TIGHT, equal_nan=True)
+
+
+def test_height_sharding_needs_no_collective(R):
+    """raider_amd.distributed.raytrace_heights_sharded: three "ranks" taking disjoint blocks of the output heights reproduce the
+    one-launch cube bit for bit - slices share nothing (own level table, maxima, nParts), so this sharding has no all-reduce."""
+    from raider_amd import distributed as D
+    c = O.synthetic_cube(30, 34, 28, seed=4, y0=31.0, y1=35.0, x0=-120.0, x1=-115.0)
+    cube = R.Cube(c['ys'], c['xs'], c['zs'], c['wet'], c['hydro'], order='zyx')
+    xp = np.linspace(-118.5, -116.5, 37); yp = np.linspace(33.9, 32.1, 29)
+    hts = np.array([-50.0, 0.0, 300.0, 1200.0, 2500.0, 6000.0, 11000.0])
+    zref = float(c['zs'].max() - 1)
+    inc = np.broadcast_to(np.linspace(25, 44, 37), (29, 37)).copy()
+    rays_for = lambda h: R.Rays.grid(xp, yp, inc=inc, hd=-167.9)
+    w0, h0, K0, np0, f0 = cube.raytrace_slices(rays_for(hts), hts, zref)
+    seen = np.zeros(hts.size, bool)
+    for rank in range(3):
+        a, n, w, h, K, npr, fl = D.raytrace_heights_sharded(cube, rays_for, hts, zref, world=3, rank=rank)
+        assert n > 0 and not seen[a:a + n].any()
+        seen[a:a + n] = True
+        assert np.array_equal(w, w0[a:a + n]) and np.array_equal(h, h0[a:a + n]) and np.array_equal(npr, np0[a:a + n]) and np.array_equal(K, K0[a:a + n])
+    assert seen.all()
+    assert D.raytrace_heights_sharded(cube, rays_for, hts[:2], zref, world=3, rank=2)[1] == 0          # more ranks than heights
