@@ -194,3 +194,32 @@ def rio_open(path, userNDV=None, band=None):
         profile = src.profile
         data = src.read(band).squeeze() if band is not None else src.read().squeeze()
     return np.array(data), profile
+
+
+_ENVI_CODE = {'uint8': 1, 'int16': 2, 'int32': 3, 'float32': 4, 'float64': 5, 'complex64': 6, 'complex128': 9, 'uint16': 12, 'uint32': 13, 'int64': 14, 'uint64': 15}
+
+
+def write_envi(array, path, nodata=None, geotransform=None, description=None):
+    """One band as an ENVI raster: `<path>` flat binary (native little-endian) + `<path with .hdr>` - the `fmt='ENVI'` product of
+    utilFcns.writeArrayToRaster (utilFcns.py:257-304) without GDAL.  geotransform: GDAL's 6 numbers (x0, dx, 0, y0, 0, dy); written as
+    the header's `map info` (pixel-corner tie point, as GDAL writes it)."""
+    path = Path(path)
+    a = np.ascontiguousarray(array)
+    if a.ndim != 2:
+        raise RuntimeError(f'writeArrayToRaster: cannot write an array of shape {np.shape(array)} to a raster image')
+    a = a.astype(a.dtype.newbyteorder('<'), copy=False)
+    if str(a.dtype) not in _ENVI_CODE:
+        raise TypeError(f'no ENVI data type for {a.dtype}')
+    a.tofile(path)
+    hdr = ['ENVI', f'description = {{{description or path.name}}}', f'samples = {a.shape[1]}', f'lines   = {a.shape[0]}', 'bands   = 1', 'header offset = 0',
+           'file type = ENVI Standard', f'data type = {_ENVI_CODE[str(a.dtype)]}', 'interleave = bsq', 'byte order = 0']
+    if geotransform is not None:
+        x0, dx, rx, y0, ry, dy = (float(v) for v in geotransform)
+        if rx != 0.0 or ry != 0.0:
+            raise ValueError('rotated geotransforms have no ENVI map info')
+        hdr.append(f'map info = {{Geographic Lat/Lon, 1, 1, {x0:.15g}, {y0:.15g}, {abs(dx):.15g}, {abs(dy):.15g}, WGS-84}}')
+    if nodata is not None:
+        hdr.append(f'data ignore value = {float(nodata):.15g}')
+    hdr_path = path.with_suffix('.hdr') if path.suffix else Path(str(path) + '.hdr')
+    hdr_path.write_text('\n'.join(hdr) + '\n')
+    return str(path)

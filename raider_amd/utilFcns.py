@@ -127,3 +127,57 @@ def rio_open(path, userNDV=None, band=None):
     """utilFcns.py:164-202 (rasterio when installed, else flat-binary rasters with a .vrt / ENVI .hdr side-car)."""
     from .rawraster import rio_open as _rio_open
     return _rio_open(path, userNDV=userNDV, band=band)
+
+
+def writeArrayToRaster(array, path, noDataValue=0.0, fmt='ENVI', proj=None, gt=None):
+    """utilFcns.py:257-304: a 2-D array as a GDAL-readable raster (float -> float32, complex -> complex64, anything else -> uint8).
+    rasterio writes it when installed; without it the ENVI format is written natively (flat binary + .hdr), other formats raise."""
+    from pathlib import Path
+    array = np.asarray(array)
+    if array.ndim != 2:
+        raise RuntimeError(f'writeArrayToRaster: cannot write an array of shape {np.shape(array)} to a raster image')
+    dtype = np.complex64 if 'complex' in str(array.dtype) else (np.float32 if 'float' in str(array.dtype) else np.uint8)
+    path = Path(path)
+    if fmt == 'nc':
+        fmt = 'GTiff'; path = path.with_suffix('.tif')
+    try:
+        import rasterio
+    except ImportError:
+        rasterio = None
+    if rasterio is not None:
+        trans = None
+        if gt is not None:
+            try:
+                trans = rasterio.Affine.from_gdal(*gt)
+            except TypeError:
+                trans = gt
+        with rasterio.open(path, mode='w', count=1, width=array.shape[1], height=array.shape[0], dtype=dtype, crs=proj, nodata=noDataValue, driver=fmt,
+                           transform=trans) as dst:
+            dst.write(array.astype(dtype), 1)
+        return
+    if str(fmt).upper() != 'ENVI':
+        raise ImportError(f'writing {fmt} rasters needs rasterio, which is not installed (ENVI is written without it)')
+    from .rawraster import write_envi
+    write_envi(array.astype(dtype), path, nodata=noDataValue, geotransform=gt)
+
+
+def writeDelays(aoi, wetDelay, hydroDelay, wet_path, hydro_path=None, outformat=None, ndv=0.0):
+    """utilFcns.py:431-464: station AOIs -> the station CSV with wetDelay / hydroDelay / totalDelay columns; raster AOIs -> two rasters."""
+    from pathlib import Path
+    import pandas as pd
+    wetDelay[np.isnan(wetDelay)] = ndv                  # (in place, as the reference does)
+    hydroDelay[np.isnan(hydroDelay)] = ndv
+    t = aoi.type() if callable(getattr(aoi, 'type', None)) else getattr(aoi, 'type', None)
+    if t == 'station_file':
+        df = pd.read_csv(aoi._filename).drop_duplicates(subset=['Lat', 'Lon'])
+        df['wetDelay'] = wetDelay
+        df['hydroDelay'] = hydroDelay
+        df['totalDelay'] = wetDelay + hydroDelay
+        df.to_csv(str(wet_path), index=False)
+        return
+    if hydro_path is None:
+        raise ValueError('Hydro delay file path must be specified if the AOI is not a station file')
+    proj = aoi.projection() if hasattr(aoi, 'projection') else None
+    gt = aoi.geotransform() if hasattr(aoi, 'geotransform') else None
+    writeArrayToRaster(wetDelay, Path(wet_path), noDataValue=ndv, fmt=outformat or 'ENVI', proj=proj, gt=gt)
+    writeArrayToRaster(hydroDelay, Path(hydro_path), noDataValue=ndv, fmt=outformat or 'ENVI', proj=proj, gt=gt)

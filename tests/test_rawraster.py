@@ -114,3 +114,34 @@ def test_conventional_los_from_a_raster_file(tmp_path):
     los2 = Conventional(filename=str(bad)); los2.setPoints(lats, lons, np.zeros((6, 8)))
     with pytest.raises(ValueError, match='line-of-sight raster'):
         los2(ztd)
+
+
+def test_write_delays_station_csv_and_envi_rasters(tmp_path):
+    """utilFcns.writeDelays (utilFcns.py:431-464), the output side of the point branch in cli/raider.py: the station CSV gains the three
+    delay columns (duplicates dropped, NaN -> no-data value IN PLACE); raster AOIs get two ENVI rasters this package reads back."""
+    import pandas as pd
+    from raider_amd.utilFcns import rio_open, writeArrayToRaster, writeDelays
+    csv = tmp_path / 'stations.csv'
+    csv.write_text('ID,Lat,Lon,Hgt_m\nA,33.1,-117.2,10\nB,33.5,-117.9,200\nB2,33.5,-117.9,200\nC,34.0,-118.4,1500\n')
+    aoi = type('A', (), dict(type=lambda self: 'station_file', _filename=str(csv)))()
+    wet = np.array([0.10, np.nan, 0.05]); hyd = np.array([2.3, 2.2, 1.9])
+    writeDelays(aoi, wet, hyd, tmp_path / 'out.csv')
+    df = pd.read_csv(tmp_path / 'out.csv')
+    assert list(df['ID']) == ['A', 'B', 'C'] and list(df['wetDelay']) == [0.10, 0.0, 0.05] and np.allclose(df['totalDelay'], [2.4, 2.2, 1.95]) and wet[1] == 0.0
+    rng = np.random.default_rng(0)
+    w2 = rng.uniform(0, 0.3, (7, 9)); h2 = rng.uniform(1.8, 2.4, (7, 9)); w2[2, 3] = np.nan
+    raoi = type('R', (), dict(type=lambda self: 'radar_rasters', projection=lambda self: None, geotransform=lambda self: (-118.0, 0.01, 0.0, 34.0, 0.0, -0.01)))()
+    with pytest.raises(ValueError, match='Hydro delay file path'):
+        writeDelays(raoi, w2.copy(), h2.copy(), tmp_path / 'wet.envi')
+    writeDelays(raoi, w2, h2, tmp_path / 'wet.envi', tmp_path / 'hydro.envi', outformat='ENVI', ndv=-9999.0)
+    back, prof = rio_open(tmp_path / 'wet.envi')
+    assert back.dtype == np.float32 and back.shape == (7, 9) and back[2, 3] == -9999.0 and prof['nodata'] == -9999.0
+    assert np.array_equal(back, w2.astype(np.float32)) and np.array_equal(rio_open(tmp_path / 'hydro.envi')[0], h2.astype(np.float32))
+    assert 'map info = {Geographic Lat/Lon, 1, 1, -118, 34, 0.01, 0.01, WGS-84}' in (tmp_path / 'wet.hdr').read_text()
+    with pytest.raises(RuntimeError, match='cannot write an array of shape'):
+        writeArrayToRaster(np.zeros((2, 3, 4)), tmp_path / 'x.envi')
+    try:
+        import rasterio  # noqa: F401
+    except ImportError:
+        with pytest.raises(ImportError, match='rasterio'):
+            writeArrayToRaster(np.zeros((2, 3)), tmp_path / 'x.tif', fmt='GTiff')
