@@ -466,8 +466,14 @@ def _build_cube_ray(xpts, ypts, zpts, los, model_crs, pts_crs, interpolators, ou
             zz = np.ascontiguousarray(zpts[s0:s0 + 512], dtype=np.float64)
             logger.info(f'Processing slices {s0 + 1}-{s0 + zz.size} / {len(zpts)}')
             rays = los.ray_batch_slices(xpts, ypts, zz)
-            _, _, K, _nparts, flags = cube.raytrace_slices(rays, zz, MAX_TROPO_HEIGHT, MAX_SEGMENT_LENGTH,
-                                                           out=(outputArrs[0][s0:s0 + zz.size], outputArrs[1][s0:s0 + zz.size]))
+            if rays._torch_device is None:
+                _, _, K, _nparts, flags = cube.raytrace_slices(rays, zz, MAX_TROPO_HEIGHT, MAX_SEGMENT_LENGTH,
+                                                               out=(outputArrs[0][s0:s0 + zz.size], outputArrs[1][s0:s0 + zz.size]))
+            else:           # a device-resident batch (orbit-based look vectors made on the GPU): device outputs, one download per field
+                import torch
+                dw, dh, K, _nparts, flags = cube.raytrace_slices(rays, zz, MAX_TROPO_HEIGHT, MAX_SEGMENT_LENGTH)
+                torch.from_numpy(outputArrs[0][s0:s0 + zz.size]).copy_(dw); torch.from_numpy(outputArrs[1][s0:s0 + zz.size]).copy_(dh)
+                del dw, dh
             for hh, ht in enumerate(zz):                                   # the reference's failure modes, in slice order
                 if K[hh] == 0:
                     if ht == zpts[-1]:                                     # delay.py:276-277: the slice stays zero (the kernels wrote 0)
@@ -498,9 +504,10 @@ def _build_cube_ray(xpts, ypts, zpts, los, model_crs, pts_crs, interpolators, ou
                 rays = Rays.grid(xpts, ypts, los=LOS)
             else:
                 rays = Rays.points(lat=llh[1], lon=llh[0], los=LOS)
+        on_device = getattr(rays, '_torch_device', None) is not None
         try:
             wet, hyd, _nparts, _flags = cube.raytrace(rays, ht, MAX_TROPO_HEIGHT, MAX_SEGMENT_LENGTH,
-                                                      out=(outputArrs[0][hh], outputArrs[1][hh]) if direct else None)
+                                                      out=(outputArrs[0][hh], outputArrs[1][hh]) if (direct and not on_device) else None)
         except NoLevels:
             if ht == zpts[-1]:                                             # delay.py:276-277: the slice stays zero
                 if output_created_here:
@@ -508,6 +515,10 @@ def _build_cube_ray(xpts, ypts, zpts, los, model_crs, pts_crs, interpolators, ou
                         arr[hh, ...] = 0.0
                 continue
             raise TypeError("ufunc 'isnan' not supported for the input types (build_ray returned None)")   # delay.py:279
+        if on_device:
+            wet, hyd = wet.cpu().numpy(), hyd.cpu().numpy()
+            if direct:
+                outputArrs[0][hh, ...] = wet; outputArrs[1][hh, ...] = hyd
         if direct:
             continue
         res = (wet, hyd)

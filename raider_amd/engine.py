@@ -475,3 +475,28 @@ def nparts_from_maxlen(maxlen, max_seg=1000.0):
     out = np.empty(maxlen.size, dtype=np.int32)
     check(L.load().rdr_nparts(ptr(maxlen), maxlen.size, float(max_seg), ptr(out)))
     return out
+
+
+def torch_device_or_none():
+    """The torch device of the default context when torch with a GPU is importable, else None (NumPy-only callers never need torch)."""
+    try:
+        import torch
+    except ImportError:
+        return None
+    if not torch.cuda.is_available():
+        return None
+    import os
+    idx = int(os.environ.get('RAIDER_HIP_DEVICE', os.environ.get('LOCAL_RANK', '-1')))
+    return torch.device('cuda', idx if idx >= 0 else torch.cuda.current_device())
+
+
+def lla2ecef_device(lat, lon, h, ctx=None):
+    """utilFcns.lla2ecef on device tensors (same kernel, no host round trip): broadcastable float64 tensors -> (..., 3) ECEF."""
+    import torch
+    ctx = ctx or Context.default()
+    lat, lon, h = torch.broadcast_tensors(lat, lon, h)
+    lat, lon, h = (_dev_f64(t.contiguous(), 'lla2ecef_device input') for t in (lat, lon, h))
+    ctx.adopt_torch_stream(lat)
+    out = torch.empty(tuple(lat.shape) + (3,), dtype=torch.float64, device=lat.device)
+    check(ctx.lib.rdr_lla2ecef(ctx.handle, ptr(lat), ptr(lon), ptr(h), lat.numel(), ptr(out), L.RDR_DEVICE), ctx.handle)
+    return out

@@ -179,13 +179,34 @@ class Raytracing(LOS):
             # orbit-based: zero-Doppler solve per pixel on the device (replaces the isce3 loop, losreader.py:230-254)
             if self._orbit is None:
                 raise ValueError('The orbit has not been set (call setTime)')
-            from .utilFcns import lla2ecef
-            xx, yy = np.meshgrid(xpts, ypts)
-            xyz = np.stack(lla2ecef(yy, xx, np.full(yy.shape, float(ht))), axis=-1)
-            return Rays.grid(xpts, ypts, los=self._orbit.look_vectors(xyz))
+            return self._orbit_rays(xpts, ypts, [float(ht)], slices=0)
         if self._lv is not None:
             return Rays.grid(xpts, ypts, los=self._lv)
         return Rays.grid(xpts, ypts, inc=self._inc, hd=self._hd)
+
+    def _orbit_rays(self, xpts, ypts, hts, slices):
+        """Orbit-based look vectors for every (height, y, x) target in ONE zero-Doppler launch.  With torch on the GPU the targets,
+        the look vectors and the ray batch stay on the device (grid -> ECEF -> look vectors -> Rays, no host round trip: for a
+        1000 x 1000 x 8 job the host route spends 20x the kernels' time moving 48 B per target back and forth); otherwise NumPy."""
+        import sys
+        from .engine import Rays, lla2ecef_device, torch_device_or_none
+        # (importing torch costs a second or two once per process: worth it for anything but a small one-off job)
+        big = np.size(xpts) * np.size(ypts) * np.size(hts) >= 1_000_000
+        dev = torch_device_or_none() if (big or 'torch' in sys.modules) else None
+        if dev is not None:
+            import torch
+            xt = torch.as_tensor(np.ascontiguousarray(xpts, dtype=np.float64), device=dev)
+            yt = torch.as_tensor(np.ascontiguousarray(ypts, dtype=np.float64), device=dev)
+            ht = torch.as_tensor(np.ascontiguousarray(hts, dtype=np.float64), device=dev)
+            xyz = lla2ecef_device(yt[None, :, None], xt[None, None, :], ht[:, None, None])         # (S, ny, nx, 3)
+            los = self._orbit.look_vectors(xyz)
+            del xyz
+            return Rays.grid(xt, yt, los=los if slices else los[0], slices=slices)
+        from .utilFcns import lla2ecef
+        xx, yy = np.meshgrid(xpts, ypts)
+        xyz = np.stack([np.stack(lla2ecef(yy, xx, np.full(yy.shape, float(h))), axis=-1) for h in hts], axis=0)
+        los = self._orbit.look_vectors(xyz)
+        return Rays.grid(xpts, ypts, los=los if slices else los[0], slices=slices)
 
     def ray_batch_slices(self, xpts, ypts, hts):
         """Engine fast path for the whole height loop of _build_cube_ray: ONE `Rays` batch covering every slice.  Look vectors
@@ -196,10 +217,7 @@ class Raytracing(LOS):
         if self._lv is None and self._inc is None:
             if self._orbit is None:
                 raise ValueError('The orbit has not been set (call setTime)')
-            from .utilFcns import lla2ecef
-            xx, yy = np.meshgrid(xpts, ypts)
-            xyz = np.stack([np.stack(lla2ecef(yy, xx, np.full(yy.shape, float(h))), axis=-1) for h in hts], axis=0)
-            return Rays.grid(xpts, ypts, los=self._orbit.look_vectors(xyz), slices=hts.size)
+            return self._orbit_rays(xpts, ypts, hts, slices=hts.size)
         if self._lv is not None:
             return Rays.grid(xpts, ypts, los=self._lv)
         return Rays.grid(xpts, ypts, inc=self._inc, hd=self._hd)

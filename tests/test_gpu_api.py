@@ -567,3 +567,40 @@ def test_zenith_cube_on_a_utm_grid_over_a_projected_model():
         pts = np.stack([py, px, np.full(px.shape, ht)], -1)
         np.testing.assert_allclose(zw[k], ip[0](pts), rtol=0, atol=1e-12); np.testing.assert_allclose(zh[k], ip[1](pts), rtol=0, atol=1e-12)
         assert np.isfinite(zw[k]).all()
+
+
+def test_orbit_rays_device_and_host_routes_agree(monkeypatch):
+    """Raytracing(<orbit file>): the look vectors of all heights are made on the device when torch is around (grid -> ECEF -> zero-Doppler
+    solve -> ray batch, nothing crosses PCIe) and through NumPy otherwise: the same kernels either way, so the same bits."""
+    import datetime as dt
+    from pathlib import Path
+    import torch
+    import raider_amd.engine as E
+    from raider_amd.delay import _build_cube_ray
+    from raider_amd.delayFcns import getInterpolators
+    from raider_amd.losreader import Raytracing
+    d = Path(__file__).resolve().parent / 'golden' / 'orbit_files'
+    los_obj = Raytracing(str(d / 'S1_sv_file.txt'), time=dt.datetime(2018, 11, 12, 23, 0, 2) + dt.timedelta(seconds=35))
+    orb = los_obj._orbit
+    mid, _ = O.orbit_hermite(orb.time, orb.position, orb.velocity, [35.0])
+    lon_s, lat_s, _ = O.ecef2lla(mid[:, 0], mid[:, 1], mid[:, 2])
+    ypts = lat_s[0] + np.linspace(0.12, -0.12, 21); xpts = lon_s[0] - np.linspace(2.4, 4.6, 33)
+    hts = np.array([0.0, 1500.0, 4000.0])
+    dev_rays = los_obj.ray_batch_slices(xpts, ypts, hts)
+    assert dev_rays._torch_device is not None and dev_rays.slices == 3
+    monkeypatch.setattr(E, 'torch_device_or_none', lambda: None)
+    host_rays = los_obj.ray_batch_slices(xpts, ypts, hts)
+    assert host_rays._torch_device is None
+    kept = [t for t in dev_rays._keep if hasattr(t, 'shape') and tuple(t.shape) == (3, 21, 33, 3)]
+    hk = [a for item in host_rays._keep if isinstance(item, tuple) for a in [item[1]] if a.shape == (3, 21, 33, 3)]
+    assert len(kept) == 1 and len(hk) == 1 and np.array_equal(kept[0].cpu().numpy(), hk[0])
+    c = O.synthetic_cube(40, 44, 30, seed=4, y0=lat_s[0] - 2, y1=lat_s[0] + 2, x0=lon_s[0] - 7, x1=lon_s[0] - 0.5)
+    wm = dict(x=c['xs'], y=c['ys'], z=c['zs'], wet=c['wet'], hydro=c['hydro'])
+    zref = float(c['zs'].max() - 1)
+    wh, hh = _build_cube_ray(xpts, ypts, hts, los_obj, 4326, 4326, list(getInterpolators(wm)), MAX_TROPO_HEIGHT=zref)       # host route (patched)
+    monkeypatch.undo()
+    wd, hd = _build_cube_ray(xpts, ypts, hts, los_obj, 4326, 4326, list(getInterpolators(wm)), MAX_TROPO_HEIGHT=zref)       # device route
+    assert np.array_equal(wh, wd) and np.array_equal(hh, hd) and np.isfinite(hd).all()
+    # the single-slice protocol (ray_batch) takes the same route
+    one = los_obj.ray_batch(xpts, ypts, 1500.0)
+    assert one._torch_device is not None and one.slices == 0
