@@ -7,9 +7,11 @@ SURVEY.md §8(d), per-pixel ECEF look vectors (an input array resident in HBM), 
 MAX_SEGMENT_LENGTH = 1000 m.  One "step" = one pass of the hot path over that batch:
    pass 1 (build_ray fused: per-level batch max of ray length)  ->  [N>1: all-reduce MAX over ranks]
    pass 2 (trapezoid integration of wet+hydro along every ray).
-N GPUs: weak scaling - every rank traces its own rows x cols slab of a (N*rows) x cols scene; the cube is
-broadcast once over RCCL; the only data-path collective is the K-double MAX all-reduce that keeps nParts
-batch-global.
+N GPUs (`--scaling`): default for N > 1 is STRONG scaling on BASELINE.json configs[3] - ONE 10000x10000 scene (100 M rays)
+split into contiguous row blocks (raider_amd.distributed.shard_rows), `value` = 100 M rays x steps / time; `--rows R` (or
+`--scaling weak`) gives weak scaling instead: every rank traces its own R x cols slab of an (N*R) x cols scene.  Either way
+the cube goes out ONCE in one packed RCCL broadcast and the only data-path collective is the MAX all-reduce of K+4 doubles
+between the two passes that keeps nParts batch-global; there is no output collective.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
 """
@@ -32,12 +34,8 @@ VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4
 
 def kernel_source_hash():
     """sha256 over the HIP sources of libraider_hip.so: ties the counter digests under profiles/ to the code they measured."""
-    import hashlib
-    h = hashlib.sha256()
-    for f in sorted((REPO / 'raider_amd' / 'csrc').glob('*')):
-        if f.suffix in ('.h', '.hip'):
-            h.update(f.name.encode()); h.update(f.read_bytes())
-    return h.hexdigest()[:16]
+    from raider_amd import _lib
+    return _lib.source_hash()
 
 
 def load_counters(cube, rows, cols):
@@ -79,8 +77,15 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--rows', type=int, default=4000)
-    ap.add_argument('--cols', type=int, default=4000)
+    ap.add_argument('--rows', type=int, default=None, help='N = 1: rows of the scene (default 4000); N > 1: rows PER RANK (implies --scaling weak)')
+    ap.add_argument('--cols', type=int, default=None, help='columns of the scene (default 4000; 10000 for the strong-scaling scene)')
+    ap.add_argument('--scaling', choices=('auto', 'strong', 'weak'), default='auto',
+                    help='N > 1: strong = one --total-rows x cols scene (default 10000x10000 = configs[3]) sharded by rows; weak = --rows per rank. '
+                         'auto = strong unless --rows is given')
+    ap.add_argument('--total-rows', type=int, default=None, help='rows of the whole scene in strong scaling (default 10000)')
+    ap.add_argument('--force-dist', action='store_true', help='N = 1: still create the process group and issue every collective of the N > 1 path '
+                                                              '(one-rank RCCL group: how the nccl path is exercised on a single-GPU box)')
+    ap.add_argument('--no-e2e', action='store_true', help='skip the end-to-end (H2D + kernels + D2H through the NumPy boundary) figure')
     ap.add_argument('--cube', type=str, default='300x300x80')
     ap.add_argument('--cube-f64', action='store_true', help='experiment: upload the f32 refractivities as f64 (no cvt in the gather)')
     ap.add_argument('--axes-f32', action='store_true', help='experiment: lat / lon axes rounded to float32 (not exactly uniform any more: the LDS-table cell search)')
@@ -90,6 +95,10 @@ def main():
     ap.add_argument('--dump', type=str, default='', help='write this rank\'s slab of the hydrostatic / wet delays to <dump>.rank<r>.npz (tests)')
     ap.add_argument('--cpu-sample', type=int, default=640, help='edge of the square ray block timed on the CPU oracle (0 = skip)')
     args = ap.parse_args()
+    if args.scaling == 'auto':
+        args.scaling = 'strong' if (args.gpus > 1 and args.rows is None) else 'weak'
+    if args.scaling == 'strong' and args.rows is not None:
+        raise SystemExit('bench.py: --rows is the per-rank slab of weak scaling; the strong-scaling scene is --total-rows x --cols')
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         self_launch(args)
 
@@ -114,8 +123,13 @@ def main():
         args.backend = 'nccl' if world <= ndev else 'gloo'
         if args.backend == 'gloo':
             args.coll_device = True
-    if world > 1:
+    dist_on = world > 1 or args.force_dist
+    if dist_on:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if 'MASTER_PORT' not in os.environ:
+            import socket
+            with socket.socket() as s_:
+                s_.bind(('127.0.0.1', 0)); os.environ['MASTER_PORT'] = str(s_.getsockname()[1])
         if args.backend == 'nccl':
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
         else:
@@ -125,29 +139,26 @@ def main():
     ctx = R.Context(local)
     # (raider_amd launches on torch's current stream whenever it is handed device tensors)
 
-    # ---- weather cube: generated on rank 0, broadcast once over RCCL/xGMI, packed on device -----------
+    # ---- weather cube: generated on rank 0, sent to every rank in ONE packed broadcast (RCCL over xGMI), packed (y,x,z) on device
     ny, nx, nz = (int(v) for v in args.cube.split('x'))
+    fields = None
     if rank == 0:
         c = synthetic_cube(ny, nx, nz, seed=0)
-        axes = torch.from_numpy(np.concatenate([c['ys'], c['xs'], c['zs']])).to(dev)
-        wet = torch.from_numpy(c['wet']).to(dev)
-        hyd = torch.from_numpy(c['hydro']).to(dev)
-    else:
-        axes = torch.empty(ny + nx + nz, dtype=torch.float64, device=dev)
-        wet = torch.empty((nz, ny, nx), dtype=torch.float32, device=dev)
-        hyd = torch.empty((nz, ny, nx), dtype=torch.float32, device=dev)
+        fields = {k: c[k] for k in ('ys', 'xs', 'zs', 'wet', 'hydro')}
     t_bcast = 0.0
-    if world > 1:
+    if dist_on:
         torch.cuda.synchronize(); dist.barrier()
         t0 = time.perf_counter()
-        if coll_dev is None:      # gloo dry run: stage through the host
-            for t_ in (axes, wet, hyd):
-                h_ = t_.cpu(); dist.broadcast(h_, 0); t_.copy_(h_)
-        else:
-            dist.broadcast(axes, 0); dist.broadcast(wet, 0); dist.broadcast(hyd, 0)
+        # every rank knows the cube's shape from --cube: no header round, one collective
+        axes, wet, hyd = D.broadcast_cube_packed(fields, src=0, device=coll_dev, header=(ny, nx, nz, 0, nz, ny, nx))
+        if coll_dev is None:      # gloo dry run on host tensors
+            axes, wet, hyd = axes.to(dev), wet.to(dev), hyd.to(dev)
         torch.cuda.synchronize()
         t_bcast = time.perf_counter() - t0
-    ax = axes.cpu().numpy()
+        ax = axes.cpu().numpy()
+    else:
+        ax = np.concatenate([c['ys'], c['xs'], c['zs']])
+        wet = torch.from_numpy(c['wet']).to(dev); hyd = torch.from_numpy(c['hydro']).to(dev)
     ys, xs, zs = ax[:ny], ax[ny:ny + nx], ax[ny + nx:]
     if args.cube_f64:
         wet, hyd = wet.double(), hyd.double()
@@ -158,8 +169,15 @@ def main():
     ht = 0.0
 
     # ---- this rank's slab of the scene; look vectors generated on device, then used as an INPUT array ---
-    rows, cols = args.rows, args.cols
-    xpts, ypts, inc_cols, hd = scene_grid(rows, cols, row0=rank * rows, nrows=rows, total_rows=rows * world)
+    if args.scaling == 'strong':
+        total_rows = args.total_rows or 10000
+        cols = args.cols or 10000
+        row0, rows = D.shard_rows(total_rows, world, rank)
+    else:
+        rows = args.rows or 4000
+        cols = args.cols or 4000
+        total_rows, row0 = rows * world, rank * rows
+    xpts, ypts, inc_cols, hd = scene_grid(rows, cols, row0=row0, nrows=rows, total_rows=total_rows)
     xpts_t = torch.from_numpy(xpts).to(dev); ypts_t = torch.from_numpy(ypts).to(dev)
     inc_t = torch.from_numpy(np.ascontiguousarray(np.broadcast_to(inc_cols, (rows, cols)))).to(dev)
     hd_t = torch.full((rows, cols), hd, dtype=torch.float64, device=dev)
@@ -173,7 +191,7 @@ def main():
     partition = None      # device-resident pass-1 result (K+4 doubles) the RCCL all-reduce works on
 
     def step():
-        if world == 1:
+        if not dist_on:
             cube.raytrace(rays, ht, zref, out=(out_w, out_h), want_nparts=False)       # fully asynchronous
         elif partition is not None:                                                    # pass 1 -> RCCL MAX all-reduce (K+4 doubles, on the device) -> pass 2
             D.raytrace_slab_async(cube, rays, ht, zref, partition, out=(out_w, out_h))
@@ -181,18 +199,18 @@ def main():
             D.raytrace_slab(cube, rays, ht, zref, out=(out_w, out_h), device=coll_dev)
 
     # nParts / S for the roofline formula (one synchronous untimed call, which also raises the reference's error conditions)
-    if world == 1:
+    if not dist_on:
         _, _, nparts, flags = cube.raytrace(rays, ht, zref, out=(out_w, out_h), want_nparts=True)
     else:
         _, _, nparts = D.raytrace_slab(cube, rays, ht, zref, out=(out_w, out_h), device=coll_dev)
     S = int(np.sum(nparts)); K = int(len(nparts))
-    if world > 1 and coll_dev is not None:
+    if dist_on and coll_dev is not None:
         partition = torch.zeros(K + 4, dtype=torch.float64, device=dev)
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     ctx.set_profiling(True)                                      # HIP event pairs around every kernel launch
     torch.cuda.synchronize()
@@ -200,13 +218,13 @@ def main():
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     dt = time.perf_counter() - t0
     n_pre, ms_pre = ctx.profile_get(0)
     n_march, ms_march = ctx.profile_get(1)
     ctx.set_profiling(False)
-    if world > 1:
+    if dist_on:
         tmax = torch.tensor([dt], dtype=torch.float64, device=coll_dev if coll_dev is not None else 'cpu')
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -216,8 +234,27 @@ def main():
     nan_frac = float(torch.isnan(out_h).double().mean().item())
     mean_h = float(torch.nanmean(out_h).item()); mean_w = float(torch.nanmean(out_w).item())
 
+    # ---- end to end through the NumPy boundary (reported separately, never `value`): the same scene handed over as
+    # HOST arrays - look vectors up (24 B/ray), both passes, both delays down (16 B/ray); the library pipelines the transfers
+    e2e = None
+    if world == 1 and not args.no_e2e:
+        los_np = los_t.cpu().numpy()
+        eo = (np.empty((rows, cols)), np.empty((rows, cols)))
+        cube.raytrace(R.Rays.grid(xpts, ypts, los=los_np), ht, zref, out=eo, want_nparts=False)      # warm-up (stages, page faults)
+        reps = 3
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            cube.raytrace(R.Rays.grid(xpts, ypts, los=los_np), ht, zref, out=eo, want_nparts=False)
+        dte = (time.perf_counter() - t0) / reps
+        same = bool(np.array_equal(eo[1], out_h.cpu().numpy(), equal_nan=True))
+        e2e = {'value': n_rays / dte, 'unit': 'rays/s', 'ms': dte * 1e3, 'h2d_bytes': n_rays * 24, 'd2h_bytes': n_rays * 16,
+               'what': 'same scene through the NumPy (host-buffer) boundary: look-vector upload + pass 1 + pass 2 + download, pageable host '
+                       'memory, transfers overlapped with the kernels in 8 row chunks', 'bit_identical_to_device_path': same}
+        del los_np, eo
+
     if rank == 0:
-        total_rays = n_rays * world * args.steps
+        scene_rays = total_rows * cols                            # all ranks together
+        total_rays = scene_rays * args.steps
         value = total_rays / dt
         bytes_per_ray = 64 * S + 64                               # SURVEY.md §8(d) gather model
         # per-STEP kernel time (a step may launch a kernel several times when the batch is marched in chunks)
@@ -234,50 +271,70 @@ def main():
         traffic = (km.get('hbm_read_bytes', 0) + km.get('hbm_write_bytes', 0)) if (scene_ok and 'hbm_read_bytes' in km) else None
         step_traffic = (traffic + kc.get('hbm_read_bytes', 0) + kc.get('hbm_write_bytes', 0)) if (traffic is not None and 'hbm_read_bytes' in kc) else None
         valu_rate = (valu_rw * (n_rays / 64.0) / (march_ms * 1e-3)) if valu_rw else None
+        compulsory = 64 + (ny * nx * nz * 8) / n_rays             # B/ray: look vector in, two delays out, the cube once
+        ka_m, ka_c = cube.ray_kernel_attributes(1), cube.ray_kernel_attributes(0)      # from the loaded code object
+        frac_valu = valu_rate / VALU_ISSUE_PEAK if valu_rate else None
+        frac_hbm = (traffic / (march_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic is not None else None
+        if world == 1:
+            wl = (f'configs[2]: Raytracing LOS, {rows}x{cols} scene ({n_rays/1e6:.1f}M rays), one slice at ht=0, per-pixel ECEF look vectors, '
+                  f'synthetic ERA5-sized {args.cube} f32 cube, zref=max(z)-1, MAX_SEGMENT_LENGTH=1000')
+        elif args.scaling == 'strong':
+            wl = (f'configs[3]: Raytracing LOS, ONE {total_rows}x{cols} scene ({scene_rays/1e6:.0f}M rays) sharded into {world} contiguous row blocks, '
+                  f'one slice at ht=0, per-pixel ECEF look vectors, synthetic ERA5-sized {args.cube} f32 cube broadcast over RCCL, zref=max(z)-1, '
+                  f'MAX_SEGMENT_LENGTH=1000')
+        else:
+            wl = (f'configs[2] per GPU (weak scaling): Raytracing LOS, {rows}x{cols} slab per rank of a {total_rows}x{cols} scene, one slice at ht=0, '
+                  f'per-pixel ECEF look vectors, synthetic ERA5-sized {args.cube} f32 cube broadcast over RCCL, zref=max(z)-1, MAX_SEGMENT_LENGTH=1000')
         res = {
             'metric': 'LOS rays/sec (wet+hydro slant delay) through ERA5 cube; achieved HBM GB/s',
             'value': value, 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': args.scaling if world > 1 else 'weak', 'vs_baseline': None,
             'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': f'configs[2]: Raytracing LOS, {rows}x{cols} scene per GPU ({n_rays/1e6:.1f}M rays), one slice at ht=0, '
-                                   f'per-pixel ECEF look vectors, synthetic ERA5-sized {args.cube} f32 cube, zref=max(z)-1, MAX_SEGMENT_LENGTH=1000',
-                       'rays_per_gpu': n_rays, 'cube': args.cube, 'levels_K': K, 'samples_per_ray_S': S,
-                       'parallelism': (f'rows sharded x{world} ({args.backend}, {ndev} device(s) visible), cube broadcast ({t_bcast*1e3:.1f} ms), '
-                                       f'MAX all-reduce of {K}+4 doubles per step') if world > 1 else 'single GPU',
-                       'ranks': world, 'backend': args.backend if world > 1 else None,
+            'config': {'workload': wl,
+                       'rays_per_gpu': n_rays, 'rays_per_step_all_gpus': scene_rays, 'cube': args.cube, 'levels_K': K, 'samples_per_ray_S': S,
+                       'parallelism': (f'rows sharded x{world} ({args.backend}, {ndev} device(s) visible), cube: one packed broadcast ({t_bcast*1e3:.1f} ms), '
+                                       f'MAX all-reduce of {K}+4 doubles per step, no output collective') if dist_on else 'single GPU',
+                       'ranks': world, 'backend': (dist.get_backend() if dist_on else None),
+                       'world_size_seen_by_backend': (dist.get_world_size() if dist_on else 1),
                        'mean_hydro_m': mean_h, 'mean_wet_m': mean_w, 'nan_fraction': nan_frac},
             # The limiter the SQ counters show is fp64 vector-ALU issue, so THAT is the roofline (frac <= 1 by construction:
-            # instructions actually issued / issue slots of the chip).  The SURVEY 8(d) gather-model byte rate and the
-            # PMC-measured DRAM rate are reported beside it under "hbm".
+            # instructions actually issued / issue slots of the chip).  north_star's ">= 60 % of HBM" is not meetable at S = 178:
+            # the gathers never reach HBM.  Both fractions are at the top level of this object.
             'roofline': {'bound': 'valu_fp64_issue', 'kernel': 'march_kernel<float2,false,1>',
                          'achieved': valu_rate / 1e9 if valu_rate else None, 'peak': VALU_ISSUE_PEAK / 1e9, 'unit': 'G wave64-instr/s',
-                         'frac': valu_rate / VALU_ISSUE_PEAK if valu_rate else None,
+                         'frac': frac_valu, 'frac_valu': frac_valu, 'frac_hbm_measured': frac_hbm,
                          'traffic': traffic, 'traffic_unit': 'HBM bytes per march_kernel launch (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE, separate passes)',
+                         'traffic_over_compulsory': (step_traffic / (compulsory * n_rays)) if step_traffic is not None else None,
                          'valu_instr_per_raywave': valu_rw, 'valu_busy_frac': km.get('valu_busy_frac'),
                          'valu_per_evaluated_sample': (valu_rw / (S - (K - 1))) if valu_rw else None,
-                         'vgpr': km.get('vgpr'), 'scratch_bytes': km.get('scratch'),
+                         'vgpr': ka_m['vgpr'], 'lds_bytes': ka_m['lds_static'] + ka_m['lds_dynamic'], 'scratch_bytes': ka_m['scratch'],
+                         'resources_source': 'hipFuncGetAttributes on the loaded code object + the launch\'s dynamic LDS size',
                          'crossings': {'valu_instr_per_raywave': kc.get('valu_per_raywave'), 'valu_busy_frac': kc.get('valu_busy_frac'),
-                                       'vgpr': kc.get('vgpr'), 'scratch_bytes': kc.get('scratch'),
+                                       'vgpr': ka_c['vgpr'], 'lds_bytes': ka_c['lds_static'] + ka_c['lds_dynamic'], 'scratch_bytes': ka_c['scratch'],
                                        'frac': (kc['valu_per_raywave'] * (n_rays / 64.0) / (pre_ms * 1e-3) / VALU_ISSUE_PEAK) if kc.get('valu_per_raywave') and pre_ms > 0 else None},
                          'march_ms_per_step': march_ms, 'crossings_ms_per_step': pre_ms, 'march_launches_timed': n_march,
                          'counters_source': prof_src if prof is not None else None, 'counters_note': None if prof is not None else prof_src,
+                         'source_hash': kernel_source_hash(), 'library_source_hash': R.load_library().rdr_source_hash().decode(),
                          'hbm': {'peak_GBps': HBM_PEAK_GBS,
-                                 'gather_model_GBps': gather_GBps, 'gather_model_frac': gather_GBps / HBM_PEAK_GBS,
-                                 'gather_model_note': '(64*S+64) B/ray of SURVEY 8d x rays / march time: an algorithmic rate, the gathers are L2/MALL hits - NOT a utilisation',
-                                 'algorithmic_bytes_per_ray': bytes_per_ray, 'compulsory_bytes_per_ray': 64 + (ny * nx * nz * 8) / n_rays,
+                                 'algorithmic_bytes_per_ray': bytes_per_ray, 'compulsory_bytes_per_ray': compulsory,
                                  'measured_GBps': (traffic / (march_ms * 1e-3) / 1e9) if traffic is not None else None,
-                                 'hbm_measured_frac': (traffic / (march_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic is not None else None,
+                                 'hbm_measured_frac': frac_hbm,
                                  'step_traffic_bytes': step_traffic,
-                                 'step_measured_frac': (step_traffic / ((march_ms + pre_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS) if step_traffic is not None else None}},
+                                 'step_measured_frac': (step_traffic / ((march_ms + pre_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS) if step_traffic is not None else None,
+                                 'gather_model_GBps': gather_GBps,
+                                 'gather_model_note': '(64*S+64) B/ray of SURVEY 8d x rays / march time: an ALGORITHMIC rate above the HBM peak because the '
+                                                      'gathers are L2/MALL hits - not a utilisation'}},
         }
+        if e2e is not None:
+            res['end_to_end'] = e2e
         if world == 1 and args.cpu_sample > 0:
-            res['cpu_baseline'] = cpu_baseline(args, xpts, ypts, inc_cols, hd, nparts, zref, out_w, out_h)
+            res['cpu_baseline'] = cpu_baseline(args, rows, cols, xpts, ypts, inc_cols, hd, nparts, zref, out_w, out_h)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 
-def cpu_baseline(args, xpts, ypts, inc_cols, hd, nparts, zref, out_w, out_h):
+def cpu_baseline(args, rows, cols, xpts, ypts, inc_cols, hd, nparts, zref, out_w, out_h):
     """CPU baseline on the GPU box's host, same scene, whole-slice nParts:
       * value: the C/OpenMP restatement (oracle/oracle_c.c) on ALL host cores, on a centre block sized for ~10-20 s;
       * numpy_1thread: the NumPy oracle (the reference's own formulation), one thread, on a 320x320 block.
@@ -289,8 +346,8 @@ def cpu_baseline(args, xpts, ypts, inc_cols, hd, nparts, zref, out_w, out_h):
     c = synthetic_cube(ny, nx, nz, seed=0)
 
     def block(n):
-        n = min(n, args.rows, args.cols)
-        r0 = (args.rows - n) // 2; c0 = (args.cols - n) // 2
+        n = min(n, rows, cols)
+        r0 = (rows - n) // 2; c0 = (cols - n) // 2
         xp = xpts[c0:c0 + n]; yp = ypts[r0:r0 + n]
         inc = np.broadcast_to(inc_cols[c0:c0 + n], (n, n))
         xx, yy = np.meshgrid(xp, yp)
@@ -302,7 +359,7 @@ def cpu_baseline(args, xpts, ypts, inc_cols, hd, nparts, zref, out_w, out_h):
     n, xp, yp, inc, los, gw, gh = block(256)
     t0 = time.perf_counter(); OC.build_cube_ray_slice(c, xp, yp, 0.0, los, zref, nparts=nparts); t_cal = time.perf_counter() - t0
     rate = n * n / t_cal
-    n_big = int(min(max(256, np.sqrt(rate * 15.0)), args.cpu_sample * 4, args.rows, args.cols))
+    n_big = int(min(max(256, np.sqrt(rate * 15.0)), args.cpu_sample * 4, rows, cols))
     n, xp, yp, inc, los, gw, gh = block(n_big)
     t0 = time.perf_counter(); cw, ch, _ = OC.build_cube_ray_slice(c, xp, yp, 0.0, los, zref, nparts=nparts); dt_c = time.perf_counter() - t0
     err_c = float(max(np.nanmax(np.abs(gw - cw)), np.nanmax(np.abs(gh - ch))))

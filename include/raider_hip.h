@@ -82,6 +82,9 @@ typedef struct rdr_rays {
 
 /* ---- lifecycle ------------------------------------------------------------------------------- */
 int rdr_version(void);
+/* sha256[:16] over the sources the library was compiled from (raider_amd/csrc/*.{h,hip} + this header; "unknown" when the
+ * build recipe did not pass it).  raider_amd._lib.source_hash() computes the same digest from the tree. */
+const char* rdr_source_hash(void);
 /* device < 0: use HIP's current device.  Fails with RDR_ERR_NODEVICE when there is no GPU. */
 int rdr_create(int device, rdr_ctx** out);
 void rdr_destroy(rdr_ctx* ctx);
@@ -109,6 +112,11 @@ int rdr_set_workspace_limit(rdr_ctx* ctx, int64_t bytes);
 /* Columns of the generic-ray side buffer: >= 0 fixes the capacity (0: always recompute), -1 restores the automatic sizing. */
 int rdr_set_side_capacity(rdr_ctx* ctx, int64_t columns);
 int rdr_profile_get(rdr_ctx* ctx, int which, int* count, float* total_ms);
+/* diagnostics: resources of the light ray kernel a GRID + look-vector batch on `cube` launches (which 0: pass 1 crossings_kernel,
+ * 1: pass 2 march_kernel), read from the loaded code object (hipFuncGetAttributes): vector registers per lane, static LDS bytes,
+ * dynamic LDS bytes of the launch (axis / level tables), scratch bytes per lane, max threads per block.  Any output may be NULL. */
+int rdr_ray_kernel_attributes(rdr_ctx* ctx, const rdr_cube* cube, int which, int32_t* vgprs, int32_t* static_lds, int32_t* dynamic_lds,
+                              int32_t* scratch, int32_t* max_threads);
 /* diagnostics: rays the static classification sent to the generic-geodesy kernels in the last ray pass 1 whose result this ctx read
  * back (rdr_ray_prepass, and rdr_raytrace / rdr_raytrace_slices when they synchronise); -1 for a NULL ctx */
 int64_t rdr_generic_ray_count(rdr_ctx* ctx);

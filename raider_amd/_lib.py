@@ -47,6 +47,7 @@ _lock = threading.Lock()
 _VP = C.c_void_p
 SYMBOLS = [
     ('rdr_version', C.c_int, []),
+    ('rdr_source_hash', C.c_char_p, []),
     ('rdr_create', C.c_int, [C.c_int, C.POINTER(_VP)]),
     ('rdr_destroy', None, [_VP]),
     ('rdr_last_error', C.c_char_p, [_VP]),
@@ -58,6 +59,7 @@ SYMBOLS = [
     ('rdr_set_side_capacity', C.c_int, [_VP, C.c_int64]),
     ('rdr_generic_ray_count', C.c_int64, [_VP]),
     ('rdr_profile_get', C.c_int, [_VP, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_float)]),
+    ('rdr_ray_kernel_attributes', C.c_int, [_VP, _VP, C.c_int, c_ip, c_ip, c_ip, c_ip, c_ip]),
     ('rdr_cube_create', C.c_int, [_VP, _VP, C.c_int64, _VP, C.c_int64, _VP, C.c_int64, _VP, _VP, C.c_int,
                                   C.c_int64, C.c_int64, C.c_int64, C.c_int, C.POINTER(_VP)]),
     ('rdr_cube_destroy', None, [_VP]),
@@ -121,6 +123,37 @@ def _preload_hip_runtime():
         cand = Path(list(spec.submodule_search_locations)[0]) / 'lib' / 'libamdhip64.so'
         if cand.exists():
             C.CDLL(str(cand), mode=C.RTLD_GLOBAL)
+
+
+def source_files():
+    """The files libraider_hip.so is compiled from: ONE translation unit (csrc/raider_hip.hip) including every header beside it
+    and the public C header."""
+    return sorted(f for f in (_HERE / 'csrc').glob('*') if f.suffix in ('.h', '.hip')) + [_HERE.parent / 'include' / 'raider_hip.h']
+
+
+def source_hash():
+    """sha256[:16] over the library's sources as they are in the tree.  The build recipe compiles it into the binary
+    (rdr_source_hash), profiles/ digests carry it: a stale binary or a stale counter digest cannot pass for the current code."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in source_files():
+        h.update(f.name.encode()); h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
+def binary_source_hash(path=None):
+    """The digest compiled into a built library (None: missing file / a build without rdr_source_hash)."""
+    path = Path(path or LIB_PATH)
+    if not path.exists():
+        return None
+    if _lib is not None and path == LIB_PATH:
+        return _lib.rdr_source_hash().decode()
+    # read it without dlopen-ing a possibly stale library into this process: the string sits in .rodata behind a marker
+    data = path.read_bytes()
+    k = data.find(b'rdr-source-hash:')
+    if k < 0:
+        return None
+    return data[k + 16:k + 32].decode(errors='replace')
 
 
 def load():

@@ -168,7 +168,15 @@ static hipError_t launch_lds(void (*kern)(KArgs...), dim3 g, dim3 b, size_t sm, 
 // ------------------------------------------------------------------------------------------------
 // (definitions below get C linkage from their extern "C" declarations in include/raider_hip.h)
 
-int rdr_version(void) { return 100; }
+int rdr_version(void) { return 101; }
+
+// sha256[:16] over the sources of this translation unit, handed in by the build recipe (-DRDR_SOURCE_HASH=...; __graft_entry__.build):
+// lets the loader prove that the binary it opened was compiled from the tree it sits in (mtimes do not survive a copy).
+#ifndef RDR_SOURCE_HASH
+#define RDR_SOURCE_HASH "unknown"
+#endif
+static const char k_source_hash[] = "rdr-source-hash:" RDR_SOURCE_HASH;      // (the marker lets the build recipe read it without dlopen)
+const char* rdr_source_hash(void) { return k_source_hash + 16; }
 
 const char* rdr_last_error(rdr_ctx* ctx) { return (ctx && !ctx->err.empty()) ? ctx->err.c_str() : g_err.c_str(); }
 
@@ -997,6 +1005,33 @@ static int launch_march(rdr_ctx* c, const rdr_cube* q, RayParams P, int64_t tb, 
     if (q->dtype == RDR_F32) e = launch_lds(march_kernel<float2, true>, G, B, sm, c->stream, make_view<float2>(q), P, q->proj);
     else e = launch_lds(march_kernel<double2, true>, G, B, sm, c->stream, make_view<double2>(q), P, q->proj);
     if (e != hipSuccess) return fail(c, RDR_ERR_HIP, std::string("march_kernel launch: ") + hipGetErrorString(e));
+    return RDR_OK;
+}
+
+// Registers / LDS / scratch of the light ray kernel a GRID + look-vector batch on this cube launches, read from the LOADED code
+// object (hipFuncGetAttributes) - what bench.py prints, instead of a profiler's metadata column.
+int rdr_ray_kernel_attributes(rdr_ctx* c, const rdr_cube* q, int which, int32_t* vgprs, int32_t* static_lds, int32_t* dynamic_lds,
+                              int32_t* scratch, int32_t* max_threads) {
+    if (!c || !q || (which != 0 && which != 1)) return fail(c, RDR_ERR_INVALID, "rdr_ray_kernel_attributes: bad argument");
+    const void* fn = nullptr;
+    const bool lcc = q->proj.kind == 1;
+    if (which == 0) {
+        if (q->dtype == RDR_F32) fn = lcc ? (const void*)crossings_kernel<float2, false, true, 1> : (const void*)crossings_kernel<float2, false, false, 1>;
+        else fn = lcc ? (const void*)crossings_kernel<double2, false, true, 1> : (const void*)crossings_kernel<double2, false, false, 1>;
+    } else {
+        const auto v32 = make_view<float2>(q);
+        const bool small = v32.small && (q->dtype == RDR_F32 || make_view<double2>(q).small);
+        const int grid = !small ? 0 : (q->exact[0] && q->exact[1]) ? 1 : (!q->exact[0] && !q->exact[1] && q->uni[0] && q->uni[1]) ? 2 : 0;
+        if (q->dtype == RDR_F32) fn = grid == 1 ? (const void*)march_kernel<float2, false, 1> : grid == 2 ? (const void*)march_kernel<float2, false, 2> : (const void*)march_kernel<float2, false, 0>;
+        else fn = grid == 1 ? (const void*)march_kernel<double2, false, 1> : grid == 2 ? (const void*)march_kernel<double2, false, 2> : (const void*)march_kernel<double2, false, 0>;
+    }
+    hipFuncAttributes a;
+    HIPCHECK(c, hipFuncGetAttributes(&a, fn));
+    if (vgprs) *vgprs = a.numRegs;
+    if (static_lds) *static_lds = (int32_t)a.sharedSizeBytes;
+    if (dynamic_lds) *dynamic_lds = (int32_t)ray_smem(q);
+    if (scratch) *scratch = (int32_t)a.localSizeBytes;
+    if (max_threads) *max_threads = a.maxThreadsPerBlock;
     return RDR_OK;
 }
 

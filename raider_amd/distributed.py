@@ -28,9 +28,11 @@ def _dist():
 
 
 def is_distributed():
+    """A process group exists (of ANY size: a one-rank group still issues its collectives, which is how the RCCL path is
+    exercised on a single-GPU box)."""
     try:
         dist = _dist()
-        return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        return dist.is_available() and dist.is_initialized()
     except ImportError:
         return False
 
@@ -62,8 +64,8 @@ def check_partition_flags(flags):
 
 
 def broadcast_cube_fields(fields, src=0, device=None, group=None):
-    """Broadcast {xs, ys, zs, wet, hydro} (NumPy on `src`, None elsewhere) to every rank.  With the nccl
-    backend the payload travels GPU->GPU over xGMI (57.6 MB for an ERA5-sized f32 cube)."""
+    """Broadcast {xs, ys, zs, wet, hydro} (NumPy on `src`, None elsewhere) to every rank, field by field (kept for callers
+    with other field sets; the cube itself goes out in one piece through broadcast_cube_packed)."""
     import torch
     dist = _dist()
     meta = [None]
@@ -81,6 +83,64 @@ def broadcast_cube_fields(fields, src=0, device=None, group=None):
         dist.broadcast(t, src=src, group=group)
         out[k] = t
     return out
+
+
+_DTYPES = {0: 'float32', 1: 'float64'}
+
+
+def pack_cube(ys, xs, zs, wet, hydro, device=None):
+    """ONE contiguous byte buffer holding a cube: ys | xs | zs (float64) | wet | hydro (the cube's dtype, any layout - the layout
+    travels as the shape).  Returns (uint8 tensor, header) with header = (ny, nx, nz, dtype code, d0, d1, d2) describing it."""
+    import torch
+    wet = np.ascontiguousarray(wet); hydro = np.ascontiguousarray(hydro, dtype=wet.dtype)
+    if wet.dtype not in (np.float32, np.float64) or wet.shape != hydro.shape or wet.ndim != 3:
+        raise ValueError('pack_cube: wet / hydro must be float32 or float64 arrays of one 3-D shape')
+    ax = np.concatenate([np.asarray(a, dtype=np.float64).ravel() for a in (ys, xs, zs)])
+    buf = np.concatenate([ax.view(np.uint8), wet.reshape(-1).view(np.uint8), hydro.reshape(-1).view(np.uint8)])
+    header = (np.size(ys), np.size(xs), np.size(zs), 0 if wet.dtype == np.float32 else 1) + tuple(wet.shape)
+    t = torch.from_numpy(buf)
+    return (t.to(device) if device is not None else t), header
+
+
+def unpack_cube(buf, header):
+    """Views into a packed cube buffer: (axes float64 [ny+nx+nz], wet, hydro) - no copy."""
+    import torch
+    ny, nx, nz, code, d0, d1, d2 = (int(v) for v in header)
+    dt = getattr(torch, _DTYPES[code])
+    na = (ny + nx + nz) * 8
+    nf = d0 * d1 * d2 * (4 if code == 0 else 8)
+    if buf.numel() != na + 2 * nf:
+        raise ValueError(f'packed cube buffer holds {buf.numel()} bytes, header describes {na + 2 * nf}')
+    axes = buf[:na].view(torch.float64)
+    wet = buf[na:na + nf].view(dt).view(d0, d1, d2)
+    hyd = buf[na + nf:].view(dt).view(d0, d1, d2)
+    return axes, wet, hyd
+
+
+def broadcast_cube_packed(cube_fields, src=0, device=None, group=None, header=None):
+    """The weather cube to every rank in ONE broadcast (once per job, 57.6 MB for an ERA5-sized f32 cube, GPU -> GPU
+    over xGMI with the nccl backend): `cube_fields` = dict(ys, xs, zs, wet, hydro) of NumPy arrays on `src`, ignored elsewhere.
+    `header` = (ny, nx, nz, dtype code, d0, d1, d2) when every rank already knows the cube's shape (bench.py does); otherwise a
+    7-integer header goes round first.  Returns (axes, wet, hydro) tensors on `device` (views of the one received buffer)."""
+    import torch
+    dist = _dist()
+    rank = dist.get_rank()                  # (`src` is a global rank)
+    announce = header is None              # (the same on every rank: it is an argument of the collective call)
+    buf = None
+    if rank == src:
+        buf, hdr = pack_cube(cube_fields['ys'], cube_fields['xs'], cube_fields['zs'], cube_fields['wet'], cube_fields['hydro'], device=device)
+        if header is not None and tuple(int(v) for v in header) != tuple(int(v) for v in hdr):
+            raise ValueError(f'broadcast_cube_packed: header {tuple(header)} does not describe the cube {hdr}')
+        header = hdr
+    if announce:
+        h = torch.tensor([int(v) for v in header] if rank == src else [0] * 7, dtype=torch.int64, device=device)
+        dist.broadcast(h, src=src, group=group)
+        header = tuple(int(v) for v in h.cpu())
+    if buf is None:
+        ny, nx, nz, code, d0, d1, d2 = (int(v) for v in header)
+        buf = torch.empty((ny + nx + nz) * 8 + 2 * d0 * d1 * d2 * (4 if code == 0 else 8), dtype=torch.uint8, device=device)
+    dist.broadcast(buf, src=src, group=group)
+    return unpack_cube(buf, header)
 
 
 def raytrace_slab_async(cube, rays, ht, zref, partition, max_seg=1000.0, out=None, group=None):

@@ -182,6 +182,13 @@ class Cube:
         return wet, hyd
 
     # ---- rays ------------------------------------------------------------------------------------
+    def ray_kernel_attributes(self, which):
+        """Resources of the light ray kernel (0: pass 1, 1: pass 2) a GRID + look-vector batch on this cube launches, from the loaded
+        code object: dict(vgpr, lds_static, lds_dynamic, scratch, max_threads)."""
+        v = [C.c_int32() for _ in range(5)]
+        check(self.ctx.lib.rdr_ray_kernel_attributes(self.ctx.handle, self.handle, int(which), *[C.byref(x) for x in v]), self.ctx.handle)
+        return dict(zip(('vgpr', 'lds_static', 'lds_dynamic', 'scratch', 'max_threads'), (x.value for x in v)))
+
     def ray_levels(self, ht, zref):
         """(lo, hi, kz) of the contributing model intervals (losreader.py:785-808); raises NoLevels."""
         nz = self.shape[2]

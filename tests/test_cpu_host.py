@@ -32,6 +32,23 @@ def test_library_exports_every_header_symbol(built):
     assert _lib.load().rdr_version() >= 100
 
 
+def test_binary_carries_the_hash_of_the_tree_it_was_built_from(built, tmp_path, monkeypatch):
+    """build() compiles the sha256 of the sources into the library and rebuilds when the tree's differs (file times do not
+    survive a copy to the GPU box); the digest is readable without dlopen-ing a possibly stale binary."""
+    from raider_amd import _lib
+    want = _lib.source_hash()
+    assert len(want) == 16 and _lib.load().rdr_source_hash().decode() == want
+    monkeypatch.setattr(_lib, '_lib', None)                       # force the read-the-file path
+    assert _lib.binary_source_hash(_lib.LIB_PATH) == want
+    assert _lib.binary_source_hash(tmp_path / 'missing.so') is None
+    stale = tmp_path / 'stale.so'
+    data = _lib.LIB_PATH.read_bytes()
+    k = data.find(b'rdr-source-hash:')
+    stale.write_bytes(data[:k + 16] + b'0' * 16 + data[k + 32:])
+    assert _lib.binary_source_hash(stale) == '0' * 16             # what build() would see for a binary of another tree -> recompile
+    assert {f.name for f in _lib.source_files()} >= {'raider_hip.hip', 'raider_kernels.h', 'cube_kernels.h', 'raider_hip.h'}
+
+
 def test_rays_struct_layout_matches_header(built):
     from raider_amd import _lib
     # 8 + 4 + 4 + 8 + 8 + 8*8 + 8 + 8 + 4 + 4

@@ -31,7 +31,14 @@ def _worker(rank, world, port, q):
         if rank == 0:
             c = O.synthetic_cube(50, 50, 40, seed=0)
             fields = {k: c[k] for k in ('xs', 'ys', 'zs', 'wet', 'hydro')}
-        got = {k: v.numpy() for k, v in D.broadcast_cube_fields(fields, src=0).items()}
+        # the cube in ONE broadcast: header announced by the collective (rank 1 does not know the shape) ...
+        axes, wet_t, hyd_t = D.broadcast_cube_packed(fields, src=0)
+        got = dict(ys=axes[:50].numpy(), xs=axes[50:100].numpy(), zs=axes[100:].numpy(), wet=wet_t.numpy(), hydro=hyd_t.numpy())
+        # ... and with the shape known to every rank (what bench.py does): the same bytes, no header round
+        axes2, wet2, hyd2 = D.broadcast_cube_packed(fields, src=0, header=(50, 50, 40, 0, 40, 50, 50))
+        assert bool((axes2 == axes).all()) and bool((wet2 == wet_t).all()) and bool((hyd2 == hyd_t).all())
+        old = {k: v.numpy() for k, v in D.broadcast_cube_fields(fields, src=0).items()}
+        assert all(np.array_equal(old[k], got[k]) for k in got) and got['wet'].dtype == np.float32 and got['wet'].shape == (40, 50, 50)
         ip = list(O.getInterpolators(got['xs'], got['ys'], got['zs'], got['wet'], got['hydro']))
         zref = float(g['zref'])
         # column shard here (the golden halves are column halves); shard_rows is exercised on the column count
@@ -92,3 +99,20 @@ def test_reduce_partition_single_process_passthrough():
         check_partition_flags(1)
     with pytest.raises(ValueError):
         check_partition_flags(3)
+
+
+def test_pack_unpack_cube_roundtrip_f32_f64_any_layout():
+    from raider_amd.distributed import pack_cube, unpack_cube
+    rng = np.random.default_rng(0)
+    for dt in (np.float32, np.float64):
+        for shape in ((5, 6, 7), (7, 5, 6)):
+            ys, xs, zs = rng.random(5), rng.random(6), rng.random(7)
+            w, h = rng.random(shape).astype(dt), rng.random(shape).astype(dt)
+            buf, hdr = pack_cube(ys, xs, zs, w, h)
+            assert buf.numel() == 18 * 8 + 2 * w.nbytes and hdr == (5, 6, 7, 0 if dt == np.float32 else 1) + shape
+            ax, w2, h2 = unpack_cube(buf, hdr)
+            assert np.array_equal(ax.numpy(), np.concatenate([ys, xs, zs])) and np.array_equal(w2.numpy(), w) and np.array_equal(h2.numpy(), h)
+    with pytest.raises(ValueError):
+        unpack_cube(buf[:-8], hdr)
+    with pytest.raises(ValueError):
+        pack_cube(ys, xs, zs, w.astype(np.int32), h)

@@ -16,7 +16,7 @@ ROOT = Path(__file__).resolve().parent.parent
 
 def _bench(tmp_path, tag, *args):
     out = subprocess.run([sys.executable, str(ROOT / 'bench.py'), '--steps', '2', '--warmup', '1', '--cpu-sample', '0', '--cols', '1200',
-                          '--dump', str(tmp_path / tag)] + list(args), capture_output=True, text=True, timeout=900)
+                          '--no-e2e', '--dump', str(tmp_path / tag)] + list(args), capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-4000:])
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
     assert len(lines) == 1, out.stdout[-2000:]
@@ -37,3 +37,19 @@ def test_bench_self_launches_two_ranks_and_matches_one_rank(tmp_path):
     assert np.array_equal(a['nparts'], b0['nparts']) and np.array_equal(a['nparts'], b1['nparts'])
     assert np.array_equal(a['hydro'], np.concatenate([b0['hydro'], b1['hydro']])) and np.array_equal(a['wet'], np.concatenate([b0['wet'], b1['wet']]))
     assert np.isfinite(a['hydro']).all()
+
+
+def test_strong_scaling_is_the_default_for_n_gt_1(tmp_path):
+    """`python bench.py --gpus 2` with no --rows = BASELINE configs[3] semantics: ONE scene split into contiguous row blocks
+    (shard_rows), `value` counts the scene's rays once, `scaling` = "strong"; here on a reduced 1401 x 1200 scene (uneven split:
+    701 + 700 rows) against the one-rank run of the whole scene."""
+    one = _bench(tmp_path, 'one', '--gpus', '1', '--rows', '1401')
+    two = _bench(tmp_path, 'two', '--gpus', '2', '--total-rows', '1401')
+    assert two['scaling'] == 'strong' and two['config']['rays_per_step_all_gpus'] == 1401 * 1200 and two['config']['rays_per_gpu'] == 701 * 1200
+    assert 'configs[3]' in two['config']['workload'] and two['config']['world_size_seen_by_backend'] == 2
+    assert abs(two['value'] * two['ms_per_step'] * 1e-3 - 1401 * 1200) < 1.0          # value = scene rays / step time
+    a = np.load(tmp_path / 'one.rank0.npz')
+    b0, b1 = np.load(tmp_path / 'two.rank0.npz'), np.load(tmp_path / 'two.rank1.npz')
+    assert b0['hydro'].shape == (701, 1200) and b1['hydro'].shape == (700, 1200)
+    assert np.array_equal(a['nparts'], b0['nparts']) and np.array_equal(a['nparts'], b1['nparts'])
+    assert np.array_equal(a['hydro'], np.concatenate([b0['hydro'], b1['hydro']])) and np.array_equal(a['wet'], np.concatenate([b0['wet'], b1['wet']]))
