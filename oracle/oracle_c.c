@@ -202,3 +202,101 @@ void orc_march(const double* lat, const double* lon, const double* los, int64_t 
         out_w[i] = aw; out_h[i] = ah;
     }
 }
+
+/* ---- per-ray origin heights (BASELINE configs' "c3b") ---------------------------------------------
+ * The reference integrates one (ny,nx) slice at ONE height (delay.py:256-323); a batch whose rays start at their own heights has
+ * no reference semantics.  The rule restated here applies the reference's per-slice algorithm ray by ray
+ * wherever it is per-ray, and keeps its slice-level reductions batch-level:
+ *   - every ray is build_ray'd with ITS height: model interval zz contributes to ray i under the tests of losreader.py:785-808
+ *     with ht = hts[i] (clipped to [hts[i], zref], top interval shortened by 0.01 m, < 1 m skipped); the ray's first contributing
+ *     interval gets the 10-iteration factor-1 crossings and fixes its cos_factor, later ones 3 iterations (losreader.py:812-825);
+ *   - nParts[zz] = ceil(max over the rays interval zz contributes to (length) / MAX_SEGMENT_LENGTH) + 1   (delay.py:283);
+ *   - the all-pixels z-clamp (delay.py:306-311) asks about every ray's own first / last sample.
+ * With all heights equal this IS the slice algorithm (orc_prepass / orc_march): tests/test_oracle_c.py.
+ * maxlen / nparts are indexed by the model interval zz (nz-1 entries; 0 / unused where no ray contributes). */
+static int ray_level(const double* zs, int nz, int zz, double ht, double zref, double* lo, double* hi) {
+    double l = zs[zz], h = zs[zz + 1];
+    if (h == zs[nz - 1]) h = h - 0.01;
+    if (h < ht || l >= zref) return 0;
+    if (l < ht) l = ht;
+    if (h > zref) h = zref;
+    if (fabs(h - l) < 1.0) return 0;
+    *lo = l; *hi = h;
+    return 1;
+}
+
+void orc_prepass_pp(const double* lat, const double* lon, const double* hts, const double* los, int64_t n, const double* zs, int nz,
+                    double zref, double zmin, double zmax, double* maxlen, int* clamp, int* any_level) {
+    const int M = nz - 1;
+    for (int k = 0; k < M; ++k) maxlen[k] = 0.0;
+    int all_below = 1, all_above = 1, any = 0;
+#pragma omp parallel reduction(&& : all_below, all_above) reduction(|| : any)
+    {
+        double* loc = (double*)calloc((size_t)M, sizeof(double));
+#pragma omp for schedule(static)
+        for (int64_t i = 0; i < n; ++i) {
+            double o[3], low[3], high[3] = {0, 0, 0}, cosf = 1.0, dx = 0, dy = 0, dz = 0;
+            lla2ecef(lat[i], lon[i], hts[i], &o[0], &o[1], &o[2]);
+            const double* l = los + 3 * i;
+            int first = 1;
+            for (int zz = 0; zz < M; ++zz) {
+                double lo, hi;
+                if (!ray_level(zs, nz, zz, hts[i], zref, &lo, &hi)) continue;
+                if (first) toa(o, l, lo, 10, 1.0, low); else { low[0] = high[0]; low[1] = high[1]; low[2] = high[2]; }
+                toa(o, l, hi, first ? 10 : 3, cosf, high);
+                dx = high[0] - low[0]; dy = high[1] - low[1]; dz = high[2] - low[2];
+                const double L = sqrt(dx * dx + dy * dy + dz * dz);
+                if (first) cosf = (hi - lo) / L;
+                if (!isnan(loc[zz]) && (isnan(L) || L > loc[zz])) loc[zz] = L;
+                if (first) all_below = all_below && (ecef_h(low[0] + 0.0 * dx, low[1] + 0.0 * dy, low[2] + 0.0 * dz) < zmin);
+                first = 0;
+            }
+            if (!first) { any = 1; all_above = all_above && (ecef_h(low[0] + 1.0 * dx, low[1] + 1.0 * dy, low[2] + 1.0 * dz) > zmax); }
+        }
+#pragma omp critical
+        for (int k = 0; k < M; ++k) if (!isnan(maxlen[k]) && (isnan(loc[k]) || loc[k] > maxlen[k])) maxlen[k] = loc[k];
+        free(loc);
+    }
+    clamp[0] = all_below; clamp[1] = all_above; *any_level = any;
+}
+
+void orc_march_pp(const double* lat, const double* lon, const double* hts, const double* los, int64_t n, const double* zs_lev, double zref,
+                  const int* nparts, int clamp_lo, int clamp_hi,
+                  const double* ys, int ny, const double* xs, int nx, const double* zs, int nz, const void* wet, const void* hyd, int dtype,
+                  double* out_w, double* out_h) {
+    (void)zs_lev;
+    const int M = nz - 1;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) {
+        double o[3], low[3], high[3] = {0, 0, 0}, cosf = 1.0, aw = 0.0, ah = 0.0;
+        lla2ecef(lat[i], lon[i], hts[i], &o[0], &o[1], &o[2]);
+        const double* l = los + 3 * i;
+        int first = 1, last_zz = -1;
+        for (int zz = 0; zz < M; ++zz) { double lo, hi; if (ray_level(zs, nz, zz, hts[i], zref, &lo, &hi)) last_zz = zz; }
+        for (int zz = 0; zz < M; ++zz) {
+            double lo, hi;
+            if (!ray_level(zs, nz, zz, hts[i], zref, &lo, &hi)) continue;
+            if (first) toa(o, l, lo, 10, 1.0, low); else { low[0] = high[0]; low[1] = high[1]; low[2] = high[2]; }
+            toa(o, l, hi, first ? 10 : 3, cosf, high);
+            const double dx = high[0] - low[0], dy = high[1] - low[1], dz = high[2] - low[2];
+            const double L = sqrt(dx * dx + dy * dy + dz * dz);
+            if (first) cosf = (hi - lo) / L;
+            const int np = nparts[zz];
+            const double step = 1.0 / (np - 1.0);
+            for (int j = 0; j < np; ++j) {
+                const double f = (j == np - 1) ? 1.0 : j * step;
+                double plon, plat, ph;
+                ecef2lla(low[0] + f * dx, low[1] + f * dy, low[2] + f * dz, &plon, &plat, &ph);
+                if (clamp_lo && first && j == 0) ph = zs[0];
+                if (clamp_hi && zz == last_zz && j == np - 1) ph = zs[nz - 1];
+                double vw, vh;
+                rgi2(ys, ny, xs, nx, zs, nz, wet, hyd, dtype, plat, plon, ph, &vw, &vh);
+                double wt = (j == 0 || j == np - 1) ? 0.5 : 1.0;
+                wt = wt * (L * 1.0e-6 / (np - 1.0));
+                aw += wt * vw; ah += wt * vh;
+            }
+            first = 0;
+        }
+        out_w[i] = aw; out_h[i] = ah;
+    }
+}

@@ -97,3 +97,31 @@ def build_cube_ray_slice(cube, xpts, ypts, ht, los, zref, max_seg=1000.0, nparts
     L.orc_march(_p(lat), _p(lon), _p(los), C.c_int64(n), C.c_double(ht), _p(lo), _p(hi), C.c_int(K), _p(np32), C.c_int(clamp[0]), C.c_int(clamp[1]),
                 _p(ys), C.c_int(ys.size), _p(xs), C.c_int(xs.size), _p(zs), C.c_int(zs.size), _p(wet), _p(hyd), C.c_int(dtype), _p(ow), _p(oh))
     return ow.reshape(yy.shape), oh.reshape(yy.shape), np.asarray(nparts)
+
+
+def build_cube_ray_per_pixel(cube, lat, lon, hts, los, zref, max_seg=1000.0, nparts=None):
+    """Rays with their OWN origin heights (no reference semantics; rule in oracle_c.c / DESIGN.md 5c): lat, lon, hts of one shape,
+    los (..., 3).  Returns (wet, hydro, nparts[nz-1]) with nparts indexed by model interval (0 where no ray passes)."""
+    L = lib()
+    shape = np.shape(lat)
+    lat = np.ascontiguousarray(np.asarray(lat, dtype=np.float64).ravel()); lon = np.ascontiguousarray(np.asarray(lon, dtype=np.float64).ravel())
+    hts = np.ascontiguousarray(np.broadcast_to(np.asarray(hts, dtype=np.float64), shape).ravel())
+    los = np.ascontiguousarray(np.asarray(los, dtype=np.float64).reshape(-1, 3))
+    n = lat.size
+    ys, xs, zs = (np.ascontiguousarray(cube[k], dtype=np.float64) for k in ('ys', 'xs', 'zs'))
+    wet, hyd = _yxz(cube)
+    dtype = 0 if wet.dtype == np.float32 else 1
+    M = zs.size - 1
+    maxlen = np.zeros(M); clamp = (C.c_int * 2)(); anyl = C.c_int()
+    L.orc_prepass_pp(_p(lat), _p(lon), _p(hts), _p(los), C.c_int64(n), _p(zs), C.c_int(zs.size), C.c_double(zref), C.c_double(zs.min()),
+                     C.c_double(zs.max()), _p(maxlen), clamp, C.byref(anyl))
+    if nparts is None:
+        with np.errstate(invalid='ignore'):
+            nparts = np.where(maxlen > 0, np.ceil(maxlen / max_seg) + 1, 0)
+        if np.isnan(maxlen).any():
+            raise ValueError('some ray lengths are NaN: the number of integration parts (delay.py:283) is undefined')
+    np32 = np.ascontiguousarray(nparts, dtype=np.int32)
+    ow, oh = np.empty(n), np.empty(n)
+    L.orc_march_pp(_p(lat), _p(lon), _p(hts), _p(los), C.c_int64(n), _p(zs), C.c_double(zref), _p(np32), C.c_int(clamp[0]), C.c_int(clamp[1]),
+                   _p(ys), C.c_int(ys.size), _p(xs), C.c_int(xs.size), _p(zs), C.c_int(zs.size), _p(wet), _p(hyd), C.c_int(dtype), _p(ow), _p(oh))
+    return ow.reshape(shape), oh.reshape(shape), np.asarray(np32)

@@ -630,6 +630,86 @@ def build_cube_ray(xpts, ypts, zpts, look_fn, interpolators, MAX_SEGMENT_LENGTH=
     return outputArrs
 
 
+def ray_levels_idx(model_zs, ht, zref):
+    """ray_levels with the index zz of the model interval each entry comes from: list of (zz, low_ht, high_ht)."""
+    model_zs = np.asarray(model_zs, dtype=np.float64)
+    out = []
+    lv = ray_levels(model_zs, ht, zref)
+    # match every contributing (low, high) back to its interval: high_ht (before the zref clip) identifies it
+    k = 0
+    for zz in range(model_zs.size - 1):
+        if k == len(lv):
+            break
+        high = model_zs[zz + 1] - (0.01 if model_zs[zz + 1] == model_zs[-1] else 0.0)
+        low = model_zs[zz]
+        if (high < ht) or (low >= zref):
+            continue
+        lo_c, hi_c = max(low, ht), min(high, zref)
+        if np.abs(hi_c - lo_c) < 1.0:
+            continue
+        assert lv[k] == (float(lo_c), float(hi_c))
+        out.append((zz, lv[k][0], lv[k][1]))
+        k += 1
+    assert k == len(lv)
+    return out
+
+
+def build_cube_ray_per_pixel(lat, lon, hts, LOS, interpolators, MAX_SEGMENT_LENGTH=1000.0, MAX_TROPO_HEIGHT=_ZREF, nParts_override=None):
+    """Rays with their OWN origin heights (SURVEY 8d "c3b": no reference semantics).  The rule: the reference's
+    slice algorithm (delay.py:256-323) ray by ray wherever it is per ray - build_ray with the ray's height, its first contributing
+    interval fixing cos_factor - and batch-level wherever the reference reduces over the slice: nParts[zz] = ceil(max over the
+    rays interval zz contributes to / MAX_SEGMENT_LENGTH) + 1 (delay.py:283), and the all-pixels z-clamp (delay.py:306-311) asked
+    about every ray's own first / last sample.  Built from the pinned slice functions (build_ray, scipy-RGI restatement), one ray
+    at a time - small inputs only; oracle_c.build_cube_ray_per_pixel is the fast form.
+    lat, lon, hts: 1-D arrays; LOS (n, 3).  Returns (wet[n], hydro[n], nparts[nz-1] indexed by model interval)."""
+    model_zs = np.asarray(interpolators[0].grid[2], dtype=np.float64)
+    lat = np.asarray(lat, dtype=np.float64).ravel(); lon = np.asarray(lon, dtype=np.float64).ravel()
+    hts = np.asarray(hts, dtype=np.float64)
+    hts = hts.ravel() if hts.size == lat.size else np.broadcast_to(hts, lat.shape).ravel()
+    LOS = np.asarray(LOS, dtype=np.float64).reshape(-1, 3)
+    n = lat.size
+    M = model_zs.size - 1
+    rays = []
+    maxlen = np.zeros(M)
+    for i in range(n):
+        xyz = np.stack(lla2ecef(lat[i:i + 1], lon[i:i + 1], hts[i:i + 1]), axis=-1)
+        lens, lows, highs = build_ray(model_zs, hts[i], xyz, LOS[i:i + 1], MAX_TROPO_HEIGHT)
+        idx = [zz for zz, _, _ in ray_levels_idx(model_zs, hts[i], MAX_TROPO_HEIGHT)]
+        rays.append((idx, lens, lows, highs))
+        for k, zz in enumerate(idx):
+            L = lens[k][0]
+            if not np.isnan(maxlen[zz]) and (np.isnan(L) or L > maxlen[zz]):
+                maxlen[zz] = L
+    if nParts_override is not None:
+        nparts = np.asarray(nParts_override)
+    else:
+        if np.isnan(maxlen).any():
+            raise ValueError('some ray lengths are NaN: the number of integration parts (delay.py:283) is undefined')
+        nparts = np.where(maxlen > 0, np.ceil(maxlen / MAX_SEGMENT_LENGTH) + 1, 0).astype(int)
+    zmin, zmax = model_zs.min(), model_zs.max()
+    firsts = [ecef2lla(*(r[2][0][0]))[2] for r in rays if r[0]]
+    lasts = [ecef2lla(*(r[3][-1][0]))[2] for r in rays if r[0]]
+    clamp_lo = bool(firsts) and all(h < zmin for h in firsts)
+    clamp_hi = bool(lasts) and all(h > zmax for h in lasts)
+    wet = np.zeros(n); hyd = np.zeros(n)
+    for i, (idx, lens, lows, highs) in enumerate(rays):
+        for k, zz in enumerate(idx):
+            fracs = np.linspace(0.0, 1.0, num=int(nparts[zz]))
+            for findex, ff in enumerate(fracs):
+                pts_xyz = lows[k] + ff * (highs[k] - lows[k])
+                plon, plat, ph = ecef2lla(pts_xyz[..., 0], pts_xyz[..., 1], pts_xyz[..., 2])
+                pts = np.stack((plat, plon, ph), axis=-1)
+                if clamp_lo and k == 0 and findex == 0:
+                    pts[..., -1] = zmin
+                if clamp_hi and k == len(idx) - 1 and findex == fracs.size - 1:
+                    pts[..., -1] = zmax
+                wt = 0.5 if findex in [0, fracs.size - 1] else 1.0
+                wt = wt * (lens[k] * 1.0e-6 / (nparts[zz] - 1.0))
+                wet[i] += (wt * interpolators[0](pts))[0]
+                hyd[i] += (wt * interpolators[1](pts))[0]
+    return wet, hyd, nparts
+
+
 def points_from_cube(lats, lons, hgts, xpts, ypts, zpts, wet_cube, hydro_cube):
     """delay.py:110-121: second-stage interpolation of an output delay cube (z,y,x) to stations;
     `getInterpolators(ds,'ztd')` on the output Dataset (delayFcns.py:37-41: kind!='total' picks

@@ -43,3 +43,52 @@ def test_c_oracle_whole_slice_partition(golden, c1):
     w, h, npn = OC.build_cube_ray_slice(c1, xp[:32], yp, 0.0, _los(xp[:32], yp, inc[:, :32], -167.9, 0.0), zref, nparts=g['nparts'])
     np.testing.assert_allclose(h, g['hydro'][0][:, :32], rtol=0, atol=1e-11)
     assert OC.num_threads() >= 1
+
+
+def test_per_pixel_height_rule_reduces_to_the_slice_algorithm(golden, c1):
+    """Rays with their own origin heights have no reference semantics; the stated rule must BE the
+    reference's slice algorithm when all heights are equal - pinned here on the reference goldens g5, for the NumPy restatement
+    (built ray by ray from the pinned slice functions) and for the C one."""
+    g = golden('g5_build_cube_ray')
+    zref = float(g['c1_zref'])
+    xp, yp = g['c1_xpts'][:12], g['c1_ypts'][:10]
+    xx, yy = np.meshgrid(xp, yp)
+    ip = list(O.getInterpolators(c1['xs'], c1['ys'], c1['zs'], c1['wet'], c1['hydro']))
+    for i, ht in enumerate(g['c1_zpts']):
+        los = _los(xp, yp, 39.0, -167.9, ht)
+        ws, hs, nps = OC.build_cube_ray_slice(c1, xp, yp, float(ht), los, zref)
+        idx = [zz for zz, _, _ in O.ray_levels_idx(c1['zs'], float(ht), zref)]
+        w, h, npp = OC.build_cube_ray_per_pixel(c1, yy, xx, np.full(yy.shape, float(ht)), los, zref)
+        assert np.array_equal(npp[idx], nps) and not npp[[z for z in range(npp.size) if z not in idx]].any()
+        assert np.array_equal(w, ws) and np.array_equal(h, hs)                          # same arithmetic, bit for bit
+        wn, hn, npn = O.build_cube_ray_per_pixel(yy, xx, np.full(yy.shape, float(ht)), los, ip, MAX_TROPO_HEIGHT=zref)
+        assert np.array_equal(npn, npp)
+        np.testing.assert_allclose(wn.reshape(yy.shape), ws, rtol=0, atol=1e-12); np.testing.assert_allclose(hn.reshape(yy.shape), hs, rtol=0, atol=1e-12)
+        # ... and with the whole-slice nParts of the golden it IS the golden (the sub-block's own maxima differ from the slice's)
+        full = np.zeros(c1['zs'].size - 1, dtype=int); full[idx] = g[f'c1_fixed_nparts{i}']
+        w2, h2, _ = OC.build_cube_ray_per_pixel(c1, yy, xx, np.full(yy.shape, float(ht)), los, zref, nparts=full)
+        np.testing.assert_allclose(h2, g['c1_fixed_hydro'][i][:10, :12], rtol=0, atol=1e-11)
+
+
+def test_per_pixel_heights_c_vs_numpy(c1):
+    """Mixed heights (below the model, between nodes, ON a node, within 1 m of a node, above the integration top): the C restatement
+    against the NumPy one, which applies the pinned build_ray to every ray with its own height."""
+    rng = np.random.default_rng(5)
+    n = 60
+    lat = rng.uniform(31.0, 35.0, n); lon = rng.uniform(-120.0, -114.5, n)
+    zs = c1['zs']
+    hts = rng.uniform(-99.0, 4000.0, n)          # (an origin BELOW the model puts its first sample on the bottom node +- round-off: NaN or not is a coin toss in the reference too)
+    hts[:6] = [zs[3], zs[4] - 0.4, zs[4] + 0.3, -99.5, zs[0] + 0.5, 36000.0]
+    zref = 30000.0
+    inc = rng.uniform(15.0, 55.0, n)
+    los = O.look_vectors_from_inc_hd(inc, np.full(n, -167.9), lat, lon, hts)
+    ip = list(O.getInterpolators(c1['xs'], c1['ys'], c1['zs'], c1['wet'], c1['hydro']))
+    wn, hn, npn = O.build_cube_ray_per_pixel(lat, lon, hts, los, ip, MAX_TROPO_HEIGHT=zref)
+    wc, hc, npc = OC.build_cube_ray_per_pixel(c1, lat, lon, hts, los, zref)
+    assert np.array_equal(npn, npc)
+    np.testing.assert_allclose(wc, wn, rtol=0, atol=1e-11); np.testing.assert_allclose(hc, hn, rtol=0, atol=1e-11)
+    assert hc[5] == 0.0 and wc[5] == 0.0                       # origin above the integration top: no interval contributes
+    assert hc[3] > hc[0] > 0                                   # a lower origin integrates more atmosphere
+    # a different partition than any single slice would give: the per-level maximum comes from the rays that REACH the level
+    lo_only = OC.build_cube_ray_per_pixel(c1, lat[6:], lon[6:], np.full(n - 6, hts[6:].min()), los[6:], zref)[2]
+    assert (npc >= 0).all() and npc.max() >= 2 and lo_only.shape == npc.shape
