@@ -83,6 +83,9 @@ def main():
                     help='N > 1: strong = one --total-rows x cols scene (default 10000x10000 = configs[3]) sharded by rows; weak = --rows per rank. '
                          'auto = strong unless --rows is given')
     ap.add_argument('--total-rows', type=int, default=None, help='rows of the whole scene in strong scaling (default 10000)')
+    ap.add_argument('--per-pixel-ht', action='store_true', help='the secondary workload "c3b" of SURVEY 8(d): every pixel starts at its own height, '
+                                                                'rng(2).uniform(0, 3000) m (a scene on a DEM) instead of one slice at ht = 0; no reference '
+                                                                'semantics - the rule is in include/raider_hip.h (rdr_rays.hts) and DESIGN.md 5c')
     ap.add_argument('--force-dist', action='store_true', help='N = 1: still create the process group and issue every collective of the N > 1 path '
                                                               '(one-rank RCCL group: how the nccl path is exercised on a single-GPU box)')
     ap.add_argument('--no-e2e', action='store_true', help='skip the end-to-end (H2D + kernels + D2H through the NumPy boundary) figure')
@@ -183,7 +186,16 @@ def main():
     hd_t = torch.full((rows, cols), hd, dtype=torch.float64, device=dev)
     los_t = R.Rays.grid(xpts_t, ypts_t, inc=inc_t, hd=hd_t).look_vectors(ctx)       # (rows, cols, 3) f64 in HBM
     del inc_t, hd_t
-    rays = R.Rays.grid(xpts_t, ypts_t, los=los_t)
+    hts_t = None
+    if args.per_pixel_ht:      # drawn for the WHOLE scene, this rank keeps its rows
+        hts_np = np.random.default_rng(2).uniform(0.0, 3000.0, (total_rows, cols))[row0:row0 + rows]
+        hts_t = torch.from_numpy(np.ascontiguousarray(hts_np)).to(dev)
+        ht = None
+    rays = R.Rays.grid(xpts_t, ypts_t, los=los_t, hts=hts_t)
+    if hts_t is not None and dist_on:       # the level table of the whole scene starts at the lowest pixel of ALL ranks
+        hmin = torch.tensor([rays.ht_min], dtype=torch.float64, device=coll_dev if coll_dev is not None else 'cpu')
+        dist.all_reduce(hmin, op=dist.ReduceOp.MIN)
+        ht = float(hmin.item())
     out_w = torch.empty((rows, cols), dtype=torch.float64, device=dev)
     out_h = torch.empty_like(out_w)
     n_rays = rows * cols
@@ -239,15 +251,16 @@ def main():
     e2e = None
     if world == 1 and not args.no_e2e:
         los_np = los_t.cpu().numpy()
+        hts_h = hts_np if args.per_pixel_ht else None
         eo = (np.empty((rows, cols)), np.empty((rows, cols)))
-        cube.raytrace(R.Rays.grid(xpts, ypts, los=los_np), ht, zref, out=eo, want_nparts=False)      # warm-up (stages, page faults)
+        cube.raytrace(R.Rays.grid(xpts, ypts, los=los_np, hts=hts_h), ht, zref, out=eo, want_nparts=False)      # warm-up (stages, page faults)
         reps = 3
         t0 = time.perf_counter()
         for _ in range(reps):
-            cube.raytrace(R.Rays.grid(xpts, ypts, los=los_np), ht, zref, out=eo, want_nparts=False)
+            cube.raytrace(R.Rays.grid(xpts, ypts, los=los_np, hts=hts_h), ht, zref, out=eo, want_nparts=False)
         dte = (time.perf_counter() - t0) / reps
         same = bool(np.array_equal(eo[1], out_h.cpu().numpy(), equal_nan=True))
-        e2e = {'value': n_rays / dte, 'unit': 'rays/s', 'ms': dte * 1e3, 'h2d_bytes': n_rays * 24, 'd2h_bytes': n_rays * 16,
+        e2e = {'value': n_rays / dte, 'unit': 'rays/s', 'ms': dte * 1e3, 'h2d_bytes': n_rays * (32 if args.per_pixel_ht else 24), 'd2h_bytes': n_rays * 16,
                'what': 'same scene through the NumPy (host-buffer) boundary: look-vector upload + pass 1 + pass 2 + download, pageable host '
                        'memory, transfers overlapped with the kernels in 8 row chunks', 'bit_identical_to_device_path': same}
         del los_np, eo
@@ -263,7 +276,7 @@ def main():
         gather_GBps = bytes_per_ray * n_rays / (march_ms * 1e-3) / 1e9
         # SQ / HBM counters of THIS source version on THIS workload, from the tracked digest tools/profile_digest.py wrote
         prof, prof_src = load_counters(args.cube, rows, cols)
-        wl_ok = prof is not None and prof.get('cube') == args.cube
+        wl_ok = prof is not None and prof.get('cube') == args.cube and not args.per_pixel_ht
         km = (prof or {}).get('kernels', {}).get('march_kernel', {}) if wl_ok else {}
         kc = (prof or {}).get('kernels', {}).get('crossings_kernel', {}) if wl_ok else {}
         valu_rw = km.get('valu_per_raywave')                      # per 64-ray wave: independent of the number of rays
@@ -275,7 +288,11 @@ def main():
         ka_m, ka_c = cube.ray_kernel_attributes(1), cube.ray_kernel_attributes(0)      # from the loaded code object
         frac_valu = valu_rate / VALU_ISSUE_PEAK if valu_rate else None
         frac_hbm = (traffic / (march_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic is not None else None
-        if world == 1:
+        if args.per_pixel_ht:
+            wl = (f'c3b (SURVEY 8d secondary workload, no reference semantics): Raytracing LOS, {total_rows}x{cols} scene on a DEM - per-pixel origin heights '
+                  f'rng(2).uniform(0, 3000) m - per-pixel ECEF look vectors, synthetic ERA5-sized {args.cube} f32 cube, zref=max(z)-1, MAX_SEGMENT_LENGTH=1000; '
+                  f'level table from the lowest pixel, nParts from the per-level maximum over the rays that reach the level')
+        elif world == 1:
             wl = (f'configs[2]: Raytracing LOS, {rows}x{cols} scene ({n_rays/1e6:.1f}M rays), one slice at ht=0, per-pixel ECEF look vectors, '
                   f'synthetic ERA5-sized {args.cube} f32 cube, zref=max(z)-1, MAX_SEGMENT_LENGTH=1000')
         elif args.scaling == 'strong':
@@ -300,7 +317,7 @@ def main():
             # The limiter the SQ counters show is fp64 vector-ALU issue, so THAT is the roofline (frac <= 1 by construction:
             # instructions actually issued / issue slots of the chip).  north_star's ">= 60 % of HBM" is not meetable at S = 178:
             # the gathers never reach HBM.  Both fractions are at the top level of this object.
-            'roofline': {'bound': 'valu_fp64_issue', 'kernel': 'march_kernel<float2,false,1>',
+            'roofline': {'bound': 'valu_fp64_issue', 'kernel': 'march_kernel<float2,false,1,true>' if args.per_pixel_ht else 'march_kernel<float2,false,1>',
                          'achieved': valu_rate / 1e9 if valu_rate else None, 'peak': VALU_ISSUE_PEAK / 1e9, 'unit': 'G wave64-instr/s',
                          'frac': frac_valu, 'frac_valu': frac_valu, 'frac_hbm_measured': frac_hbm,
                          'traffic': traffic, 'traffic_unit': 'HBM bytes per march_kernel launch (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE, separate passes)',
@@ -328,22 +345,27 @@ def main():
         if e2e is not None:
             res['end_to_end'] = e2e
         if world == 1 and args.cpu_sample > 0:
-            res['cpu_baseline'] = cpu_baseline(args, rows, cols, xpts, ypts, inc_cols, hd, nparts, zref, out_w, out_h)
+            pp = (hts_np, cube.ray_levels(rays.ht_min, zref)[2]) if args.per_pixel_ht else None
+            res['cpu_baseline'] = cpu_baseline(args, rows, cols, xpts, ypts, inc_cols, hd, nparts, zref, out_w, out_h, pp)
         print(json.dumps(res), flush=True)
     if dist_on:
         dist.destroy_process_group()
 
 
-def cpu_baseline(args, rows, cols, xpts, ypts, inc_cols, hd, nparts, zref, out_w, out_h):
+def cpu_baseline(args, rows, cols, xpts, ypts, inc_cols, hd, nparts, zref, out_w, out_h, per_pixel=None):
     """CPU baseline on the GPU box's host, same scene, whole-slice nParts:
       * value: the C/OpenMP restatement (oracle/oracle_c.c) on ALL host cores, on a centre block sized for ~10-20 s;
       * numpy_1thread: the NumPy oracle (the reference's own formulation), one thread, on a 320x320 block.
-    Both legs also check the GPU result on their block (max |GPU - oracle|)."""
+    Both legs also check the GPU result on their block (max |GPU - oracle|).
+    per_pixel = (heights of the scene, model interval of every level-table entry): the per-pixel-height workload (C leg only)."""
     from oracle import raider_oracle as O
     from oracle import oracle_c as OC
     from raider_amd.synthetic import synthetic_cube
     ny, nx, nz = (int(v) for v in args.cube.split('x'))
     c = synthetic_cube(ny, nx, nz, seed=0)
+    full = None
+    if per_pixel is not None:
+        full = np.zeros(nz - 1, dtype=np.int32); full[per_pixel[1]] = nparts
 
     def block(n):
         n = min(n, rows, cols)
@@ -353,22 +375,30 @@ def cpu_baseline(args, rows, cols, xpts, ypts, inc_cols, hd, nparts, zref, out_w
         xx, yy = np.meshgrid(xp, yp)
         los = O.look_vectors_from_inc_hd(inc, np.full(yy.shape, hd), yy, xx, 0.0)
         gw = out_w[r0:r0 + n, c0:c0 + n].cpu().numpy(); gh = out_h[r0:r0 + n, c0:c0 + n].cpu().numpy()
-        return n, xp, yp, inc, los, gw, gh
+        hb = per_pixel[0][r0:r0 + n, c0:c0 + n] if per_pixel is not None else None
+        return n, xp, yp, inc, los, gw, gh, xx, yy, hb
+
+    def run_c(xp, yp, los, xx, yy, hb):
+        if per_pixel is None:
+            return OC.build_cube_ray_slice(c, xp, yp, 0.0, los, zref, nparts=nparts)
+        return OC.build_cube_ray_per_pixel(c, yy, xx, hb, los, zref, nparts=full)
 
     # --- C / OpenMP, all cores: calibrate on 256x256, then ~15 s worth of rays
-    n, xp, yp, inc, los, gw, gh = block(256)
-    t0 = time.perf_counter(); OC.build_cube_ray_slice(c, xp, yp, 0.0, los, zref, nparts=nparts); t_cal = time.perf_counter() - t0
+    n, xp, yp, inc, los, gw, gh, xx, yy, hb = block(256)
+    t0 = time.perf_counter(); run_c(xp, yp, los, xx, yy, hb); t_cal = time.perf_counter() - t0
     rate = n * n / t_cal
     n_big = int(min(max(256, np.sqrt(rate * 15.0)), args.cpu_sample * 4, rows, cols))
-    n, xp, yp, inc, los, gw, gh = block(n_big)
-    t0 = time.perf_counter(); cw, ch, _ = OC.build_cube_ray_slice(c, xp, yp, 0.0, los, zref, nparts=nparts); dt_c = time.perf_counter() - t0
+    n, xp, yp, inc, los, gw, gh, xx, yy, hb = block(n_big)
+    t0 = time.perf_counter(); cw, ch, _ = run_c(xp, yp, los, xx, yy, hb); dt_c = time.perf_counter() - t0
     err_c = float(max(np.nanmax(np.abs(gw - cw)), np.nanmax(np.abs(gh - ch))))
     res = {'value': n * n / dt_c, 'unit': 'rays/s', 'cores': OC.num_threads(), 'kind': 'port',
            'sample': f'{n}x{n} centre block of the same scene ({n*n} rays, {dt_c:.1f} s), C/OpenMP oracle (oracle/oracle_c.c, '
-                     f'both passes, whole-slice nParts) on {OC.num_threads()} threads; host has {os.cpu_count()} logical cores',
+                     f'both passes, whole-{"batch" if per_pixel is not None else "slice"} nParts) on {OC.num_threads()} threads; host has {os.cpu_count()} logical cores',
            'gpu_vs_oracle_max_abs_m': err_c}
+    if per_pixel is not None:
+        return res
     # --- NumPy, one thread (the reference's own array formulation)
-    n, xp, yp, inc, los, gw, gh = block(min(args.cpu_sample, 320))
+    n, xp, yp, inc, los, gw, gh, xx, yy, hb = block(min(args.cpu_sample, 320))
     look = lambda ht, llh, xyz, yy: los
     ip = list(O.getInterpolators(c['xs'], c['ys'], c['zs'], c['wet'], c['hydro']))
     t0 = time.perf_counter()

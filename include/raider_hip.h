@@ -58,6 +58,9 @@ extern "C" {
                                     * finite): the level crossings diverged, e.g. look vectors far from unit length.  The
                                     * slice's outputs are NaN and synchronous calls return RDR_ERR_INVALID.               */
 
+#define RDR_FLAG_BAD_HEIGHT 32    /* per-ray heights: some rays->hts[i] lies below the `ht` the batch's level table was built for:
+                                    * the outputs are NaN and synchronous calls return RDR_ERR_INVALID.                        */
+
 typedef struct rdr_ctx rdr_ctx;
 typedef struct rdr_cube rdr_cube;
 
@@ -78,11 +81,22 @@ typedef struct rdr_rays {
     double inc0, hd0;   /* LOS_INC_HD_SCALAR (hd0 also: LOS_INC_HD with hd == NULL)             */
     int32_t loc;        /* RDR_HOST / RDR_DEVICE for every pointer above                        */
     int32_t _pad;
+    const double* hts;  /* NULL: every ray starts at the `ht` of the call (the reference's slice, delay.py:256-273).
+                         * [n]: PER-RAY origin heights (a scene on a DEM; BASELINE configs "c3b").  The reference has no
+                         * such batch; the rule is its slice algorithm ray by ray: the level tests of
+                         * losreader.py:785-808 with the ray's own height (its first contributing interval gets the
+                         * 10-iteration crossings and fixes its cos_factor), nParts[k] from the maximum over the rays level k
+                         * contributes to (delay.py:283), the all-pixels z-clamp asked about every ray's own first / last
+                         * sample.  Equal heights reproduce the slice result bit for bit.  The `ht` argument of the ray
+                         * entry points must then be <= min(hts) - normally min(hts): it fixes the batch's level table
+                         * (K, the layout of maxlen / nparts); a ray whose no interval contributes gets 0.
+                         * GRID / LLH origins are placed at hts[i]; XYZ origins are taken as given.  Not with
+                         * rdr_raytrace_slices.                                                     */
 } rdr_rays;
 
 /* ---- lifecycle ------------------------------------------------------------------------------- */
 int rdr_version(void);
-/* sha256[:16] over the sources the library was compiled from (raider_amd/csrc/*.{h,hip} + this header; "unknown" when the
+/* sha256[:16] over the sources the library was compiled from (every .h / .hip under raider_amd/csrc + this header; "unknown" when the
  * build recipe did not pass it).  raider_amd._lib.source_hash() computes the same digest from the tree. */
 const char* rdr_source_hash(void);
 /* device < 0: use HIP's current device.  Fails with RDR_ERR_NODEVICE when there is no GPU. */

@@ -19,7 +19,7 @@ RDR_F32, RDR_F64 = 0, 1
 RDR_HOST, RDR_DEVICE = 0, 1
 ORIGIN_GRID, ORIGIN_LLH, ORIGIN_XYZ = 0, 1, 2
 LOS_VEC, LOS_INC_HD, LOS_INC_HD_SCALAR, LOS_ZENITH = 0, 1, 2, 3
-FLAG_ANY_NAN, FLAG_ANY_FINITE, FLAG_FIRST_NOT_BELOW, FLAG_LAST_NOT_ABOVE = 1, 2, 4, 8
+FLAG_ANY_NAN, FLAG_ANY_FINITE, FLAG_FIRST_NOT_BELOW, FLAG_LAST_NOT_ABOVE, FLAG_DIVERGED, FLAG_BAD_HEIGHT = 1, 2, 4, 8, 16, 32
 
 c_dp = C.POINTER(C.c_double)
 c_ip = C.POINTER(C.c_int32)
@@ -33,6 +33,7 @@ class RdrRays(C.Structure):
         ('xpts', C.c_void_p), ('ypts', C.c_void_p), ('lat', C.c_void_p), ('lon', C.c_void_p),
         ('xyz', C.c_void_p), ('los', C.c_void_p), ('inc', C.c_void_p), ('hd', C.c_void_p),
         ('inc0', C.c_double), ('hd0', C.c_double), ('loc', C.c_int32), ('_pad', C.c_int32),
+        ('hts', C.c_void_p),
     ]
 
 

@@ -92,7 +92,7 @@ __global__ void unpack_partition_kernel(const double* __restrict__ in, int K, un
     if (threadIdx.x == 0) {
         int f = 0;
         for (int b = 0; b < 4; ++b) if (in[K + b] > 0.0) f |= 1 << b;
-        *flags = f;
+        *flags = f | (*flags & 32);       // (a bad per-ray height seen by THIS rank's pass 1 keeps poisoning its outputs)
     }
 }
 

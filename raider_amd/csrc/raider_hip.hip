@@ -28,7 +28,7 @@ struct DevBuf {
 
 constexpr int MAX_SLICES = 512;   // height slices per rdr_raytrace_slices call
 
-enum { SLOT_IN0 = 0, SLOT_IN1, SLOT_IN2, SLOT_IN3, SLOT_IN4, SLOT_IN5, SLOT_OUT0, SLOT_OUT1, SLOT_OUT2, SLOT_AUX, NSLOT };
+enum { SLOT_IN0 = 0, SLOT_IN1, SLOT_IN2, SLOT_IN3, SLOT_IN4, SLOT_IN5, SLOT_IN6, SLOT_OUT0, SLOT_OUT1, SLOT_OUT2, SLOT_AUX, NSLOT };
 
 struct rdr_ctx {
     int device = 0;
@@ -56,7 +56,7 @@ struct rdr_ctx {
     int64_t last_nslow = 0;                   // generic rays seen by the last pass 1 whose count the host happened to read back
     size_t ws_limit = (size_t)48 << 30;       // cap on that workspace; bigger batches are marched in chunks
     // which ray batch the stored records belong to (a later rdr_ray_march reuses them only for the identical batch)
-    struct { const void* cube = nullptr; int64_t n = -1; double ht = 0, zref = 0; const void* a = nullptr; const void* b = nullptr; const void* c = nullptr; int K = 0; bool valid = false; } wsig;
+    struct { const void* cube = nullptr; int64_t n = -1; double ht = 0, zref = 0; const void* a = nullptr; const void* b = nullptr; const void* c = nullptr; const void* d = nullptr; int K = 0; bool valid = false; } wsig;
     std::string err;
 };
 
@@ -836,6 +836,10 @@ static int stage_rays(rdr_ctx* c, const rdr_rays* r, RayParams& P, int64_t los_m
         rc = stage_in(c, SLOT_IN4, r->inc, nl * 8, loc, &d); if (rc) return rc; P.inc = (const double*)d;
         if (r->hd) { rc = stage_in(c, SLOT_IN5, r->hd, nl * 8, loc, &d); if (rc) return rc; P.hd = (const double*)d; }   // NULL: hd0 for every ray
     }
+    if (r->hts) {                                           // per-ray origin heights (one batch = one slice)
+        if (los_mult != 1) return fail(c, RDR_ERR_INVALID, "per-ray heights (rays->hts) and height slices exclude each other");
+        rc = stage_in(c, SLOT_IN6, r->hts, (size_t)r->n * 8, loc, &d); if (rc) return rc; P.ht_ray = (const double*)d;
+    }
     if (r->origin_mode == RDR_ORIGIN_GRID) {
         P.tiles_x = (int)((r->nx + TILE - 1) / TILE);
         P.ntiles = (int64_t)P.tiles_x * ((r->ny + TILE - 1) / TILE);
@@ -930,6 +934,7 @@ static void wsig_set(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, double ht
     c->wsig.a = r->origin_mode == RDR_ORIGIN_GRID ? (const void*)r->xpts : (r->origin_mode == RDR_ORIGIN_XYZ ? (const void*)r->xyz : (const void*)r->lat);
     c->wsig.b = r->origin_mode == RDR_ORIGIN_GRID ? (const void*)r->ypts : (const void*)r->lon;
     c->wsig.c = r->los_mode == RDR_LOS_VEC ? (const void*)r->los : (const void*)r->inc;
+    c->wsig.d = (const void*)r->hts;
 }
 
 static bool wsig_match(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, double ht, double zref, int K) {
@@ -938,7 +943,7 @@ static bool wsig_match(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, double 
     const void* a = r->origin_mode == RDR_ORIGIN_GRID ? (const void*)r->xpts : (r->origin_mode == RDR_ORIGIN_XYZ ? (const void*)r->xyz : (const void*)r->lat);
     const void* b = r->origin_mode == RDR_ORIGIN_GRID ? (const void*)r->ypts : (const void*)r->lon;
     const void* cc = r->los_mode == RDR_LOS_VEC ? (const void*)r->los : (const void*)r->inc;
-    return a == c->wsig.a && b == c->wsig.b && cc == c->wsig.c;
+    return a == c->wsig.a && b == c->wsig.b && cc == c->wsig.c && (const void*)r->hts == c->wsig.d;
 }
 
 // pass 1 over tiles [tb, tb+tc): optional reduction (P.maxlen_bits != null) and/or record store (P.ws != null)
@@ -964,7 +969,8 @@ static int launch_crossings(rdr_ctx* c, const rdr_cube* q, RayParams P, int64_t 
         // input form of the batch, fixed at compile time for the two hot ones (crossings_kernel's OM parameter)
         const int om = P.origin_mode != RDR_ORIGIN_GRID ? 0 : (P.los_mode == RDR_LOS_VEC ? 1 : 2);
         const dim3 G(g), B(BLOCK);
-#define RDR_LAUNCH_X(T2, LCC_, OM_) e = launch_lds(crossings_kernel<T2, false, LCC_, OM_>, G, B, sm, c->stream, make_view<T2>(q), P, q->proj)
+#define RDR_LAUNCH_X(T2, LCC_, OM_) e = (P.ht_ray ? launch_lds(crossings_kernel<T2, false, LCC_, OM_, true>, G, B, sm, c->stream, make_view<T2>(q), P, q->proj) \
+                                                  : launch_lds(crossings_kernel<T2, false, LCC_, OM_, false>, G, B, sm, c->stream, make_view<T2>(q), P, q->proj))
 #define RDR_LAUNCH_X_OM(T2, LCC_) do { if (om == 1) RDR_LAUNCH_X(T2, LCC_, 1); else if (om == 2) RDR_LAUNCH_X(T2, LCC_, 2); else RDR_LAUNCH_X(T2, LCC_, 0); } while (0)
         if (q->dtype == RDR_F32) { if (lcc) RDR_LAUNCH_X_OM(float2, true); else RDR_LAUNCH_X_OM(float2, false); }
         else { if (lcc) RDR_LAUNCH_X_OM(double2, true); else RDR_LAUNCH_X_OM(double2, false); }
@@ -993,7 +999,9 @@ static int launch_march(rdr_ctx* c, const rdr_cube* q, RayParams P, int64_t tb, 
         const auto v32 = make_view<float2>(q);
         const bool small = v32.small && (q->dtype == RDR_F32 || make_view<double2>(q).small);
         const int grid = !small ? 0 : (q->exact[0] && q->exact[1]) ? 1 : (!q->exact[0] && !q->exact[1] && q->uni[0] && q->uni[1]) ? 2 : 0;
-#define RDR_LAUNCH_M(T2, V) (grid == 1 ? launch_lds(march_kernel<T2, false, 1>, G, B, sm, c->stream, V, P, q->proj)   \
+#define RDR_LAUNCH_M(T2, V) (P.ht_ray ? (grid == 1 ? launch_lds(march_kernel<T2, false, 1, true>, G, B, sm, c->stream, V, P, q->proj)   \
+                                                    : launch_lds(march_kernel<T2, false, 0, true>, G, B, sm, c->stream, V, P, q->proj)) \
+                             : grid == 1 ? launch_lds(march_kernel<T2, false, 1>, G, B, sm, c->stream, V, P, q->proj)   \
                              : grid == 2 ? launch_lds(march_kernel<T2, false, 2>, G, B, sm, c->stream, V, P, q->proj) \
                                          : launch_lds(march_kernel<T2, false, 0>, G, B, sm, c->stream, V, P, q->proj))
         if (q->dtype == RDR_F32) e = RDR_LAUNCH_M(float2, v32);
@@ -1106,6 +1114,7 @@ static int raytrace_pipelined(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, 
 static int flags_to_status(rdr_ctx* c, int flags) {
     if (!(flags & RDR_FLAG_ANY_FINITE)) return fail(c, RDR_ERR_ALL_NAN, "geo2rdr did not converge. Check orbit coverage");
     if (flags & RDR_FLAG_ANY_NAN) return fail(c, RDR_ERR_NAN_LENGTH, "some ray lengths are NaN: the number of integration parts (delay.py:283) is undefined");
+    if (flags & RDR_FLAG_BAD_HEIGHT) return fail(c, RDR_ERR_INVALID, "per-ray heights: a ray starts below the height the batch's level table was built for (pass ht <= min(rays->hts))");
     if (flags & RDR_FLAG_DIVERGED) return fail(c, RDR_ERR_INVALID, "ray lengths diverged: a model level asks for fewer than 2 or more than 65536 integration parts (are the look vectors unit vectors?)");
     return RDR_OK;
 }
@@ -1304,6 +1313,7 @@ int rdr_raytrace_slices(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, const 
     if (nparts_out && ld < (int32_t)q->nz - 1) return fail(c, RDR_ERR_INVALID, "rdr_raytrace_slices: nparts_out needs a row length of at least nz-1");
     int rc = check_rays(c, r); if (rc) return rc;
     if (r->origin_mode == RDR_ORIGIN_XYZ && nslices > 1) return fail(c, RDR_ERR_INVALID, "rdr_raytrace_slices: XYZ origins belong to one height; use GRID or LLH origins");
+    if (r->hts) return fail(c, RDR_ERR_INVALID, "rdr_raytrace_slices: per-ray heights (rays->hts) describe ONE batch; use rdr_raytrace");
     std::vector<int> Ks(nslices);
     int Kmax = 0;
     for (int s = 0; s < nslices; ++s) {

@@ -423,6 +423,8 @@ struct RayParams {
     // per-level maxima, flags, nParts - is kept per slice, so a batched launch gives exactly what slice-by-slice launches give.
     int nslices; int64_t tiles_per_slice;
     const double* hts;                 // [nslices] slice heights, or nullptr: one slice at `ht`
+    const double* ht_ray;              // [n] per-ray origin heights (one slice only), or nullptr.  The slice's level table is then built
+                                       // for `ht` <= min(ht_ray); ray i joins it at its own first contributing level (first_level)
     int64_t los_stride;                // rays between consecutive slices in los / inc / hd (0: the same arrays for every slice)
     double ht, zref, max_seg;
     // batch-global state
@@ -457,6 +459,26 @@ __device__ inline int build_levels(const double2* ez, int nz, double ht, double 
         ++K;
     }
     return min(K, MAX_LEVELS);
+}
+
+// Per-ray origin heights (RayParams::ht_ray; no reference semantics - DESIGN.md 5c): the reference's level tests
+// (losreader.py:785-808) applied with the RAY's height against the slice table built for the lowest one.  Returns the first entry
+// k of the table the ray contributes to (K: none) and its clipped bottom lo_i = max(z_kz, hti); every later entry contributes
+// unclipped.  Both passes call it with the same inputs.
+__device__ __forceinline__ int first_level(const double2* ez, int nz, const double* s_lo, const double* s_hi, const int* s_kz, int K,
+                                           double hti, double& lo_i) {
+    const double ztop = ez[nz - 1].x;
+    for (int k = 0; k < K; ++k) {
+        double hr = ez[s_kz[k] + 1].x;                       // the interval's top before the zref clip
+        if (hr == ztop) hr -= 0.01;
+        if (hr < hti) continue;
+        const double lo = fmax(s_lo[k], hti);                // `if low_ht < ht: low_ht = ht`
+        if (fabs(s_hi[k] - lo) < 1.0) continue;
+        lo_i = lo;
+        return k;
+    }
+    lo_i = 0.0;
+    return K;
 }
 
 // Shared LDS layout of the two ray kernels.  Axis tables are (g[i], 1/(g[i+1]-g[i])) pairs; an x / y axis that is uniform to
@@ -590,9 +612,12 @@ __device__ __forceinline__ void tile_trig(double v, int lane, const LccParams& p
 // code of the other input forms (atan / atan2 of XYZ origins, four sincos of inc/heading look vectors) - with everything in one
 // body the compiler hoisted so many of their invariants that the per-level loop spilled (220 B of scratch per lane in round 1):
 //   1: GRID origins + per-pixel look vectors;  2: GRID origins + incidence / heading (arrays or scalars) or zenith;  0: any.
-template <typename T2, bool SLOW, bool LCC = false, int OM = 0>
+// PR (light kernel only): per-ray origin heights (P.ht_ray) - a separate instantiation so that the slice kernels carry none of it; the
+// generic kernel looks at P.ht_ray at run time.
+template <typename T2, bool SLOW, bool LCC = false, int OM = 0, bool PR = false>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 : 4, SLOW ? 8 : 4))) void crossings_kernel(CubeView<T2> c, RayParams P, LccParams proj) {
-    static_assert(!SLOW || OM == 0, "the generic kernel takes every input form");
+    static_assert(!SLOW || (OM == 0 && !PR), "the generic kernel takes every input form");
+    const bool per_ray = PR || (SLOW && P.ht_ray != nullptr);
     if (SLOW && *P.nslow == 0) return;
     const int origin_mode = OM != 0 ? 0 : P.origin_mode;
     const int los_mode = OM == 1 ? 0 : P.los_mode;
@@ -657,6 +682,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
         }
         // ---- origin: llh -> ECEF (delay.py:262-267)
         double lat = 0, lon = 0, ox = qnan(), oy = qnan(), oz = qnan();
+        double hti = ht;                                   // the ray's origin height: the slice's, or its own
+        if (PR || SLOW) { if (per_ray && active) hti = P.ht_ray[i]; }
         RayBase base;
         if (!SLOW && origin_mode == 0) {
             // a tile has 16 distinct latitudes and 16 distinct longitudes: 32 lanes take the sines / cosines for everybody
@@ -674,9 +701,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
             base.sl0 = active ? m.trig[32 + 2 * (tl & 15)] : 0.0; base.cl0 = active ? m.trig[33 + 2 * (tl & 15)] : 1.0;
             if (active) {                                          // lla2ecef (geodesy.h) with the shared sines / cosines
                 const double N = WGS84_A / sqrt(1.0 - WGS84_ES * base.s0 * base.s0);
-                ox = (N + ht) * base.c0 * base.cl0;
-                oy = (N + ht) * base.c0 * base.sl0;
-                oz = (N * (1.0 - WGS84_ES) + ht) * base.s0;
+                ox = (N + hti) * base.c0 * base.cl0;
+                oy = (N + hti) * base.c0 * base.sl0;
+                oz = (N * (1.0 - WGS84_ES) + hti) * base.s0;
             }
         } else {
             if (active) {
@@ -685,7 +712,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
                 if (origin_mode == 2) {
                     ox = P.xyz[3 * i]; oy = P.xyz[3 * i + 1]; oz = P.xyz[3 * i + 2];
                     if (!P.lat) { double h0_; ecef2lla(ox, oy, oz, lon, lat, h0_); }   // frame for the delta lat/lon formulas
-                } else lla2ecef(lat, lon, ht, ox, oy, oz);
+                } else lla2ecef(lat, lon, hti, ox, oy, oz);
             }
             base = make_base(lat, lon);
         }
@@ -708,7 +735,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
         // on the ground (tools/ray_poly_probe.py), which moves delays by < 1e-10 m - and must not reach the +-180 meridian
         // (the light path does not wrap longitudes).
         const double cosi = (lx * base.c0 * base.cl0 + ly * base.c0 * base.sl0 + lz * base.s0) / nl;
-        const double gam = (P.zref - ht) / (cosi * 6.3e6);
+        const double gam = (P.zref - hti) / (cosi * 6.3e6);
         // LCC cubes: spherical cones only (HRRR), and the node projections use short series in log(t/t_origin) <= gam / cos(lat)
         // (geodesy_fast.h); an ellipsoidal cone goes to the generic kernels (lcc_forward) ray by ray.
         // The +-180 deg meridian: the light path carries longitude UNWRAPPED (origin + small delta), the reference wraps every
@@ -737,7 +764,17 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
         }
         const bool mine = SLOW ? !fast_ok : fast_ok;      // lanes this instantiation is responsible for
         if (SLOW && !__any(mine)) continue;               // (wave-uniform) nothing to mop up in this wave
-        const bool cnt = active && mine;
+        // per-ray heights: the ray's first level of the slice table and that level's clipped bottom (k0 == K: no level at all -
+        // the ray counts for nothing and its delays are 0, as a slice without levels).  A height below the table's is a caller
+        // error (flag 32: the slice's outputs are NaN).
+        int k0 = 0; double lo_first = K > 0 ? m.lo[0] : 0.0;
+        if (PR || SLOW) {
+            if (per_ray) {
+                k0 = first_level(m.ax.ez, c.nz, m.lo, m.hi, m.kz, K, hti, lo_first);
+                if (active && mine && hti < ht) my_flags |= 32;
+            }
+        }
+        const bool cnt = active && mine && k0 < K;
         // this lane's column of the per-level maxima; derived afresh per tile (an address kept live across the polynomial fit,
         // the register-hungriest stretch of the kernel, is the one value the allocator had to spill)
         int mxcol_idx = tl & (MXCOLS - 1);
@@ -771,22 +808,23 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
             double t_hi = 0.0, inv_cosf = 1.0;
 #pragma unroll 1
             for (int k = 0; k < K; ++k) {
-                const double lo = m.lo[k], hi = m.hi[k];
+                if (k < k0) continue;                // (per-ray heights: the ray joins the slice's level table at k0)
+                const double lo = k == k0 ? lo_first : m.lo[k], hi = m.hi[k];
                 // first interval: cos_factor is None -> 10 iterations with factor 1 for both ends (losreader.py:812-825);
                 // later intervals reuse the previous top as their bottom (losreader.py:811-812)
                 double t_lo = t_hi;
-                if (k == 0) t_lo = toa_newton_t(ox, oy, oz, lx, ly, lz, lo, 10, 1.0);
-                t_hi = toa_newton_t(ox, oy, oz, lx, ly, lz, hi, k == 0 ? 10 : 3, inv_cosf);
+                if (k == k0) t_lo = toa_newton_t(ox, oy, oz, lx, ly, lz, lo, 10, 1.0);
+                t_hi = toa_newton_t(ox, oy, oz, lx, ly, lz, hi, k == k0 ? 10 : 3, inv_cosf);
                 const double L = (t_hi - t_lo) * nl;
-                if (k == 0) inv_cosf = L / (hi - lo);                                       // 1/cos_factor, losreader.py:824-825
+                if (k == k0) inv_cosf = L / (hi - lo);                                      // 1/cos_factor, losreader.py:824-825
                 if (sd) {
-                    if (k == 0) sd[0] = t_lo;
+                    if (k == k0) sd[0] = t_lo;
                     sd[(int64_t)(k + 1) * P.side_cap] = t_hi;
                 }
                 if (reduce) {
                     if (cnt) my_flags |= (L != L) ? 1 : 2;
                     atomicMax(&mxc[k * MXCOLS], (unsigned long long)__double_as_longlong((cnt && L > 0.0) ? L : 0.0));
-                    if (k == 0 && cnt) {             // first sample of the ray (fraction 0)
+                    if (k == k0 && cnt) {            // first sample of the ray (fraction 0)
                         const double h0 = ecef_height(fma(t_lo, lx, ox), fma(t_lo, ly, oy), fma(t_lo, lz, oz));
                         if (!(h0 < c.z_lo)) my_flags |= 4;
                     }
@@ -800,8 +838,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
             // ---- light rays: fit h(u), lat(u), lon(u) once, then everything is polynomial arithmetic.
             // Range of the ray parameter any Newton iterate / sample can take: iterates start at t0 = level height
             // (>= ht) and move monotonically to the crossing, which lies in [0, (zref - ht)/cos(inc)].
-            const double t_a = fmin(0.0, ht) - 1.0;
-            const double t_b = fmax(P.zref, (P.zref - ht) / (cosi * nl)) + 1.0;
+            const double t_a = fmin(0.0, hti) - 1.0;
+            const double t_b = fmax(P.zref, (P.zref - hti) / (cosi * nl)) + 1.0;
             const double half = 0.5 * (t_b - t_a), mid = 0.5 * (t_b + t_a);
             const double su = 1.0 / half, ou = -mid * su;
             RayPoly q;
@@ -834,8 +872,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
             // Level 0 (ten plain Newton steps per end, losreader.py:770-777) sets the gain of every later level.
             double u_hi = 0.0, gain = su;
             double last_len = 0.0;      // a light ray's lengths are NaN for every level or for none (they all stem from one polynomial)
-            if (K > 0) {
-                const double lo = m.lo[0], hi = m.hi[0];
+            if (PR ? (k0 < K) : (K > 0)) {
+                const double lo = PR ? lo_first : m.lo[0], hi = PR ? m.hi[k0] : m.hi[0];
                 double u_lo = fma(lo, su, ou);
                 u_hi = fma(hi, su, ou);
 #pragma unroll 1
@@ -848,7 +886,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
                 gain = su * (L / (hi - lo));                                                   // su / cos_factor, losreader.py:824-825
                 if (w && mine) { w[(int64_t)WS_U0 * ns] = u_lo; w[(int64_t)WS_U1 * ns] = u_hi; }
                 if (reduce) {
-                    atomicMax(&mxc[0], (unsigned long long)__double_as_longlong((cnt && L > 0.0) ? L : 0.0));
+                    atomicMax(&mxc[PR ? k0 * MXCOLS : 0], (unsigned long long)__double_as_longlong((cnt && L > 0.0) ? L : 0.0));
                     if (cnt && !(poly5(q.h, u_lo) < c.z_lo)) my_flags |= 4;                    // first sample of the ray
                 }
             }
@@ -869,12 +907,23 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
                 // The metres-per-unit-u scale is folded into the polynomial once (8 multiplications), so a level costs 7 FMAs, one
                 // subtraction and the v_max.
                 const double mscale = cnt ? scale : 0.0;
-                const double u_end = K > 1 ? poly7(xc, m.xv[K - 1]) : u_hi;                    // the ray's last crossing (flags below)
+                const double u_end = (PR ? (k0 + 1 < K) : (K > 1)) ? poly7(xc, m.xv[K - 1]) : u_hi;   // the ray's last crossing (flags below)
                 double xm[PX];
 #pragma unroll
                 for (int n = 0; n < PX; ++n) xm[n] = xc[n] * mscale;
                 double s_hi = u_hi * mscale;                                                   // scaled crossing of the previous level
                 int k = 1;
+                if constexpr (PR) {
+                    // per-ray heights: levels up to the ray's own first one (k <= k0) count 0; level k0 + 1 starts from the
+                    // ten-iteration crossing u_hi of level k0, as level 1 of a slice does
+                    const double s_first = s_hi;
+                    for (; k < K; ++k) {
+                        const double st = poly7(xm, m.xv[k]);
+                        const double L = st - (k == k0 + 1 ? s_first : s_hi);
+                        s_hi = st;
+                        atomicMax(&mxc[k * MXCOLS], (unsigned long long)__double_as_longlong(k > k0 ? fmax(L, 0.0) : 0.0));
+                    }
+                }
                 for (; k + 2 <= K; k += 2) {
                     const double v0 = m.xv[k], v1 = m.xv[k + 1];
                     const double sa = poly7(xm, v0), sb = poly7(xm, v1);
@@ -889,7 +938,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
                     s_hi = st;
                     atomicMax(&mxc[k * MXCOLS], (unsigned long long)__double_as_longlong(fmax(L, 0.0)));
                 }
-                if (K > 1) last_len = u_end * scale;                                          // (only its NaN-ness is used)
+                if (PR ? (k0 + 1 < K) : (K > 1)) last_len = u_end * scale;                    // (only its NaN-ness is used)
                 if (K > 0 && cnt && !(poly5(q.h, u_end) > c.z_hi)) my_flags |= 8;              // last sample of the ray
             }
             if (reduce && cnt && K > 0) my_flags |= (last_len != last_len) ? 1 : 2;
@@ -905,9 +954,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
 //   1 (REGULAR): both horizontal axes are exactly uniform and the cube allows 32-bit offsets - the usual lat/lon or LCC model grid;
 //   2 (TABLES): both axes only NEARLY uniform (e.g. 0.1-degree nodes stored as float32) - guess-and-verify against the LDS tables -
 //               and 32-bit offsets;   0: whatever the run-time flags say.
-template <typename T2, bool SLOW, int GRID = 0>
+// PR (light kernel only): per-ray origin heights (P.ht_ray) - its own instantiation, the slice kernels carry none of it.
+template <typename T2, bool SLOW, int GRID = 0, bool PR = false>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 : 4, SLOW ? 8 : 4))) void march_kernel(CubeView<T2> c_in, RayParams P, LccParams proj) {
+    static_assert(!SLOW || !PR, "the generic kernel looks at P.ht_ray at run time");
     if (SLOW && *P.nslow == 0) return;
+    const bool per_ray = PR || (SLOW && P.ht_ray != nullptr);
     constexpr bool REGULAR = GRID == 1;
     CubeView<T2> c = c_in;
     if (REGULAR) { c.exact_y = 1; c.exact_x = 1; c.small = 1; }
@@ -954,7 +1006,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
             // the slice - ndarray.max poisons nParts and the reference raises (delay.py:283).  The synchronous entry points raise
             // the same error; a caller of the asynchronous ones (device arrays, no host round trip) gets NaN, never a finite
             // delay computed with a partition the reference does not define.
-            poison = (m.K[1] || (flags_in & 1)) ? qnan() : 0.0;
+            poison = (m.K[1] || (flags_in & (1 | 32))) ? qnan() : 0.0;      // (32: a per-ray height below the slice table's)
             clamp_lo = !(flags_in & 4);               // ALL first samples below zmin  (delay.py:306-307)
             clamp_hi = !(flags_in & 8);               // ALL last samples above zmax   (delay.py:310-311)
             clamp_any = clamp_lo | clamp_hi;
@@ -978,6 +1030,11 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
         const bool mine = SLOW ? !fast_ok : fast_ok;
         if (SLOW && !__any(mine)) continue;
         double acc_w = 0.0, acc_h = 0.0;
+        // per-ray heights: the ray's first level of the slice table, found exactly as pass 1 found it (idle lanes: none)
+        int k0 = 0; double lo_first = K > 0 ? m.lo[0] : 0.0;
+        if (PR || SLOW) {
+            if (per_ray) k0 = (active && mine) ? first_level(m.ax.ez, c.nz, m.lo, m.hi, m.kz, K, P.ht_ray[i], lo_first) : K;
+        }
         if constexpr (!SLOW) {
             // ---- light rays: every distinct sample point of the ray once, level by level --------------------------------
             // The sample schedule (level k, fraction j/(np-1)) is the same for every ray of the slice, so the loop counters
@@ -1020,6 +1077,52 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
                 sample_finish_lerp(s, vw, vh);
                 acc_w = fma(wv, vw, acc_w); acc_h = fma(wv, vh, acc_h);              // delay.py:323
             };
+            if constexpr (PR) {
+                // Per-ray heights: the level schedule (k, j) stays slice-uniform - scalar loop counters, the partition of the slice - and a
+                // lane joins it at its own first level k0 with its own first sample; until then it idles (execution mask).  The loop
+                // starts at the wave's lowest k0.  Same arithmetic per sample as the slice loop below, so that equal heights give the
+                // slice kernel's delays bit for bit.
+                int kmin = k0;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) kmin = min(kmin, __shfl_xor(kmin, off, 64));
+                kmin = __builtin_amdgcn_readfirstlane(kmin);
+                double u_k = 0.0, du = 0.0, u_last = 0.0;
+#pragma unroll 1
+                for (int k = kmin; k < K; ++k) {
+                    const int np = __builtin_amdgcn_readfirstlane(m.np[k]);
+                    const int kz = __builtin_amdgcn_readfirstlane(m.kz[k]);
+                    const double step = m.step[k], hs = m.hs[k];
+                    const bool more = k + 1 < K;
+                    if (k == k0) {                                                   // this lane's ray starts here: its first sample
+                        u_k = w[(int64_t)WS_U0 * ns]; u_last = w[(int64_t)WS_U1 * ns];
+                        du = u_last - u_k;
+                        PendingSample<T2> s;
+                        issue_top(fma(0.0 * step, du, u_k), window2_base(c.nz, kz - ((lo_first <= m.ax.ez[kz].x) ? 1 : 0)), clamp_lo, false, s);
+                        finish(s, hs * du);
+                    }
+                    if (k >= k0) {
+                        const int zbase = window2_base(c.nz, kz);
+                        const double w_mid = (2.0 * hs) * du;
+#pragma unroll 1
+                        for (int j = 1; j < np - 1; ++j) {
+                            PendingSample<T2> s;
+                            issue_mid(fma((double)j * step, du, u_k), kz, s);
+                            finish(s, w_mid);
+                        }
+                        PendingSample<T2> top;
+                        issue_top(u_k + du, zbase, false, clamp_hi && !more, top);
+                        double du1 = 0.0;
+                        double w_top = hs * du;
+                        if (more) {
+                            const double t2 = poly7(xc, m.xv[k + 1]);
+                            du1 = t2 - u_last; u_last = t2;
+                            w_top = fma(m.hs[k + 1], du1, w_top);
+                        }
+                        finish(top, w_top);
+                        u_k += du; du = du1;
+                    }
+                }
+            } else {
             int np = __builtin_amdgcn_readfirstlane(m.np[0]);                        // >= 2 (fill above)
             int kz = __builtin_amdgcn_readfirstlane(m.kz[0]);
             double step = m.step[0], hs = m.hs[0];
@@ -1064,6 +1167,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
                     step = m.step[k + 1];
                 }
             }
+            }   // (slice loop)
             };
             // Bounds of the horizontal cell search, decided ONCE per wave from the polynomial coefficients.  Every sample's ray
             // parameter lies between the ray's crossings: the two of the first level (u0, u1 of the record) and X(v_k), |v_k| <= 1,
@@ -1109,17 +1213,18 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
             const int64_t sidx = mine ? (int64_t)w[(int64_t)WS_SIDE * ns] : -1;
             const double* const sd = (sidx >= 0 && P.side) ? P.side + sidx : nullptr;
             double t_hi = 0.0, t_next = 0.0, inv_cosf = 1.0;
-            if (sd) { t_hi = sd[0]; t_next = sd[P.side_cap]; }
-            else if (mine && K > 0) t_hi = toa_newton_t(ox, oy, oz, lx, ly, lz, m.lo[0], 10, 1.0);
+            if (sd) { t_hi = sd[0]; if (k0 < K) t_next = sd[(int64_t)(k0 + 1) * P.side_cap]; }
+            else if (mine && k0 < K) t_hi = toa_newton_t(ox, oy, oz, lx, ly, lz, lo_first, 10, 1.0);
     #pragma unroll 1
             for (int k = 0; k < K; ++k) {
+                if (k < k0) continue;                // (per-ray heights: the ray joins the slice's level table at k0; else k0 = 0)
                 const double t_lo = t_hi;
                 if (sd) {
                     t_hi = t_next;
                     if (k + 2 <= K) t_next = sd[(int64_t)(k + 2) * P.side_cap];
                 } else if (mine) {
-                    t_hi = toa_newton_t(ox, oy, oz, lx, ly, lz, m.hi[k], k == 0 ? 10 : 3, inv_cosf);
-                    if (k == 0) inv_cosf = ((t_hi - t_lo) * scale) / (m.hi[0] - m.lo[0]);      // losreader.py:824-825, as in pass 1
+                    t_hi = toa_newton_t(ox, oy, oz, lx, ly, lz, m.hi[k], k == k0 ? 10 : 3, inv_cosf);
+                    if (k == k0) inv_cosf = ((t_hi - t_lo) * scale) / (m.hi[k0] - lo_first);   // losreader.py:824-825, as in pass 1
                 }
                 const double dt = t_hi - t_lo;
                 const int np = m.np[k];
@@ -1130,9 +1235,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
                 // j = 0 of this segment is the SAME point as j = np-1 of the previous one (low_xyz is high_xyz,
                 // losreader.py:811-812): its interpolated value is reused instead of recomputed (the reference evaluates
                 // it twice and gets the same number both times).  The order of accumulation is unchanged.
-                if (k > 0) { acc_w = fma(0.5 * segw, vw_top, acc_w); acc_h = fma(0.5 * segw, vh_top, acc_h); }
+                if (k > k0) { acc_w = fma(0.5 * segw, vw_top, acc_w); acc_h = fma(0.5 * segw, vh_top, acc_h); }
     #pragma unroll 1
-                for (int j = (k == 0 ? 0 : 1); j < np; ++j) {
+                for (int j = (k == k0 ? 0 : 1); j < np; ++j) {
                     const double ts = fma((double)j, dts, t_lo);
                     double plon, plat, ph;
                     ecef2lla(fma(ts, lx, ox), fma(ts, ly, oy), fma(ts, lz, oz), plon, plat, ph);                     // delay.py:295
@@ -1140,7 +1245,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
                     // all-pixels z-clamp of the very first / very last sample (delay.py:306-311): when it applies every
                     // pixel is below (above) the cube, so "set to zmin" == max(ph, zmin); the bounds are wave-uniform
                     if (clamp_any) {
-                        const double zfloor = (clamp_lo && k == 0 && j == 0) ? c.z_lo : -__builtin_huge_val();
+                        const double zfloor = (clamp_lo && k == k0 && j == 0) ? c.z_lo : -__builtin_huge_val();
                         const double zceil = (clamp_hi && k == K - 1 && j == np - 1) ? c.z_hi : __builtin_huge_val();
                         ph = fmin(fmax(ph, zfloor), zceil);
                     }

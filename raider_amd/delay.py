@@ -11,7 +11,7 @@ import os
 
 import numpy as np
 
-from ._lib import NoLevels
+from ._lib import FLAG_DIVERGED, NoLevels
 from .constants import _ZREF
 from .delayFcns import FieldInterpolator, getInterpolators, _load_fields
 from .engine import Cube, Rays
@@ -483,7 +483,7 @@ def _build_cube_ray(xpts, ypts, zpts, los, model_crs, pts_crs, interpolators, ou
                     raise ValueError('geo2rdr did not converge. Check orbit coverage')            # delay.py:279-280
                 if flags[hh] & FLAG_ANY_NAN:
                     raise ValueError('some ray lengths are NaN: the number of integration parts (delay.py:283) is undefined')
-                if flags[hh] & 16:
+                if flags[hh] & FLAG_DIVERGED:
                     raise ValueError('ray lengths diverged: a model level asks for fewer than 2 or more than 65536 integration parts '
                                      '(are the look vectors unit vectors?)')
         return outputArrs

@@ -199,6 +199,7 @@ class Cube:
 
     def ray_prepass(self, rays, ht, zref):
         rays.adopt_stream(self.ctx)
+        ht = rays.table_height(ht)
         K = len(self.ray_levels(ht, zref)[0])
         maxlen = np.zeros(K)
         flags = C.c_int32()
@@ -216,6 +217,7 @@ class Cube:
         """Pass 1 with its result left on the device: `partition` = torch float64 tensor of K+4 elements (per-level maxima,
         then the 4 flag bits as 0/1) - ready for an element-wise MAX all-reduce.  Asynchronous."""
         rays.adopt_stream(self.ctx)
+        ht = rays.table_height(ht)
         self._check_partition(partition, ht, zref)
         check(self.ctx.lib.rdr_ray_prepass_device(self.ctx.handle, self.handle, C.byref(rays.struct), float(ht), float(zref), ptr(partition)),
               self.ctx.handle)
@@ -224,6 +226,7 @@ class Cube:
     def ray_march_device(self, rays, ht, zref, partition, max_seg=1000.0, out=None):
         """Pass 2 driven by a device-resident (all-reduced) partition.  Asynchronous."""
         rays.adopt_stream(self.ctx)
+        ht = rays.table_height(ht)
         wet, hyd = out if out is not None else rays.empty_outputs()
         rays.check_outputs(wet, hyd)
         self._check_partition(partition, ht, zref)
@@ -233,6 +236,7 @@ class Cube:
 
     def ray_march(self, rays, ht, zref, nparts, flags, out=None):
         rays.adopt_stream(self.ctx)
+        ht = rays.table_height(ht)
         nparts = np.ascontiguousarray(nparts, dtype=np.int32)
         wet, hyd = out if out is not None else rays.empty_outputs()
         rays.check_outputs(wet, hyd)
@@ -242,8 +246,11 @@ class Cube:
 
     def raytrace(self, rays, ht, zref, max_seg=1000.0, out=None, want_nparts=True):
         """One slice of _build_cube_ray (delay.py:256-323).  Returns (wet, hydro, nparts, flags);
-        nparts/flags are None when want_nparts is False (fully asynchronous for device arrays)."""
+        nparts/flags are None when want_nparts is False (fully asynchronous for device arrays).
+        A batch with per-ray origin heights (Rays.grid(..., hts=...)) takes ht=None; nparts then has one entry per level of the
+        table built for the LOWEST ray (ray_levels(rays.ht_min, zref))."""
         rays.adopt_stream(self.ctx)
+        ht = rays.table_height(ht)
         wet, hyd = out if out is not None else rays.empty_outputs()
         rays.check_outputs(wet, hyd)
         if want_nparts:
@@ -264,6 +271,8 @@ class Cube:
         Returns (wet[S,...], hydro[S,...], K[S], nparts[S, nz-1], flags[S]); the last three are None when want_partition is
         False (fully asynchronous for device arrays).  K[s] == 0: build_ray -> None for that slice (its delays are 0)."""
         rays.adopt_stream(self.ctx)
+        if rays.ht_min is not None:
+            raise ValueError('a batch with per-ray heights is ONE slice: use raytrace()')
         hts = f64(np.atleast_1d(hts)).ravel()
         S = hts.size
         if rays.slices not in (0, S):
@@ -308,6 +317,7 @@ class Rays:
         self._keep_tensor = None
         self._has_host = False
         self.slices = 0          # > 0: the look-vector / incidence / heading arrays hold one block of n rays per height slice
+        self.ht_min = None       # per-ray origin heights (hts=...): their minimum = the height the batch's level table is built for
 
     def _set(self, field, arr):
         """Every array of a batch lives in ONE place (the C struct has a single `loc`): all NumPy, or all tensors on one GPU.
@@ -377,10 +387,12 @@ class Rays:
                 raise ValueError('output arrays must be C-contiguous float64 NumPy arrays')
 
     @classmethod
-    def grid(cls, xpts, ypts, los=None, inc=None, hd=None, zenith=False, slices=0):
+    def grid(cls, xpts, ypts, los=None, inc=None, hd=None, zenith=False, slices=0, hts=None):
         """Origins on meshgrid(xpts, ypts) (delay.py:242).  LOS: `los` (ny,nx,3) ECEF unit vectors, or
         inc/hd (scalars or (ny,nx) arrays, degrees), or zenith.  slices=S: los / inc / hd carry a leading slice axis of
-        length S (look vectors that depend on the slice height; Cube.raytrace_slices)."""
+        length S (look vectors that depend on the slice height; Cube.raytrace_slices).
+        hts=(ny,nx): PER-PIXEL origin heights (a scene on a DEM) instead of one slice height - no reference semantics, the rule
+        is in include/raider_hip.h (rdr_rays.hts); then pass ht=None to the ray-tracing calls."""
         r = cls()
         r.slices = int(slices)
         nx = xpts.numel() if _is_dev(xpts) else np.size(xpts)
@@ -389,12 +401,13 @@ class Rays:
         r.struct.nx, r.struct.ny, r.struct.n = nx, ny, nx * ny
         r._set('xpts', xpts); r._set('ypts', ypts)
         r.shape = (ny, nx)
+        r._set_heights(hts)
         r._set_los(los, inc, hd, zenith)
         return r
 
     @classmethod
-    def points(cls, lat=None, lon=None, xyz=None, los=None, inc=None, hd=None, zenith=False):
-        """Arbitrary ray list: lat/lon (deg) at the slice height, or ECEF xyz (n,3)."""
+    def points(cls, lat=None, lon=None, xyz=None, los=None, inc=None, hd=None, zenith=False, hts=None):
+        """Arbitrary ray list: lat/lon (deg) at the slice height (or at per-ray heights hts[n]), or ECEF xyz (n,3)."""
         r = cls()
         if xyz is not None:
             r.struct.origin_mode = L.ORIGIN_XYZ
@@ -408,8 +421,37 @@ class Rays:
             r.shape = tuple(lat.shape) if hasattr(lat, 'shape') else (n,)
             r._set('lat', lat); r._set('lon', lon)
         r.struct.n = n
+        r._set_heights(hts)
         r._set_los(los, inc, hd, zenith)
         return r
+
+    def _set_heights(self, hts):
+        """Per-ray origin heights: one float64 per ray; their minimum (one reduction, and for device arrays one read-back, at
+        construction) is the height the batch's level table is built for."""
+        if hts is None:
+            return
+        cnt = hts.numel() if _is_dev(hts) else np.size(hts)
+        if cnt != self.struct.n:
+            raise ValueError(f'per-ray heights must have shape {tuple(self.shape)} (got {cnt} values for {self.struct.n} rays)')
+        if self.slices:
+            raise ValueError('per-ray heights and height slices exclude each other')
+        self.ht_min = float(hts.min()) if cnt else 0.0
+        if self.ht_min != self.ht_min:
+            raise ValueError('per-ray heights contain NaN')
+        self._set('hts', hts)
+
+    def table_height(self, ht):
+        """The `ht` argument of the C entry points for this batch: the slice height, or min(hts) for per-ray heights (an explicit
+        ht below it is allowed: the same rays in a taller level table)."""
+        if self.ht_min is None:
+            if ht is None:
+                raise ValueError('this ray batch has no per-ray heights: a slice height ht is needed')
+            return float(ht)
+        if ht is None:
+            return self.ht_min
+        if float(ht) > self.ht_min:
+            raise ValueError(f'ht = {ht} lies above the lowest per-ray height {self.ht_min}')
+        return float(ht)
 
     def _set_los(self, los, inc, hd, zenith):
         n = self.struct.n
