@@ -197,6 +197,14 @@ int rdr_cube_read(rdr_ctx* ctx, const rdr_cube* cube, void* wet, void* hydro);
  * scipy RegularGridInterpolator.__call__ on both fields (delay.py:214,120-121): pts[n,3] = (y,x,z). */
 int rdr_interp3(rdr_ctx* ctx, const rdr_cube* cube, const double* pts, int64_t n, double* wet,
                 double* hydro, int loc);
+/* Large random point sets on a cube beyond the caches (BASELINE configs[4]: 5 M stations on a 1000 x 1000 x 50 cube): rdr_interp3
+ * then reads four 128 B lines per point for 16 B each.  The cube can carry a second, cell-column-major copy ("corner quads",
+ * 5.3 x its bytes for f32, 8 x for f64) from which a point's eight corners are ONE line - same values, same arithmetic, 3.3 x less
+ * HBM traffic.  mode 1: build it now; mode 0: free it.  Without this call rdr_interp3 builds it by itself from the second call with
+ * >= 262144 points on a cube beyond 32 MB, if it fits a quarter of the free memory (env RAIDER_HIP_POINT_INDEX=0 never, =1 at the
+ * first such call).  rdr_cube_point_index_bytes: bytes the copy holds now (0: none). */
+int rdr_cube_point_index(rdr_ctx* ctx, rdr_cube* cube, int mode);
+int64_t rdr_cube_point_index_bytes(const rdr_cube* cube);
 /* _build_cube (delay.py:196-216) for model_crs == pts_crs: out[(iz*ny+iy)*nx+ix] = f(ypts[iy],xpts[ix],zpts[iz]) */
 int rdr_build_cube(rdr_ctx* ctx, const rdr_cube* cube, const double* xpts, int64_t nx, const double* ypts,
                    int64_t ny, const double* zpts, int64_t nz, double* wet, double* hydro, int loc);

@@ -72,6 +72,8 @@ SYMBOLS = [
     ('rdr_transform_cone', C.c_int, [_VP, C.c_int, _VP, C.c_int, C.c_int, _VP, _VP, C.c_int64, _VP, _VP, C.c_int]),
     ('rdr_cube_blend', C.c_int, [_VP, _VP, C.c_double, _VP, C.c_double, C.POINTER(_VP)]),
     ('rdr_cube_read', C.c_int, [_VP, _VP, _VP, _VP]),
+    ('rdr_cube_point_index', C.c_int, [_VP, _VP, C.c_int]),
+    ('rdr_cube_point_index_bytes', C.c_int64, [_VP]),
     ('rdr_interp3', C.c_int, [_VP, _VP, _VP, C.c_int64, _VP, _VP, C.c_int]),
     ('rdr_build_cube', C.c_int, [_VP, _VP, _VP, C.c_int64, _VP, C.c_int64, _VP, C.c_int64, _VP, _VP, C.c_int]),
     ('rdr_project_cosinc', C.c_int, [_VP, _VP, _VP, _VP, C.c_int64, C.c_int]),

@@ -165,6 +165,109 @@ __global__ __launch_bounds__(256) void interp_points_kernel(CubeView<T2> c, cons
     }
 }
 
+// ---- station queries on a cube that fits no cache: the corner-quad copy ----------------------------------------------------
+// A random point's 2 x 2 x 2 corners sit in FOUR columns of the (y,x,z) cube, i.e. four 128 B lines for 16 B each: 5 M stations on
+// a 1000 x 1000 x 50 f32 cube move 2.78 GB (556 B per point) for 0.52 GB of algorithmic bytes - and the kernel runs at the HBM
+// rate of those lines (profiles/r02_secondary.json).  The quad copy stores the cube CELL-COLUMN-major instead: for every cell
+// column (iy, ix) the four corner columns interleaved level by level, in 128 B blocks of LPB levels that overlap by one level
+//     block j of cell column (iy, ix):  levels CPB j .. CPB j + LPB - 1,  each level = v(y0,x0) v(y0,x1) v(y1,x0) v(y1,x1)
+// so that the two levels of ANY cell iz lie in ONE block (j = iz / CPB): one line per point, 168 B measured instead of 556.
+// f32 cubes: LPB = 4 levels, CPB = 3 cells per block (5.3 x the cube's bytes); f64 cubes: LPB = 2, CPB = 1 (8 x).
+// Built once per cube, on demand (rdr_cube_point_index / the second large rdr_interp3 call on a cube beyond 32 MB).
+template <typename T2> struct Quad {
+    static constexpr int LPB = 128 / (4 * (int)sizeof(T2));
+    static constexpr int CPB = LPB - 1;
+};
+
+// one thread per 16-byte part of a block: a wave writes 8 consecutive blocks = 1 KB
+template <typename T2>
+__global__ __launch_bounds__(256) void quad_build_kernel(const T2* __restrict__ v, int ny, int nx, int nz, int nblk, uint4* __restrict__ q) {
+    const int64_t total = (int64_t)(ny - 1) * (nx - 1) * nblk * 8;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int p = (int)(t & 7);
+        const int64_t b = t >> 3;
+        const int j = (int)(b % nblk);
+        const int64_t col = b / nblk;
+        const int ix = (int)(col % (nx - 1)), iy = (int)(col / (nx - 1));
+        uint4 out;
+        if constexpr (sizeof(T2) == 8) {            // float2: part p = level p/2, row y0 / y1 = p%2, both x corners
+            const int lev = min(j * Quad<T2>::CPB + (p >> 1), nz - 1);
+            const T2* a = v + ((int64_t)(iy + (p & 1)) * nx + ix) * nz + lev;
+            const T2 v0 = a[0], v1 = a[nz];
+            out.x = __float_as_uint(v0.x); out.y = __float_as_uint(v0.y); out.z = __float_as_uint(v1.x); out.w = __float_as_uint(v1.y);
+        } else {                                      // double2: part p = level p/4, corner p%4
+            const int lev = min(j * Quad<T2>::CPB + (p >> 2), nz - 1);
+            const T2 v0 = v[((int64_t)(iy + ((p >> 1) & 1)) * nx + ix + (p & 1)) * nz + lev];
+            const unsigned long long lo = (unsigned long long)__double_as_longlong(v0.x), hi = (unsigned long long)__double_as_longlong(v0.y);
+            out.x = (unsigned)lo; out.y = (unsigned)(lo >> 32); out.z = (unsigned)hi; out.w = (unsigned)(hi >> 32);
+        }
+        q[t] = out;
+    }
+}
+
+// the same interpolant as interp_points_kernel / trilinear<> (cell search, weights, summation order: bit-identical results), corners
+// from the quad copy: 64 contiguous bytes of one block for an f32 cube, the whole 128 B block for an f64 one
+template <typename T2>
+__global__ __launch_bounds__(256) void interp_points_quad_kernel(CubeView<T2> c, const uint4* __restrict__ q, int nblk, const double* __restrict__ pts,
+                                                                 int64_t n, double* __restrict__ wet, double* __restrict__ hyd, int axes_in_lds) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const double* s_y = c.axes;
+    if (axes_in_lds) {
+        double* t = reinterpret_cast<double*>(smem_raw);
+        for (int i = threadIdx.x; i < c.ny + c.nx + c.nz; i += blockDim.x) t[i] = c.axes[i];
+        __syncthreads();
+        s_y = t;
+    }
+    const double* s_x = s_y + c.ny;
+    const double* s_z = s_x + c.nx;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double y = pts[3 * i], x = pts[3 * i + 1], z = pts[3 * i + 2];
+        double sw = qnan(), sh = qnan();
+        const bool inside = (y >= c.y_lo) && (y <= c.y_hi) && (x >= c.x_lo) && (x <= c.x_hi) && (z >= c.z_lo) && (z <= c.z_hi);
+        if (inside) {
+            const int iy = find_cell(s_y, c.ny, y, c.y_lo, c.inv_dy, c.uni_y);
+            const int ix = find_cell(s_x, c.nx, x, c.x_lo, c.inv_dx, c.uni_x);
+            const int iz = find_cell(s_z, c.nz, z, c.z_lo, c.inv_dz, c.uni_z);
+            const double ty = (y - s_y[iy]) / (s_y[iy + 1] - s_y[iy]);
+            const double tx = (x - s_x[ix]) / (s_x[ix + 1] - s_x[ix]);
+            const double tz = (z - s_z[iz]) / (s_z[iz + 1] - s_z[iz]);
+            const int j = iz / Quad<T2>::CPB, l0 = iz - j * Quad<T2>::CPB;
+            const uint4* blk = q + (((int64_t)iy * (c.nx - 1) + ix) * nblk + j) * 8;
+            double w[8], h[8];
+            if constexpr (sizeof(T2) == 8) {
+                const uint4 A = blk[2 * l0], B = blk[2 * l0 + 1], C = blk[2 * l0 + 2], D = blk[2 * l0 + 3];
+                w[0] = (double)__uint_as_float(A.x); h[0] = (double)__uint_as_float(A.y); w[2] = (double)__uint_as_float(A.z); h[2] = (double)__uint_as_float(A.w);
+                w[4] = (double)__uint_as_float(B.x); h[4] = (double)__uint_as_float(B.y); w[6] = (double)__uint_as_float(B.z); h[6] = (double)__uint_as_float(B.w);
+                w[1] = (double)__uint_as_float(C.x); h[1] = (double)__uint_as_float(C.y); w[3] = (double)__uint_as_float(C.z); h[3] = (double)__uint_as_float(C.w);
+                w[5] = (double)__uint_as_float(D.x); h[5] = (double)__uint_as_float(D.y); w[7] = (double)__uint_as_float(D.z); h[7] = (double)__uint_as_float(D.w);
+            } else {
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+                    for (int l = 0; l < 2; ++l) {
+                        const uint4 P = blk[l * 4 + cc];
+                        w[2 * cc + l] = __longlong_as_double((long long)(((unsigned long long)P.y << 32) | P.x));
+                        h[2 * cc + l] = __longlong_as_double((long long)(((unsigned long long)P.w << 32) | P.z));
+                    }
+            }
+            const double wy0 = 1.0 - ty, wx0 = 1.0 - tx, wz0 = 1.0 - tz;
+            const double a00 = wy0 * wx0, a01 = wy0 * tx, a10 = ty * wx0, a11 = ty * tx;
+            const double k0 = a00 * wz0, k1 = a00 * tz, k2 = a01 * wz0, k3 = a01 * tz;
+            const double k4 = a10 * wz0, k5 = a10 * tz, k6 = a11 * wz0, k7 = a11 * tz;
+            sw = 0.0; sh = 0.0;
+            sw += w[0] * k0; sh += h[0] * k0;
+            sw += w[1] * k1; sh += h[1] * k1;
+            sw += w[2] * k2; sh += h[2] * k2;
+            sw += w[3] * k3; sh += h[3] * k3;
+            sw += w[4] * k4; sh += h[4] * k4;
+            sw += w[5] * k5; sh += h[5] * k5;
+            sw += w[6] * k6; sh += h[6] * k6;
+            sw += w[7] * k7; sh += h[7] * k7;
+        }
+        wet[i] = sw; hyd[i] = sh;
+    }
+}
+
 // _build_cube (delay.py:196-216): points generated on the fly from (xpts, ypts, zpts).  One thread per output NODE (iy, ix) and
 // z chunk: the model-CRS projection of the node (LCC / polar stereographic cubes), its x / y cells and the four horizontal
 // weight products are computed once and reused for every height of the chunk; the arithmetic per point is that of trilinear<>
@@ -219,31 +322,48 @@ __global__ __launch_bounds__(256) void build_cube_kernel(CubeView<T2> c, LccPara
         const T2* col01 = col00 + c.nz;
         const T2* col10 = col00 + (int64_t)c.nx * c.nz;
         const T2* col11 = col10 + c.nz;
-        for (int64_t iz = z0; iz < z1; ++iz) {
-            const int cz = s_cz[iz - z0];
-            double sw = qnan(), sh = qnan();
-            if (in_xy && cz >= 0) {
-                const double tz = s_tz[iz - z0];
-                const double wz0 = 1.0 - tz;
-                double w[8], h[8];
-                ld2(col00 + cz, w[0], h[0]); ld2(col00 + cz + 1, w[1], h[1]);
-                ld2(col01 + cz, w[2], h[2]); ld2(col01 + cz + 1, w[3], h[3]);
-                ld2(col10 + cz, w[4], h[4]); ld2(col10 + cz + 1, w[5], h[5]);
-                ld2(col11 + cz, w[6], h[6]); ld2(col11 + cz + 1, w[7], h[7]);
-                const double k0 = a00 * wz0, k1 = a00 * tz, k2 = a01 * wz0, k3 = a01 * tz;
-                const double k4 = a10 * wz0, k5 = a10 * tz, k6 = a11 * wz0, k7 = a11 * tz;
-                sw = 0.0; sh = 0.0;
-                sw += w[0] * k0; sh += h[0] * k0;
-                sw += w[1] * k1; sh += h[1] * k1;
-                sw += w[2] * k2; sh += h[2] * k2;
-                sw += w[3] * k3; sh += h[3] * k3;
-                sw += w[4] * k4; sh += h[4] * k4;
-                sw += w[5] * k5; sh += h[5] * k5;
-                sw += w[6] * k6; sh += h[6] * k6;
-                sw += w[7] * k7; sh += h[7] * k7;
+        // U heights per trip: their 8 U corner-pair loads are issued back to back (clamped, hence unconditional, addresses - a
+        // conditional load would fence the batch), then the arithmetic, then the stores.  One height per trip left the kernel
+        // waiting out a full L2 round trip per height (the stores may alias the cube as far as the compiler knows, so it never
+        // hoisted the next height's loads above them): 0.28 ms for the 640 MB of config 2, a third of the HBM write rate.
+        // The outputs are written once and not read back here: non-temporal stores keep them from evicting the cube from L2.
+        constexpr int U = sizeof(T2) == 8 ? 4 : 2;
+        for (int64_t iz = z0; iz < z1; iz += U) {
+            T2 v[U][8];
+            int czs[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t k = min(iz + u, z1 - 1) - z0;
+                czs[u] = s_cz[k];
+                const int cz = max(czs[u], 0);
+                v[u][0] = col00[cz]; v[u][1] = col00[cz + 1];
+                v[u][2] = col01[cz]; v[u][3] = col01[cz + 1];
+                v[u][4] = col10[cz]; v[u][5] = col10[cz + 1];
+                v[u][6] = col11[cz]; v[u][7] = col11[cz + 1];
             }
-            const int64_t o = iz * nodes + i;
-            wet[o] = sw; hyd[o] = sh;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (iz + u >= z1) break;
+                double sw = qnan(), sh = qnan();
+                if (in_xy && czs[u] >= 0) {
+                    const double tz = s_tz[iz + u - z0];
+                    const double wz0 = 1.0 - tz;
+                    const double k0 = a00 * wz0, k1 = a00 * tz, k2 = a01 * wz0, k3 = a01 * tz;
+                    const double k4 = a10 * wz0, k5 = a10 * tz, k6 = a11 * wz0, k7 = a11 * tz;
+                    sw = 0.0; sh = 0.0;
+                    sw += (double)v[u][0].x * k0; sh += (double)v[u][0].y * k0;
+                    sw += (double)v[u][1].x * k1; sh += (double)v[u][1].y * k1;
+                    sw += (double)v[u][2].x * k2; sh += (double)v[u][2].y * k2;
+                    sw += (double)v[u][3].x * k3; sh += (double)v[u][3].y * k3;
+                    sw += (double)v[u][4].x * k4; sh += (double)v[u][4].y * k4;
+                    sw += (double)v[u][5].x * k5; sh += (double)v[u][5].y * k5;
+                    sw += (double)v[u][6].x * k6; sh += (double)v[u][6].y * k6;
+                    sw += (double)v[u][7].x * k7; sh += (double)v[u][7].y * k7;
+                }
+                const int64_t o = (iz + u) * nodes + i;
+                __builtin_nontemporal_store(sw, wet + o);
+                __builtin_nontemporal_store(sh, hyd + o);
+            }
         }
     }
 }

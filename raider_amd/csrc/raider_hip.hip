@@ -71,6 +71,11 @@ struct rdr_cube {
     int exact[2] = {0, 0};
     double inv_d[3] = {0, 0, 0};
     LccParams proj = {0, 0, 0, 0, 0, 0, 0, 0};   // kind 0: the cube axes are lon/lat degrees
+    // corner-quad copy for large random point sets (cube_kernels.h): built on demand, owned by the cube
+    mutable void* d_quad = nullptr;
+    mutable size_t quad_bytes = 0;
+    mutable int quad_nblk = 0;
+    mutable int big_point_calls = 0;             // rdr_interp3 calls that would have profited
 };
 
 static int fail(rdr_ctx* ctx, int code, const std::string& msg) {
@@ -407,6 +412,7 @@ void rdr_cube_destroy(rdr_cube* q) {
     if (q->ctx) { (void)hipSetDevice(q->ctx->device); (void)hipStreamSynchronize(q->ctx->stream); }
     if (q->d_vals) (void)hipFree(q->d_vals);
     if (q->d_axes) (void)hipFree(q->d_axes);
+    if (q->d_quad) (void)hipFree(q->d_quad);
     delete q;
 }
 
@@ -678,6 +684,59 @@ int rdr_cube_read(rdr_ctx* c, const rdr_cube* q, void* wet, void* hydro) {
 }
 
 // ---- zenith / projected ---------------------------------------------------------------------------
+// ---- corner-quad copy (cube_kernels.h): when, and how --------------------------------------------------------------------------
+static size_t quad_need_bytes(const rdr_cube* q, int* nblk) {
+    const int cpb = q->dtype == RDR_F32 ? Quad<float2>::CPB : Quad<double2>::CPB;
+    *nblk = (int)((q->nz - 1 + cpb - 1) / cpb);
+    return (size_t)(q->ny - 1) * (size_t)(q->nx - 1) * (size_t)*nblk * 128;
+}
+
+static int quad_build(rdr_ctx* c, const rdr_cube* q) {
+    if (q->d_quad) return RDR_OK;
+    int nblk = 0;
+    const size_t need = quad_need_bytes(q, &nblk);
+    HIPCHECK(c, hipMalloc(&q->d_quad, need));
+    q->quad_bytes = need; q->quad_nblk = nblk;
+    const int64_t parts = (int64_t)(need / 16);
+    const int g = grid_for(parts, 256, c->num_cus * 32);
+    if (q->dtype == RDR_F32) hipLaunchKernelGGL((quad_build_kernel<float2>), dim3(g), dim3(256), 0, c->stream, (const float2*)q->d_vals, (int)q->ny, (int)q->nx, (int)q->nz, nblk, (uint4*)q->d_quad);
+    else hipLaunchKernelGGL((quad_build_kernel<double2>), dim3(g), dim3(256), 0, c->stream, (const double2*)q->d_vals, (int)q->ny, (int)q->nx, (int)q->nz, nblk, (uint4*)q->d_quad);
+    HIPCHECK(c, hipGetLastError());
+    return RDR_OK;
+}
+
+// Policy of the automatic build: only for point sets and cubes large enough that the four-lines-per-point gather is what bounds
+// the call (>= 256 k points, a cube beyond 32 MB - smaller ones live in L2 / the Infinity Cache), only when the copy fits a quarter
+// of the free memory, and only from the SECOND such call on a cube: building costs about one query of 5 M points (one pass over
+// the cube, 5-8 x its bytes written), so a cube queried once never pays for it.  RAIDER_HIP_POINT_INDEX=0 never, =1 at the first call.
+static bool quad_wanted(rdr_ctx* c, const rdr_cube* q, int64_t n) {
+    if (q->d_quad) return true;
+    static const int env = []() { const char* e = std::getenv("RAIDER_HIP_POINT_INDEX"); return e ? std::atoi(e) : -1; }();
+    if (env == 0) return false;
+    const size_t cube_bytes = (size_t)q->ny * q->nx * q->nz * (q->dtype == RDR_F32 ? 8 : 16);
+    if (n < (1 << 18) || cube_bytes < ((size_t)32 << 20) || q->ny < 2 || q->nx < 2 || q->nz < 2) return false;
+    if (++q->big_point_calls < 2 && env != 1) return false;
+    int nblk; const size_t need = quad_need_bytes(q, &nblk);
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || need > free_b / 4) return false;
+    (void)c;
+    return true;
+}
+
+int rdr_cube_point_index(rdr_ctx* c, rdr_cube* q, int mode) {
+    if (!c || !q) return fail(c, RDR_ERR_INVALID, "rdr_cube_point_index: NULL argument");
+    HIPCHECK(c, hipSetDevice(c->device));
+    if (mode == 0) {
+        if (q->d_quad) { HIPCHECK(c, hipStreamSynchronize(c->stream)); HIPCHECK(c, hipFree(q->d_quad)); q->d_quad = nullptr; q->quad_bytes = 0; q->quad_nblk = 0; }
+        q->big_point_calls = 0;
+        return RDR_OK;
+    }
+    if (q->ny < 2 || q->nx < 2 || q->nz < 2) return fail(c, RDR_ERR_INVALID, "rdr_cube_point_index: the cube needs two nodes per axis");
+    return quad_build(c, q);
+}
+
+int64_t rdr_cube_point_index_bytes(const rdr_cube* q) { return q ? (int64_t)q->quad_bytes : -1; }
+
 int rdr_interp3(rdr_ctx* c, const rdr_cube* q, const double* pts, int64_t n, double* wet, double* hydro, int loc) {
     if (!c || !q || (n > 0 && (!pts || !wet || !hydro))) return fail(c, RDR_ERR_INVALID, "rdr_interp3: NULL argument");
     if (n == 0) return RDR_OK;
@@ -687,9 +746,18 @@ int rdr_interp3(rdr_ctx* c, const rdr_cube* q, const double* pts, int64_t n, dou
     rc = stage_out(c, SLOT_OUT0, wet, (size_t)n * 8, loc, &dw); if (rc) return rc;
     rc = stage_out(c, SLOT_OUT1, hydro, (size_t)n * 8, loc, &dh); if (rc) return rc;
     const int g = grid_for(n, 256, c->num_cus * 8);
+    const bool quad = quad_wanted(c, q, n);
+    if (quad) { rc = quad_build(c, q); if (rc) return rc; }
     {
         KTimer t(c, 2);
-        if (q->dtype == RDR_F32)
+        if (quad) {
+            if (q->dtype == RDR_F32)
+                hipLaunchKernelGGL((interp_points_quad_kernel<float2>), dim3(g), dim3(256), axes_smem(q), c->stream, make_view<float2>(q),
+                                   (const uint4*)q->d_quad, q->quad_nblk, (const double*)dp, n, (double*)dw, (double*)dh, (int)axes_fit_lds(q));
+            else
+                hipLaunchKernelGGL((interp_points_quad_kernel<double2>), dim3(g), dim3(256), axes_smem(q), c->stream, make_view<double2>(q),
+                                   (const uint4*)q->d_quad, q->quad_nblk, (const double*)dp, n, (double*)dw, (double*)dh, (int)axes_fit_lds(q));
+        } else if (q->dtype == RDR_F32)
             hipLaunchKernelGGL((interp_points_kernel<float2>), dim3(g), dim3(256), axes_smem(q), c->stream, make_view<float2>(q),
                                (const double*)dp, n, (double*)dw, (double*)dh, (int)axes_fit_lds(q));
         else

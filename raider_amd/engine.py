@@ -138,6 +138,12 @@ class Cube:
         return wet, hydro
 
     # ---- zenith / projected ------------------------------------------------------------------
+    def point_index(self, build=True):
+        """Build (or free) the corner-quad copy that serves large random point sets with one 128 B line per point instead of four
+        (rdr_cube_point_index); interp() builds it by itself on the second large call.  Returns the bytes it holds."""
+        check(self.ctx.lib.rdr_cube_point_index(self.ctx.handle, self.handle, 1 if build else 0), self.ctx.handle)
+        return int(self.ctx.lib.rdr_cube_point_index_bytes(self.handle))
+
     def interp(self, pts):
         """scipy RGI __call__ on both fields; pts[...,3] = (y,x,z).  Returns (wet, hydro) f64."""
         if _is_dev(pts):

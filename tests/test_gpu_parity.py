@@ -383,3 +383,52 @@ def test_dateline_scenes(R, case):
         assert np.isfinite(oh[0]).mean() > 0.95               # rays crossing the dateline keep finite delays
     np.testing.assert_allclose(wet, ow[0], rtol=0, atol=5 * TIGHT, equal_nan=True)
     np.testing.assert_allclose(hyd, oh[0], rtol=0, atol=5 * TIGHT, equal_nan=True)
+
+
+def test_point_index_gives_the_same_bits(R):
+    """Large random point sets on a cube beyond the caches read one 128 B line per point from the corner-quad copy instead of four from
+    the (y,x,z) cube (cube_kernels.h).  Same cell search, same weights, same summation order: the values must be IDENTICAL - f32 and f64
+    cubes, level counts that do and do not fill the last block, points on the last nodes / outside / NaN, descending axes."""
+    rng = np.random.default_rng(21)
+    for dt, shape in ((np.float32, (37, 41, 23)), (np.float32, (12, 9, 20)), (np.float32, (5, 6, 2)), (np.float64, (17, 19, 11)), (np.float64, (6, 5, 2))):
+        ny, nx, nz = shape
+        ys = np.sort(rng.uniform(-3, 9, ny))[::-1].copy(); xs = np.linspace(-7.0, 4.0, nx); zs = np.sort(rng.uniform(0, 9000, nz))
+        w = rng.normal(size=shape).astype(dt); h = rng.normal(size=shape).astype(dt)
+        cube = R.Cube(ys, xs, zs, w, h, order='yxz')
+        n = 20000
+        q = np.stack([rng.uniform(ys.min() - 0.2, ys.max() + 0.2, n), rng.uniform(-7.3, 4.3, n), rng.uniform(zs[0] - 50, zs[-1] + 50, n)], -1)
+        q[:7] = [[ys[0], xs[0], zs[0]], [ys[-1], xs[-1], zs[-1]], [ys[1], xs[2], zs[-1]], [ys[-1], xs[3], zs[0]], [np.nan, 0, 100], [0, 0, zs[-1] + 1e-9], [ys[2], xs[-1], zs[nz // 2]]]
+        a_w, a_h = cube.interp(q)
+        assert cube.ctx.lib.rdr_cube_point_index_bytes(cube.handle) == 0
+        nbytes = cube.point_index()
+        cpb = 3 if dt == np.float32 else 1
+        assert nbytes == (ny - 1) * (nx - 1) * -(-(nz - 1) // cpb) * 128
+        b_w, b_h = cube.interp(q)
+        assert np.array_equal(a_w, b_w, equal_nan=True) and np.array_equal(a_h, b_h, equal_nan=True)
+        assert np.isnan(a_w[4]) and np.isnan(a_w[5]) and np.isfinite(a_w[:4]).all() and 0.2 < np.isfinite(a_w).mean() < 1.0
+        assert cube.point_index(build=False) == 0
+        c_w, _ = cube.interp(q)
+        assert np.array_equal(a_w, c_w, equal_nan=True)
+
+
+def test_point_index_is_built_by_the_second_large_call(R):
+    import torch
+    rng = np.random.default_rng(3)
+    ny, nx, nz = 210, 200, 110                                             # 37 MB as float2: beyond the 32 MB threshold
+    ys = np.linspace(30, 40, ny); xs = np.linspace(-120, -110, nx); zs = np.round(-100 + 30000 * np.linspace(0, 1, nz) ** 2, 3)
+    dev = torch.device('cuda:0')
+    w = torch.randn((ny, nx, nz), dtype=torch.float32, device=dev); h = torch.randn_like(w)
+    cube = R.Cube(ys, xs, zs, w, h, order='yxz')
+    held = lambda: cube.ctx.lib.rdr_cube_point_index_bytes(cube.handle)
+    small = torch.from_numpy(np.stack([rng.uniform(30, 40, 1000), rng.uniform(-120, -110, 1000), rng.uniform(0, 9000, 1000)], -1)).to(dev)
+    n = 300000
+    big = torch.from_numpy(np.stack([rng.uniform(30, 40, n), rng.uniform(-120, -110, n), rng.uniform(0, 9000, n)], -1)).to(dev)
+    cube.interp(small); cube.interp(small); cube.interp(small)
+    assert held() == 0                                                       # small point sets never trigger it
+    r1 = cube.interp(big)
+    assert held() == 0                                                       # a cube queried once never pays for the copy
+    r2 = cube.interp(big)
+    assert held() == (ny - 1) * (nx - 1) * -(-(nz - 1) // 3) * 128
+    r3 = cube.interp(small)
+    torch.cuda.synchronize()
+    assert torch.equal(r1[0], r2[0]) and torch.equal(r1[1], r2[1]) and torch.isfinite(r3[0]).all()

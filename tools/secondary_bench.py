@@ -58,9 +58,18 @@ res['blend_kernel'] = dict(what='configs[4]: blend of two 1000x1000x50 f32 epoch
 m = a.blend(0.25, b, 0.75)
 npt = 5_000_000
 pts = torch.from_numpy(np.stack([rng.uniform(-1.4e6, 1.4e6, npt), rng.uniform(-1.4e6, 1.4e6, npt), rng.uniform(0, 4000, npt)], -1)).to(dev)
+m.point_index(build=False)
+import os  # noqa: E402
+os.environ['RAIDER_HIP_POINT_INDEX'] = '0'          # (read once by the library: set before the first large call; the copy is built explicitly below)
 t = timed(lambda: m.interp(pts))
-res['interp_points_kernel'] = dict(what='configs[4]: 5 M random station points on the blended 1000x1000x50 f32 cube', units=npt, unit='points', bytes_per_unit=104,
+res['interp_points_kernel'] = dict(what='configs[4]: 5 M random station points on the blended 1000x1000x50 f32 cube, gathered from the (y,x,z) cube', units=npt, unit='points', bytes_per_unit=104,
                                    wall_ms=t * 1e3, reps=REPS + 1)
+tb = timed(lambda: (m.point_index(build=False), m.point_index()), reps=2)
+res['quad_build_kernel'] = dict(what='corner-quad copy of the 1000x1000x50 f32 cube (built once per cube)', units=cells, unit='cells', bytes_per_unit=8 + 128.0 / 3.0,
+                                wall_ms=tb * 1e3, reps=3, note='wall time includes hipMalloc / hipFree of the 2.2 GB copy')
+t = timed(lambda: m.interp(pts))
+res['interp_points_quad_kernel'] = dict(what='configs[4]: the same 5 M points gathered from the corner-quad copy (one 128 B line per point)', units=npt, unit='points', bytes_per_unit=104,
+                                        wall_ms=t * 1e3, reps=REPS + 1)
 del a, b, m, pts
 # ---- cube producer: 300 x 300 columns, 137 model levels -> 145 levels -------------------------------------------------------------
 from raider_amd.weather import cubes_from_model_levels, MODEL_LEVEL_HEIGHTS  # noqa: E402
