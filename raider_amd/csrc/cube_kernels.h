@@ -323,10 +323,12 @@ __global__ __launch_bounds__(256) void build_cube_kernel(CubeView<T2> c, LccPara
         const T2* col10 = col00 + (int64_t)c.nx * c.nz;
         const T2* col11 = col10 + c.nz;
         // U heights per trip: their 8 U corner-pair loads are issued back to back (clamped, hence unconditional, addresses - a
-        // conditional load would fence the batch), then the arithmetic, then the stores.  One height per trip left the kernel
-        // waiting out a full L2 round trip per height (the stores may alias the cube as far as the compiler knows, so it never
-        // hoisted the next height's loads above them): 0.28 ms for the 640 MB of config 2, a third of the HBM write rate.
-        // The outputs are written once and not read back here: non-temporal stores keep them from evicting the cube from L2.
+        // conditional load would fence the batch), then the arithmetic, then the stores; the outputs are written once and not read
+        // back here: non-temporal stores.  Measured on config 2 (1000 x 1000 nodes x 40 heights, f64 cube: 640 MB out): 0.267 ms
+        // against 0.276 with one height per trip - the limiter is neither latency nor the write side (tools/probes/write_probe.hip:
+        // this very store pattern alone runs at 5.4-5.8 TB/s = 0.115 ms) but the eight 16 B corner loads per point: 128 B per
+        // point through the vector L1's 64 B/clk/CU return path is 0.15 ms by itself (profiles/r03_secondary.json: VALU issue 0.20,
+        // HBM 0.34 of peak - neither bound).  Fewer corner bytes per point would need the tile's cube footprint staged in LDS.
         constexpr int U = sizeof(T2) == 8 ? 4 : 2;
         for (int64_t iz = z0; iz < z1; iz += U) {
             T2 v[U][8];

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""gpurun_out/secondary (tools/profile_secondary.sh) -> profiles/r02_secondary.json + r02_secondary_kernel_stats.txt: per secondary
+"""gpurun_out/secondary (tools/profile_secondary.sh) -> profiles/r03_secondary.json + r03_secondary_kernel_stats.txt: per secondary
 kernel the rocprofv3 average duration, the SURVEY 8(d) algorithmic bytes and the resulting rate against the 8 TB/s HBM peak."""
 import csv
 import glob
@@ -13,7 +13,7 @@ src = REPO / 'gpurun_out' / 'secondary'
 line = [ln for ln in (src / 'bench.json').read_text().splitlines() if ln.startswith('{')][-1]
 res = json.loads(line)
 stats = max(glob.glob(str(src / 'kt') + '/**/*kernel_stats.csv', recursive=True), key=lambda f: Path(f).stat().st_mtime)   # (gpurun merges runs: newest)
-subprocess.run([sys.executable, str(REPO / 'tools' / 'rocprof_summary.py'), stats, str(REPO / 'profiles' / 'r02_secondary_kernel_stats.txt'),
+subprocess.run([sys.executable, str(REPO / 'tools' / 'rocprof_summary.py'), stats, str(REPO / 'profiles' / 'r03_secondary_kernel_stats.txt'),
                 'tools/secondary_bench.py: configs 2 / 5 sizes, producer, orbit look vectors'], check=True, stdout=subprocess.DEVNULL)
 rows = list(csv.DictReader(open(stats)))
 for k, d in res.items():
@@ -45,6 +45,42 @@ for k, d in res.items():
         d['hbm_read_bytes'] = fr * 2.0 * 1024; d['hbm_write_bytes'] = wr * 1024
         d['hbm_measured_GBps'] = (d['hbm_read_bytes'] + d['hbm_write_bytes']) / (d['rocprof_avg_us'] * 1e-6) / 1e9
         d['hbm_measured_frac'] = d['hbm_measured_GBps'] / 8000.0
-(REPO / 'profiles' / 'r02_secondary.json').write_text(json.dumps(res, indent=1) + '\n')
+# issue side (tools/profile_secondary.sh, two SQ passes): VALU instructions per launch against the issue peak of 256 CUs x 4 SIMDs x 2.4 GHz / 4
+# cycles per wave64 instruction; VALU-busy = SQ_ACTIVE_INST_VALU x 4 / SQ_BUSY_CYCLES-normalised wave cycles is not defined across kernels
+# of different occupancy, so the two robust figures are kept: instructions issued / issue slots of the launch, and instructions per unit
+VALU_PEAK = 256 * 4 * 2.4e9 / 4
+
+
+def sq(sub):
+    out = {}
+    for f in glob.glob(str(src / sub) + '/**/*counter_collection.csv', recursive=True):
+        for r in csv.DictReader(open(f)):
+            out.setdefault((r['Kernel_Name'], r['Counter_Name']), []).append(float(r['Counter_Value']))
+    return out
+
+
+sqc = {}
+for sub in ('sq1', 'sq2'):
+    for (name, cn), vals in sq(sub).items():
+        sqc.setdefault(name, {})[cn] = sorted(vals)[len(vals) // 2]
 for k, d in res.items():
-    print(f"{k:24s} {d.get('rocprof_avg_us', float('nan')):10.1f} us  {d.get('units_per_s', 0)/1e9:8.2f} G {d['unit']}/s  {d.get('algorithmic_GBps', 0):9.1f} GB/s  = {d.get('frac_of_hbm_peak_8TBps', 0):.3f} of 8 TB/s;  measured HBM {d.get('hbm_measured_GBps', float('nan')):8.1f} GB/s = {d.get('hbm_measured_frac', float('nan')):.3f}")
+    hit = [v for name, v in sqc.items() if k in name]
+    if not hit or 'rocprof_avg_us' not in d:
+        continue
+    v = hit[0]
+    t = d['rocprof_avg_us'] * 1e-6
+    if 'SQ_INSTS_VALU' in v:
+        d['valu_instr_per_launch'] = v['SQ_INSTS_VALU']
+        d['valu_instr_per_unit'] = v['SQ_INSTS_VALU'] * 64.0 / d['units']          # lane-instructions per unit
+        d['valu_issue_frac'] = v['SQ_INSTS_VALU'] / t / VALU_PEAK
+    if 'SQ_ACTIVE_INST_VALU' in v and 'SQ_BUSY_CYCLES' in v and v['SQ_BUSY_CYCLES'] > 0:
+        d['valu_active_cycles_over_busy_cycles'] = v['SQ_ACTIVE_INST_VALU'] / v['SQ_BUSY_CYCLES']
+    for cn, key in (('SQ_INSTS_VMEM_RD', 'vmem_rd_instr_per_launch'), ('SQ_INSTS_VMEM_WR', 'vmem_wr_instr_per_launch'), ('SQ_INSTS_SALU', 'salu_instr_per_launch'),
+                    ('SQ_WAVES', 'waves_per_launch'), ('SQ_WAVE_CYCLES', 'wave_cycles_per_launch')):
+        if cn in v:
+            d[key] = v[cn]
+    if 'hbm_read_bytes' in d:
+        d['hbm_bytes_per_unit'] = (d['hbm_read_bytes'] + d['hbm_write_bytes']) / d['units']
+(REPO / 'profiles' / 'r03_secondary.json').write_text(json.dumps(res, indent=1) + '\n')
+for k, d in res.items():
+    print(f"{k:24s} {d.get('rocprof_avg_us', float('nan')):10.1f} us  {d.get('units_per_s', 0)/1e9:8.2f} G {d['unit']}/s  {d.get('algorithmic_GBps', 0):9.1f} GB/s  = {d.get('frac_of_hbm_peak_8TBps', 0):.3f} of 8 TB/s;  measured HBM {d.get('hbm_measured_GBps', float('nan')):8.1f} GB/s = {d.get('hbm_measured_frac', float('nan')):.3f} ({d.get('hbm_bytes_per_unit', float('nan')):.1f} B/{d['unit'][:-1]});  VALU issue {d.get('valu_issue_frac', float('nan')):.3f} ({d.get('valu_instr_per_unit', float('nan')):.0f} lane-instr/{d['unit'][:-1]})")
