@@ -61,6 +61,8 @@ extern "C" {
 #define RDR_FLAG_BAD_HEIGHT 32    /* per-ray heights: some rays->hts[i] lies below the `ht` the batch's level table was built for:
                                     * the outputs are NaN and synchronous calls return RDR_ERR_INVALID.                        */
 
+#define RDR_FLAG_NAN_OUTPUT 64    /* rdr_raytrace_slices: some delay of the slice is NaN (what delay.py:187 scans the result for) */
+
 typedef struct rdr_ctx rdr_ctx;
 typedef struct rdr_cube rdr_cube;
 
@@ -114,6 +116,11 @@ int rdr_device_info(rdr_ctx* ctx, char* name, int name_len, int* compute_units, 
  * events and returns how many launches of kernel kind `which` (0 ray prepass, 1 ray march, 2 interp,
  * 3 other) were recorded and their summed duration in ms. */
 int rdr_set_profiling(rdr_ctx* ctx, int on);
+/* Page-locked host memory for result arrays (hipHostMalloc): downloads into it run at the link rate, without first-touch page
+ * faults, and asynchronously - rdr_raytrace_slices overlaps them with the kernels of the next slices.  The Python layer keeps a
+ * recycling pool of such blocks behind the delay cubes tropo_delay returns (raider_amd/_pinned.py). */
+int rdr_host_alloc(int64_t bytes, void** out);
+int rdr_host_free(void* p);
 /* Ray pass 1 hands each ray's record to pass 2 through an HBM workspace of 232 B per ray (29 doubles: the degree-5 ray
  * polynomials h(u), lat(u), lon(u), the degree-7 level-crossing polynomial, the ray-length scale and the two crossings of
  * the first level; 3.7 GB for 16 M rays).  The few rays the static classification sends to the generic-geodesy kernels

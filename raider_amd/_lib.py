@@ -19,7 +19,7 @@ RDR_F32, RDR_F64 = 0, 1
 RDR_HOST, RDR_DEVICE = 0, 1
 ORIGIN_GRID, ORIGIN_LLH, ORIGIN_XYZ = 0, 1, 2
 LOS_VEC, LOS_INC_HD, LOS_INC_HD_SCALAR, LOS_ZENITH = 0, 1, 2, 3
-FLAG_ANY_NAN, FLAG_ANY_FINITE, FLAG_FIRST_NOT_BELOW, FLAG_LAST_NOT_ABOVE, FLAG_DIVERGED, FLAG_BAD_HEIGHT = 1, 2, 4, 8, 16, 32
+FLAG_ANY_NAN, FLAG_ANY_FINITE, FLAG_FIRST_NOT_BELOW, FLAG_LAST_NOT_ABOVE, FLAG_DIVERGED, FLAG_BAD_HEIGHT, FLAG_NAN_OUTPUT = 1, 2, 4, 8, 16, 32, 64
 
 c_dp = C.POINTER(C.c_double)
 c_ip = C.POINTER(C.c_int32)
@@ -56,6 +56,8 @@ SYMBOLS = [
     ('rdr_synchronize', C.c_int, [_VP]),
     ('rdr_device_info', C.c_int, [_VP, C.c_char_p, C.c_int, C.POINTER(C.c_int), c_lp]),
     ('rdr_set_profiling', C.c_int, [_VP, C.c_int]),
+    ('rdr_host_alloc', C.c_int, [C.c_int64, C.POINTER(_VP)]),
+    ('rdr_host_free', C.c_int, [_VP]),
     ('rdr_set_workspace_limit', C.c_int, [_VP, C.c_int64]),
     ('rdr_set_side_capacity', C.c_int, [_VP, C.c_int64]),
     ('rdr_generic_ray_count', C.c_int64, [_VP]),

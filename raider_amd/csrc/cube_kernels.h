@@ -87,12 +87,25 @@ __global__ void pack_partition_kernel(const unsigned long long* __restrict__ bit
         out[k] = k < K ? __longlong_as_double((long long)bits[k]) : (((f >> (k - K)) & 1) ? 1.0 : 0.0);
 }
 
+// np.isnan(out).any() per slice (delay.py:187) on the device, before the outputs leave it: a[0 .. n) and b[0 .. n) are consecutive
+// slices of `per` values each; slice s gets RDR_FLAG_NAN_OUTPUT (64) or-ed into flags[s] when either field holds a NaN.
+__global__ __launch_bounds__(256) void nan_scan_kernel(const double* __restrict__ a, const double* __restrict__ b, int64_t n, int64_t per,
+                                                       int* __restrict__ flags) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double x = a[i], y = b[i];
+        if ((x != x) | (y != y)) {
+            int* f = flags + i / per;
+            if (!(__atomic_load_n(f, __ATOMIC_RELAXED) & 64)) atomicOr(f, 64);
+        }
+    }
+}
+
 __global__ void unpack_partition_kernel(const double* __restrict__ in, int K, unsigned long long* __restrict__ bits, int* __restrict__ flags) {
     for (int k = threadIdx.x; k < K; k += blockDim.x) bits[k] = (unsigned long long)__double_as_longlong(in[k]);
     if (threadIdx.x == 0) {
         int f = 0;
         for (int b = 0; b < 4; ++b) if (in[K + b] > 0.0) f |= 1 << b;
-        *flags = f | (*flags & 32);       // (a bad per-ray height seen by THIS rank's pass 1 keeps poisoning its outputs)
+        *flags = f | (*flags & (32 | 64));       // (a bad per-ray height seen by THIS rank's pass 1 keeps poisoning its outputs)
     }
 }
 

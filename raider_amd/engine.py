@@ -297,6 +297,10 @@ class Cube:
             K = np.zeros(S, dtype=np.int32); nparts = np.zeros((S, ld), dtype=np.int32); flags = np.zeros(S, dtype=np.int32)
             check(self.ctx.lib.rdr_raytrace_slices(self.ctx.handle, self.handle, C.byref(rays.struct), ptr(hts), S, int(rays.slices > 0), float(zref),
                                                    float(max_seg), ptr(wet), ptr(hyd), ptr(K), ptr(nparts), ld, ptr(flags)), self.ctx.handle)
+            # RDR_FLAG_NAN_OUTPUT (np.isnan(result).any() per slice, scanned on the device before the download) is reported apart
+            # from the partition flags, which stay what rdr_raytrace returns for the slice
+            self.last_nan_output = (flags & L.FLAG_NAN_OUTPUT) != 0
+            flags &= ~np.int32(L.FLAG_NAN_OUTPUT)
             return wet, hyd, K, nparts, flags
         check(self.ctx.lib.rdr_raytrace_slices(self.ctx.handle, self.handle, C.byref(rays.struct), ptr(hts), S, int(rays.slices > 0), float(zref),
                                                float(max_seg), ptr(wet), ptr(hyd), None, None, ld, None), self.ctx.handle)

@@ -51,8 +51,9 @@ def test_binary_carries_the_hash_of_the_tree_it_was_built_from(built, tmp_path, 
 
 def test_rays_struct_layout_matches_header(built):
     from raider_amd import _lib
-    # 8 + 4 + 4 + 8 + 8 + 8*8 + 8 + 8 + 4 + 4
-    assert ctypes.sizeof(_lib.RdrRays) == 120
+    # 8 + 4 + 4 + 8 + 8 + 8*8 + 8 + 8 + 4 + 4 + 8 (hts, round 3)
+    assert ctypes.sizeof(_lib.RdrRays) == 128
+    assert _lib.RdrRays.hts.offset == 120 and _lib.RdrRays.loc.offset == 112
 
 
 def test_no_gpu_fails_loudly(built):
