@@ -606,11 +606,12 @@ def test_orbit_rays_device_and_host_routes_agree(monkeypatch):
     assert one._torch_device is not None and one.slices == 0
 
 
-def test_large_result_cubes_pinned_pipelined_and_nan_scanned(R, tmp_path):
+def test_large_result_cubes_pinned_pipelined_and_nan_scanned():
     """Host API on a large job: the delay cubes come back in recycled page-locked memory (raider_amd/_pinned.py), downloaded slice
     group by slice group while the next groups are integrated (rdr_raytrace_slices), and np.isnan(result).any() (delay.py:187) is
     answered by the device-side scan - same bits as the slice-by-slice path through plain arrays, NaNs found where they are."""
     import gc
+    import raider_amd as R
     from raider_amd import _pinned
     from raider_amd.delay import _build_cube_ray, _nan_hints
     from raider_amd.delayFcns import interpolators_from_cube
