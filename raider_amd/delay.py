@@ -297,16 +297,17 @@ def _cube_of(interpolators):
     # cached upload, valid only for the SAME pair of interpolators still holding the SAME value arrays (an interpolator whose
     # `.values` were replaced, or paired with a different partner, is uploaded again)
     last = interpolators[-1]
-    key = (id(last), id(first.values), id(last.values), np.shape(first.values))
+    fv, lv = first.values, last.values
     cached = getattr(first, '_raider_amd_cube', None)
-    if cached is not None and cached[0] == key:
-        return cached[1], list(range(len(interpolators)))
+    # (the cache entry HOLDS the partner and the two value arrays it was made from, so `is` cannot be fooled by a recycled id())
+    if cached is not None and cached[0] is last and cached[1] is fv and cached[2] is lv and cached[3] == np.shape(fv):
+        return cached[4], list(range(len(interpolators)))
     grid = first.grid
-    a = np.asarray(first.values)
-    b = np.asarray(last.values)
+    a = np.asarray(fv)
+    b = np.asarray(lv)
     cube = Cube(grid[0], grid[1], grid[2], a, b.astype(a.dtype, copy=False), order='yxz')
     try:
-        first._raider_amd_cube = (key, cube)
+        first._raider_amd_cube = (last, fv, lv, np.shape(fv), cube)
     except AttributeError:
         pass
     return cube, list(range(len(interpolators)))
@@ -450,7 +451,10 @@ def _build_cube_ray(xpts, ypts, zpts, los, model_crs, pts_crs, interpolators, ou
     pass 1 = build_ray's per-level ray lengths reduced to the slice maximum (-> nParts, delay.py:283),
     pass 2 = Newton level intersections + ECEF->geodetic + trilinear gather + trapezoid, per ray."""
     cube, fields = _cube_of(interpolators)
-    if not _is_4326(model_crs) and not _apply_model_crs(cube, model_crs):
+    if _is_4326(model_crs):
+        if cube.projection is not None:
+            cube.clear_projection()                        # (a cached cube that served a projected model before)
+    elif not _apply_model_crs(cube, model_crs):
         raise NotImplementedError('ray tracing needs the weather cube on an EPSG:4326 lat/lon grid, a Lambert-conformal-conic grid '
                                   f'(HRRR) or a polar-stereographic grid (HRRR-AK); got {model_crs!r}')
     xpts = np.asarray(xpts, dtype=np.float64)
@@ -470,20 +474,36 @@ def _build_cube_ray(xpts, ypts, zpts, los, model_crs, pts_crs, interpolators, ou
         # loop below, but a production job (20 heights x 1e4-1e5 rays) fills the GPU instead of a tenth of it
         from ._lib import FLAG_ANY_FINITE, FLAG_ANY_NAN
         any_nan = False
-        for s0 in range(0, zpts.size, 512):
-            zz = np.ascontiguousarray(zpts[s0:s0 + 512], dtype=np.float64)
+        # slices per call from a byte budget, not a fixed count: a batch holds per ray and slice its look vector (orbit-based ones
+        # depend on the height: 24 B, plus the 24 B target they were solved from) and 16 B of delays on the device, next to the 232 B
+        # ray records the library chunks by itself.  RAIDER_HIP_SLICE_BUDGET_BYTES (default 8 GiB); a batch the device still cannot
+        # hold is halved until it fits.
+        n_per = max(1, xpts.size * ypts.size)
+        budget = int(os.environ.get('RAIDER_HIP_SLICE_BUDGET_BYTES', 8 << 30))
+        chunk = int(min(512, max(1, budget // (n_per * 64))))
+        s0 = 0
+        while s0 < zpts.size:
+            zz = np.ascontiguousarray(zpts[s0:s0 + chunk], dtype=np.float64)
             logger.info(f'Processing slices {s0 + 1}-{s0 + zz.size} / {len(zpts)}')
-            rays = los.ray_batch_slices(xpts, ypts, zz)
-            if rays._torch_device is None:
-                _, _, K, _nparts, flags = cube.raytrace_slices(rays, zz, MAX_TROPO_HEIGHT, MAX_SEGMENT_LENGTH,
-                                                               out=(outputArrs[0][s0:s0 + zz.size], outputArrs[1][s0:s0 + zz.size]))
-                any_nan = any_nan or bool(cube.last_nan_output.any())
-            else:           # a device-resident batch (orbit-based look vectors made on the GPU): device outputs, one download per field
-                import torch
-                dw, dh, K, _nparts, flags = cube.raytrace_slices(rays, zz, MAX_TROPO_HEIGHT, MAX_SEGMENT_LENGTH)
-                any_nan = any_nan or bool(cube.last_nan_output.any())
-                torch.from_numpy(outputArrs[0][s0:s0 + zz.size]).copy_(dw); torch.from_numpy(outputArrs[1][s0:s0 + zz.size]).copy_(dh)
-                del dw, dh
+            try:
+                rays = los.ray_batch_slices(xpts, ypts, zz)
+                if rays._torch_device is None:
+                    _, _, K, _nparts, flags = cube.raytrace_slices(rays, zz, MAX_TROPO_HEIGHT, MAX_SEGMENT_LENGTH,
+                                                                   out=(outputArrs[0][s0:s0 + zz.size], outputArrs[1][s0:s0 + zz.size]))
+                    any_nan = any_nan or bool(cube.last_nan_output.any())
+                else:           # a device-resident batch (orbit-based look vectors made on the GPU): device outputs, one download per field
+                    import torch
+                    dw, dh, K, _nparts, flags = cube.raytrace_slices(rays, zz, MAX_TROPO_HEIGHT, MAX_SEGMENT_LENGTH)
+                    any_nan = any_nan or bool(cube.last_nan_output.any())
+                    torch.from_numpy(outputArrs[0][s0:s0 + zz.size]).copy_(dw); torch.from_numpy(outputArrs[1][s0:s0 + zz.size]).copy_(dh)
+                    del dw, dh
+            except (RuntimeError, MemoryError) as exc:
+                if chunk == 1 or 'memory' not in str(exc).lower():
+                    raise
+                chunk = max(1, chunk // 2)                                 # the device could not hold the batch: smaller ones
+                logger.info(f'slice batch did not fit the device ({exc}); continuing with {chunk} slices per call')
+                continue
+            s0 += zz.size
             for hh, ht in enumerate(zz):                                   # the reference's failure modes, in slice order
                 if K[hh] == 0:
                     if ht == zpts[-1]:                                     # delay.py:276-277: the slice stays zero (the kernels wrote 0)

@@ -29,14 +29,11 @@ class FieldInterpolator:
 
     @staticmethod
     def _sig(pts):
-        """Content key of a point set: shape, dtype and a checksum over EVERY coordinate (two differently weighted sums, so that
-        a caller who edits the array in place between the wet and the hydro call is never served the other call's result)."""
-        flat = np.ascontiguousarray(pts).reshape(-1)
-        n = flat.size
-        if n == 0:
-            return (pts.shape, pts.dtype.str, 0.0, 0.0)
-        v = flat.view(np.uint64).astype(np.float64)          # bit patterns: NaNs and signed zeros take part too
-        return (pts.shape, pts.dtype.str, float(v.sum()), float(np.dot(v, np.arange(1, n + 1, dtype=np.float64) % 8191.0)))
+        """Content key of a point set: shape, dtype and an exact 128-bit digest of its bytes - a caller who edits the array in place
+        (or hands over a different one) between the wet and the hydro call is never served the other call's result."""
+        import hashlib
+        flat = np.ascontiguousarray(pts)
+        return (pts.shape, pts.dtype.str, hashlib.blake2b(flat.reshape(-1).view(np.uint8), digest_size=16).digest())
 
     def __call__(self, xi):
         """Both fields are gathered in one kernel launch; the sibling interpolator reuses the result when it

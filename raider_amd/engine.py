@@ -338,10 +338,10 @@ class Rays:
             import torch
             if arr.dtype != torch.float64:
                 raise TypeError(f'ray arrays must be float64 (got {arr.dtype} for {field})')
-            if self._torch_device is not None and arr.device != self._torch_device:
-                raise ValueError(f'ray arrays live on different devices ({self._torch_device} and {arr.device})')
             if not arr.is_cuda:
-                arr = arr.numpy()                      # a CPU tensor is a host array
+                arr = arr.numpy()                      # a CPU tensor is a host array (uploaded below when the batch lives on a GPU)
+            elif self._torch_device is not None and arr.device != self._torch_device:
+                raise ValueError(f'ray arrays live on different devices ({self._torch_device} and {arr.device})')
             else:
                 if self._has_host:
                     self._upload_host_fields(arr.device)

@@ -72,8 +72,23 @@ def cut_times(times, ref_time, pad):
     return np.abs(diff) < pad
 
 
+def read_shelve(filename):
+    """losreader.py:399-426: the state vectors of an isce2 shelve (`shelve.open(filename)['frame'].orbit.stateVectors`, each with
+    .time / .position / .velocity).  Unpickling the frame needs the classes it was pickled from - isce2's, when isce2 wrote it."""
+    import shelve
+    with shelve.open(str(filename), 'r') as db:
+        frame = db['frame']
+    vectors = list(frame.orbit.stateVectors)
+    if not vectors:
+        raise ValueError('read_shelve: the file has not statevectors')
+    t = np.array([sv.time for sv in vectors])
+    pos = np.array([[float(v) for v in sv.position[:3]] for sv in vectors], dtype=np.float64)
+    vel = np.array([[float(v) for v in sv.velocity[:3]] for sv in vectors], dtype=np.float64)
+    return t, pos[:, 0].copy(), pos[:, 1].copy(), pos[:, 2].copy(), vel[:, 0].copy(), vel[:, 1].copy(), vel[:, 2].copy()
+
+
 def get_sv(los_file, ref_time, pad):
-    """losreader.py:319-371 (text file, else ESA orbit file(s); the isce2 shelve branch is not supported)."""
+    """losreader.py:319-371: a 7-column text file, else ESA orbit file(s), else an isce2 shelve."""
     try:
         svs = read_txt_file(los_file)
     except (ValueError, TypeError, OSError, IsADirectoryError):
@@ -89,7 +104,13 @@ def get_sv(los_file, ref_time, pad):
             parts = [read_ESA_Orbit_file(f) for f in files]
             svs = [np.concatenate([p[k] for p in parts]) for k in range(7)]
         except Exception:
-            raise ValueError(f'get_sv: I cannot parse the statevector file {los_file}')
+            try:
+                svs = list(read_shelve(los_file))
+            except (ImportError, AttributeError) as exc:      # a shelve all right, but its pickled classes cannot be rebuilt here
+                raise ValueError(f'get_sv: {los_file} looks like an isce2 shelve, but its objects cannot be unpickled without the package '
+                                 f'that wrote them ({exc})')
+            except Exception:
+                raise ValueError(f'get_sv: I cannot parse the statevector file {los_file}')
     if ref_time:
         idx = cut_times(svs[0], ref_time, pad=pad)
         svs = [d[idx] for d in svs]

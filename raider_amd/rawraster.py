@@ -199,7 +199,27 @@ def rio_open(path, userNDV=None, band=None):
 _ENVI_CODE = {'uint8': 1, 'int16': 2, 'int32': 3, 'float32': 4, 'float64': 5, 'complex64': 6, 'complex128': 9, 'uint16': 12, 'uint32': 13, 'int64': 14, 'uint64': 15}
 
 
-def write_envi(array, path, nodata=None, geotransform=None, description=None):
+def _envi_map_info(proj, x0, y0, dx, dy):
+    """The header's `map info` for the raster's CRS: geographic WGS 84 (None / EPSG:4326), a WGS 84 UTM zone (EPSG:326xx / 327xx),
+    or None when the CRS has no ENVI spelling known here (the header then says nothing rather than something wrong)."""
+    code = None
+    if proj is None:
+        code = 4326
+    else:
+        txt = str(getattr(proj, 'to_epsg', lambda: None)() or proj).strip().upper().replace('EPSG:', '')
+        if txt.isdigit():
+            code = int(txt)
+        elif 'WGS 84' in txt and 'UTM' not in txt and 'PROJ' not in txt.replace('PROJCS', 'PROJ') and ('GEOGCS' in txt or 'GEOGCRS' in txt):
+            code = 4326
+    tie = f'1, 1, {x0:.15g}, {y0:.15g}, {abs(dx):.15g}, {abs(dy):.15g}'
+    if code == 4326:
+        return f'map info = {{Geographic Lat/Lon, {tie}, WGS-84}}'
+    if code is not None and (32601 <= code <= 32660 or 32701 <= code <= 32760):
+        return f'map info = {{UTM, {tie}, {code % 100}, {"North" if code < 32700 else "South"}, WGS-84}}'
+    return None
+
+
+def write_envi(array, path, nodata=None, geotransform=None, description=None, proj=None):
     """One band as an ENVI raster: `<path>` flat binary (native little-endian) + `<path with .hdr>` - the `fmt='ENVI'` product of
     utilFcns.writeArrayToRaster (utilFcns.py:257-304) without GDAL.  geotransform: GDAL's 6 numbers (x0, dx, 0, y0, 0, dy); written as
     the header's `map info` (pixel-corner tie point, as GDAL writes it)."""
@@ -217,7 +237,11 @@ def write_envi(array, path, nodata=None, geotransform=None, description=None):
         x0, dx, rx, y0, ry, dy = (float(v) for v in geotransform)
         if rx != 0.0 or ry != 0.0:
             raise ValueError('rotated geotransforms have no ENVI map info')
-        hdr.append(f'map info = {{Geographic Lat/Lon, 1, 1, {x0:.15g}, {y0:.15g}, {abs(dx):.15g}, {abs(dy):.15g}, WGS-84}}')
+        mi = _envi_map_info(proj, x0, y0, dx, dy)
+        if mi is not None:
+            hdr.append(mi)
+        elif isinstance(proj, str) and ('[' in proj):                    # a WKT: GDAL reads it back from this key
+            hdr.append(f'coordinate system string = {{{proj}}}')
     if nodata is not None:
         hdr.append(f'data ignore value = {float(nodata):.15g}')
     hdr_path = path.with_suffix('.hdr') if path.suffix else Path(str(path) + '.hdr')

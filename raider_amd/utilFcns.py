@@ -158,7 +158,7 @@ def writeArrayToRaster(array, path, noDataValue=0.0, fmt='ENVI', proj=None, gt=N
     if str(fmt).upper() != 'ENVI':
         raise ImportError(f'writing {fmt} rasters needs rasterio, which is not installed (ENVI is written without it)')
     from .rawraster import write_envi
-    write_envi(array.astype(dtype), path, nodata=noDataValue, geotransform=gt)
+    write_envi(array.astype(dtype), path, nodata=noDataValue, geotransform=gt, proj=proj)
 
 
 def writeDelays(aoi, wetDelay, hydroDelay, wet_path, hydro_path=None, outformat=None, ndv=0.0):

@@ -227,3 +227,67 @@ def test_cube_file_variables_are_read_lazily(tmp_path):
     assert _has_nan(big) and _has_nan(big[1::2]) and _has_nan(big.astype(np.float32)) and not _has_nan(np.zeros(5))
     big[33, 7, 9] = np.inf
     assert not _has_nan(big)
+
+
+class _SV:        # (module level: picklable)
+    def __init__(self, time, position, velocity):
+        self.time, self.position, self.velocity = time, position, velocity
+
+
+class _Holder:
+    pass
+
+
+def test_get_sv_reads_an_isce2_style_shelve(tmp_path):
+    """losreader.py:360-362,399-426: the last resort of get_sv is a shelve holding `frame.orbit.stateVectors`."""
+    import datetime
+    import shelve
+    from raider_amd import orbits
+    t0 = datetime.datetime(2020, 1, 30, 13, 52, 45)
+    frame = _Holder(); frame.orbit = _Holder()
+    frame.orbit.stateVectors = [_SV(t0 + datetime.timedelta(seconds=10 * i), [7.0e6 + i, 1.0 * i, -2.0 * i], [1.0, 7.5e3 + i, 0.5]) for i in range(-70, 71)]
+    path = tmp_path / 'frame_shelve'
+    with shelve.open(str(path), 'c') as db:
+        db['frame'] = frame
+    t, x, y, z, vx, vy, vz = orbits.get_sv(str(path), t0, 600)
+    assert len(t) == 119 and t[0] == t0 - datetime.timedelta(seconds=590) and x[0] == 7.0e6 - 59 and vy[-1] == 7.5e3 + 59   # cut to |dt| < pad
+    orb = orbits.Orbit(t, np.stack([x, y, z], -1), np.stack([vx, vy, vz], -1))
+    assert orb.time.size == 119
+    empty = _Holder(); empty.orbit = _Holder(); empty.orbit.stateVectors = []
+    with shelve.open(str(tmp_path / 'empty_shelve'), 'c') as db:
+        db['frame'] = empty
+    with pytest.raises(ValueError, match='cannot parse'):
+        orbits.get_sv(str(tmp_path / 'empty_shelve'), t0, 600)
+
+
+def test_hand_over_cache_key_is_an_exact_digest():
+    """the wet -> hydro hand-over cache of FieldInterpolator must never serve another point set's result: one coordinate
+    changed by 1e-6 deg in a million points, or two rows 8191 apart swapped, gave the same float-sum key before."""
+    from raider_amd.delayFcns import FieldInterpolator
+    rng = np.random.default_rng(0)
+    a = rng.uniform(-100, 100, (1_000_000, 3))
+    b = a.copy(); b[123456, 1] += 1e-6
+    c = a.copy(); c[[10, 10 + 8191]] = c[[10 + 8191, 10]]
+    k = FieldInterpolator._sig
+    assert k(a) == k(a.copy()) and k(a) != k(b) and k(a) != k(c) and k(a) != k(a.astype(np.float32)) and k(a) != k(a.reshape(-1, 6))
+    z = np.zeros((4, 3)); nz = z.copy(); nz[0, 0] = -0.0
+    assert k(z) != k(nz)                                        # bit patterns, not values
+
+
+def test_envi_header_names_the_rasters_own_crs(tmp_path):
+    """a UTM raster must not be declared geographic; a CRS without an ENVI spelling gets no map info at all."""
+    from raider_amd.utilFcns import writeArrayToRaster
+    try:
+        import rasterio  # noqa: F401
+        pytest.skip('rasterio writes the raster itself')
+    except ImportError:
+        pass
+    a = np.arange(12, dtype=np.float64).reshape(3, 4)
+    gt = (500000.0, 30.0, 0.0, 3700000.0, 0.0, -30.0)
+    writeArrayToRaster(a, tmp_path / 'utm.envi', proj='EPSG:32611', gt=gt)
+    hdr = (tmp_path / 'utm.hdr').read_text()
+    assert 'map info = {UTM, 1, 1, 500000, 3700000, 30, 30, 11, North, WGS-84}' in hdr and 'Geographic' not in hdr
+    writeArrayToRaster(a, tmp_path / 'ps.envi', proj='EPSG:3413', gt=gt)
+    assert 'map info' not in (tmp_path / 'ps.hdr').read_text()
+    writeArrayToRaster(a, tmp_path / 'll.envi', gt=(-118.0, 0.01, 0.0, 34.0, 0.0, -0.01))
+    assert 'Geographic Lat/Lon' in (tmp_path / 'll.hdr').read_text()

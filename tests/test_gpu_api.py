@@ -666,3 +666,86 @@ def test_large_result_cubes_pinned_pipelined_and_nan_scanned():
     assert not _pinned.is_pinned(w3) and np.array_equal(w3, wet2)
     _pinned.trim()
     assert _pinned.free_bytes() == 0
+
+
+def test_constant_refractivity_invariant_through_an_orbit_file():
+    """The reference's own end-to-end invariant for orbit-based ray tracing (test/test_synthetic.py:75-97,217-274 `test_hydrostatic_eq`):
+    with the hydrostatic refractivity constant (P = T: N = k1) the delay is k1 x 1e-6 x the summed ray length, so
+    delay x 1e6 and k1 x sum(build_ray lengths) - the lengths built HERE from the look vectors Raytracing(<orbit file>) hands out - must
+    agree to 6 decimals of their ratio, over the reference's height levels arange(-500, 9500, 500).  Orbit: the reference's
+    Sentinel-1 example file (test/orbit_files/S1_orbit_example.EOF)."""
+    import datetime as dt
+    from pathlib import Path
+    from raider_amd.delay import _build_cube_ray
+    from raider_amd.delayFcns import getInterpolators
+    from raider_amd.losreader import Raytracing, build_ray
+    from raider_amd.utilFcns import lla2ecef
+    d = Path(__file__).resolve().parent / 'golden' / 'orbit_files'
+    los = Raytracing(str(d / 'S1_orbit_example.EOF'), time=dt.datetime(2018, 11, 12, 23, 0, 2) + dt.timedelta(seconds=35))
+    orb = los._orbit
+    mid, _ = O.orbit_hermite(orb.time, orb.position, orb.velocity, [35.0])
+    lon_s, lat_s, _ = O.ecef2lla(mid[:, 0], mid[:, 1], mid[:, 2])
+    k1 = 0.776                                                                    # models/ecmwf.py:26
+    zs = np.concatenate([[-600.0, -300.0], np.round(41000.0 * np.linspace(0, 1, 38) ** 2, 3)])
+    ys = np.linspace(lat_s[0] - 2, lat_s[0] + 2, 30); xs = np.linspace(lon_s[0] - 7, lon_s[0] - 0.5, 40)
+    hyd = np.full((zs.size, ys.size, xs.size), k1, dtype=np.float32)              # P = T
+    wm = dict(x=xs, y=ys, z=zs, wet=np.zeros_like(hyd), hydro=hyd)
+    max_tropo_height = float(zs[-1] - 1)                                          # test_synthetic.py:251
+    hgt_lvls = np.arange(-500, 9500, 500).astype(float)                           # test_synthetic.py:121
+    ypts = lat_s[0] + np.linspace(0.5, -0.5, 12); xpts = lon_s[0] - np.linspace(2.4, 4.6, 15)
+    wet, hydro = _build_cube_ray(xpts, ypts, hgt_lvls, los, 4326, 4326, list(getInterpolators(wm)), MAX_TROPO_HEIGHT=max_tropo_height)
+    # length_of_ray (test_synthetic.py:75-97)
+    xx, yy = np.meshgrid(xpts, ypts)
+    ray_length = np.zeros((hgt_lvls.size, ypts.size, xpts.size))
+    for hh, ht in enumerate(hgt_lvls):
+        llh = [xx, yy, np.full(yy.shape, ht)]
+        xyz = np.stack(lla2ecef(llh[1], llh[0], np.full(yy.shape, ht)), axis=-1)
+        LOS = los.getLookVectors(ht, llh, xyz, yy)
+        ray_length[hh] = build_ray(zs, ht, xyz, LOS, max_tropo_height)[0].sum(0)
+    ray_data = ray_length * np.float64(np.float32(k1))
+    raid_data = hydro * 1e6
+    assert np.all(np.abs(ray_data) > 1) and np.all(np.abs(raid_data) > 1)
+    resid = (ray_data - raid_data) / ray_data
+    np.testing.assert_almost_equal(0, resid, decimal=6)
+    assert np.abs(resid).max() < 1e-12 and np.all(wet == 0.0)
+    # the geometry is a Sentinel-1 one: incidence between ~30 and ~46 degrees, slant / zenith path ratio accordingly
+    zen = (max_tropo_height - hgt_lvls[1])
+    assert 1.1 < ray_length[1].min() / zen < ray_length[1].max() / zen < 1.5
+
+
+def test_advice_r2_host_fixes():
+    """(a) a CPU tensor handed to a batch that already lives on the GPU is uploaded like a NumPy array (it used to raise 'different
+    devices'); (b) the slice batches of _build_cube_ray are sized from a byte budget and give the same bits whatever the batch size;
+    (c) a cached cube that served a projected model is a lon/lat cube again when EPSG:4326 is asked for on the ray path."""
+    import os
+    import torch
+    import raider_amd as R
+    from raider_amd.delay import _build_cube_ray
+    from raider_amd.delayFcns import interpolators_from_cube
+    from raider_amd.losreader import Raytracing
+    c = O.synthetic_cube(50, 50, 40, seed=0)
+    cube = R.Cube(c['ys'], c['xs'], c['zs'], c['wet'], c['hydro'], order='zyx')
+    zref = float(c['zs'].max() - 1)
+    xp = np.linspace(-119.0, -116.0, 33); yp = np.linspace(34.5, 31.5, 29)
+    dev = torch.device('cuda:0')
+    inc = np.full((29, 33), 37.0)
+    rays = R.Rays.grid(torch.from_numpy(xp).to(dev), torch.from_numpy(yp), inc=torch.from_numpy(inc), hd=-167.9)       # ypts, inc: CPU tensors
+    assert rays._torch_device == dev
+    w, h, _, _ = cube.raytrace(rays, 0.0, zref)
+    w0, h0, _, _ = cube.raytrace(R.Rays.grid(xp, yp, inc=inc, hd=-167.9), 0.0, zref)
+    assert np.array_equal(w.cpu().numpy(), w0) and np.array_equal(h.cpu().numpy(), h0)
+    # (b)
+    zpts = np.array([0.0, 300.0, 900.0, 2000.0, 3500.0])
+    los = Raytracing(inc=inc, heading=-167.9)
+    ip = list(interpolators_from_cube(cube))
+    a = _build_cube_ray(xp, yp, zpts, los, 4326, 4326, ip, MAX_TROPO_HEIGHT=zref)
+    os.environ['RAIDER_HIP_SLICE_BUDGET_BYTES'] = str(29 * 33 * 64 * 2)          # two slices per call
+    try:
+        b = _build_cube_ray(xp, yp, zpts, los, 4326, 4326, ip, MAX_TROPO_HEIGHT=zref)
+    finally:
+        del os.environ['RAIDER_HIP_SLICE_BUDGET_BYTES']
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    # (c)
+    cube.set_projection_lcc(38.5, 38.5, 38.5, 262.5)
+    d = _build_cube_ray(xp, yp, zpts[:2], los, 4326, 4326, ip, MAX_TROPO_HEIGHT=zref)
+    assert cube.projection is None and np.array_equal(d[0], a[0][:2])
