@@ -468,10 +468,16 @@ __device__ inline int build_levels(const double2* ez, int nz, double ht, double 
 __device__ __forceinline__ int first_level(const double2* ez, int nz, const double* s_lo, const double* s_hi, const int* s_kz, int K,
                                            double hti, double& lo_i) {
     const double ztop = ez[nz - 1].x;
-    for (int k = 0; k < K; ++k) {
-        double hr = ez[s_kz[k] + 1].x;                       // the interval's top before the zref clip
+    // `if high_ht < ht: continue`: the interval tops (before the zref clip) ascend with k, so the entries passing this test are a
+    // suffix of the table - found by bisection; (hti NaN: every comparison fails, the search ends at 0 and the ray is NaN anyway)
+    int a = 0, b = K;
+    while (a < b) {
+        const int mid = (a + b) >> 1;
+        double hr = ez[s_kz[mid] + 1].x;
         if (hr == ztop) hr -= 0.01;
-        if (hr < hti) continue;
+        if (hr < hti) a = mid + 1; else b = mid;
+    }
+    for (int k = a; k < K; ++k) {                            // then the first one at least 1 m thick above the ray's own bottom
         const double lo = fmax(s_lo[k], hti);                // `if low_ht < ht: low_ht = ht`
         if (fabs(s_hi[k] - lo) < 1.0) continue;
         lo_i = lo;
@@ -1086,20 +1092,24 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
 #pragma unroll
                 for (int off = 32; off > 0; off >>= 1) kmin = min(kmin, __shfl_xor(kmin, off, 64));
                 kmin = __builtin_amdgcn_readfirstlane(kmin);
-                double u_k = 0.0, du = 0.0, u_last = 0.0;
+                // every lane's FIRST sample (the bottom of its own first level) in one evaluation for the whole wave - per-lane level
+                // constants from LDS - instead of once per distinct k0 inside the loop (a DEM tile has a dozen of those)
+                const bool has = k0 < K;
+                const int kf = has ? k0 : 0;
+                double u_k = has ? w[(int64_t)WS_U0 * ns] : 0.0, u_last = has ? w[(int64_t)WS_U1 * ns] : 0.0;
+                double du = u_last - u_k;
+                if (K > 0) {
+                    const int kzf = m.kz[kf];
+                    PendingSample<T2> s;
+                    issue_top(fma(0.0 * m.step[kf], du, u_k), window2_base(c.nz, kzf - ((lo_first <= m.ax.ez[kzf].x) ? 1 : 0)), clamp_lo, false, s);
+                    if (has) finish(s, m.hs[kf] * du);
+                }
 #pragma unroll 1
                 for (int k = kmin; k < K; ++k) {
                     const int np = __builtin_amdgcn_readfirstlane(m.np[k]);
                     const int kz = __builtin_amdgcn_readfirstlane(m.kz[k]);
                     const double step = m.step[k], hs = m.hs[k];
                     const bool more = k + 1 < K;
-                    if (k == k0) {                                                   // this lane's ray starts here: its first sample
-                        u_k = w[(int64_t)WS_U0 * ns]; u_last = w[(int64_t)WS_U1 * ns];
-                        du = u_last - u_k;
-                        PendingSample<T2> s;
-                        issue_top(fma(0.0 * step, du, u_k), window2_base(c.nz, kz - ((lo_first <= m.ax.ez[kz].x) ? 1 : 0)), clamp_lo, false, s);
-                        finish(s, hs * du);
-                    }
                     if (k >= k0) {
                         const int zbase = window2_base(c.nz, kz);
                         const double w_mid = (2.0 * hs) * du;
