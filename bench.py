@@ -285,7 +285,8 @@ def main():
         step_traffic = (traffic + kc.get('hbm_read_bytes', 0) + kc.get('hbm_write_bytes', 0)) if (traffic is not None and 'hbm_read_bytes' in kc) else None
         valu_rate = (valu_rw * (n_rays / 64.0) / (march_ms * 1e-3)) if valu_rw else None
         compulsory = 64 + (ny * nx * nz * 8) / n_rays             # B/ray: look vector in, two delays out, the cube once
-        ka_m, ka_c = cube.ray_kernel_attributes(1), cube.ray_kernel_attributes(0)      # from the loaded code object
+        pr_ = 2 if args.per_pixel_ht else 0
+        ka_m, ka_c = cube.ray_kernel_attributes(1 + pr_), cube.ray_kernel_attributes(0 + pr_)      # from the loaded code object
         frac_valu = valu_rate / VALU_ISSUE_PEAK if valu_rate else None
         frac_hbm = (traffic / (march_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic is not None else None
         if args.per_pixel_ht:

@@ -134,7 +134,7 @@ int rdr_set_workspace_limit(rdr_ctx* ctx, int64_t bytes);
 int rdr_set_side_capacity(rdr_ctx* ctx, int64_t columns);
 int rdr_profile_get(rdr_ctx* ctx, int which, int* count, float* total_ms);
 /* diagnostics: resources of the light ray kernel a GRID + look-vector batch on `cube` launches (which 0: pass 1 crossings_kernel,
- * 1: pass 2 march_kernel), read from the loaded code object (hipFuncGetAttributes): vector registers per lane, static LDS bytes,
+ * 1: pass 2 march_kernel; 2 / 3: their per-ray-height instantiations, rdr_rays.hts), read from the loaded code object (hipFuncGetAttributes): vector registers per lane, static LDS bytes,
  * dynamic LDS bytes of the launch (axis / level tables), scratch bytes per lane, max threads per block.  Any output may be NULL. */
 int rdr_ray_kernel_attributes(rdr_ctx* ctx, const rdr_cube* cube, int which, int32_t* vgprs, int32_t* static_lds, int32_t* dynamic_lds,
                               int32_t* scratch, int32_t* max_threads);

@@ -54,19 +54,19 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
-_cube_cache = {}
+_cube_cache = []
 
 
 def _yxz(cube):
-    """(y,x,z) C-order copies of the fields, cached per cube dict (the transposes are not part of the path)."""
-    key = id(cube['wet'])
-    if key not in _cube_cache:
-        _cube_cache.clear()
-        wet = np.ascontiguousarray(np.asarray(cube['wet']).transpose(1, 2, 0)); hyd = np.ascontiguousarray(np.asarray(cube['hydro']).transpose(1, 2, 0))
-        if wet.dtype != np.float32:
-            wet, hyd = wet.astype(np.float64), hyd.astype(np.float64)
-        _cube_cache[key] = (wet, hyd)
-    return _cube_cache[key]
+    """(y,x,z) C-order copies of the fields, cached for the LAST cube (the transposes are not part of the path).  The entry holds the
+    source arrays themselves: identity is checked with `is`, which a recycled id() of a freed array cannot fool."""
+    if _cube_cache and _cube_cache[0] is cube['wet'] and _cube_cache[1] is cube['hydro']:
+        return _cube_cache[2], _cube_cache[3]
+    wet = np.ascontiguousarray(np.asarray(cube['wet']).transpose(1, 2, 0)); hyd = np.ascontiguousarray(np.asarray(cube['hydro']).transpose(1, 2, 0))
+    if wet.dtype != np.float32:
+        wet, hyd = wet.astype(np.float64), hyd.astype(np.float64)
+    _cube_cache[:] = [cube['wet'], cube['hydro'], wet, hyd]
+    return wet, hyd
 
 
 def num_threads():

@@ -1107,17 +1107,23 @@ static int launch_march(rdr_ctx* c, const rdr_cube* q, RayParams P, int64_t tb, 
 // object (hipFuncGetAttributes) - what bench.py prints, instead of a profiler's metadata column.
 int rdr_ray_kernel_attributes(rdr_ctx* c, const rdr_cube* q, int which, int32_t* vgprs, int32_t* static_lds, int32_t* dynamic_lds,
                               int32_t* scratch, int32_t* max_threads) {
-    if (!c || !q || (which != 0 && which != 1)) return fail(c, RDR_ERR_INVALID, "rdr_ray_kernel_attributes: bad argument");
+    if (!c || !q || which < 0 || which > 3) return fail(c, RDR_ERR_INVALID, "rdr_ray_kernel_attributes: bad argument");
     const void* fn = nullptr;
     const bool lcc = q->proj.kind == 1;
-    if (which == 0) {
-        if (q->dtype == RDR_F32) fn = lcc ? (const void*)crossings_kernel<float2, false, true, 1> : (const void*)crossings_kernel<float2, false, false, 1>;
-        else fn = lcc ? (const void*)crossings_kernel<double2, false, true, 1> : (const void*)crossings_kernel<double2, false, false, 1>;
+    const bool pr = which >= 2;                    // 2 / 3: the per-ray-height instantiations of pass 1 / pass 2
+    if ((which & 1) == 0) {
+        if (q->dtype == RDR_F32) fn = pr ? (lcc ? (const void*)crossings_kernel<float2, false, true, 1, true> : (const void*)crossings_kernel<float2, false, false, 1, true>)
+                                         : (lcc ? (const void*)crossings_kernel<float2, false, true, 1> : (const void*)crossings_kernel<float2, false, false, 1>);
+        else fn = pr ? (lcc ? (const void*)crossings_kernel<double2, false, true, 1, true> : (const void*)crossings_kernel<double2, false, false, 1, true>)
+                     : (lcc ? (const void*)crossings_kernel<double2, false, true, 1> : (const void*)crossings_kernel<double2, false, false, 1>);
     } else {
         const auto v32 = make_view<float2>(q);
         const bool small = v32.small && (q->dtype == RDR_F32 || make_view<double2>(q).small);
         const int grid = !small ? 0 : (q->exact[0] && q->exact[1]) ? 1 : (!q->exact[0] && !q->exact[1] && q->uni[0] && q->uni[1]) ? 2 : 0;
-        if (q->dtype == RDR_F32) fn = grid == 1 ? (const void*)march_kernel<float2, false, 1> : grid == 2 ? (const void*)march_kernel<float2, false, 2> : (const void*)march_kernel<float2, false, 0>;
+        if (pr) {
+            if (q->dtype == RDR_F32) fn = grid == 1 ? (const void*)march_kernel<float2, false, 1, true> : (const void*)march_kernel<float2, false, 0, true>;
+            else fn = grid == 1 ? (const void*)march_kernel<double2, false, 1, true> : (const void*)march_kernel<double2, false, 0, true>;
+        } else if (q->dtype == RDR_F32) fn = grid == 1 ? (const void*)march_kernel<float2, false, 1> : grid == 2 ? (const void*)march_kernel<float2, false, 2> : (const void*)march_kernel<float2, false, 0>;
         else fn = grid == 1 ? (const void*)march_kernel<double2, false, 1> : grid == 2 ? (const void*)march_kernel<double2, false, 2> : (const void*)march_kernel<double2, false, 0>;
     }
     hipFuncAttributes a;

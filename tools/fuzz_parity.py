@@ -140,6 +140,47 @@ for trial in range(ntrials):
             bad.append(dict(tag, kind='point list vs grid', d=dp, nparts_equal=bool(np.array_equal(pn, nparts))))
     if max(dw, dh) > 2e-8:
         bad.append(dict(tag, kind='value', d_wet=dw, d_hydro=dh, max_inc=float(inc.max())))
+    # the same scene on a DEM: per-pixel origin heights (rdr_rays.hts) against the oracle's per-ray restatement (lon/lat cubes:
+    # the C oracle has no projected-model branch); every fourth of these with all heights equal = the slice result, bit for bit
+    if proj is None and not nan_los and trial % 2 == 0:
+        from oracle import oracle_c as OC
+        equal = trial % 8 == 0
+        hts = np.full((gy, gx), ht) if equal else ht + rng.uniform(0.0, rng.choice([30.0, 800.0, 4000.0]), (gy, gx))
+        stats['per_pixel_trials'] = stats.get('per_pixel_trials', 0) + 1
+        try:
+            pw_, ph_, pnp, _ = cube.raytrace(R.Rays.grid(xpts, ypts, los=np.ascontiguousarray(los), hts=hts), None, zref, max_seg)
+            g2 = None
+        except R.NoLevels:
+            g2 = 'NoLevels'
+        except Exception as e:
+            g2 = type(e).__name__
+        if equal:
+            if g2 or not (np.array_equal(pw_, wet, equal_nan=True) and np.array_equal(ph_, hyd, equal_nan=True) and np.array_equal(pnp, nparts)):
+                bad.append(dict(tag, kind='per-pixel heights, all equal: not the slice result', gpu=g2))
+        else:
+            try:
+                cc = c
+                if c['ys'][0] > c['ys'][-1]:        # (the C oracle takes ascending axes: flip as scipy / the library do)
+                    cc = dict(c, ys=c['ys'][::-1].copy(), wet=c['wet'][:, ::-1, :].copy(), hydro=c['hydro'][:, ::-1, :].copy())
+                qw, qh, qnp = OC.build_cube_ray_per_pixel(cc, yy, xx, hts, los, zref, max_seg=max_seg)
+                o2 = None
+                import os
+                if os.environ.get('FUZZ_DEBUG_TRIAL') == str(trial):
+                    nw, nh, nnp = O.build_cube_ray_per_pixel(yy.ravel(), xx.ravel(), hts.ravel(), los.reshape(-1, 3), ip, MAX_SEGMENT_LENGTH=max_seg, MAX_TROPO_HEIGHT=zref)
+                    print('DEBUG hts', hts.ravel()[:8], 'zs', c['zs'][:6], 'GPU', ph_.ravel()[:6], 'C', qh.ravel()[:6], 'NumPy', nh[:6], 'nparts gpu', pnp, 'C', qnp, 'np', nnp,
+                          'max|GPU-NumPy|', np.nanmax(np.abs(ph_.ravel() - nh)), 'max|C-NumPy|', np.nanmax(np.abs(qh.ravel() - nh)))
+            except Exception as e:
+                o2 = type(e).__name__
+            if g2 or o2:
+                if not (g2 == 'NoLevels' and o2 is None and not qnp.any()) and not (g2 == o2 == 'ValueError'):
+                    bad.append(dict(tag, kind='per-pixel heights: error mismatch', oracle=o2, gpu=g2))
+            else:
+                kzt = cube.ray_levels(float(hts.min()), zref)[2]
+                dpp = max(float(np.nanmax(np.abs(pw_ - qw))) if np.isfinite(qw).any() else 0.0, float(np.nanmax(np.abs(ph_ - qh))) if np.isfinite(qh).any() else 0.0)
+                worst['per_pixel_heights'] = max(worst.get('per_pixel_heights', 0.0), dpp)
+                if not np.array_equal(pnp, qnp[kzt]) or not np.array_equal(np.isnan(ph_), np.isnan(qh)) or dpp > 2e-8:
+                    bad.append(dict(tag, kind='per-pixel heights vs oracle', d=dpp, nparts_equal=bool(np.array_equal(pnp, qnp[kzt])),
+                                    gpu_nan=int(np.isnan(ph_).sum()), oracle_nan=int(np.isnan(qh).sum())))
 print(json.dumps(dict(stats=stats, worst_abs_m=worst, n_bad=len(bad))))
 for b in bad[:40]:
     print(json.dumps(b))
