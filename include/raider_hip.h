@@ -36,6 +36,8 @@ extern "C" {
 
 #define RDR_F32 0
 #define RDR_F64 1
+#define RDR_BYTESWAPPED 0x100 /* or-ed into the dtype of rdr_cube_create: the source fields are in the OTHER byte order than the host
+                               * (a NetCDF-3 file is big-endian) - swapped on the device while packing, so a file mapping is uploaded as is */
 #define RDR_HOST 0
 #define RDR_DEVICE 1
 
@@ -154,6 +156,9 @@ int rdr_cube_create(rdr_ctx* ctx, const double* ys, int64_t ny, const double* xs
                     const double* zs, int64_t nz, const void* wet, const void* hydro, int dtype,
                     int64_t sy, int64_t sx, int64_t sz, int loc, rdr_cube** out);
 void rdr_cube_destroy(rdr_cube* cube);
+/* 1 when a NaN was seen among the two source fields while the cube was packed (what delayFcns.py:50-52 scans for on the host:
+ * "Weather model contains NaNs!"), 0 otherwise (also for blended cubes: their sources were scanned), -1 for NULL */
+int rdr_cube_has_nan(const rdr_cube* cube);
 int rdr_cube_shape(const rdr_cube* cube, int64_t* ny, int64_t* nx, int64_t* nz, int* dtype);
 /* ascending copies of the axes as the interpolator's `.grid` exposes them (delay.py:239) */
 int rdr_cube_axes(const rdr_cube* cube, double* ys, double* xs, double* zs);

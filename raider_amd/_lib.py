@@ -16,6 +16,7 @@ LIB_PATH = Path(os.environ.get('RAIDER_HIP_LIB', _HERE / 'libraider_hip.so'))
 RDR_OK = 0
 RDR_ERR_INVALID, RDR_ERR_HIP, RDR_ERR_NODEVICE, RDR_ERR_ALL_NAN, RDR_ERR_NO_LEVELS, RDR_ERR_NAN_LENGTH = -1, -2, -3, -4, -5, -6
 RDR_F32, RDR_F64 = 0, 1
+RDR_BYTESWAPPED = 0x100
 RDR_HOST, RDR_DEVICE = 0, 1
 ORIGIN_GRID, ORIGIN_LLH, ORIGIN_XYZ = 0, 1, 2
 LOS_VEC, LOS_INC_HD, LOS_INC_HD_SCALAR, LOS_ZENITH = 0, 1, 2, 3
@@ -66,6 +67,7 @@ SYMBOLS = [
     ('rdr_cube_create', C.c_int, [_VP, _VP, C.c_int64, _VP, C.c_int64, _VP, C.c_int64, _VP, _VP, C.c_int,
                                   C.c_int64, C.c_int64, C.c_int64, C.c_int, C.POINTER(_VP)]),
     ('rdr_cube_destroy', None, [_VP]),
+    ('rdr_cube_has_nan', C.c_int, [_VP]),
     ('rdr_cube_shape', C.c_int, [_VP, c_lp, c_lp, c_lp, C.POINTER(C.c_int)]),
     ('rdr_cube_axes', C.c_int, [_VP, _VP, _VP, _VP]),
     ('rdr_cube_set_projection', C.c_int, [_VP, C.c_int, _VP, C.c_int]),

@@ -12,18 +12,29 @@ using namespace rdr;
 // ------------------------------------------------------------------------------------------------
 // small kernels
 // ------------------------------------------------------------------------------------------------
-template <typename T, typename T2>
+// (y,x,z) interleaved device cube from two strided source fields.  SWAP: the source is in the OTHER byte order (a NetCDF-3 file is
+// big-endian): the bytes are swapped here, on the way through, so that a file mapping can be uploaded as it is - no host pass over
+// the data.  nan_flag: set to 1 when a value is NaN (delayFcns.py:50-52 scans the fields for NaNs on the host).
+template <typename T, typename T2, bool SWAP>
 __global__ void pack_cube_kernel(const T* __restrict__ wet, const T* __restrict__ hyd, T2* __restrict__ dst,
                                  int64_t ny, int64_t nx, int64_t nz, int64_t sy, int64_t sx, int64_t sz,
-                                 int fy, int fx, int fz) {
+                                 int fy, int fx, int fz, int* __restrict__ nan_flag) {
     const int64_t total = ny * nx * nz;
+    bool bad = false;
+    auto fix = [](T v) -> T {
+        if constexpr (!SWAP) return v;
+        else if constexpr (sizeof(T) == 4) return __uint_as_float(__builtin_bswap32(__float_as_uint(v)));
+        else return __longlong_as_double((long long)__builtin_bswap64((unsigned long long)__double_as_longlong(v)));
+    };
     for (int64_t o = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x) {
         const int64_t iz = o % nz, r = o / nz, ix = r % nx, iy = r / nx;
         const int64_t jy = fy ? ny - 1 - iy : iy, jx = fx ? nx - 1 - ix : ix, jz = fz ? nz - 1 - iz : iz;
         const int64_t s = jy * sy + jx * sx + jz * sz;
-        T2 v; v.x = wet[s]; v.y = hyd[s];
+        T2 v; v.x = fix(wet[s]); v.y = fix(hyd[s]);
+        bad |= (v.x != v.x) | (v.y != v.y);
         dst[o] = v;
     }
+    if (nan_flag && __any(bad) && (threadIdx.x & 63) == 0) atomicOr(nan_flag, 1);
 }
 
 template <typename T, typename T2>

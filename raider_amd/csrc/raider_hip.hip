@@ -76,6 +76,7 @@ struct rdr_cube {
     mutable size_t quad_bytes = 0;
     mutable int quad_nblk = 0;
     mutable int big_point_calls = 0;             // rdr_interp3 calls that would have profited
+    bool has_nan = false;                        // a NaN among the fields (seen while packing; blends: unknown -> false)
 };
 
 static int fail(rdr_ctx* ctx, int code, const std::string& msg) {
@@ -210,7 +211,7 @@ int rdr_create(int device, rdr_ctx** out) {
         HIPCHECK(nullptr, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
         c->stream = c->own_stream;
         HIPCHECK(nullptr, hipMalloc((void**)&c->d_maxlen, (size_t)MAX_SLICES * MAX_LEVELS * sizeof(unsigned long long)));
-        HIPCHECK(nullptr, hipMalloc((void**)&c->d_flags, MAX_SLICES * sizeof(int)));
+        HIPCHECK(nullptr, hipMalloc((void**)&c->d_flags, (MAX_SLICES + 4) * sizeof(int)));      // (+ the cube packer's NaN word)
         HIPCHECK(nullptr, hipMalloc((void**)&c->d_nparts, MAX_LEVELS * sizeof(int)));
         HIPCHECK(nullptr, hipMalloc((void**)&c->d_nslow, sizeof(int)));
         HIPCHECK(nullptr, hipMalloc((void**)&c->d_tilectr, 32 * sizeof(int)));
@@ -387,7 +388,9 @@ int rdr_cube_create(rdr_ctx* c, const double* ys, int64_t ny, const double* xs, 
                     const void* wet, const void* hydro, int dtype, int64_t sy, int64_t sx, int64_t sz, int loc,
                     rdr_cube** out) {
     if (!c || !out || !ys || !xs || !zs || !wet || !hydro) return fail(c, RDR_ERR_INVALID, "rdr_cube_create: NULL argument");
-    if (dtype != RDR_F32 && dtype != RDR_F64) return fail(c, RDR_ERR_INVALID, "rdr_cube_create: dtype must be RDR_F32 or RDR_F64");
+    const bool swapped = (dtype & RDR_BYTESWAPPED) != 0;       // the source fields are in the other byte order (NetCDF-3: big-endian)
+    dtype &= ~RDR_BYTESWAPPED;
+    if (dtype != RDR_F32 && dtype != RDR_F64) return fail(c, RDR_ERR_INVALID, "rdr_cube_create: dtype must be RDR_F32 or RDR_F64 (optionally | RDR_BYTESWAPPED)");
     if (nz > MAX_LEVELS) return fail(c, RDR_ERR_INVALID, "rdr_cube_create: more than 512 z levels");
     if (ny + nx + nz > 100000) return fail(c, RDR_ERR_INVALID, "rdr_cube_create: axes too long");
     int fy, fx, fz;
@@ -411,17 +414,22 @@ int rdr_cube_create(rdr_ctx* c, const double* ys, int64_t ny, const double* xs, 
     rc = stage_in(c, SLOT_IN0, wet, span * esz, loc, &dw); if (rc) { rdr_cube_destroy(q); return rc; }
     rc = stage_in(c, SLOT_IN1, hydro, span * esz, loc, &dh); if (rc) { rdr_cube_destroy(q); return rc; }
     const int g = grid_for((int64_t)total, 256, c->num_cus * 8);
-    if (dtype == RDR_F32)
-        hipLaunchKernelGGL((pack_cube_kernel<float, float2>), dim3(g), dim3(256), 0, c->stream, (const float*)dw, (const float*)dh,
-                           (float2*)q->d_vals, ny, nx, nz, sy, sx, sz, fy, fx, fz);
-    else
-        hipLaunchKernelGGL((pack_cube_kernel<double, double2>), dim3(g), dim3(256), 0, c->stream, (const double*)dw, (const double*)dh,
-                           (double2*)q->d_vals, ny, nx, nz, sy, sx, sz, fy, fx, fz);
-    hipError_t e = hipGetLastError();
+    int* const nf = c->d_flags + MAX_SLICES;      // (a word of the flag array no ray batch uses)
+    hipError_t e = hipMemsetAsync(nf, 0, sizeof(int), c->stream);
+    if (e != hipSuccess) { rdr_cube_destroy(q); return fail(c, RDR_ERR_HIP, hipGetErrorString(e)); }
+#define RDR_PACK(T, T2, SW) hipLaunchKernelGGL((pack_cube_kernel<T, T2, SW>), dim3(g), dim3(256), 0, c->stream, (const T*)dw, (const T*)dh, \
+                                               (T2*)q->d_vals, ny, nx, nz, sy, sx, sz, fy, fx, fz, nf)
+    if (dtype == RDR_F32) { if (swapped) RDR_PACK(float, float2, true); else RDR_PACK(float, float2, false); }
+    else { if (swapped) RDR_PACK(double, double2, true); else RDR_PACK(double, double2, false); }
+#undef RDR_PACK
+    e = hipGetLastError();
     if (e != hipSuccess) { rdr_cube_destroy(q); return fail(c, RDR_ERR_HIP, hipGetErrorString(e)); }
     // one-time: the cube must be complete before it is used from any other stream (and the staging slots reused)
-    e = hipStreamSynchronize(c->stream);
+    int has_nan = 0;
+    e = hipMemcpyAsync(&has_nan, nf, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) { rdr_cube_destroy(q); return fail(c, RDR_ERR_HIP, hipGetErrorString(e)); }
+    q->has_nan = has_nan != 0;
     *out = q;
     return RDR_OK;
 }
@@ -434,6 +442,8 @@ void rdr_cube_destroy(rdr_cube* q) {
     if (q->d_quad) (void)hipFree(q->d_quad);
     delete q;
 }
+
+int rdr_cube_has_nan(const rdr_cube* q) { return q ? (q->has_nan ? 1 : 0) : -1; }
 
 int rdr_cube_shape(const rdr_cube* q, int64_t* ny, int64_t* nx, int64_t* nz, int* dtype) {
     if (!q) return fail(nullptr, RDR_ERR_INVALID, "cube is NULL");
@@ -552,7 +562,7 @@ int rdr_cube_blend(rdr_ctx* c, const rdr_cube* a, double w1, const rdr_cube* b, 
     HIPCHECK(c, hipSetDevice(c->device));
     rdr_cube* q = new rdr_cube();
     q->ctx = c; q->ny = a->ny; q->nx = a->nx; q->nz = a->nz; q->dtype = a->dtype;
-    q->ys = a->ys; q->xs = a->xs; q->zs = a->zs; q->proj = a->proj;
+    q->ys = a->ys; q->xs = a->xs; q->zs = a->zs; q->proj = a->proj; q->has_nan = a->has_nan || b->has_nan;
     int rc = cube_alloc(c, q);
     if (rc) { rdr_cube_destroy(q); return rc; }
     const int64_t nscal = 2 * a->ny * a->nx * a->nz;                  // (wet, hydro) pairs as one flat array

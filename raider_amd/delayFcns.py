@@ -58,8 +58,13 @@ class _Var:
     `data` may be a zero-argument loader: the array is then read from the file on first use (a ray-traced run never touches
     the f64 `*_total` fields, two thirds of a processed-cube file)."""
 
-    def __init__(self, data, attrs):
-        self._data, self.attrs = data, attrs
+    def __init__(self, data, attrs, raw=None):
+        self._data, self.attrs, self._raw = data, attrs, raw
+
+    def raw(self):
+        """The variable as it lies in the file - a read-only, possibly other-endian view of the file mapping, no copy - or None when
+        the file's layout has to be decoded (then `data`).  What the GPU upload of the two big fields takes."""
+        return self._raw() if self._raw is not None else None
 
     @property
     def data(self):
@@ -89,7 +94,9 @@ def _read_cube_file(path):
         def loader(name):
             # a private native-endian copy (NetCDF-3 is big-endian): nothing refers to the mapped file afterwards
             return lambda: np.array(f.variables[name].data, dtype=f.variables[name].data.dtype.newbyteorder('='))
-        return {k: _Var(loader(k), {a: (b.decode() if isinstance(b, bytes) else b) for a, b in v._attributes.items()})
+        def rawview(name):
+            return lambda: f.variables[name].data if f.variables[name].data.dtype.kind == 'f' else None
+        return {k: _Var(loader(k), {a: (b.decode() if isinstance(b, bytes) else b) for a, b in v._attributes.items()}, rawview(k))
                 for k, v in f.variables.items()}
     from . import h5lite
     f = h5lite.File(path)
@@ -97,7 +104,8 @@ def _read_cube_file(path):
     for k in f.keys():
         obj = f[k]
         if isinstance(obj, h5lite.Dataset) and obj.dtype is not None and obj.dtype.kind in 'fiu':
-            out[k] = _Var(obj.read, {n: v for n, v in obj.attrs.items() if not n.startswith('_N') and n not in ('CLASS', 'NAME')})
+            out[k] = _Var(obj.read, {n: v for n, v in obj.attrs.items() if not n.startswith('_N') and n not in ('CLASS', 'NAME')},
+                          obj.raw if obj.dtype.kind == 'f' else None)
     return out
 
 
@@ -124,12 +132,19 @@ def getInterpolators(wm_file, kind='pointwise', shared=False, ctx=None):
         return wm_file.interpolators('total' if kind == 'total' else 'pointwise')    # weather.ProcessedModel: already on the device
     var, get = _load_fields(wm_file)
     xs, ys, zs = get('x'), get('y'), get('z')
-    wet = get('wet_total' if kind == 'total' else 'wet')
-    hydro = get('hydro_total' if kind == 'total' else 'hydro')
-    if np.any(np.isnan(wet)) or np.any(np.isnan(hydro)):
+
+    def field(name):
+        # the two big fields straight from the file mapping when the file allows it (contiguous data, any byte order): uploaded as
+        # they lie there, byte-swapped and NaN-scanned on the device - no host pass over 58 MB (ERA5-sized) to 400 MB (HRRR-sized)
+        v = var[name]
+        r = v.raw() if hasattr(v, 'raw') else None
+        return r if r is not None else get(name)
+    wet = field('wet_total' if kind == 'total' else 'wet')
+    hydro = field('hydro_total' if kind == 'total' else 'hydro')
+    cube = Cube(ys, xs, zs, wet, hydro, order='zyx', ctx=ctx)      # no host transpose (delayFcns.py:40-41 does one)
+    if cube.has_nan():                                             # delayFcns.py:50-52, answered by the packing kernel
         from .logger import logger
         logger.critical('Weather model contains NaNs!')
-    cube = Cube(ys, xs, zs, wet, hydro, order='zyx', ctx=ctx)      # no host transpose (delayFcns.py:40-41 does one)
     ifWet, ifHydro = FieldInterpolator(cube, 0), FieldInterpolator(cube, 1)
     ifWet._sibling, ifHydro._sibling = ifHydro, ifWet
     return ifWet, ifHydro

@@ -41,12 +41,17 @@ class Cube:
         if not dev:
             wet = np.asarray(wet)
             hydro = np.asarray(hydro)
-            if wet.dtype not in (np.float32, np.float64):
+            # float32 / float64 in EITHER byte order go up as they are (a big-endian NetCDF-3 mapping is swapped on the device while
+            # the cube is packed - no host pass over the fields); anything else is converted to float64 first
+            if wet.dtype.kind != 'f' or wet.dtype.itemsize not in (4, 8):
                 wet = wet.astype(np.float64)
-            hydro = np.asarray(hydro, dtype=wet.dtype)
+            if hydro.dtype != wet.dtype:
+                hydro = hydro.astype(wet.dtype)
             wet = np.ascontiguousarray(wet)
             hydro = np.ascontiguousarray(hydro)
-            dt = L.RDR_F32 if wet.dtype == np.float32 else L.RDR_F64
+            dt = L.RDR_F32 if wet.dtype.itemsize == 4 else L.RDR_F64
+            if not wet.dtype.isnative:
+                dt |= L.RDR_BYTESWAPPED
             shape = wet.shape
         else:
             import torch
@@ -72,7 +77,7 @@ class Cube:
         check(self.ctx.lib.rdr_cube_create(self.ctx.handle, ptr(ys), ny, ptr(xs), nx, ptr(zs), nz, ptr(wet), ptr(hydro), dt,
                                            sy, sx, sz, L.RDR_DEVICE if dev else L.RDR_HOST, C.byref(h)), self.ctx.handle)
         self.handle = h
-        self.dtype = np.float32 if dt == L.RDR_F32 else np.float64
+        self.dtype = np.float32 if (dt & 0xff) == L.RDR_F32 else np.float64
         self.shape = (ny, nx, nz)
         gy, gx, gz = np.empty(ny), np.empty(nx), np.empty(nz)
         check(self.ctx.lib.rdr_cube_axes(h, ptr(gy), ptr(gx), ptr(gz)))
@@ -130,6 +135,10 @@ class Cube:
         out = Cube._from_handle(self.ctx, h)
         out.projection = self.projection       # the C side copies the projection too
         return out
+
+    def has_nan(self):
+        """A NaN among the two fields this cube was made from (seen on the device while packing; delayFcns.py:50-52)."""
+        return bool(self.ctx.lib.rdr_cube_has_nan(self.handle) == 1)
 
     def read(self):
         wet = np.empty(self.shape, dtype=self.dtype)

@@ -118,6 +118,22 @@ class Dataset:
     def __getitem__(self, key):
         return self.read()[key]
 
+    def raw(self):
+        """Zero-copy view of a CONTIGUOUS dataset in the file's own byte order (a read-only array over the mapped file), or None when
+        the layout needs decoding (compact / chunked / filtered / never written): the caller then takes read()."""
+        if self.dtype is None or self.dtype.kind not in 'fiu':
+            return None
+        lay = self.layout
+        if lay[0] not in (3, 4) or lay[1] != 1:
+            return None
+        shape = self.shape if self.shape is not None else ()
+        count = int(np.prod(shape)) if shape else 1
+        addr = _u(lay, 2, 8)
+        if addr == UNDEF:
+            return None
+        f = self.file
+        return np.frombuffer(f.buf, dtype=self.dtype, count=count, offset=f.base + addr).reshape(shape)
+
     def read(self):
         if self.dtype is None or self.dtype.kind == 'S':
             raise UnsupportedHDF5Feature(f'dataset {self.name}: element type class {self.dt.cls} is not numeric')
@@ -271,8 +287,16 @@ class File(Group):
     """`File(path)['wet'][:]`, `File(path)['proj'].attrs['crs_wkt']`, `File(path).attrs['datetime']`."""
 
     def __init__(self, path):
+        # the file is MAPPED, not read: opening a 170 MB processed cube costs nothing until a dataset is asked for, and a contiguous
+        # dataset can be handed to the GPU upload straight from the page cache (Dataset.raw)
+        import mmap
         with open(path, 'rb') as fh:
-            self.buf = fh.read()
+            try:
+                self._map = mmap.mmap(fh.fileno(), 0, access=mmap.ACCESS_READ)
+                self.buf = memoryview(self._map)
+            except (ValueError, OSError):              # empty file / no mmap on this file system
+                self._map = None
+                self.buf = memoryview(fh.read())
         b = self.buf
         self.path = str(path)
         # the superblock may sit at 0, 512, 1024, ...
@@ -558,7 +582,9 @@ class File(Group):
                 p = a + 8
                 for i in range(n):
                     noff, oaddr = _u(b, p, 8), _u(b, p + 8, 8)
-                    e = b.index(b'\0', data + noff)
+                    e = data + noff
+                    while b[e] != 0:                      # (a memoryview has no .index)
+                        e += 1
                     out[bytes(b[data + noff:e]).decode()] = oaddr
                     p += 40
             else:

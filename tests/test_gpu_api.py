@@ -749,3 +749,52 @@ def test_advice_r2_host_fixes():
     cube.set_projection_lcc(38.5, 38.5, 38.5, 262.5)
     d = _build_cube_ray(xp, yp, zpts[:2], los, 4326, 4326, ip, MAX_TROPO_HEIGHT=zref)
     assert cube.projection is None and np.array_equal(d[0], a[0][:2])
+
+
+def test_cube_files_are_uploaded_from_the_mapping(tmp_path, caplog):
+    """getInterpolators on a file: the two big fields go to the device as they lie in the file mapping - a big-endian NetCDF-3 file is
+    byte-swapped by the packing kernel, a NetCDF-4 file's contiguous little-endian datasets are taken as they are - and the NaN scan
+    of delayFcns.py:50-52 is answered by the same kernel.  The device cube must hold the file's values bit for bit."""
+    import logging
+    from scipy.io import netcdf_file
+    from raider_amd.delayFcns import getInterpolators, _read_cube_file
+    from raider_amd.weather import ProcessedModel
+    c = O.synthetic_cube(23, 31, 17, seed=9)
+
+    def write3(path, wet, hydro):
+        with netcdf_file(str(path), 'w', version=2) as f:
+            for d, k in (('z', 'zs'), ('y', 'ys'), ('x', 'xs')):
+                f.createDimension(d, c[k].size)
+                f.createVariable(d, 'f8', (d,))[:] = c[k]
+            f.createVariable('wet', 'f4', ('z', 'y', 'x'))[:] = wet
+            f.createVariable('hydro', 'f4', ('z', 'y', 'x'))[:] = hydro
+            f.createVariable('wet_total', 'f8', ('z', 'y', 'x'))[:] = c['wet_total']
+            f.createVariable('hydro_total', 'f8', ('z', 'y', 'x'))[:] = c['hydro_total']
+    p3 = tmp_path / 'cube3.nc'
+    write3(p3, c['wet'], c['hydro'])
+    raw = _read_cube_file(p3)['wet'].raw()
+    assert raw is not None and not raw.dtype.isnative and not raw.flags.writeable           # the big-endian mapping itself
+    for kind, a, b in (('pointwise', 'wet', 'hydro'), ('total', 'wet_total', 'hydro_total')):
+        iw, ih = getInterpolators(str(p3), kind)
+        w, h = iw.cube.read()
+        assert w.dtype == c[a].dtype and np.array_equal(w, c[a].transpose(1, 2, 0)) and np.array_equal(h, c[b].transpose(1, 2, 0))
+        assert not iw.cube.has_nan()
+    # NaNs are found on the device and reported like the reference reports them
+    wn = c['wet'].copy(); wn[3, 4, 5] = np.nan
+    pn = tmp_path / 'cube3_nan.nc'
+    write3(pn, wn, c['hydro'])
+    with caplog.at_level(logging.CRITICAL):
+        iw, _ = getInterpolators(str(pn))
+    assert iw.cube.has_nan() and any('NaNs' in r.getMessage() for r in caplog.records)
+    assert np.array_equal(iw.cube.read()[0], wn.transpose(1, 2, 0), equal_nan=True)
+    # NetCDF-4 (HDF5, contiguous little-endian; a processed ERA-5 cube the real RAiDER wrote): the mapping is the upload source as well
+    from pathlib import Path
+    from raider_amd import h5lite
+    p4 = sorted((Path(__file__).resolve().parent / 'golden' / 'ref_files').glob('ERA-5_2019_11_17*.nc'))[0]
+    v = _read_cube_file(p4)
+    raw4 = v['wet'].raw()
+    assert raw4 is not None and raw4.dtype == np.float32 and not raw4.flags.writeable
+    iw, _ = getInterpolators(str(p4))
+    f = h5lite.File(p4)
+    assert np.array_equal(iw.cube.read()[0], f['wet'].read().transpose(1, 2, 0), equal_nan=True)
+    assert np.array_equal(iw.cube.read()[1], f['hydro'].read().transpose(1, 2, 0), equal_nan=True)
