@@ -95,7 +95,18 @@ def _read_cube_file(path):
             # a private native-endian copy (NetCDF-3 is big-endian): nothing refers to the mapped file afterwards
             return lambda: np.array(f.variables[name].data, dtype=f.variables[name].data.dtype.newbyteorder('='))
         def rawview(name):
-            return lambda: f.variables[name].data if f.variables[name].data.dtype.kind == 'f' else None
+            # an OWN read-only mapping of the variable's bytes (big-endian, as NetCDF-3 stores them), independent of scipy's file
+            # object: nothing keeps that from closing, and the GPU upload reads the page cache directly
+            def get():
+                v = f.variables[name]
+                d, base = v.data, getattr(f, '_mm_buf', None)
+                if d.dtype.kind != 'f' or getattr(v, 'isrec', False) or not isinstance(base, np.ndarray) or not d.flags.c_contiguous:
+                    return None
+                off = d.__array_interface__['data'][0] - base.__array_interface__['data'][0]
+                if off < 0 or off + d.nbytes > base.nbytes:
+                    return None
+                return np.memmap(str(path), dtype=d.dtype, mode='r', offset=off, shape=d.shape)
+            return get
         return {k: _Var(loader(k), {a: (b.decode() if isinstance(b, bytes) else b) for a, b in v._attributes.items()}, rawview(k))
                 for k, v in f.variables.items()}
     from . import h5lite

@@ -790,7 +790,7 @@ def test_cube_files_are_uploaded_from_the_mapping(tmp_path, caplog):
     # NetCDF-4 (HDF5, contiguous little-endian; a processed ERA-5 cube the real RAiDER wrote): the mapping is the upload source as well
     from pathlib import Path
     from raider_amd import h5lite
-    p4 = sorted((Path(__file__).resolve().parent / 'golden' / 'ref_files').glob('ERA-5_2019_11_17*.nc'))[0]
+    p4 = sorted((Path(__file__).resolve().parent / 'golden' / 'ref_files').glob('ERA-5_2019_11_17*_5S_*.nc'))[0]
     v = _read_cube_file(p4)
     raw4 = v['wet'].raw()
     assert raw4 is not None and raw4.dtype == np.float32 and not raw4.flags.writeable
