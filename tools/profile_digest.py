@@ -85,7 +85,8 @@ def main():
         if d.get('SQ_WAVE_CYCLES'):
             e['valu_busy_frac'] = round(WAVES_PER_SIMD * d.get('SQ_ACTIVE_INST_VALU', 0.0) / d['SQ_WAVE_CYCLES'], 4)
             e['wait_inst_any_frac'] = round(d.get('SQ_WAIT_INST_ANY', 0.0) / d['SQ_WAVE_CYCLES'], 4)
-        e['vgpr'] = d['vgpr']; e['scratch'] = d['scratch']
+        # (registers / LDS / scratch are NOT taken from rocprof's metadata columns - VGPR_Count reads 64 for a 128-register kernel here -
+        # bench.py asks the loaded code object: rdr_ray_kernel_attributes)
         lines.append(k + ': ' + json.dumps({c: round(v, 1) for c, v in sorted(d.items())}))
     (prof / f'{rnd}_{tag}_sq_counters_per_raywave.txt').write_text('\n'.join(lines) + '\n')
 

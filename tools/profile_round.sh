@@ -13,10 +13,10 @@ print(json.dumps(dict(source_hash=bench.kernel_source_hash(), cube='$CUBE', sq_s
                       device=torch.cuda.get_device_name(0))))
 PY
 python $R/bench.py --cube $CUBE > $O/bench.json 2> $O/bench.err
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python $R/bench.py --cube $CUBE --steps 10 --warmup 3 --cpu-sample 0 > $O/kt.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python $R/bench.py --cube $CUBE --steps 10 --warmup 3 --cpu-sample 0 --no-e2e > $O/kt.log 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python $R/tools/pmc_probe.py $CUBE > $O/fetch.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python $R/tools/pmc_probe.py $CUBE > $O/write.log 2>&1
-timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $O/sq1 -- python $R/bench.py --cube $CUBE --rows 2000 --cols 2000 --steps 2 --warmup 1 --cpu-sample 0 > $O/sq1.log 2>&1
-timeout 600 rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAIT_INST_ANY --output-format csv -d $O/sq2 -- python $R/bench.py --cube $CUBE --rows 2000 --cols 2000 --steps 2 --warmup 1 --cpu-sample 0 > $O/sq2.log 2>&1
+timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $O/sq1 -- python $R/bench.py --cube $CUBE --rows 2000 --cols 2000 --steps 2 --warmup 1 --cpu-sample 0 --no-e2e > $O/sq1.log 2>&1
+timeout 600 rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAIT_INST_ANY --output-format csv -d $O/sq2 -- python $R/bench.py --cube $CUBE --rows 2000 --cols 2000 --steps 2 --warmup 1 --cpu-sample 0 --no-e2e > $O/sq2.log 2>&1
 find $O -name "*.csv" | head -20
 cat $O/bench.json
