@@ -292,16 +292,32 @@ __global__ __launch_bounds__(256) void interp_points_quad_kernel(CubeView<T2> c,
     }
 }
 
-// _build_cube (delay.py:196-216): points generated on the fly from (xpts, ypts, zpts).  One thread per output NODE (iy, ix) and
-// z chunk: the model-CRS projection of the node (LCC / polar stereographic cubes), its x / y cells and the four horizontal
-// weight products are computed once and reused for every height of the chunk; the arithmetic per point is that of trilinear<>
-// (scipy's weight order, _rgi.py:490-498), so the values are the same bit for bit.  Output (nz, ny, nx): consecutive lanes write
-// consecutive addresses at every height.
+constexpr int BUILD_STAGE_BYTES = 32 << 10;   // LDS staging area of build_cube_kernel: (2 levels x heights per round) x footprint columns x 16 B (8 B for f32 cubes)
+constexpr int BUILD_NCOL_MAX = 256;           // a tile footprint of more cube columns than this takes the direct loads
+
+// _build_cube (delay.py:196-216): points generated on the fly from (xpts, ypts, zpts); the arithmetic per point is that of
+// trilinear<> (scipy's weight order, _rgi.py:490-498), so the values are the same bit for bit.  Output (nz, ny, nx).  Two kernels:
+//
+// build_cube_setup_kernel - everything that depends on ONE coordinate only, once: per output node (iy, ix) the model-CRS projection
+//   (LCC / polar stereographic cubes), its x / y cell and the two weights; per output height its z cell and weight.  24 B per node
+//   and 16 B per height in a scratch buffer.  (Fused into the gather kernel this code - bisections, four fp64 divisions, the
+//   projection's libm calls - set that kernel's register allocation and spilled into its loop.)
+// build_cube_kernel - the gather.  What bounds it is neither HBM nor arithmetic but the EIGHT 16 B corner loads per point through the
+//   vector L1's 64 B/clk/CU return path (config 2, f64 cube: 128 B per point = 0.15 ms by themselves, 0.27 ms with their latency
+//   exposed; tools/probes/buildcube_probe.hip), while the output alone can be written in 0.10-0.115 ms (tools/probes/write_probe.hip).
+//   A workgroup takes a 64 x 4-node TILE of the output grid (a wave = 64 consecutive nodes of one row: 512 B per store); the nodes
+//   of a tile interpolate from a handful of cube columns (config 2: 3 x 12 of them for 256 nodes), so the tile's FOOTPRINT - columns
+//   [cy_min, cy_max + 1] x [cx_min, cx_max + 1], two LDS min / max atomics per thread - is staged in LDS for as many heights as fit
+//   (2 level slots per height x columns; usually the whole chunk in one round) and the corners are read from there at the LDS rate.
+//   Same operands, same arithmetic order: bit-identical values.  A tile whose footprint does not fit (an output grid much coarser
+//   than the model's) takes the direct loads, batched ahead of the stores.
+struct BuildNode { int cy, cx; double ty, tx; };      // cy < 0: the node lies outside the cube's x / y range (or is NaN) -> fill value
+struct BuildLevel { double tz; int cz; int pad; };    // cz < 0: the height lies outside the z axis -> fill value
+
 template <typename T2>
-__global__ __launch_bounds__(256) void build_cube_kernel(CubeView<T2> c, LccParams proj, const double* __restrict__ xpts, int64_t nx,
-                                                         const double* __restrict__ ypts, int64_t ny,
-                                                         const double* __restrict__ zpts, int64_t nz, int64_t zchunk,
-                                                         double* __restrict__ wet, double* __restrict__ hyd, int axes_in_lds) {
+__global__ __launch_bounds__(256) void build_cube_setup_kernel(CubeView<T2> c, LccParams proj, const double* __restrict__ xpts, int64_t nx,
+                                                               const double* __restrict__ ypts, int64_t ny, const double* __restrict__ zpts, int64_t nz,
+                                                               BuildNode* __restrict__ nodes_out, BuildLevel* __restrict__ levels_out, int axes_in_lds) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const double* s_y = c.axes;                       // very long axes stay in global memory (L1 / L2 hits)
     if (axes_in_lds) {
@@ -313,82 +329,153 @@ __global__ __launch_bounds__(256) void build_cube_kernel(CubeView<T2> c, LccPara
     const double* s_x = s_y + c.ny;
     const double* s_z = s_x + c.nx;
     const int64_t nodes = nx * ny;
-    const int64_t z0 = (int64_t)blockIdx.y * zchunk, z1 = min(z0 + zchunk, nz);
-    // the heights are the same for every node: their z cells and weights once per workgroup (zchunk <= BUILD_ZCHUNK_MAX)
-    double* s_tz = reinterpret_cast<double*>(smem_raw) + (axes_in_lds ? c.ny + c.nx + c.nz : 0);
-    int* s_cz = reinterpret_cast<int*>(s_tz + zchunk);
-    for (int k = threadIdx.x; k < (int)(z1 - z0); k += blockDim.x) {
-        const double z = zpts[z0 + k];
-        int cz = -1; double tz = 0.0;
-        if ((z >= c.z_lo) && (z <= c.z_hi)) {
-            cz = find_cell(s_z, c.nz, z, c.z_lo, c.inv_dz, c.uni_z);
-            tz = (z - s_z[cz]) / (s_z[cz + 1] - s_z[cz]);
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nodes + nz; i += (int64_t)gridDim.x * blockDim.x) {
+        if (i >= nodes) {                             // the heights: the same for every node
+            const double z = zpts[i - nodes];
+            BuildLevel L; L.cz = -1; L.tz = 0.0; L.pad = 0;
+            if ((z >= c.z_lo) && (z <= c.z_hi)) {
+                L.cz = find_cell(s_z, c.nz, z, c.z_lo, c.inv_dz, c.uni_z);
+                L.tz = (z - s_z[L.cz]) / (s_z[L.cz + 1] - s_z[L.cz]);
+            }
+            levels_out[i - nodes] = L;
+            continue;
         }
-        s_tz[k] = tz; s_cz[k] = cz;                   // cz < 0: outside the axis (or NaN) -> fill value
-    }
-    __syncthreads();
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nodes; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t ix = i % nx, iy = i / nx;
         double qy = ypts[iy], qx = xpts[ix];
         if (proj.kind == 1) { double px_, py_; lcc_forward(proj, qy, qx, px_, py_); qx = px_; qy = py_; }   // transformPoints, delay.py:207-209
-        const bool in_xy = (qy >= c.y_lo) && (qy <= c.y_hi) && (qx >= c.x_lo) && (qx <= c.x_hi);
-        int cy = 0, cx = 0;
-        double a00 = 0, a01 = 0, a10 = 0, a11 = 0;
-        if (in_xy) {
-            cy = find_cell(s_y, c.ny, qy, c.y_lo, c.inv_dy, c.uni_y);
-            cx = find_cell(s_x, c.nx, qx, c.x_lo, c.inv_dx, c.uni_x);
-            const double ty = (qy - s_y[cy]) / (s_y[cy + 1] - s_y[cy]);
-            const double tx = (qx - s_x[cx]) / (s_x[cx + 1] - s_x[cx]);
-            const double wy0 = 1.0 - ty, wx0 = 1.0 - tx;
-            a00 = wy0 * wx0; a01 = wy0 * tx; a10 = ty * wx0; a11 = ty * tx;
+        BuildNode N; N.cy = -1; N.cx = 0; N.ty = 0.0; N.tx = 0.0;
+        if ((qy >= c.y_lo) && (qy <= c.y_hi) && (qx >= c.x_lo) && (qx <= c.x_hi)) {
+            N.cy = find_cell(s_y, c.ny, qy, c.y_lo, c.inv_dy, c.uni_y);
+            N.cx = find_cell(s_x, c.nx, qx, c.x_lo, c.inv_dx, c.uni_x);
+            N.ty = (qy - s_y[N.cy]) / (s_y[N.cy + 1] - s_y[N.cy]);
+            N.tx = (qx - s_x[N.cx]) / (s_x[N.cx + 1] - s_x[N.cx]);
         }
-        const T2* col00 = c.v + ((int64_t)cy * c.nx + cx) * c.nz;            // column (y0, x0); the others follow at fixed strides
-        const T2* col01 = col00 + c.nz;
-        const T2* col10 = col00 + (int64_t)c.nx * c.nz;
-        const T2* col11 = col10 + c.nz;
-        // U heights per trip: their 8 U corner-pair loads are issued back to back (clamped, hence unconditional, addresses - a
-        // conditional load would fence the batch), then the arithmetic, then the stores; the outputs are written once and not read
-        // back here: non-temporal stores.  Measured on config 2 (1000 x 1000 nodes x 40 heights, f64 cube: 640 MB out): 0.267 ms
-        // against 0.276 with one height per trip - the limiter is neither latency nor the write side (tools/probes/write_probe.hip:
-        // this very store pattern alone runs at 5.4-5.8 TB/s = 0.115 ms) but the eight 16 B corner loads per point: 128 B per
-        // point through the vector L1's 64 B/clk/CU return path is 0.15 ms by itself (profiles/r03_secondary.json: VALU issue 0.20,
-        // HBM 0.34 of peak - neither bound).  Fewer corner bytes per point would need the tile's cube footprint staged in LDS.
-        constexpr int U = sizeof(T2) == 8 ? 4 : 2;
-        for (int64_t iz = z0; iz < z1; iz += U) {
-            T2 v[U][8];
-            int czs[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int64_t k = min(iz + u, z1 - 1) - z0;
-                czs[u] = s_cz[k];
-                const int cz = max(czs[u], 0);
-                v[u][0] = col00[cz]; v[u][1] = col00[cz + 1];
-                v[u][2] = col01[cz]; v[u][3] = col01[cz + 1];
-                v[u][4] = col10[cz]; v[u][5] = col10[cz + 1];
-                v[u][6] = col11[cz]; v[u][7] = col11[cz + 1];
+        nodes_out[i] = N;
+    }
+}
+
+template <typename T2>
+__global__ __launch_bounds__(256) void build_cube_kernel(const T2* __restrict__ cv, int cny, int cnx, int cnz, const BuildNode* __restrict__ nrec,
+                                                         const BuildLevel* __restrict__ lrec, int64_t nx, int64_t ny, int64_t nz, int64_t zchunk,
+                                                         double* __restrict__ wet, double* __restrict__ hyd) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int STAGE_ELEMS = BUILD_STAGE_BYTES / (int)sizeof(T2);
+    T2* s_stage = reinterpret_cast<T2*>(smem_raw);
+    double* s_tz = reinterpret_cast<double*>(smem_raw + BUILD_STAGE_BYTES);
+    int* s_cz = reinterpret_cast<int*>(s_tz + zchunk);
+    int* s_fp = s_cz + zchunk;                                                 // cy_min, cy_max, cx_min, cx_max, "a height outside the z axis"
+    const int64_t nodes = nx * ny;
+    const int64_t z0 = (int64_t)blockIdx.y * zchunk, z1 = min(z0 + zchunk, nz);
+    const int nzc = (int)(z1 - z0);
+    if (threadIdx.x == 0) s_fp[4] = 0;
+    __syncthreads();
+    for (int k = threadIdx.x; k < nzc; k += blockDim.x) {
+        const BuildLevel L = lrec[z0 + k];
+        s_tz[k] = L.tz; s_cz[k] = L.cz;
+        if (L.cz < 0) s_fp[4] = 1;
+    }
+    __syncthreads();
+    const bool all_z_inside = s_fp[4] == 0;
+    const int64_t tiles_x = (nx + 63) / 64, tiles_y = (ny + 3) / 4;
+    for (int64_t t = blockIdx.x; t < tiles_x * tiles_y; t += gridDim.x) {       // (workgroup-uniform trip count: barriers inside)
+        const int64_t ix = (t % tiles_x) * 64 + (threadIdx.x & 63), iy = (t / tiles_x) * 4 + (threadIdx.x >> 6);
+        const bool act = ix < nx && iy < ny;
+        const int64_t i = iy * nx + ix;
+        BuildNode N; N.cy = -1; N.cx = 0; N.ty = 0.0; N.tx = 0.0;
+        if (act) N = nrec[i];
+        const bool in_xy = N.cy >= 0;
+        const int cy = max(N.cy, 0), cx = N.cx;
+        const double wy0 = 1.0 - N.ty, wx0 = 1.0 - N.tx;
+        const double a00 = wy0 * wx0, a01 = wy0 * N.tx, a10 = N.ty * wx0, a11 = N.ty * N.tx;
+        if (threadIdx.x == 0) { s_fp[0] = 0x7fffffff; s_fp[1] = -1; s_fp[2] = 0x7fffffff; s_fp[3] = -1; }
+        __syncthreads();                               // (also: the previous tile's readers are done with the staging area)
+        if (in_xy) { atomicMin(&s_fp[0], cy); atomicMax(&s_fp[1], cy); atomicMin(&s_fp[2], cx); atomicMax(&s_fp[3], cx); }
+        __syncthreads();
+        const int fy0 = s_fp[0], fy1 = s_fp[1], fx0 = s_fp[2], fx1 = s_fp[3];
+        const int nfx = fx1 - fx0 + 2, ncol = fy1 >= 0 ? (fy1 - fy0 + 2) * nfx : 0;       // (no node inside the cube: nothing to stage)
+        const bool staged = ncol > 0 && ncol <= BUILD_NCOL_MAX && 2 * ncol <= STAGE_ELEMS;    // workgroup-uniform
+        const int U = staged ? max(1, min(nzc, STAGE_ELEMS / (2 * ncol))) : 1;                // heights per staging round (often the whole chunk)
+        const int lc = in_xy ? (cy - fy0) * nfx + (cx - fx0) : 0;                         // this node's (y0, x0) column in the staging area
+        // one output point from its eight corners.  CLEAN: every lane of the wave is an output node inside the cube's x / y range
+        // and every height of the chunk lies inside the z axis (the usual case) - no validity selects, no store guards
+        auto emit = [&](auto clean, int k, const T2* v) {
+            constexpr bool CLEAN = decltype(clean)::value;
+            const double tz = s_tz[k];
+            const double wz0 = 1.0 - tz;
+            const double k0 = a00 * wz0, k1 = a00 * tz, k2 = a01 * wz0, k3 = a01 * tz;
+            const double k4 = a10 * wz0, k5 = a10 * tz, k6 = a11 * wz0, k7 = a11 * tz;
+            double sw = 0.0, sh = 0.0;
+            sw += (double)v[0].x * k0; sh += (double)v[0].y * k0;
+            sw += (double)v[1].x * k1; sh += (double)v[1].y * k1;
+            sw += (double)v[2].x * k2; sh += (double)v[2].y * k2;
+            sw += (double)v[3].x * k3; sh += (double)v[3].y * k3;
+            sw += (double)v[4].x * k4; sh += (double)v[4].y * k4;
+            sw += (double)v[5].x * k5; sh += (double)v[5].y * k5;
+            sw += (double)v[6].x * k6; sh += (double)v[6].y * k6;
+            sw += (double)v[7].x * k7; sh += (double)v[7].y * k7;
+            if (!CLEAN) {
+                // (a select, not a branch around the arithmetic: under `if (valid)` the compiler sinks a height's loads into the branch)
+                const bool ok = in_xy && s_cz[k] >= 0;
+                sw = ok ? sw : qnan(); sh = ok ? sh : qnan();
             }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (iz + u >= z1) break;
-                double sw = qnan(), sh = qnan();
-                if (in_xy && czs[u] >= 0) {
-                    const double tz = s_tz[iz + u - z0];
-                    const double wz0 = 1.0 - tz;
-                    const double k0 = a00 * wz0, k1 = a00 * tz, k2 = a01 * wz0, k3 = a01 * tz;
-                    const double k4 = a10 * wz0, k5 = a10 * tz, k6 = a11 * wz0, k7 = a11 * tz;
-                    sw = 0.0; sh = 0.0;
-                    sw += (double)v[u][0].x * k0; sh += (double)v[u][0].y * k0;
-                    sw += (double)v[u][1].x * k1; sh += (double)v[u][1].y * k1;
-                    sw += (double)v[u][2].x * k2; sh += (double)v[u][2].y * k2;
-                    sw += (double)v[u][3].x * k3; sh += (double)v[u][3].y * k3;
-                    sw += (double)v[u][4].x * k4; sh += (double)v[u][4].y * k4;
-                    sw += (double)v[u][5].x * k5; sh += (double)v[u][5].y * k5;
-                    sw += (double)v[u][6].x * k6; sh += (double)v[u][6].y * k6;
-                    sw += (double)v[u][7].x * k7; sh += (double)v[u][7].y * k7;
-                }
-                const int64_t o = (iz + u) * nodes + i;
+            if (CLEAN || act) {
+                const int64_t o = (z0 + k) * nodes + i;
                 __builtin_nontemporal_store(sw, wet + o);
                 __builtin_nontemporal_store(sh, hyd + o);
+            }
+        };
+        const bool wave_clean = __all(act && in_xy) && all_z_inside;
+        if (staged) {
+            for (int kb = 0; kb < nzc; kb += U) {
+                if (kb > 0) __syncthreads();           // the previous round has been read
+                // lane -> footprint column (one integer division per column and thread), wave -> every fourth level slot
+                const int nu = min(U, nzc - kb);
+                for (int col = threadIdx.x & 63; col < ncol; col += 64) {
+                    const int fy = col / nfx, fx = col - fy * nfx;
+                    // (rows / columns beyond the cube's last node belong to no node's corners: clamped, never read)
+                    const T2* colp = cv + ((int64_t)min(fy0 + fy, cny - 1) * cnx + min(fx0 + fx, cnx - 1)) * cnz;
+                    for (int slot = threadIdx.x >> 6; slot < 2 * nu; slot += 4)
+                        s_stage[slot * ncol + col] = colp[max(s_cz[kb + (slot >> 1)], 0) + (slot & 1)];
+                }
+                __syncthreads();
+                auto round = [&](auto clean) {
+                    const T2* lo = s_stage + lc;
+#pragma unroll 2
+                    for (int u = 0; u < nu; ++u, lo += 2 * ncol) {
+                        const T2* hi = lo + ncol;
+                        T2 v[8];
+                        v[0] = lo[0]; v[1] = hi[0];
+                        v[2] = lo[1]; v[3] = hi[1];
+                        v[4] = lo[nfx]; v[5] = hi[nfx];
+                        v[6] = lo[nfx + 1]; v[7] = hi[nfx + 1];
+                        emit(clean, kb + u, v);
+                    }
+                };
+                if (wave_clean) round(std::true_type{}); else round(std::false_type{});
+            }
+        } else {
+            // direct loads: UD heights per trip, their 8 UD corner loads issued back to back ahead of the first store
+            constexpr int UD = sizeof(T2) == 8 ? 4 : 2;
+            const T2* col00 = cv + ((int64_t)cy * cnx + cx) * cnz;             // column (y0, x0); the others at fixed strides
+            const T2* col01 = col00 + cnz;
+            const T2* col10 = col00 + (int64_t)cnx * cnz;
+            const T2* col11 = col10 + cnz;
+            for (int kb = 0; kb < nzc; kb += UD) {
+                T2 v[UD][8];
+#pragma unroll
+                for (int u = 0; u < UD; ++u) {
+                    const int cz = max(s_cz[min(kb + u, nzc - 1)], 0);
+                    v[u][0] = col00[cz]; v[u][1] = col00[cz + 1];
+                    v[u][2] = col01[cz]; v[u][3] = col01[cz + 1];
+                    v[u][4] = col10[cz]; v[u][5] = col10[cz + 1];
+                    v[u][6] = col11[cz]; v[u][7] = col11[cz + 1];
+                }
+                asm volatile("" ::: "memory");      // (the compiler sank the later heights' loads behind the first store otherwise)
+#pragma unroll
+                for (int u = 0; u < UD; ++u) {
+                    if (kb + u >= nzc) break;
+                    emit(std::false_type{}, kb + u, v[u]);
+                }
             }
         }
     }

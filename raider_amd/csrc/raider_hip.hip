@@ -812,27 +812,41 @@ int rdr_build_cube(rdr_ctx* c, const rdr_cube* q, const double* xpts, int64_t nx
     rc = stage_in(c, SLOT_IN2, zpts, (size_t)nz * 8, loc, &dz); if (rc) return rc;
     rc = stage_out(c, SLOT_OUT0, wet, (size_t)n * 8, loc, &dw); if (rc) return rc;
     rc = stage_out(c, SLOT_OUT1, hydro, (size_t)n * 8, loc, &dh); if (rc) return rc;
-    // one thread per (node, z chunk): enough chunks that a small grid still fills the chip, as few as possible otherwise (the
-    // horizontal work of a node is redone per chunk)
+    // Setup kernel: per-node and per-height records (24 B / 16 B) into scratch; then the gather: 64 x 4-node tiles x chunks of
+    // heights - enough chunks that a small grid still fills the chip, as few as possible otherwise.
     const int64_t nodes = nx * ny;
-    const int64_t want_threads = (int64_t)c->num_cus * 256 * 8;
-    int64_t nchunks = std::min<int64_t>(nz, std::max<int64_t>(1, (want_threads + nodes - 1) / nodes));
+    void *dn, *dl;
+    rc = ensure(c, SLOT_IN3, (size_t)nodes * sizeof(BuildNode), &dn); if (rc) return rc;
+    rc = ensure(c, SLOT_IN4, (size_t)nz * sizeof(BuildLevel), &dl); if (rc) return rc;
+    const int64_t ntile = ((nx + 63) / 64) * ((ny + 3) / 4);
+    const int64_t want_tiles = (int64_t)c->num_cus * 8;
+    int64_t nchunks = std::min<int64_t>(nz, std::max<int64_t>(1, (want_tiles + ntile - 1) / ntile));
     nchunks = std::max<int64_t>(nchunks, (nz + BUILD_ZCHUNK_MAX - 1) / BUILD_ZCHUNK_MAX);      // the per-height table of a chunk lives in LDS
     if (nchunks > 65535) return fail(c, RDR_ERR_INVALID, "rdr_build_cube: more than 65535 x 1024 heights");
     const int64_t zchunk = (nz + nchunks - 1) / nchunks;
     nchunks = (nz + zchunk - 1) / zchunk;
-    const dim3 g(grid_for(nodes, 256, c->num_cus * 8), (unsigned)nchunks);
-    const size_t sm = axes_smem(q) + (size_t)zchunk * 12 + 8;
+    const dim3 g((unsigned)std::max<int64_t>(1, std::min<int64_t>(ntile, (int64_t)c->num_cus * 16)), (unsigned)nchunks);
+    // staging area of the tile footprint | per-height z weights (8 B) and cells (4 B) | footprint bounds + flag
+    const size_t sm = (size_t)BUILD_STAGE_BYTES + (size_t)zchunk * 12 + 32;
     {
         KTimer t(c, 2);
-        if (q->dtype == RDR_F32)
-            hipLaunchKernelGGL((build_cube_kernel<float2>), g, dim3(256), sm, c->stream, make_view<float2>(q), q->proj,
-                               (const double*)dx, nx, (const double*)dy, ny, (const double*)dz, nz, zchunk, (double*)dw, (double*)dh, (int)axes_fit_lds(q));
-        else
-            hipLaunchKernelGGL((build_cube_kernel<double2>), g, dim3(256), sm, c->stream, make_view<double2>(q), q->proj,
-                               (const double*)dx, nx, (const double*)dy, ny, (const double*)dz, nz, zchunk, (double*)dw, (double*)dh, (int)axes_fit_lds(q));
+        const int gs = grid_for(nodes + nz, 256, c->num_cus * 8);
+        hipError_t e;
+        if (q->dtype == RDR_F32) {
+            e = launch_lds(build_cube_setup_kernel<float2>, dim3(gs), dim3(256), axes_smem(q), c->stream, make_view<float2>(q), q->proj, (const double*)dx, nx,
+                           (const double*)dy, ny, (const double*)dz, nz, (BuildNode*)dn, (BuildLevel*)dl, (int)axes_fit_lds(q));
+            if (e == hipSuccess)
+                e = launch_lds(build_cube_kernel<float2>, g, dim3(256), sm, c->stream, (const float2*)q->d_vals, (int)q->ny, (int)q->nx, (int)q->nz,
+                               (const BuildNode*)dn, (const BuildLevel*)dl, nx, ny, nz, zchunk, (double*)dw, (double*)dh);
+        } else {
+            e = launch_lds(build_cube_setup_kernel<double2>, dim3(gs), dim3(256), axes_smem(q), c->stream, make_view<double2>(q), q->proj, (const double*)dx, nx,
+                           (const double*)dy, ny, (const double*)dz, nz, (BuildNode*)dn, (BuildLevel*)dl, (int)axes_fit_lds(q));
+            if (e == hipSuccess)
+                e = launch_lds(build_cube_kernel<double2>, g, dim3(256), sm, c->stream, (const double2*)q->d_vals, (int)q->ny, (int)q->nx, (int)q->nz,
+                               (const BuildNode*)dn, (const BuildLevel*)dl, nx, ny, nz, zchunk, (double*)dw, (double*)dh);
+        }
+        if (e != hipSuccess) return fail(c, RDR_ERR_HIP, std::string("build_cube_kernel launch: ") + hipGetErrorString(e));
     }
-    HIPCHECK(c, hipGetLastError());
     rc = finish_out(c, wet, dw, (size_t)n * 8, loc); if (rc) return rc;
     rc = finish_out(c, hydro, dh, (size_t)n * 8, loc); if (rc) return rc;
     if (loc == RDR_HOST) HIPCHECK(c, hipStreamSynchronize(c->stream));

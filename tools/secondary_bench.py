@@ -44,6 +44,8 @@ t = timed(lambda: tot.build_cube(xt, yt, zt, out=(ow, oh)))
 n = 40 * 1000 * 1000
 res['build_cube_kernel'] = dict(what='configs[1]: _build_cube 1000x1000 nodes x 40 heights, 300x300x80 f64 totals cube', units=n, unit='points', bytes_per_unit=168,
                                 wall_ms=t * 1e3, reps=REPS + 1)
+res['build_cube_setup_kernel'] = dict(what='configs[1]: per-node cells / weights (24 B) and per-height cells / weights of the same _build_cube call (first of its two kernels)',
+                                      units=1000 * 1000, unit='nodes', bytes_per_unit=24, wall_ms=0.0, reps=REPS + 1)
 # ---- config 5: two-epoch blend of 1000 x 1000 x 50 f32 cubes on the HRRR 3-km LCC grid, 5 M stations ---------------------------
 rng = np.random.default_rng(3)
 xs = -1.5e6 + 3000.0 * np.arange(1000); ys = -1.5e6 + 3000.0 * np.arange(1000)
