@@ -962,7 +962,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
 //               and 32-bit offsets;   0: whatever the run-time flags say.
 // PR (light kernel only): per-ray origin heights (P.ht_ray) - its own instantiation, the slice kernels carry none of it.
 template <typename T2, bool SLOW, int GRID = 0, bool PR = false>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 : 4, SLOW ? 8 : 4))) void march_kernel(CubeView<T2> c_in, RayParams P, LccParams proj) {
+// (f64 cubes - azimuth-time-grid blends - hold 8 x 16 B of corners per sample: three waves per SIMD without scratch beat four with 80 B of
+// it, 6.8 against 11.4 ms per 16 M rays; the per-ray-height instantiation, 24 B of scratch at four waves, is better off as it is: 5.7 against 6.4 ms)
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 : (sizeof(T2) == 16 ? 3 : 4), SLOW ? 8 : (sizeof(T2) == 16 ? 3 : 4)))) void march_kernel(CubeView<T2> c_in, RayParams P, LccParams proj) {
     static_assert(!SLOW || !PR, "the generic kernel looks at P.ht_ray at run time");
     if (SLOW && *P.nslow == 0) return;
     const bool per_ray = PR || (SLOW && P.ht_ray != nullptr);
