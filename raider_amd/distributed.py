@@ -185,3 +185,46 @@ def raytrace_heights_sharded(cube, rays_for, hts, zref, max_seg=1000.0, world=No
     mine = np.ascontiguousarray(hts[h0:h0 + nh])
     wet, hyd, K, nparts, flags = cube.raytrace_slices(rays_for(mine), mine, zref, max_seg)
     return h0, nh, wet, hyd, K, nparts, flags
+
+
+def interp_points_sharded(cube, pts, world=None, rank=None):
+    """Station / zenith queries (BASELINE configs[1], configs[4]: 5 M GNSS stations on 8 GPUs) shard with NO collective at all: every
+    rank holds the (broadcast, possibly blended) cube and interpolates its contiguous block of the point list
+    (delay.py:116-121 applied to rows [p0, p0 + np) of `pts[n, 3]` = (y, x, z)).  Returns (p0, np, wet, hydro); np == 0 when there are
+    more ranks than points."""
+    if world is None or rank is None:
+        if is_distributed():
+            dist = _dist()
+            world, rank = dist.get_world_size(), dist.get_rank()
+        else:
+            world, rank = 1, 0
+    n = pts.shape[0]
+    p0, cnt = shard_rows(n, world, rank)
+    if cnt == 0:
+        return p0, 0, None, None
+    wet, hyd = cube.interp(pts[p0:p0 + cnt])
+    return p0, cnt, wet, hyd
+
+
+def broadcast_and_blend(epochs, weights, src=0, device=None, group=None, header=None, ctx=None):
+    """The two-epoch temporal interpolation of cli/raider.py:817-819 on every rank of a multi-GPU job: each epoch's cube goes out in one
+    packed broadcast (broadcast_cube_packed), the blend w1 * a + w2 * b runs on each rank's own device (blend_kernel) - cheaper than
+    blending on one rank and broadcasting, since the epochs are what the ranks need anyway when several times are interpolated.
+    `epochs`: on `src` a list of dict(ys, xs, zs, wet, hydro) (file order z, y, x), elsewhere ignored (None); `weights`: one float per
+    epoch, known to every rank.  Returns the blended device Cube."""
+    from .engine import Cube
+    cubes = []
+    for k in range(len(weights)):
+        f = epochs[k] if (epochs is not None and _dist().get_rank() == src) else None
+        axes, wet, hyd = broadcast_cube_packed(f, src=src, device=device, group=group, header=header)
+        nz, ny, nx = (int(v) for v in wet.shape)
+        ax = axes.cpu().numpy()
+        if device is None:
+            wet, hyd = wet.numpy(), hyd.numpy()
+        cubes.append(Cube(ax[:ny], ax[ny:ny + nx], ax[ny + nx:], wet, hyd, order='zyx', ctx=ctx))
+    out = cubes[0]
+    if len(cubes) == 1:
+        return out
+    if len(cubes) != 2:
+        raise ValueError('broadcast_and_blend: one or two epochs (more: s1_azimuth_timing.combine_cubes)')
+    return cubes[0].blend(float(weights[0]), cubes[1], float(weights[1]))

@@ -116,3 +116,37 @@ def test_pack_unpack_cube_roundtrip_f32_f64_any_layout():
         unpack_cube(buf[:-8], hdr)
     with pytest.raises(ValueError):
         pack_cube(ys, xs, zs, w.astype(np.int32), h)
+
+
+def _points_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from raider_amd import distributed as D
+
+        class FakeCube:                     # (no GPU here: the per-rank arithmetic is a stand-in, the sharding logic is what is tested)
+            def interp(self, p):
+                return p[:, 0] * 2.0, p[:, 1] - 1.0
+        pts = np.arange(3 * 1001, dtype=np.float64).reshape(1001, 3)
+        p0, cnt, w, h = D.interp_points_sharded(FakeCube(), pts)
+        q.put((rank, p0, cnt, float(w.sum()), float(h.sum())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_station_points_shard_without_a_collective():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_points_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    pts = np.arange(3 * 1001, dtype=np.float64).reshape(1001, 3)
+    assert [r[1] for r in res] == [0, 334, 668] and [r[2] for r in res] == [334, 334, 333]
+    assert abs(sum(r[3] for r in res) - (pts[:, 0] * 2).sum()) < 1e-6 and abs(sum(r[4] for r in res) - (pts[:, 1] - 1).sum()) < 1e-6

@@ -63,8 +63,18 @@ with torch.cuda.stream(st):
     D.raytrace_slab_async(cube, rays, 0.0, zref, part, out=(ow, oh))
 st.synchronize()
 ok3 = torch.equal(ow, w0) and torch.equal(oh, h0)
+# config 5 on every rank: both epochs broadcast, blended on the rank's own device, the rank's block of the stations interpolated
+c2 = synthetic_cube(60, 70, 40, seed=1)
+ep = [{k: c[k] for k in ('ys', 'xs', 'zs', 'wet', 'hydro')}, {k: c2[k] for k in ('ys', 'xs', 'zs', 'wet', 'hydro')}]
+blended = D.broadcast_and_blend(ep, (0.25, 0.75), src=0, device=dev)
+want = R.Cube(c['ys'], c['xs'], c['zs'], c['wet'], c['hydro'], order='zyx').blend(0.25, R.Cube(c2['ys'], c2['xs'], c2['zs'], c2['wet'], c2['hydro'], order='zyx'), 0.75)
+rng = np.random.default_rng(3)
+pts = torch.from_numpy(np.stack([rng.uniform(30.2, 35.8, 5000), rng.uniform(-120.8, -113.2, 5000), rng.uniform(0, 4000, 5000)], -1)).to(dev)
+p0, cnt, sw, sh = D.interp_points_sharded(blended, pts)
+rw, rh = want.interp(pts)
+ok4 = p0 == 0 and cnt == 5000 and torch.equal(sw, rw) and torch.equal(sh, rh) and bool(torch.isfinite(sw).all())
 nan_frac = float(torch.isnan(h0).double().mean())
-print(json.dumps(dict(ok=bool(ok), ok2=bool(ok2), ok3=bool(ok3), K=K, nan_frac=nan_frac, partition_max=float(part[:K].max()))))
+print(json.dumps(dict(ok=bool(ok), ok2=bool(ok2), ok3=bool(ok3), ok4=bool(ok4), K=K, nan_frac=nan_frac, partition_max=float(part[:K].max()))))
 dist.destroy_process_group()
 '''
 
@@ -77,6 +87,7 @@ def test_one_rank_rccl_group_broadcast_allreduce_bit_identical():
     assert res['ok'], 'pass 1 -> ncclAllReduce -> pass 2 (asynchronous, device partition) differs from Cube.raytrace'
     assert res['ok2'], 'the synchronous slab path through the nccl backend differs from Cube.raytrace'
     assert res['ok3'], 'on a side stream the collective was not ordered against the ray kernels'
+    assert res['ok4'], 'two epochs broadcast + blended per rank + sharded station gather differ from the single-process result'
     assert res['K'] > 20 and res['partition_max'] > 1000.0 and res['nan_frac'] < 0.5
 
 
