@@ -207,12 +207,26 @@ template <typename T2> struct Quad {
 template <typename T2>
 __global__ __launch_bounds__(256) void quad_build_kernel(const T2* __restrict__ v, int ny, int nx, int nz, int nblk, uint4* __restrict__ q) {
     const int64_t total = (int64_t)(ny - 1) * (nx - 1) * nblk * 8;
-    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    // every workgroup a CONTIGUOUS range of parts, the ranges of the workgroups of one XCD (blockIdx % 8) adjacent: an XCD then builds one
+    // band of cell rows and reads each source column from ITS L2 for both rows and both columns that share it (interleaved over the whole
+    // cube every XCD read everything: 1.4 GB fetched for the 400 MB cube, 0.72 ms; now write-bound)
+    const int64_t nb = gridDim.x, per_x = (nb + 7) / 8;
+    const int64_t bid = (int64_t)(blockIdx.x & 7) * per_x + (blockIdx.x >> 3);
+    const int64_t per = ((total + per_x * 8 - 1) / (per_x * 8) + 255) / 256 * 256;
+    const int64_t t_end = min(total, (bid + 1) * per);
+    for (int64_t t = bid * per + threadIdx.x; t < t_end; t += blockDim.x) {
         const int p = (int)(t & 7);
         const int64_t b = t >> 3;
-        const int j = (int)(b % nblk);
-        const int64_t col = b / nblk;
-        const int ix = (int)(col % (nx - 1)), iy = (int)(col / (nx - 1));
+        int j, ix, iy;
+        if (total < (1LL << 34)) {                    // (32-bit divisions: a quarter of the instructions of the 64-bit ones)
+            const unsigned bu = (unsigned)b, colu = bu / (unsigned)nblk;
+            j = (int)(bu - colu * (unsigned)nblk);
+            iy = (int)(colu / (unsigned)(nx - 1)); ix = (int)(colu - (unsigned)iy * (unsigned)(nx - 1));
+        } else {
+            j = (int)(b % nblk);
+            const int64_t col = b / nblk;
+            ix = (int)(col % (nx - 1)); iy = (int)(col / (nx - 1));
+        }
         uint4 out;
         if constexpr (sizeof(T2) == 8) {            // float2: part p = level p/2, row y0 / y1 = p%2, both x corners
             const int lev = min(j * Quad<T2>::CPB + (p >> 1), nz - 1);
@@ -225,7 +239,11 @@ __global__ __launch_bounds__(256) void quad_build_kernel(const T2* __restrict__ 
             const unsigned long long lo = (unsigned long long)__double_as_longlong(v0.x), hi = (unsigned long long)__double_as_longlong(v0.y);
             out.x = (unsigned)lo; out.y = (unsigned)(lo >> 32); out.z = (unsigned)hi; out.w = (unsigned)(hi >> 32);
         }
-        q[t] = out;
+        // (written once, read by other kernels much later: non-temporal, so that the 2 GB of output do not evict the source columns the
+        // neighbouring cell columns and the next cell row are about to re-read from this XCD's L2)
+        typedef unsigned U4 __attribute__((ext_vector_type(4)));
+        U4 o4 = {out.x, out.y, out.z, out.w};
+        __builtin_nontemporal_store(o4, reinterpret_cast<U4*>(q) + t);
     }
 }
 

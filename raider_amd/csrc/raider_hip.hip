@@ -727,7 +727,7 @@ static int quad_build(rdr_ctx* c, const rdr_cube* q) {
     HIPCHECK(c, hipMalloc(&q->d_quad, need));
     q->quad_bytes = need; q->quad_nblk = nblk;
     const int64_t parts = (int64_t)(need / 16);
-    const int g = grid_for(parts, 256, c->num_cus * 32);
+    const int g = (grid_for(parts, 256, c->num_cus * 32) + 7) / 8 * 8;       // a multiple of 8: one share of the ranges per XCD (quad_build_kernel)
     if (q->dtype == RDR_F32) hipLaunchKernelGGL((quad_build_kernel<float2>), dim3(g), dim3(256), 0, c->stream, (const float2*)q->d_vals, (int)q->ny, (int)q->nx, (int)q->nz, nblk, (uint4*)q->d_quad);
     else hipLaunchKernelGGL((quad_build_kernel<double2>), dim3(g), dim3(256), 0, c->stream, (const double2*)q->d_vals, (int)q->ny, (int)q->nx, (int)q->nz, nblk, (uint4*)q->d_quad);
     HIPCHECK(c, hipGetLastError());
