@@ -1463,7 +1463,11 @@ int rdr_raytrace_slices(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, const 
     // (all kernels are enqueued first: a copy into pageable memory blocks the host thread, not the device).
     static const bool no_pipeline = std::getenv("RAIDER_HIP_NO_PIPELINE") != nullptr;
     const bool pipe = r->loc == RDR_HOST && nslices >= 2 && nout * 16 >= ((size_t)32 << 20) && per <= fit && !no_pipeline;
-    std::vector<hipEvent_t> gev;
+    struct EventList {                                   // (destroyed on every exit path)
+        std::vector<hipEvent_t> v;
+        ~EventList() { for (auto& e : v) if (e) (void)hipEventDestroy(e); }
+    } gev_owner;
+    std::vector<hipEvent_t>& gev = gev_owner.v;
     std::vector<std::pair<int64_t, int64_t>> groups;
     bool downloaded = false;
     if (per <= fit) {
@@ -1485,7 +1489,6 @@ int rdr_raytrace_slices(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, const 
             if (pipe) {
                 hipEvent_t e = nullptr;
                 if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess || hipEventRecord(e, c->stream) != hipSuccess) {
-                    for (auto& x : gev) (void)hipEventDestroy(x);
                     if (e) (void)hipEventDestroy(e);
                     return fail(c, RDR_ERR_HIP, "rdr_raytrace_slices: event");
                 }
@@ -1502,7 +1505,6 @@ int rdr_raytrace_slices(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, const 
                     status = fail(c, RDR_ERR_HIP, "rdr_raytrace_slices: output download failed");
             }
             if (hipStreamSynchronize(c->copy_stream) != hipSuccess && status == RDR_OK) status = fail(c, RDR_ERR_HIP, "rdr_raytrace_slices: sync");
-            for (auto& x : gev) (void)hipEventDestroy(x);
             if (status != RDR_OK) return status;
             downloaded = true;
         }
