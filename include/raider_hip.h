@@ -220,6 +220,9 @@ int64_t rdr_cube_point_index_bytes(const rdr_cube* cube);
 /* _build_cube (delay.py:196-216) for model_crs == pts_crs: out[(iz*ny+iy)*nx+ix] = f(ypts[iy],xpts[ix],zpts[iz]) */
 int rdr_build_cube(rdr_ctx* ctx, const rdr_cube* cube, const double* xpts, int64_t nx, const double* ypts,
                    int64_t ny, const double* zpts, int64_t nz, double* wet, double* hydro, int loc);
+/* 1 / 0: the result of the last rdr_build_cube call with HOST arrays on this ctx holds / does not hold a NaN - the scan the caller
+ * runs over the result (delay.py:187) done on the device before the download; -1: unknown (no such call yet, or device arrays). */
+int rdr_last_nan_output(rdr_ctx* ctx);
 /* Conventional.__call__ tail (losreader.py:130-133) with inc/heading rasters: out = delay / cos(inc) */
 int rdr_project_cosinc(rdr_ctx* ctx, double* wet, double* hydro, const double* inc, int64_t n, int loc);
 

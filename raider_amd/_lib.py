@@ -80,6 +80,7 @@ SYMBOLS = [
     ('rdr_cube_point_index_bytes', C.c_int64, [_VP]),
     ('rdr_interp3', C.c_int, [_VP, _VP, _VP, C.c_int64, _VP, _VP, C.c_int]),
     ('rdr_build_cube', C.c_int, [_VP, _VP, _VP, C.c_int64, _VP, C.c_int64, _VP, C.c_int64, _VP, _VP, C.c_int]),
+    ('rdr_last_nan_output', C.c_int, [_VP]),
     ('rdr_project_cosinc', C.c_int, [_VP, _VP, _VP, _VP, C.c_int64, C.c_int]),
     ('rdr_ray_levels', C.c_int, [_VP, C.c_double, C.c_double, c_ip, _VP, _VP, _VP]),
     ('rdr_ray_prepass', C.c_int, [_VP, _VP, C.POINTER(RdrRays), C.c_double, C.c_double, _VP, c_ip]),

@@ -8,7 +8,9 @@ the link rate.  The pool keeps at most RAIDER_HIP_PINNED_POOL_BYTES (default 4 G
 switches pinned results off (plain np.empty)."""
 import ctypes as C
 import os
+import sys
 import threading
+import time
 
 import numpy as np
 
@@ -37,8 +39,17 @@ class _Block:
         _release(self.ptr, self.cap)
 
 
+_DEBUG = bool(os.environ.get('RAIDER_HIP_PINNED_DEBUG'))
+
+
+def _log(*a):
+    if _DEBUG and sys is not None:
+        print(f'[pinned {time.perf_counter():.4f}]', *a, file=sys.stderr, flush=True)
+
+
 def _release(ptr, cap):
     global _free_bytes
+    _log('release', hex(ptr), cap)
     try:
         with _lock:
             if _free_bytes + cap <= _limit():
@@ -65,6 +76,7 @@ def empty(shape, dtype=np.float64):
         if lst:
             ptr = lst.pop()
             _free_bytes -= cap
+    _log('reuse' if ptr is not None else 'alloc', cap)
     if ptr is None:
         p = C.c_void_p()
         try:

@@ -54,6 +54,7 @@ struct rdr_ctx {
     int* d_sidectr = nullptr;                 // [1] next free column
     int64_t side_forced = -1;                 // rdr_set_side_capacity
     int64_t last_nslow = 0;                   // generic rays seen by the last pass 1 whose count the host happened to read back
+    int last_nan_output = -1;                 // rdr_build_cube (host arrays): 1 / 0 = its last result holds / does not hold a NaN; -1 unknown
     size_t ws_limit = (size_t)48 << 30;       // cap on that workspace; bigger batches are marched in chunks
     // which ray batch the stored records belong to (a later rdr_ray_march reuses them only for the identical batch)
     struct { const void* cube = nullptr; int64_t n = -1; double ht = 0, zref = 0; const void* a = nullptr; const void* b = nullptr; const void* c = nullptr; const void* d = nullptr; int K = 0; bool valid = false; } wsig;
@@ -847,11 +848,27 @@ int rdr_build_cube(rdr_ctx* c, const rdr_cube* q, const double* xpts, int64_t nx
         }
         if (e != hipSuccess) return fail(c, RDR_ERR_HIP, std::string("build_cube_kernel launch: ") + hipGetErrorString(e));
     }
+    // np.isnan(result).any() (delay.py:187) answered here, before the outputs leave the device (rdr_last_nan_output)
+    int* const nf = c->d_flags + MAX_SLICES + 1;
+    c->last_nan_output = -1;
+    if (loc == RDR_HOST) {
+        HIPCHECK(c, hipMemsetAsync(nf, 0, sizeof(int), c->stream));
+        hipLaunchKernelGGL(nan_scan_kernel, dim3(grid_for(n, 256, c->num_cus * 8)), dim3(256), 0, c->stream, (const double*)dw, (const double*)dh, n, n, nf);
+        HIPCHECK(c, hipGetLastError());
+    }
     rc = finish_out(c, wet, dw, (size_t)n * 8, loc); if (rc) return rc;
     rc = finish_out(c, hydro, dh, (size_t)n * 8, loc); if (rc) return rc;
-    if (loc == RDR_HOST) HIPCHECK(c, hipStreamSynchronize(c->stream));
+    if (loc == RDR_HOST) {
+        int f = 0;
+        HIPCHECK(c, hipMemcpyAsync(&f, nf, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHECK(c, hipStreamSynchronize(c->stream));
+        c->last_nan_output = (f & 64) ? 1 : 0;
+    }
     return RDR_OK;
 }
+
+int rdr_last_nan_output(rdr_ctx* c) { return c ? c->last_nan_output : -1; }
+
 
 int rdr_project_cosinc(rdr_ctx* c, double* wet, double* hydro, const double* inc, int64_t n, int loc) {
     if (!c || !wet || !hydro || !inc) return fail(c, RDR_ERR_INVALID, "rdr_project_cosinc: NULL argument");

@@ -429,12 +429,16 @@ def _build_cube(xpts, ypts, zpts, model_crs, pts_crs, interpolators):
     zpts = np.asarray(zpts)
     if _is_4326(model_crs) and cube.projection is not None:
         cube.clear_projection()                            # (a cached cube that served a projected model before)
+    def hinted(res):
+        out = [res[f] for f in fields]
+        h = getattr(cube, 'last_build_cube_has_nan', None)
+        if h is not None and len(out) == 2:               # what np.isnan(result).any() would find (delay.py:187): known from the device scan
+            _nan_hints[id(out[0])] = h; _nan_hints[id(out[1])] = h
+        return out
     if _same_crs(model_crs, pts_crs) and cube.projection is None:
-        res = cube.build_cube(xpts, ypts, zpts)            # points generated on the fly in the kernel
-        return [res[f] for f in fields]
+        return hinted(cube.build_cube(xpts, ypts, zpts))   # points generated on the fly in the kernel
     if _is_4326(pts_crs) and _apply_model_crs(cube, model_crs):
-        res = cube.build_cube(xpts, ypts, zpts)            # lon/lat nodes projected to the model's LCC grid on the device
-        return [res[f] for f in fields]
+        return hinted(cube.build_cube(xpts, ypts, zpts))   # lon/lat nodes projected to the model's LCC grid on the device
     xx, yy = np.meshgrid(xpts, ypts)
     outputArrs = [np.zeros((zpts.size, len(ypts), len(xpts))) for _ in interpolators]
     for ii, ht in enumerate(zpts):

@@ -9,6 +9,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib as L
+from . import _pinned
 from ._lib import Context, check, f64, ptr
 
 
@@ -191,9 +192,13 @@ class Cube:
                                               ptr(wet), ptr(hyd), L.RDR_DEVICE), self.ctx.handle)
             return wet, hyd
         x, y, z = f64(xpts).ravel(), f64(ypts).ravel(), f64(np.atleast_1d(zpts)).ravel()
-        wet = np.empty((z.size, y.size, x.size)); hyd = np.empty_like(wet)
+        # (large cubes in recycled page-locked memory: the 640 MB of a 1000 x 1000 x 40 zenith cube come down in 12 ms instead of 40-120 ms
+        # into freshly mapped pageable pages - _pinned.py)
+        wet = _pinned.empty((z.size, y.size, x.size)); hyd = _pinned.empty((z.size, y.size, x.size))
         check(self.ctx.lib.rdr_build_cube(self.ctx.handle, self.handle, ptr(x), x.size, ptr(y), y.size, ptr(z), z.size,
                                           ptr(wet), ptr(hyd), L.RDR_HOST), self.ctx.handle)
+        f = self.ctx.lib.rdr_last_nan_output(self.ctx.handle)
+        self.last_build_cube_has_nan = None if f < 0 else bool(f)       # np.isnan(result).any(), scanned on the device
         return wet, hyd
 
     # ---- rays ------------------------------------------------------------------------------------

@@ -798,3 +798,29 @@ def test_cube_files_are_uploaded_from_the_mapping(tmp_path, caplog):
     f = h5lite.File(p4)
     assert np.array_equal(iw.cube.read()[0], f['wet'].read().transpose(1, 2, 0), equal_nan=True)
     assert np.array_equal(iw.cube.read()[1], f['hydro'].read().transpose(1, 2, 0), equal_nan=True)
+
+
+def test_zenith_cube_nan_scan_on_the_device_and_pinned_result():
+    """_build_cube on a large grid: the result lives in recycled page-locked memory and np.isnan(result).any() (delay.py:187) is answered by
+    the device-side scan of rdr_build_cube (a threaded host scan of 640 MB trips CPU-quota throttling on the GPU box: 17 ms calls became
+    100 ms ones) - right in both directions."""
+    import raider_amd as R
+    from raider_amd import _pinned
+    from raider_amd.delay import _build_cube, _nan_hints
+    from raider_amd.delayFcns import interpolators_from_cube
+    c = O.synthetic_cube(50, 50, 40, seed=0)
+    cube = R.Cube(c['ys'], c['xs'], c['zs'], c['wet_total'], c['hydro_total'], order='zyx')
+    ip = list(interpolators_from_cube(cube))
+    xp = np.linspace(-119.5, -115.5, 700); yp = np.linspace(34.5, 31.5, 600); zp = np.array([0.0, 500.0, 2000.0])
+    w, h = _build_cube(xp, yp, zp, 4326, 4326, ip)
+    assert _pinned.is_pinned(w) and _nan_hints.get(id(w)) is False and _nan_hints.get(id(h)) is False and np.isfinite(w).all()
+    it = list(O.getInterpolators(c['xs'], c['ys'], c['zs'], c['wet_total'], c['hydro_total']))
+    ow, oh = O.build_cube(xp[::50], yp[::50], zp, it)
+    np.testing.assert_allclose(w[:, ::50, ::50], ow, rtol=0, atol=1e-13)
+    xo = np.linspace(-122.0, -115.5, 700)                                    # partly west of the cube: fill values
+    w2, h2 = _build_cube(xo, yp, zp, 4326, 4326, ip)
+    assert _nan_hints.get(id(w2)) is True and np.isnan(w2).any() and np.isfinite(w2).any()
+    zo = np.array([0.0, 50000.0])                                            # a height above the model: that whole level is NaN
+    w3, _ = _build_cube(xp, yp, zo, 4326, 4326, ip)
+    assert _nan_hints.get(id(w3)) is True and np.isnan(w3[1]).all() and np.isfinite(w3[0]).all()
+    _nan_hints.clear()

@@ -14,6 +14,12 @@ for f in sorted(src.glob('tropo_*.json')):
     out[f.stem] = dict(what='tropo_delay(datetime, processed-cube NetCDF on disk, grid AOI, Raytracing(inc raster, heading), heights) -> NumPy delay cubes '
                             '(tools/e2e_tropo_delay.py; best of 5 warm calls, each with fresh result arrays)',
                        rays=d['rays'], ms=best * 1e3, rays_per_s=d['rays'] / best, first_call_ms=d['run0_s'] * 1e3, mean_hydro_m=d['mean_hydro'], nan=d['nan'])
+zf = src / 'zenith_1000x1000x40.json'
+if zf.exists():
+    d = json.loads(zf.read_text().strip().splitlines()[-1])
+    best = min(v for k, v in d.items() if k.startswith('run') and k != 'run0_s')
+    out['zenith_1000x1000x40'] = dict(what='tropo_delay(datetime, processed-cube NetCDF on disk, 1000 x 1000 grid AOI, Zenith(), 40 heights) -> NumPy delay cubes: BASELINE configs[1] '
+                                           'sizes through the host API (tools/e2e_zenith.py)', points=d['rays'], ms=best * 1e3, points_per_s=d['rays'] / best)
 line = (src / 'orbit_1000x1000x8.json').read_text().strip().splitlines()[-1]
 m = re.search(r'= ([\d.]+) M rays in ([\d.]+) ms', line)
 out['orbit_1000x1000x8'] = dict(what='_build_cube_ray through Raytracing(<orbit file>): grid -> ECEF -> zero-Doppler look vectors -> ray batch on the device, NumPy cubes back '
