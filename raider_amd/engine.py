@@ -173,7 +173,7 @@ class Cube:
             raise ValueError(f'The requested sample points xi have dimension {pts.shape[-1]} but this '
                              'RegularGridInterpolator has dimension 3')
         p = f64(pts).reshape(-1, 3)
-        wet = np.empty(p.shape[0]); hyd = np.empty(p.shape[0])
+        wet = _pinned.empty((p.shape[0],)); hyd = _pinned.empty((p.shape[0],))          # (large point sets: recycled page-locked results)
         check(self.ctx.lib.rdr_interp3(self.ctx.handle, self.handle, ptr(p), p.shape[0], ptr(wet), ptr(hyd), L.RDR_HOST), self.ctx.handle)
         return wet.reshape(pts.shape[:-1]), hyd.reshape(pts.shape[:-1])
 
@@ -304,7 +304,7 @@ class Cube:
             wet = torch.empty((S,) + tuple(rays.shape), dtype=torch.float64, device=rays._torch_device)
             hyd = torch.empty_like(wet)
         else:
-            wet = np.empty((S,) + tuple(rays.shape)); hyd = np.empty_like(wet)
+            wet = _pinned.empty((S,) + tuple(rays.shape)); hyd = _pinned.empty((S,) + tuple(rays.shape))
         rays.check_outputs(wet, hyd, slices=S)
         ld = self.shape[2] - 1
         if want_partition:
@@ -528,7 +528,7 @@ class Rays:
             import torch
             return (torch.empty(self.shape, dtype=torch.float64, device=self._torch_device),
                     torch.empty(self.shape, dtype=torch.float64, device=self._torch_device))
-        return np.empty(self.shape), np.empty(self.shape)
+        return _pinned.empty(tuple(self.shape)), _pinned.empty(tuple(self.shape))       # (large batches: recycled page-locked results)
 
     def look_vectors(self, ctx=None):
         ctx = ctx or Context.default()
