@@ -29,11 +29,16 @@ class FieldInterpolator:
 
     @staticmethod
     def _sig(pts):
-        """Content key of a point set: shape, dtype and an exact 128-bit digest of its bytes - a caller who edits the array in place
+        """Content key of a point set: shape, dtype and a 128-bit digest of ALL its bytes - a caller who edits the array in place
         (or hands over a different one) between the wet and the hydro call is never served the other call's result."""
-        import hashlib
-        flat = np.ascontiguousarray(pts)
-        return (pts.shape, pts.dtype.str, hashlib.blake2b(flat.reshape(-1).view(np.uint8), digest_size=16).digest())
+        flat = np.ascontiguousarray(pts).reshape(-1).view(np.uint8)
+        try:                                   # 128-bit XXH3: 10 GB/s (5 M stations: 12 ms); BLAKE2b (0.7 GB/s) where xxhash is not installed
+            import xxhash
+            digest = xxhash.xxh3_128_digest(flat)
+        except ImportError:
+            import hashlib
+            digest = hashlib.blake2b(flat, digest_size=16).digest()
+        return (pts.shape, pts.dtype.str, digest)
 
     def __call__(self, xi):
         """Both fields are gathered in one kernel launch; the sibling interpolator reuses the result when it
