@@ -193,9 +193,7 @@ def main():
         ht = None
     rays = R.Rays.grid(xpts_t, ypts_t, los=los_t, hts=hts_t)
     if hts_t is not None and dist_on:       # the level table of the whole scene starts at the lowest pixel of ALL ranks
-        hmin = torch.tensor([rays.ht_min], dtype=torch.float64, device=coll_dev if coll_dev is not None else 'cpu')
-        dist.all_reduce(hmin, op=dist.ReduceOp.MIN)
-        ht = float(hmin.item())
+        ht = D.global_table_height(rays, None, device=coll_dev)
     out_w = torch.empty((rows, cols), dtype=torch.float64, device=dev)
     out_h = torch.empty_like(out_w)
     n_rays = rows * cols

@@ -143,10 +143,29 @@ def broadcast_cube_packed(cube_fields, src=0, device=None, group=None, header=No
     return unpack_cube(buf, header)
 
 
+def global_table_height(rays, ht=None, group=None, device=None):
+    """The height every rank builds its level table for.  One slice: `ht` itself.  A batch with per-pixel origin heights (Rays(hts=...)):
+    the lowest height of the WHOLE scene - one MIN all-reduce of a scalar over the ranks' own minima (a rank-local minimum would give the
+    ranks tables of different lengths and partitions that cannot be reduced against each other).  An explicit `ht` at or below it is kept."""
+    if rays.ht_min is None:
+        return rays.table_height(ht)
+    lo = rays.table_height(ht)
+    if not is_distributed():
+        return lo
+    import torch
+    dist = _dist()
+    t = torch.tensor([lo], dtype=torch.float64, device=device if device is not None else 'cpu')
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return float(t.item())
+
+
 def raytrace_slab_async(cube, rays, ht, zref, partition, max_seg=1000.0, out=None, group=None):
     """The same slice without any host round trip (device-resident rays, outputs and partition; RCCL all-reduce on the
     K+4-element device tensor `partition`): pass 1 -> MAX all-reduce -> pass 2, all enqueued asynchronously.  The
-    reference's error conditions (all-NaN slice etc.) are not raised here - the outputs are NaN instead."""
+    reference's error conditions (all-NaN slice etc.) are not raised here - the outputs are NaN instead.
+    Per-pixel heights: pass the scene-wide table height (global_table_height, once per scene - it synchronises) as `ht`."""
+    if ht is None and rays.ht_min is not None and is_distributed():
+        raise ValueError('per-pixel heights on several ranks: pass ht = global_table_height(rays) (the scene-wide lowest height)')
     cube.ray_prepass_device(rays, ht, zref, partition)
     if is_distributed():
         dist = _dist()
@@ -156,7 +175,10 @@ def raytrace_slab_async(cube, rays, ht, zref, partition, max_seg=1000.0, out=Non
 
 def raytrace_slab(cube, rays, ht, zref, max_seg=1000.0, out=None, group=None, device=None):
     """One slice of _build_cube_ray for THIS rank's slab of the scene, with the batch-global partition.
-    Returns (wet, hydro, nparts)."""
+    Returns (wet, hydro, nparts).  Per-pixel heights (Rays(hts=...), ht=None): the level table of the whole scene starts at the lowest
+    height of ALL ranks (global_table_height)."""
+    if rays.ht_min is not None:
+        ht = global_table_height(rays, ht, group=group, device=device)
     maxlen, flags = cube.ray_prepass(rays, ht, zref)
     maxlen, flags = reduce_partition(maxlen, flags, group=group, device=device)
     check_partition_flags(flags)

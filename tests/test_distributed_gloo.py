@@ -150,3 +150,42 @@ def test_station_points_shard_without_a_collective():
     pts = np.arange(3 * 1001, dtype=np.float64).reshape(1001, 3)
     assert [r[1] for r in res] == [0, 334, 668] and [r[2] for r in res] == [334, 334, 333]
     assert abs(sum(r[3] for r in res) - (pts[:, 0] * 2).sum()) < 1e-6 and abs(sum(r[4] for r in res) - (pts[:, 1] - 1).sum()) < 1e-6
+
+
+def _height_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from raider_amd import distributed as D
+        from raider_amd.engine import Rays
+        hts = np.array([[100.0 + 50.0 * rank, 900.0], [400.0, 2500.0 - 100.0 * rank]])
+        rays = Rays.grid(np.array([-118.0, -117.0]), np.array([34.0, 33.0]), inc=35.0, hd=-167.9, hts=hts)
+        lo = D.global_table_height(rays)                                   # MIN over the ranks' own minima
+        lo2 = D.global_table_height(rays, -20.0)                           # an explicit, lower table height is kept
+        one = D.global_table_height(Rays.grid(np.array([-118.0]), np.array([34.0]), inc=35.0, hd=-167.9), 250.0)
+        err = None
+        try:
+            D.raytrace_slab_async(None, rays, None, 1000.0, None)
+        except ValueError as e:
+            err = str(e)
+        q.put((rank, rays.ht_min, lo, lo2, one, err))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_per_pixel_heights_share_one_table_height_across_ranks():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_height_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == [100.0, 150.0]                           # each rank's own lowest pixel
+    assert all(r[2] == 100.0 and r[3] == -20.0 and r[4] == 250.0 for r in res)
+    assert all(r[5] and 'global_table_height' in r[5] for r in res)
