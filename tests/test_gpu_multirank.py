@@ -53,3 +53,16 @@ def test_strong_scaling_is_the_default_for_n_gt_1(tmp_path):
     assert b0['hydro'].shape == (701, 1200) and b1['hydro'].shape == (700, 1200)
     assert np.array_equal(a['nparts'], b0['nparts']) and np.array_equal(a['nparts'], b1['nparts'])
     assert np.array_equal(a['hydro'], np.concatenate([b0['hydro'], b1['hydro']])) and np.array_equal(a['wet'], np.concatenate([b0['wet'], b1['wet']]))
+
+
+def test_per_pixel_heights_across_two_ranks(tmp_path):
+    """A scene on a DEM sharded over two ranks: the level table starts at the lowest pixel of the WHOLE scene (one MIN all-reduce), the
+    per-level maxima are reduced over the ranks as for a slice - the slabs equal the one-rank result bit for bit."""
+    one = _bench(tmp_path, 'one', '--gpus', '1', '--rows', '900', '--per-pixel-ht')
+    two = _bench(tmp_path, 'two', '--gpus', '2', '--total-rows', '900', '--per-pixel-ht')
+    assert two['scaling'] == 'strong' and two['config']['workload'].startswith('c3b')
+    a = np.load(tmp_path / 'one.rank0.npz')
+    b0, b1 = np.load(tmp_path / 'two.rank0.npz'), np.load(tmp_path / 'two.rank1.npz')
+    assert np.array_equal(a['nparts'], b0['nparts']) and np.array_equal(a['nparts'], b1['nparts'])
+    assert np.array_equal(a['hydro'], np.concatenate([b0['hydro'], b1['hydro']])) and np.array_equal(a['wet'], np.concatenate([b0['wet'], b1['wet']]))
+    assert np.isfinite(a['hydro']).all()
