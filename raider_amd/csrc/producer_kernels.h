@@ -85,10 +85,11 @@ __global__ __launch_bounds__(256) void producer_kernel(ProducerParams P) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int nzo = P.nz + P.pad;
     // per-wave LDS: zs,p,t,e at model levels (f64) | t,p,e,wet,hyd at output levels (f32) | output level heights (f64)
-    double* wbase = reinterpret_cast<double*>(smem_raw) + (size_t)wave * (4 * P.nlev + nzo + (5 * nzo + 1) / 2 + 1);
+    double* wbase = reinterpret_cast<double*>(smem_raw) + (size_t)wave * (4 * P.nlev + 3 * nzo + (5 * nzo + 1) / 2 + 1);
     double* c_z = wbase; double* c_p = c_z + P.nlev; double* c_t = c_p + P.nlev; double* c_e = c_t + P.nlev;
     double* o_z = c_e + P.nlev;
-    float* o_t = reinterpret_cast<float*>(o_z + nzo); float* o_p = o_t + nzo; float* o_e = o_p + nzo; float* o_w = o_e + nzo; float* o_h = o_w + nzo;
+    double* o_sw = o_z + nzo; double* o_sh = o_sw + nzo;       // zenith totals (suffix sums of the trapezoid terms)
+    float* o_t = reinterpret_cast<float*>(o_sh + nzo); float* o_p = o_t + nzo; float* o_e = o_p + nzo; float* o_w = o_e + nzo; float* o_h = o_w + nzo;
     for (int j = lane; j < nzo; j += 64) o_z[j] = (P.pad && j == 0) ? P.zmin : P.new_z[j - P.pad];
     const int64_t wstride = (int64_t)gridDim.x * 4;
     for (int64_t col = (int64_t)blockIdx.x * 4 + wave; col < P.ncol; col += wstride) {
@@ -129,22 +130,38 @@ __global__ __launch_bounds__(256) void producer_kernel(ProducerParams P) {
         __builtin_amdgcn_wave_barrier();
         if (P.pad && lane == 0) { o_t[0] = o_t[1]; o_p[0] = o_p[1]; o_e[0] = o_e[1]; o_w[0] = o_w[1]; o_h[0] = o_h[1]; }   // utilFcns.padLower
         __builtin_amdgcn_wave_barrier();
+        // _getZTD: total[j] = 1e-6 * trapz(f[j:], zs[j:]), np.trapz = sum(d * (y[1:] + y[:-1]) / 2): the SUFFIX sums of the trapezoid
+        // terms.  One term per lane and strip of 64 levels, a reverse inclusive scan inside the wave (six shuffle steps), the strips
+        // from the top down with a running carry - O(n) instead of one O(n) loop per level (which was half of this kernel's
+        // instructions).  (NumPy's own summation is pairwise, not sequential: either order agrees with it to a few ulp.)
+        {
+            double carry_w = 0.0, carry_h = 0.0;
+            for (int s0 = ((nzo - 1 + 63) / 64 - 1) * 64; s0 >= 0; s0 -= 64) {
+                const int k = s0 + lane;
+                double tw = 0.0, th = 0.0;
+                if (k < nzo - 1) {
+#pragma clang fp contract(off)
+                    const double d = o_z[k + 1] - o_z[k];
+                    tw = d * (double)(o_w[k + 1] + o_w[k]) / 2.0;
+                    th = d * (double)(o_h[k + 1] + o_h[k]) / 2.0;
+                }
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const double uw = __shfl_down(tw, off, 64), uh = __shfl_down(th, off, 64);
+                    if (lane + off < 64) { tw += uw; th += uh; }
+                }
+                tw += carry_w; th += carry_h;
+                if (k < nzo) { o_sw[k] = tw; o_sh[k] = th; }
+                carry_w = __shfl(tw, 0, 64); carry_h = __shfl(th, 0, 64);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
         for (int j = lane; j < nzo; j += 64) {
             const int64_t g = col * nzo + j;
             float2 v; v.x = o_w[j]; v.y = o_h[j];
             P.pw[g] = v;
             if (P.t_out) { P.t_out[g] = o_t[j]; P.p_out[g] = o_p[j]; P.e_out[g] = o_e[j]; }
-            // _getZTD: 1e-6 * trapz(f[level:], zs[level:]); np.trapz = sum(d * (y[1:] + y[:-1]) / 2)
-            double sw = 0.0, sh = 0.0;
-            {
-#pragma clang fp contract(off)
-                for (int k = j; k < nzo - 1; ++k) {
-                    const double d = o_z[k + 1] - o_z[k];
-                    sw += d * (double)(o_w[k + 1] + o_w[k]) / 2.0;
-                    sh += d * (double)(o_h[k + 1] + o_h[k]) / 2.0;
-                }
-            }
-            double2 tt; tt.x = 1e-6 * sw; tt.y = 1e-6 * sh;
+            double2 tt; tt.x = 1e-6 * o_sw[j]; tt.y = 1e-6 * o_sh[j];        // (level nzo-1: the empty sum, written as 0 by the scan)
             P.tot[g] = tt;
         }
     }

@@ -1723,7 +1723,7 @@ int rdr_cubes_from_model_levels(rdr_ctx* c, const double* ys, int64_t ny, const 
         rc = stage_out(c, SLOT_OUT2, e_out, ob, loc, &de_); if (rc) return bail(rc);
     }
     P.t_out = (float*)dt_; P.p_out = (float*)dp_; P.e_out = (float*)de_;
-    const size_t per_wave = ((size_t)4 * nlev + nzo + (5 * nzo + 1) / 2 + 1) * 8;
+    const size_t per_wave = ((size_t)4 * nlev + 3 * nzo + (5 * nzo + 1) / 2 + 1) * 8;
     const int g = (int)std::max<int64_t>(1, std::min<int64_t>((ncol + 3) / 4, (int64_t)c->num_cus * 8));
     if (per_wave * 4 > c->lds_max)
         return bail(fail(c, RDR_ERR_INVALID, "rdr_cubes_from_model_levels: " + std::to_string(nlev) + " model levels -> " + std::to_string(nzo) +
