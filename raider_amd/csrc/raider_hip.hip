@@ -1198,7 +1198,7 @@ static int march_chunked(rdr_ctx* c, const rdr_cube* q, const RayParams& P0, int
 // row chunks on the copy stream while pass 1 runs on the chunks that have arrived; after the last chunk the slice-level
 // partition is complete, pass 2 runs chunk by chunk and each chunk's outputs come down while the next is integrated.
 // (hipMemcpyAsync from pageable memory blocks the HOST thread, not the device: kernels launched before it keep running.)
-static int raytrace_pipelined(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, RayParams P, int K, double* d_los, double* dw, double* dh,
+static int raytrace_pipelined(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, RayParams P, int K, double* d_los, double* d_hts, double* dw, double* dh,
                               double* wet, double* hydro) {
     const int64_t tile_rows = P.ntiles / P.tiles_x;
     const int nchunk = (int)std::min<int64_t>(8, tile_rows);
@@ -1206,6 +1206,7 @@ static int raytrace_pipelined(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, 
     double* const ws = P.ws;
     const int64_t nslots_total = P.ntiles * BLOCK;
     if (d_los) P.los = d_los;                  // (else the look vectors come from inc / heading or zenith: nothing to upload)
+    if (d_hts) P.ht_ray = d_hts;               // per-pixel heights travel with the look vectors, chunk by chunk
     std::vector<hipEvent_t> ev(2 * nchunk, nullptr);
     auto range = [&](int k, int64_t& tb, int64_t& tc, int64_t& r0, int64_t& cnt) {
         const int64_t t0 = tile_rows * k / nchunk, t1 = tile_rows * (k + 1) / nchunk;
@@ -1219,9 +1220,10 @@ static int raytrace_pipelined(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, 
         if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { cleanup(); return fail(c, RDR_ERR_HIP, "pipelined ray tracing: event creation failed"); }
     for (int k = 0; k < nchunk && status == RDR_OK; ++k) {
         int64_t tb, tc, r0, cnt; range(k, tb, tc, r0, cnt);
-        if (d_los && (hipMemcpyAsync(d_los + 3 * r0, r->los + 3 * r0, (size_t)cnt * 24, hipMemcpyHostToDevice, c->copy_stream) != hipSuccess ||
-                      hipEventRecord(ev[k], c->copy_stream) != hipSuccess || hipStreamWaitEvent(c->stream, ev[k], 0) != hipSuccess)) {
-            status = fail(c, RDR_ERR_HIP, "pipelined ray tracing: look-vector upload failed"); break;
+        if ((d_los && hipMemcpyAsync(d_los + 3 * r0, r->los + 3 * r0, (size_t)cnt * 24, hipMemcpyHostToDevice, c->copy_stream) != hipSuccess) ||
+            (d_hts && hipMemcpyAsync(d_hts + r0, r->hts + r0, (size_t)cnt * 8, hipMemcpyHostToDevice, c->copy_stream) != hipSuccess) ||
+            ((d_los || d_hts) && (hipEventRecord(ev[k], c->copy_stream) != hipSuccess || hipStreamWaitEvent(c->stream, ev[k], 0) != hipSuccess))) {
+            status = fail(c, RDR_ERR_HIP, "pipelined ray tracing: look-vector / height upload failed"); break;
         }
         RayParams Pk = P; Pk.ws = ws + tb * BLOCK;
         status = launch_crossings(c, q, Pk, tb, tc, nslots_total, k == 0);
@@ -1380,14 +1382,20 @@ int rdr_raytrace(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, double ht, do
     static const bool no_pipeline = std::getenv("RAIDER_HIP_NO_PIPELINE") != nullptr;
     bool pipelined = r->loc == RDR_HOST && r->n >= (1 << 21) && !no_pipeline;
     const bool los_chunks = pipelined && r->los_mode == RDR_LOS_VEC;
+    const bool hts_chunks = pipelined && r->hts != nullptr;
     rdr_rays rr = *r;
     if (los_chunks) rr.los = nullptr;                      // the look vectors are uploaded chunk by chunk below
+    if (hts_chunks) rr.hts = nullptr;                      // ... and so are per-pixel heights
     rc = stage_rays(c, &rr, P); if (rc) return rc;
     if (pipelined && P.ntiles > ws_chunk_tiles(c, K)) {   // records do not fit: ordinary (chunked-march) path
+        const void* d;
         if (los_chunks) {
-            const void* d;
             rc = stage_in(c, SLOT_IN3, r->los, (size_t)r->n * 24, r->loc, &d); if (rc) return rc;
             P.los = (const double*)d;
+        }
+        if (hts_chunks) {
+            rc = stage_in(c, SLOT_IN6, r->hts, (size_t)r->n * 8, r->loc, &d); if (rc) return rc;
+            P.ht_ray = (const double*)d;
         }
         pipelined = false;
     }
@@ -1400,9 +1408,10 @@ int rdr_raytrace(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, double ht, do
     HIPCHECK(c, hipMemsetAsync(c->d_flags, 0, sizeof(int), c->stream));
     c->wsig.valid = false;
     if (pipelined) {
-        void* dl = nullptr;
+        void *dl = nullptr, *dhts = nullptr;
         if (los_chunks) { rc = ensure(c, SLOT_IN3, (size_t)r->n * 24, &dl); if (rc) return rc; }
-        rc = raytrace_pipelined(c, q, r, P, K, (double*)dl, (double*)dw, (double*)dh, wet, hydro); if (rc) return rc;
+        if (hts_chunks) { rc = ensure(c, SLOT_IN6, (size_t)r->n * 8, &dhts); if (rc) return rc; }
+        rc = raytrace_pipelined(c, q, r, P, K, (double*)dl, (double*)dhts, (double*)dw, (double*)dh, wet, hydro); if (rc) return rc;
     } else if (P.ntiles <= ws_chunk_tiles(c, K)) {
         // whole batch fits: pass 1 reduces AND stores the ray records, pass 2 streams them back
         rc = ws_reserve(c, P.ntiles, K, P); if (rc) return rc;
