@@ -1,4 +1,5 @@
 # gpurun -- 'bash tools/profile_secondary.sh'   then (here)   python tools/secondary_digest.py
+# NOTE: delete the local gpurun_out/secondary first - gpurun MERGES new files into it and the digest would mix runs
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 O=$R/gpurun_out/secondary; rm -rf $O; mkdir -p $O
