@@ -214,36 +214,52 @@ __global__ __launch_bounds__(256) void quad_build_kernel(const T2* __restrict__ 
     const int64_t bid = (int64_t)(blockIdx.x & 7) * per_x + (blockIdx.x >> 3);
     const int64_t per = ((total + per_x * 8 - 1) / (per_x * 8) + 255) / 256 * 256;
     const int64_t t_end = min(total, (bid + 1) * per);
-    for (int64_t t = bid * per + threadIdx.x; t < t_end; t += blockDim.x) {
-        const int p = (int)(t & 7);
-        const int64_t b = t >> 3;
-        int j, ix, iy;
-        if (total < (1LL << 34)) {                    // (32-bit divisions: a quarter of the instructions of the 64-bit ones)
-            const unsigned bu = (unsigned)b, colu = bu / (unsigned)nblk;
-            j = (int)(bu - colu * (unsigned)nblk);
-            iy = (int)(colu / (unsigned)(nx - 1)); ix = (int)(colu - (unsigned)iy * (unsigned)(nx - 1));
-        } else {
-            j = (int)(b % nblk);
-            const int64_t col = b / nblk;
-            ix = (int)(col % (nx - 1)); iy = (int)(col / (nx - 1));
+    // UQ parts per thread and trip, their loads issued together (one part per trip left every thread with a single 8 / 16 B load in
+    // flight: latency-bound at half the write rate)
+    constexpr int UQ = 4;
+    typedef unsigned U4 __attribute__((ext_vector_type(4)));
+    for (int64_t t0 = bid * per + threadIdx.x; t0 < t_end; t0 += (int64_t)blockDim.x * UQ) {
+        T2 va[UQ], vb[UQ];
+#pragma unroll
+        for (int u = 0; u < UQ; ++u) {
+            const int64_t t = min(t0 + (int64_t)u * blockDim.x, t_end - 1);
+            const int p = (int)(t & 7);
+            const int64_t b = t >> 3;
+            int j, ix, iy;
+            if (total < (1LL << 34)) {                // (32-bit divisions: a quarter of the instructions of the 64-bit ones)
+                const unsigned bu = (unsigned)b, colu = bu / (unsigned)nblk;
+                j = (int)(bu - colu * (unsigned)nblk);
+                iy = (int)(colu / (unsigned)(nx - 1)); ix = (int)(colu - (unsigned)iy * (unsigned)(nx - 1));
+            } else {
+                j = (int)(b % nblk);
+                const int64_t col = b / nblk;
+                ix = (int)(col % (nx - 1)); iy = (int)(col / (nx - 1));
+            }
+            if constexpr (sizeof(T2) == 8) {        // float2: part p = level p/2, row y0 / y1 = p%2, both x corners
+                const int lev = min(j * Quad<T2>::CPB + (p >> 1), nz - 1);
+                const T2* a = v + ((int64_t)(iy + (p & 1)) * nx + ix) * nz + lev;
+                va[u] = a[0]; vb[u] = a[nz];
+            } else {                                  // double2: part p = level p/4, corner p%4
+                const int lev = min(j * Quad<T2>::CPB + (p >> 2), nz - 1);
+                va[u] = v[((int64_t)(iy + ((p >> 1) & 1)) * nx + ix + (p & 1)) * nz + lev];
+            }
         }
-        uint4 out;
-        if constexpr (sizeof(T2) == 8) {            // float2: part p = level p/2, row y0 / y1 = p%2, both x corners
-            const int lev = min(j * Quad<T2>::CPB + (p >> 1), nz - 1);
-            const T2* a = v + ((int64_t)(iy + (p & 1)) * nx + ix) * nz + lev;
-            const T2 v0 = a[0], v1 = a[nz];
-            out.x = __float_as_uint(v0.x); out.y = __float_as_uint(v0.y); out.z = __float_as_uint(v1.x); out.w = __float_as_uint(v1.y);
-        } else {                                      // double2: part p = level p/4, corner p%4
-            const int lev = min(j * Quad<T2>::CPB + (p >> 2), nz - 1);
-            const T2 v0 = v[((int64_t)(iy + ((p >> 1) & 1)) * nx + ix + (p & 1)) * nz + lev];
-            const unsigned long long lo = (unsigned long long)__double_as_longlong(v0.x), hi = (unsigned long long)__double_as_longlong(v0.y);
-            out.x = (unsigned)lo; out.y = (unsigned)(lo >> 32); out.z = (unsigned)hi; out.w = (unsigned)(hi >> 32);
+        asm volatile("" ::: "memory");              // (all loads of the trip ahead of its first store)
+#pragma unroll
+        for (int u = 0; u < UQ; ++u) {
+            const int64_t t = t0 + (int64_t)u * blockDim.x;
+            if (t >= t_end) break;
+            U4 o4;
+            if constexpr (sizeof(T2) == 8) {
+                o4.x = __float_as_uint(va[u].x); o4.y = __float_as_uint(va[u].y); o4.z = __float_as_uint(vb[u].x); o4.w = __float_as_uint(vb[u].y);
+            } else {
+                const unsigned long long lo = (unsigned long long)__double_as_longlong(va[u].x), hi = (unsigned long long)__double_as_longlong(va[u].y);
+                o4.x = (unsigned)lo; o4.y = (unsigned)(lo >> 32); o4.z = (unsigned)hi; o4.w = (unsigned)(hi >> 32);
+            }
+            // (written once, read by other kernels much later: non-temporal, so that the 2 GB of output do not evict the source columns
+            // the neighbouring cell columns and the next cell row are about to re-read from this XCD's L2)
+            __builtin_nontemporal_store(o4, reinterpret_cast<U4*>(q) + t);
         }
-        // (written once, read by other kernels much later: non-temporal, so that the 2 GB of output do not evict the source columns the
-        // neighbouring cell columns and the next cell row are about to re-read from this XCD's L2)
-        typedef unsigned U4 __attribute__((ext_vector_type(4)));
-        U4 o4 = {out.x, out.y, out.z, out.w};
-        __builtin_nontemporal_store(o4, reinterpret_cast<U4*>(q) + t);
     }
 }
 
