@@ -36,6 +36,25 @@ def _oracle_block(cube, xp, yp, inc_block, hd, zref, nparts, ht=0.0):
     return w[0], h[0]
 
 
+def _c_oracle_blocks(cube, xpts, ypts, inc_cols, hd, zref, nparts, wn, hn, origins, size):
+    """size x size blocks of the scene against the multi-core C restatement (oracle/oracle_c.c; itself pinned on the goldens and
+    on the NumPy oracle in tests/test_oracle_c.py) driven with the whole-slice partition: the look vectors are the oracle's own."""
+    from oracle import oracle_c as OC
+    worst = 0.0
+    for r0, c0 in origins:
+        xp, yp = xpts[c0:c0 + size], ypts[r0:r0 + size]
+        xx, yy = np.meshgrid(xp, yp)
+        los = O.look_vectors_from_inc_hd(np.broadcast_to(inc_cols[c0:c0 + size], yy.shape), np.full(yy.shape, hd), yy, xx, 0.0)
+        ow, oh, _ = OC.build_cube_ray_slice(cube, xp, yp, 0.0, los, zref, nparts=nparts)
+        gw, gh = wn[r0:r0 + size, c0:c0 + size], hn[r0:r0 + size, c0:c0 + size]
+        gw, gh = (g.cpu().numpy() if hasattr(g, 'cpu') else g for g in (gw, gh))
+        assert np.isfinite(ow).all() and np.isfinite(oh).all()
+        np.testing.assert_allclose(gw, ow, rtol=0, atol=TIGHT)
+        np.testing.assert_allclose(gh, oh, rtol=0, atol=TIGHT)
+        worst = max(worst, float(np.abs(gw - ow).max()), float(np.abs(gh - oh).max()))
+    return worst
+
+
 def test_config3_full_size_properties(R, era5):
     """configs[2]: 4000x4000 rays through the 300x300x80 cube.  (a) random blocks against the oracle driven with the
     whole-slice partition; (b) chunked workspace == single-chunk workspace bit for bit; (c) exact linearity in the cube
@@ -63,6 +82,11 @@ def test_config3_full_size_properties(R, era5):
         ow, oh = _oracle_block(era5, xpts[c0:c0 + 20], ypts[r0:r0 + 20], np.broadcast_to(inc_cols[c0:c0 + 20], (20, 20)), hd, zref, nparts)
         np.testing.assert_allclose(wn[r0:r0 + 20, c0:c0 + 20], ow, rtol=0, atol=TIGHT)
         np.testing.assert_allclose(hn[r0:r0 + 20, c0:c0 + 20], oh, rtol=0, atol=TIGHT)
+    # (a') nine 256 x 256 blocks (590 k rays: corners, edges, interior, ragged offsets) against the C oracle
+    b = 256
+    worst = _c_oracle_blocks(era5, xpts, ypts, inc_cols, hd, zref, nparts, wn, hn,
+                             ((0, 0), (0, cols - b), (rows - b, 0), (rows - b, cols - b), (1234, 2777), (3000, 16), (1871, 0), (7, 3700), (2001, 1999)), b)
+    assert worst < 1e-9
     # (b) chunked integration (1 GiB workspace -> 11 chunks)
     ctx.set_workspace_limit(1 << 30)
     try:
@@ -141,6 +165,9 @@ def test_config4_full_size_one_gpu(R, era5):
         ow, oh = _oracle_block(era5, xpts[c0:c0 + 20], ypts[r0:r0 + 20], np.broadcast_to(inc_cols[c0:c0 + 20], (20, 20)), hd, zref, nparts)
         np.testing.assert_allclose(wet[r0:r0 + 20, c0:c0 + 20].cpu().numpy(), ow, rtol=0, atol=TIGHT)
         np.testing.assert_allclose(hyd[r0:r0 + 20, c0:c0 + 20].cpu().numpy(), oh, rtol=0, atol=TIGHT)
+    b = 256                                                                # + nine 256 x 256 blocks against the C oracle
+    _c_oracle_blocks(era5, xpts, ypts, inc_cols, hd, zref, nparts, wet, hyd,
+                     ((0, 0), (0, cols - b), (rows - b, 0), (rows - b, cols - b), (6321, 2777), (9000, 16), (4999, 5001), (13, 9700), (7777, 0)), b)
     w2 = torch.empty_like(wet); h2 = torch.empty_like(wet)
     ctx.set_workspace_limit(8 << 30)
     try:
