@@ -63,6 +63,18 @@ def check_partition_flags(flags):
         raise ValueError('some ray lengths are NaN: the number of integration parts (delay.py:283) is undefined')
 
 
+def check_partition(partition, max_seg=1000.0):
+    """The deferred half of raytrace_slab_async: read the K+4-element device partition back (this synchronises), raise what the
+    reference raises on it (delay.py:279-283 - the asynchronous path itself wrote NaN in that case) and return the slice's nParts.
+    Call it whenever the host may wait: after the scene, or once per batch of scenes."""
+    p = partition.detach().cpu().numpy() if hasattr(partition, 'detach') else np.asarray(partition, dtype=np.float64)
+    K = p.size - 4
+    if K < 0:
+        raise ValueError('a partition holds K per-level maxima and 4 flag elements')
+    check_partition_flags(sum(bit for bit, v in zip((1, 2, 4, 8), p[K:]) if v > 0))
+    return nparts_from_maxlen(p[:K], max_seg)
+
+
 def broadcast_cube_fields(fields, src=0, device=None, group=None):
     """Broadcast {xs, ys, zs, wet, hydro} (NumPy on `src`, None elsewhere) to every rank, field by field (kept for callers
     with other field sets; the cube itself goes out in one piece through broadcast_cube_packed)."""
@@ -162,7 +174,8 @@ def global_table_height(rays, ht=None, group=None, device=None):
 def raytrace_slab_async(cube, rays, ht, zref, partition, max_seg=1000.0, out=None, group=None):
     """The same slice without any host round trip (device-resident rays, outputs and partition; RCCL all-reduce on the
     K+4-element device tensor `partition`): pass 1 -> MAX all-reduce -> pass 2, all enqueued asynchronously.  The
-    reference's error conditions (all-NaN slice etc.) are not raised here - the outputs are NaN instead.
+    reference's error conditions (all-NaN slice etc.) are not raised here - the outputs are NaN instead; check_partition(partition)
+    raises them afterwards, at a point where the host may wait.
     Per-pixel heights: pass the scene-wide table height (global_table_height, once per scene - it synchronises) as `ht`."""
     if ht is None and rays.ht_min is not None and is_distributed():
         raise ValueError('per-pixel heights on several ranks: pass ht = global_table_height(rays) (the scene-wide lowest height)')

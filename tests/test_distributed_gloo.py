@@ -99,6 +99,13 @@ def test_reduce_partition_single_process_passthrough():
         check_partition_flags(1)
     with pytest.raises(ValueError):
         check_partition_flags(3)
+    # the deferred check of the asynchronous path: K maxima + 4 flag elements (host copy here)
+    from raider_amd.distributed import check_partition
+    assert np.array_equal(check_partition(np.array([999.0, 1000.0, 1000.5, 0.0, 1.0, 1.0, 1.0])), [2, 2, 3])      # delay.py:283
+    with pytest.raises(ValueError, match='NaN'):
+        check_partition(np.array([999.0, 1.0, 1.0, 0.0, 0.0]))
+    with pytest.raises(ValueError, match='geo2rdr'):
+        check_partition(np.array([0.0, 0.0, 0.0, 0.0, 0.0]))
 
 
 def test_pack_unpack_cube_roundtrip_f32_f64_any_layout():

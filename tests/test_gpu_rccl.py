@@ -73,8 +73,17 @@ pts = torch.from_numpy(np.stack([rng.uniform(30.2, 35.8, 5000), rng.uniform(-120
 p0, cnt, sw, sh = D.interp_points_sharded(blended, pts)
 rw, rh = want.interp(pts)
 ok4 = p0 == 0 and cnt == 5000 and torch.equal(sw, rw) and torch.equal(sh, rh) and bool(torch.isfinite(sw).all())
+# the deferred error check of the asynchronous path: the partition gives the reference's nParts, or the reference's exception
+ok5 = np.array_equal(D.check_partition(part), nparts)
+bad = los.clone(); bad[5, 7] = float('nan')                      # one failed look vector: nParts is undefined (delay.py:283)
+bw, bh = D.raytrace_slab_async(cube, R.Rays.grid(xt, yt, los=bad), 0.0, zref, part)
+try:
+    D.check_partition(part)
+    ok5 = False
+except ValueError as e:
+    ok5 = ok5 and 'NaN' in str(e) and bool(torch.isnan(bw).all()) and bool(torch.isnan(bh).all())
 nan_frac = float(torch.isnan(h0).double().mean())
-print(json.dumps(dict(ok=bool(ok), ok2=bool(ok2), ok3=bool(ok3), ok4=bool(ok4), K=K, nan_frac=nan_frac, partition_max=float(part[:K].max()))))
+print(json.dumps(dict(ok=bool(ok), ok2=bool(ok2), ok3=bool(ok3), ok4=bool(ok4), ok5=bool(ok5), K=K, nan_frac=nan_frac, partition_max=float(part[:K].max()))))
 dist.destroy_process_group()
 '''
 
@@ -88,6 +97,7 @@ def test_one_rank_rccl_group_broadcast_allreduce_bit_identical():
     assert res['ok2'], 'the synchronous slab path through the nccl backend differs from Cube.raytrace'
     assert res['ok3'], 'on a side stream the collective was not ordered against the ray kernels'
     assert res['ok4'], 'two epochs broadcast + blended per rank + sharded station gather differ from the single-process result'
+    assert res['ok5'], 'check_partition: nParts from the device partition, or the reference\'s ValueError on a NaN look vector'
     assert res['K'] > 20 and res['partition_max'] > 1000.0 and res['nan_frac'] < 0.5
 
 
