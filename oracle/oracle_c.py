@@ -73,30 +73,55 @@ def num_threads():
     return lib().orc_num_threads()
 
 
-def build_cube_ray_slice(cube, xpts, ypts, ht, los, zref, max_seg=1000.0, nparts=None):
-    """One height slice of _build_cube_ray (delay.py:256-323) on meshgrid(xpts, ypts) with look vectors los (ny,nx,3).
-    cube: dict(xs, ys, zs, wet, hydro (z,y,x)).  Returns (wet, hydro, nparts)."""
-    L = lib()
+def _slice_inputs(cube, xpts, ypts, ht, los, zref):
     xx, yy = np.meshgrid(np.asarray(xpts, float), np.asarray(ypts, float))
     lat = np.ascontiguousarray(yy.ravel()); lon = np.ascontiguousarray(xx.ravel())
     los = np.ascontiguousarray(np.asarray(los, dtype=np.float64).reshape(-1, 3))
-    n = lat.size
     levels = O.ray_levels(cube['zs'], ht, zref)
-    K = len(levels)
     lo = np.array([a for a, _ in levels]); hi = np.array([b for _, b in levels])
+    return yy.shape, lat, lon, los, lo, hi
+
+
+def ray_prepass(cube, xpts, ypts, ht, los, zref):
+    """Pass 1 alone: (maxlen[K], (all_first_below_zmin, all_last_above_zmax)) of the rays of meshgrid(xpts, ypts).  Blocks of one
+    slice combine as element-wise max / logical AND - what the reference's whole-slice reductions (delay.py:283,306-311) do."""
+    L = lib()
+    _, lat, lon, los, lo, hi = _slice_inputs(cube, xpts, ypts, ht, los, zref)
+    zs = np.asarray(cube['zs'], dtype=np.float64)
+    maxlen = np.zeros(len(lo)); clamp = (C.c_int * 2)()
+    L.orc_prepass(_p(lat), _p(lon), _p(los), C.c_int64(lat.size), C.c_double(ht), _p(lo), _p(hi), C.c_int(len(lo)), C.c_double(zs.min()),
+                  C.c_double(zs.max()), _p(maxlen), clamp)
+    return maxlen, (int(clamp[0]), int(clamp[1]))
+
+
+def nparts_of(maxlen, max_seg=1000.0):
+    return np.ceil(np.asarray(maxlen) / max_seg).astype(int) + 1          # delay.py:283
+
+
+def build_cube_ray_slice(cube, xpts, ypts, ht, los, zref, max_seg=1000.0, nparts=None, clamp=None):
+    """One height slice of _build_cube_ray (delay.py:256-323) on meshgrid(xpts, ypts) with look vectors los (ny,nx,3).
+    cube: dict(xs, ys, zs, wet, hydro (z,y,x)).  Returns (wet, hydro, nparts).  nparts / clamp: the whole slice's partition and
+    z-clamp decisions when these rays are only a block of it (default: this block's own)."""
+    L = lib()
+    shape, lat, lon, los, lo, hi = _slice_inputs(cube, xpts, ypts, ht, los, zref)
+    n = lat.size
+    K = len(lo)
     ys, xs, zs = (np.ascontiguousarray(cube[k], dtype=np.float64) for k in ('ys', 'xs', 'zs'))
     wet, hyd = _yxz(cube)
     dtype = 0 if wet.dtype == np.float32 else 1
-    maxlen = np.zeros(K); clamp = (C.c_int * 2)()
-    L.orc_prepass(_p(lat), _p(lon), _p(los), C.c_int64(n), C.c_double(ht), _p(lo), _p(hi), C.c_int(K), C.c_double(zs.min()), C.c_double(zs.max()),
-                  _p(maxlen), clamp)
-    if nparts is None:
-        nparts = np.ceil(maxlen / max_seg).astype(int) + 1
+    if nparts is None or clamp is None:
+        maxlen = np.zeros(K); own = (C.c_int * 2)()
+        L.orc_prepass(_p(lat), _p(lon), _p(los), C.c_int64(n), C.c_double(ht), _p(lo), _p(hi), C.c_int(K), C.c_double(zs.min()), C.c_double(zs.max()),
+                      _p(maxlen), own)
+        if nparts is None:
+            nparts = nparts_of(maxlen, max_seg)
+        if clamp is None:
+            clamp = (own[0], own[1])
     np32 = np.ascontiguousarray(nparts, dtype=np.int32)
     ow, oh = np.empty(n), np.empty(n)
     L.orc_march(_p(lat), _p(lon), _p(los), C.c_int64(n), C.c_double(ht), _p(lo), _p(hi), C.c_int(K), _p(np32), C.c_int(clamp[0]), C.c_int(clamp[1]),
                 _p(ys), C.c_int(ys.size), _p(xs), C.c_int(xs.size), _p(zs), C.c_int(zs.size), _p(wet), _p(hyd), C.c_int(dtype), _p(ow), _p(oh))
-    return ow.reshape(yy.shape), oh.reshape(yy.shape), np.asarray(nparts)
+    return ow.reshape(shape), oh.reshape(shape), np.asarray(nparts)
 
 
 def build_cube_ray_per_pixel(cube, lat, lon, hts, los, zref, max_seg=1000.0, nparts=None):
