@@ -89,12 +89,15 @@ static int fail(rdr_ctx* ctx, int code, const std::string& msg) {
 #define HIPCHECK(ctx, expr)                                                                         \
     do {                                                                                            \
         hipError_t _e = (expr);                                                                     \
-        if (_e != hipSuccess)                                                                       \
+        if (_e != hipSuccess) {                                                                     \
+            (void)hipGetLastError();   /* reported here: a later launch check must not find it again */ \
             return fail(ctx, RDR_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));      \
+        }                                                                                           \
     } while (0)
 
 static int ensure(rdr_ctx* ctx, int s, size_t bytes, void** out) {
     DevBuf& b = ctx->slot[s];
+    if (bytes > ((size_t)1 << 46)) return fail(ctx, RDR_ERR_INVALID, "a size argument is negative or beyond 64 TiB");
     if (b.cap < bytes) {
         if (b.p) { HIPCHECK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHECK(ctx, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
         size_t cap = std::max(bytes, (size_t)1 << 16);
@@ -493,6 +496,7 @@ int rdr_transform_cone(rdr_ctx* c, int kind, const double* p, int np, int direct
     if (direction != 0 && direction != 1) return fail(c, RDR_ERR_INVALID, "rdr_transform_cone: direction is 0 (forward) or 1 (inverse)");
     LccParams L;
     int rc = cone_params(c, "rdr_transform_cone", kind, p, np, L); if (rc) return rc;
+    if (n < 0) return fail(c, RDR_ERR_INVALID, "rdr_transform_cone: negative count");
     if (n == 0) return RDR_OK;
     HIPCHECK(c, hipSetDevice(c->device));
     const void *da, *db; void *oa, *ob;
@@ -511,6 +515,7 @@ int rdr_transform_cone(rdr_ctx* c, int kind, const double* p, int np, int direct
 
 int rdr_project_points(rdr_ctx* c, const rdr_cube* q, const double* lat, const double* lon, int64_t n, double* y, double* x, int loc) {
     if (!c || !q || !lat || !lon || !y || !x) return fail(c, RDR_ERR_INVALID, "rdr_project_points: NULL argument");
+    if (n < 0) return fail(c, RDR_ERR_INVALID, "rdr_project_points: negative count");
     if (n == 0) return RDR_OK;
     HIPCHECK(c, hipSetDevice(c->device));
     if (q->proj.kind == 0) {     // lon/lat cube: identity
@@ -539,6 +544,7 @@ int rdr_transform_tm(rdr_ctx* c, const double* p, int np, int direction, const d
     if (!c || !p || np < 7 || (n > 0 && (!in_a || !in_b || !out_a || !out_b))) return fail(c, RDR_ERR_INVALID, "rdr_transform_tm: NULL argument / 7 parameters (a, es, lat_0, lon_0, k_0, x_0, y_0)");
     if (!(p[0] > 0) || p[1] < 0 || p[1] >= 1 || std::fabs(p[2]) > 90 || !(p[4] > 0)) return fail(c, RDR_ERR_INVALID, "rdr_transform_tm: invalid transverse-Mercator parameters");
     if (direction != 0 && direction != 1) return fail(c, RDR_ERR_INVALID, "rdr_transform_tm: direction is 0 (forward) or 1 (inverse)");
+    if (n < 0) return fail(c, RDR_ERR_INVALID, "rdr_transform_tm: negative count");
     if (n == 0) return RDR_OK;
     HIPCHECK(c, hipSetDevice(c->device));
     const TmParams T = tm_setup(p[0], p[1], p[2], p[3], p[4], p[5], p[6]);
@@ -603,6 +609,7 @@ int rdr_inverse_time_weights(rdr_ctx* c, const double* az, int64_t n, const doub
         for (int i = 2; i < nd; ++i) window_s = std::min(window_s, std::fabs(dates[i] - dates[0]));
     }
     D.window = window_s;
+    if (n < 0) return fail(c, RDR_ERR_INVALID, "rdr_inverse_time_weights: negative count");
     if (n == 0) return RDR_OK;
     HIPCHECK(c, hipSetDevice(c->device));
     const void* da; void* dw;
@@ -672,7 +679,8 @@ int rdr_delays_to_phase(rdr_ctx* c, const void* wet, const void* hydro, int64_t 
     if (!c || !wet || !hydro || !wet_out || !hydro_out) return fail(c, RDR_ERR_INVALID, "rdr_delays_to_phase: NULL argument");
     if (dtype != RDR_F32 && dtype != RDR_F64) return fail(c, RDR_ERR_INVALID, "rdr_delays_to_phase: dtype must be RDR_F32 or RDR_F64");
     if (!(wavelength > 0.0)) return fail(c, RDR_ERR_INVALID, "rdr_delays_to_phase: wavelength must be positive");
-    if (n <= 0) return RDR_OK;
+    if (n < 0) return fail(c, RDR_ERR_INVALID, "rdr_delays_to_phase: negative count");
+    if (n == 0) return RDR_OK;
     HIPCHECK(c, hipSetDevice(c->device));
     const size_t bytes = (size_t)n * (dtype == RDR_F32 ? 4 : 8);
     const void *dw, *dh; void *ow, *oh;
@@ -761,6 +769,7 @@ int rdr_cube_point_index(rdr_ctx* c, rdr_cube* q, int mode) {
         q->big_point_calls = 0;
         return RDR_OK;
     }
+    if (mode != 1) return fail(c, RDR_ERR_INVALID, "rdr_cube_point_index: mode is 0 (free) or 1 (build)");
     if (q->ny < 2 || q->nx < 2 || q->nz < 2) return fail(c, RDR_ERR_INVALID, "rdr_cube_point_index: the cube needs two nodes per axis");
     return quad_build(c, q);
 }
@@ -769,6 +778,7 @@ int64_t rdr_cube_point_index_bytes(const rdr_cube* q) { return q ? (int64_t)q->q
 
 int rdr_interp3(rdr_ctx* c, const rdr_cube* q, const double* pts, int64_t n, double* wet, double* hydro, int loc) {
     if (!c || !q || (n > 0 && (!pts || !wet || !hydro))) return fail(c, RDR_ERR_INVALID, "rdr_interp3: NULL argument");
+    if (n < 0) return fail(c, RDR_ERR_INVALID, "rdr_interp3: negative count");
     if (n == 0) return RDR_OK;
     HIPCHECK(c, hipSetDevice(c->device));
     const void* dp; void *dw, *dh;
@@ -804,6 +814,7 @@ int rdr_interp3(rdr_ctx* c, const rdr_cube* q, const double* pts, int64_t n, dou
 int rdr_build_cube(rdr_ctx* c, const rdr_cube* q, const double* xpts, int64_t nx, const double* ypts, int64_t ny,
                    const double* zpts, int64_t nz, double* wet, double* hydro, int loc) {
     if (!c || !q || !xpts || !ypts || !zpts || !wet || !hydro) return fail(c, RDR_ERR_INVALID, "rdr_build_cube: NULL argument");
+    if (nx < 0 || ny < 0 || nz < 0) return fail(c, RDR_ERR_INVALID, "rdr_build_cube: negative count");
     const int64_t n = nx * ny * nz;
     if (n == 0) return RDR_OK;
     HIPCHECK(c, hipSetDevice(c->device));
@@ -872,6 +883,7 @@ int rdr_last_nan_output(rdr_ctx* c) { return c ? c->last_nan_output : -1; }
 
 int rdr_project_cosinc(rdr_ctx* c, double* wet, double* hydro, const double* inc, int64_t n, int loc) {
     if (!c || !wet || !hydro || !inc) return fail(c, RDR_ERR_INVALID, "rdr_project_cosinc: NULL argument");
+    if (n < 0) return fail(c, RDR_ERR_INVALID, "rdr_project_cosinc: negative count");
     if (n == 0) return RDR_OK;
     HIPCHECK(c, hipSetDevice(c->device));
     const void *di, *dwi, *dhi;
@@ -917,6 +929,7 @@ int rdr_ray_levels(const rdr_cube* q, double ht, double zref, int32_t* K, double
 
 int rdr_nparts(const double* maxlen, int32_t K, double max_seg, int32_t* nparts) {
     if (!maxlen || !nparts) return fail(nullptr, RDR_ERR_INVALID, "rdr_nparts: NULL argument");
+    if (K < 0 || !(max_seg > 0.0)) return fail(nullptr, RDR_ERR_INVALID, "rdr_nparts: K >= 0 and MAX_SEGMENT_LENGTH > 0");
     for (int k = 0; k < K; ++k) {
         const double parts = std::ceil(maxlen[k] / max_seg) + 1;   // delay.py:283
         nparts[k] = (parts >= 1 && parts <= 2147483647.0) ? (int32_t)parts : 2147483647;
@@ -1582,6 +1595,7 @@ int rdr_raytrace_slices(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, const 
 
 int rdr_top_of_atmosphere(rdr_ctx* c, const double* xyz, const double* los, int64_t n, double h, const double* factor, double* pos, int loc) {
     if (!c || !xyz || !los || !pos) return fail(c, RDR_ERR_INVALID, "rdr_top_of_atmosphere: NULL argument");
+    if (n < 0) return fail(c, RDR_ERR_INVALID, "rdr_top_of_atmosphere: negative count");
     if (n == 0) return RDR_OK;
     HIPCHECK(c, hipSetDevice(c->device));
     const void *dx, *dl, *df; void* dp;
@@ -1606,6 +1620,7 @@ int rdr_build_ray(rdr_ctx* c, const double* model_zs, int64_t nz, double ht, con
     *K_out = K;
     if (K == 0) return fail(c, RDR_ERR_NO_LEVELS, "no weather-model interval contributes to the ray integral (build_ray -> None)");
     if (!lengths || !low || !high) return RDR_OK;   // size query
+    if (n < 0) return fail(c, RDR_ERR_INVALID, "rdr_build_ray: negative count");
     if (n == 0) return RDR_OK;
     HIPCHECK(c, hipSetDevice(c->device));
     const void *dx, *dl; void *dlen, *dlo, *dhi, *dtab;
@@ -1631,6 +1646,7 @@ int rdr_build_ray(rdr_ctx* c, const double* model_zs, int64_t nz, double ht, con
 // ---- geodesy ------------------------------------------------------------------------------------------
 int rdr_lla2ecef(rdr_ctx* c, const double* lat, const double* lon, const double* h, int64_t n, double* xyz, int loc) {
     if (!c || !lat || !lon || !h || !xyz) return fail(c, RDR_ERR_INVALID, "rdr_lla2ecef: NULL argument");
+    if (n < 0) return fail(c, RDR_ERR_INVALID, "rdr_lla2ecef: negative count");
     if (n == 0) return RDR_OK;
     HIPCHECK(c, hipSetDevice(c->device));
     const void *a, *b, *d; void* o;
@@ -1648,6 +1664,7 @@ int rdr_lla2ecef(rdr_ctx* c, const double* lat, const double* lon, const double*
 
 int rdr_ecef2lla(rdr_ctx* c, const double* xyz, int64_t n, double* lon, double* lat, double* h, int loc) {
     if (!c || !xyz || !lon || !lat || !h) return fail(c, RDR_ERR_INVALID, "rdr_ecef2lla: NULL argument");
+    if (n < 0) return fail(c, RDR_ERR_INVALID, "rdr_ecef2lla: negative count");
     if (n == 0) return RDR_OK;
     HIPCHECK(c, hipSetDevice(c->device));
     const void* a; void *o0, *o1, *o2;
@@ -1786,6 +1803,7 @@ int rdr_orbit_look_vectors(rdr_ctx* c, const double* sv_t, const double* sv_pos,
     if (!c || !sv_t || !sv_pos || !sv_vel || !xyz || !los) return fail(c, RDR_ERR_INVALID, "rdr_orbit_look_vectors: NULL argument");
     if (nsv < 4) return fail(c, RDR_ERR_INVALID, "state_to_los: At least 4 state vectors are required for orbit interpolation");
     for (int64_t i = 1; i < nsv; ++i) if (!(sv_t[i] > sv_t[i - 1])) return fail(c, RDR_ERR_INVALID, "rdr_orbit_look_vectors: state-vector times must be strictly increasing");
+    if (n < 0) return fail(c, RDR_ERR_INVALID, "rdr_orbit_look_vectors: negative count");
     if (n == 0) return RDR_OK;
     HIPCHECK(c, hipSetDevice(c->device));
     // the (small) state-vector table always comes from the host; targets / outputs follow `loc`
@@ -1823,6 +1841,7 @@ int rdr_interp_nd(rdr_ctx* c, int32_t ndim, const double* const* axes, const int
                   const double* q, int64_t n, int has_fill, double fill, double* out, int loc) {
     if (!c || !axes || !axis_len || !values || (n > 0 && (!q || !out))) return fail(c, RDR_ERR_INVALID, "rdr_interp_nd: NULL argument");
     if (ndim < 1 || ndim > 8) return fail(c, RDR_ERR_INVALID, "rdr_interp_nd: 1 <= ndim <= 8 supported on device");
+    if (n < 0) return fail(c, RDR_ERR_INVALID, "rdr_interp_nd: negative count");
     if (n == 0) return RDR_OK;
     HIPCHECK(c, hipSetDevice(c->device));
     NdParams P; std::memset(&P, 0, sizeof(P));
@@ -1859,6 +1878,7 @@ int rdr_interp_along_axis(rdr_ctx* c, const double* points, const double* values
                           int64_t mq, int has_fill, double fill, double* out, int loc) {
     if (!c || !points || !values || !q || !out) return fail(c, RDR_ERR_INVALID, "rdr_interp_along_axis: NULL argument");
     if (m < 2) return fail(c, RDR_ERR_INVALID, "rdr_interp_along_axis: axis needs >= 2 points");
+    if (ncol < 0 || mq < 0) return fail(c, RDR_ERR_INVALID, "rdr_interp_along_axis: negative count");
     if (ncol * mq == 0) return RDR_OK;
     HIPCHECK(c, hipSetDevice(c->device));
     const void *dp, *dv, *dq; void* dout;
@@ -1888,6 +1908,7 @@ int rdr_make_points(rdr_ctx* c, double max_len, const double* sp, const double* 
     if (!c || !sp || !slv || !out) return fail(c, RDR_ERR_INVALID, "rdr_make_points: NULL argument");
     const int64_t npts = rdr_make_points_count(max_len, step);
     if (npts < 0) return fail(c, RDR_ERR_INVALID, "rdr_make_points: need max_len >= 0 and step > 0");
+    if (nrays < 0) return fail(c, RDR_ERR_INVALID, "rdr_make_points: negative count");
     if (nrays * npts == 0) return RDR_OK;
     HIPCHECK(c, hipSetDevice(c->device));
     const void *ds, *dl; void* dout;
