@@ -194,7 +194,7 @@ def check(rc, ctx=None, exc_invalid=ValueError):
     """Map C status codes onto the exception classes the reference raises."""
     if rc == RDR_OK:
         return
-    msg = last_error(ctx)
+    msg = last_error(None) or last_error(ctx)      # (the calling thread's own message: the context's may be another thread's by now)
     if rc == RDR_ERR_INVALID:
         raise exc_invalid(msg)
     if rc == RDR_ERR_ALL_NAN:
@@ -206,10 +206,34 @@ def check(rc, ctx=None, exc_invalid=ValueError):
     raise RuntimeError(f'raider_amd HIP engine error {rc}: {msg}')
 
 
+class _SerialisedLib:
+    """The library as ONE context sees it: every call through it holds the context's lock.  A rdr_ctx is not thread-safe
+    (include/raider_hip.h: scratch slots, workspace, stream are per context) and ctypes drops the GIL around a call, so two Python
+    threads sharing a context - the default one, typically - would otherwise run inside the same context at once.  Distinct
+    contexts never wait for each other."""
+
+    def __init__(self, lib, lock):
+        self.__dict__['_lib'] = lib
+        self.__dict__['_lock'] = lock
+
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+        lock = self._lock
+
+        def call(*args):
+            with lock:
+                return fn(*args)
+        call.__name__ = name
+        self.__dict__[name] = call          # (next time: a plain attribute hit)
+        return call
+
+
 class Context:
-    """One device + one stream.  `Context.default()` is the process-wide lazily created context."""
+    """One device + one stream.  `Context.default()` is the process-wide lazily created context.  Calls from several threads into one
+    context are serialised (a lock per context); use one context per thread to run them side by side."""
 
     _default = None
+    _default_lock = threading.Lock()
 
     def __init__(self, device=-1):
         lib = load()
@@ -219,13 +243,16 @@ class Context:
             raise RuntimeError(f'raider_amd: cannot create a GPU context ({last_error()}). '
                                'raider_amd needs an AMD MI355X (gfx950); there is no CPU fallback.')
         self.handle = h
-        self.lib = lib
+        self.lock = threading.RLock()
+        self.lib = _SerialisedLib(lib, self.lock)
 
     @classmethod
     def default(cls):
         if cls._default is None:
-            dev = int(os.environ.get('RAIDER_HIP_DEVICE', os.environ.get('LOCAL_RANK', '-1')))
-            cls._default = cls(dev)
+            with cls._default_lock:
+                if cls._default is None:
+                    dev = int(os.environ.get('RAIDER_HIP_DEVICE', os.environ.get('LOCAL_RANK', '-1')))
+                    cls._default = cls(dev)
         return cls._default
 
     def set_stream(self, stream_handle):

@@ -603,6 +603,51 @@ def test_two_contexts_in_two_threads(R):
         assert np.array_equal(outs[i][0][0], serial[i][0]) and np.array_equal(outs[i][0][1], serial[i][1]) and np.array_equal(outs[i][0][2], serial[i][2])
 
 
+def test_one_context_shared_by_four_threads(R):
+    """The Python layer serialises calls into ONE context (a lock per context; the C context itself is not thread-safe and ctypes
+    drops the GIL): four threads tracing different scenes, interpolating stations and building zenith cubes through the SAME
+    context and cube get exactly the serial results, and an argument error raised in one thread carries that thread's message."""
+    import threading
+    c = O.synthetic_cube(50, 50, 40, seed=0)
+    zref = float(c['zs'].max() - 1)
+    ctx = R.Context(0)
+    cube = R.Cube(c['ys'], c['xs'], c['zs'], c['wet'], c['hydro'], order='zyx', ctx=ctx)
+    rng = np.random.default_rng(0)
+    jobs = []
+    for t in range(4):
+        nx, ny = 150 + 37 * t, 140 + 29 * t
+        jobs.append((np.linspace(-119.5 + 0.1 * t, -115.5, nx), np.linspace(34.5, 31.5 + 0.1 * t, ny), 30.0 + 4 * t,
+                     np.stack([rng.uniform(31, 35, 5000), rng.uniform(-120, -115, 5000), rng.uniform(0, 9000, 5000)], -1)))
+
+    def work(job, out, reps):
+        xp, yp, inc, pts = job
+        for _ in range(reps):
+            w, h, n, _f = cube.raytrace(R.Rays.grid(xp, yp, inc=inc, hd=-167.9), 0.0, zref)
+            pw, ph = cube.interp(pts)
+            zw, zh = cube.build_cube(xp[:40], yp[:30], np.array([0.0, 1000.0]))
+            try:
+                cube.raytrace(R.Rays.grid(xp, yp, inc=inc, hd=-167.9), 0.0, zref, max_seg=-1.0 - inc)
+                msg = None
+            except ValueError as e:
+                msg = str(e)
+        out.append((w, h, n, pw, ph, zw, zh, msg))
+
+    serial = []
+    for j in jobs:
+        work(j, serial, 1)
+    outs = [[] for _ in jobs]
+    threads = [threading.Thread(target=work, args=(jobs[i], outs[i], 5)) for i in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for i in range(4):
+        assert len(outs[i]) == 1
+        for a, b in zip(outs[i][0][:7], serial[i][:7]):
+            assert np.array_equal(a, b, equal_nan=True)
+        assert outs[i][0][7] is not None and 'MAX_SEGMENT_LENGTH' in outs[i][0][7]
+
+
 def test_lcc_projection_against_snyders_worked_examples(R):
     """The device's Lambert-conformal-conic forward (rdr_project_points) on Snyder's published numerical examples (USGS PP 1395,
     pp. 295-298; see tests/test_oracle_golden.py): sphere and Clarke 1866 ellipsoid."""
