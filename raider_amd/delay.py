@@ -372,7 +372,21 @@ def tropo_delay(datetime, weather_model_file, aoi, los, height_levels=None, out_
 getDelays = tropo_delay   # legacy name used by BASELINE.json's north_star
 
 
-_nan_hints = {}      # id(result array) -> "holds a NaN", left by _build_cube_ray when the device already scanned the slices
+_nan_hints = {}      # id(result array) -> (weak reference to it, "holds a NaN"): left by _build_cube* when the device already scanned the result
+
+
+def _hint_set(arr, flag):
+    import weakref
+    try:
+        _nan_hints[id(arr)] = (weakref.ref(arr), bool(flag))
+    except TypeError:            # (not weak-referenceable: no hint, the host scan decides)
+        pass
+
+
+def _hint_pop(arr):
+    """The device's verdict on exactly THIS array (an id recycled by a later array does not match the weak reference), else None."""
+    ent = _nan_hints.pop(id(arr), None)
+    return ent[1] if ent is not None and ent[0]() is arr else None
 
 
 def _has_nan(a):
@@ -415,7 +429,7 @@ def _get_delays_on_cube(datetime, weather_model_file, wm_proj, aoi, heights, los
         else:
             raise NotImplementedError     # delay.py:178-185 (multi-GPU: see raider_amd.distributed)
 
-    hw, hh = _nan_hints.pop(id(wetDelay), None), _nan_hints.pop(id(hydroDelay), None)
+    hw, hh = _hint_pop(wetDelay), _hint_pop(hydroDelay)
     _nan_hints.clear()
     if (hw if hw is not None else _has_nan(wetDelay)) or (hh if hh is not None else _has_nan(hydroDelay)):
         logger.critical('There are missing delay values. Check your inputs.')
@@ -433,7 +447,7 @@ def _build_cube(xpts, ypts, zpts, model_crs, pts_crs, interpolators):
         out = [res[f] for f in fields]
         h = getattr(cube, 'last_build_cube_has_nan', None)
         if h is not None and len(out) == 2:               # what np.isnan(result).any() would find (delay.py:187): known from the device scan
-            _nan_hints[id(out[0])] = h; _nan_hints[id(out[1])] = h
+            _hint_set(out[0], h); _hint_set(out[1], h)
         return out
     if _same_crs(model_crs, pts_crs) and cube.projection is None:
         return hinted(cube.build_cube(xpts, ypts, zpts))   # points generated on the fly in the kernel
@@ -521,7 +535,7 @@ def _build_cube_ray(xpts, ypts, zpts, los, model_crs, pts_crs, interpolators, ou
                     raise ValueError('ray lengths diverged: a model level asks for fewer than 2 or more than 65536 integration parts '
                                      '(are the look vectors unit vectors?)')
         # what np.isnan(result).any() would find (delay.py:187), already known from the device-side scan of every slice
-        _nan_hints[id(outputArrs[0])] = any_nan; _nan_hints[id(outputArrs[1])] = any_nan
+        _hint_set(outputArrs[0], any_nan); _hint_set(outputArrs[1], any_nan)
         return outputArrs
     for hh, ht in enumerate(zpts):
         logger.info(f'Processing slice {hh + 1} / {len(zpts)}: {ht}')
