@@ -169,10 +169,36 @@ void orc_prepass(const double* lat, const double* lon, const double* los, int64_
 
 /* Pass 2: trapezoid integration with the given partition (delay.py:285-323).  clamp_lo / clamp_hi: the all-pixels
  * z-clamp decisions (delay.py:306-311) for the first / last sample, made by the caller. */
-void orc_march(const double* lat, const double* lon, const double* los, int64_t n, double ht,
-               const double* lo, const double* hi, int K, const int* nparts, int clamp_lo, int clamp_hi,
-               const double* ys, int ny, const double* xs, int nx, const double* zs, int nz, const void* wet, const void* hyd, int dtype,
-               double* out_w, double* out_h) {
+/* Lambert conformal conic forward (PROJ `lcc`, Snyder 15-1..15-4) as oracle/raider_oracle.py:lcc_forward restates it - same
+ * operations in the same order; parity with PROJ itself is unpinned there and here.  par = a, es, lat_1, lat_2, lat_0, lon_0, x_0, y_0. */
+typedef struct { double a, e, es, n, Fc, rho0, lon0, x0, y0; } lcc_t;
+static double lcc_tsfn(double phi, double e) {
+    const double s = sin(phi), t = tan(0.5 * (M_PI / 2 - phi));
+    return e != 0 ? t / pow((1 - e * s) / (1 + e * s), 0.5 * e) : t;
+}
+static double lcc_msfn(double phi, double es) { return cos(phi) / sqrt(1 - es * sin(phi) * sin(phi)); }
+static void lcc_setup(const double* par, lcc_t* L) {
+    L->a = par[0]; L->es = par[1]; L->e = sqrt(par[1]);
+    const double p1 = par[2] * D2R, p2 = par[3] * D2R, p0 = par[4] * D2R;
+    L->n = fabs(p1 - p2) >= 1e-10 ? log(lcc_msfn(p1, L->es) / lcc_msfn(p2, L->es)) / log(lcc_tsfn(p1, L->e) / lcc_tsfn(p2, L->e)) : sin(p1);
+    L->Fc = lcc_msfn(p1, L->es) * pow(lcc_tsfn(p1, L->e), -L->n) / L->n;
+    L->rho0 = L->a * L->Fc * pow(lcc_tsfn(p0, L->e), L->n);
+    L->lon0 = par[5] * D2R; L->x0 = par[6]; L->y0 = par[7];
+}
+static void lcc_fwd(const lcc_t* L, double lat, double lon, double* x, double* y) {
+    double dlam = lon * D2R - L->lon0;
+    dlam = dlam > M_PI ? dlam - 2 * M_PI : (dlam < -M_PI ? dlam + 2 * M_PI : dlam);
+    const double rho = L->a * L->Fc * pow(lcc_tsfn(lat * D2R, L->e), L->n);
+    *x = L->x0 + rho * sin(L->n * dlam); *y = L->y0 + L->rho0 - rho * cos(L->n * dlam);
+}
+
+/* proj: NULL (a lon/lat cube) or the eight LCC parameters of the cube's CRS (ecef_to_model, delay.py:253,295) */
+void orc_march_proj(const double* lat, const double* lon, const double* los, int64_t n, double ht,
+                    const double* lo, const double* hi, int K, const int* nparts, int clamp_lo, int clamp_hi,
+                    const double* ys, int ny, const double* xs, int nx, const double* zs, int nz, const void* wet, const void* hyd, int dtype,
+                    const double* proj, double* out_w, double* out_h) {
+    lcc_t LC;
+    if (proj) lcc_setup(proj, &LC);
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < n; ++i) {
         double o[3], low[3], high[3], cosf = 1.0, aw = 0.0, ah = 0.0;
@@ -192,6 +218,7 @@ void orc_march(const double* lat, const double* lon, const double* los, int64_t 
                 ecef2lla(low[0] + f * dx, low[1] + f * dy, low[2] + f * dz, &plon, &plat, &ph);
                 if (clamp_lo && k == 0 && j == 0) ph = zs[0];
                 if (clamp_hi && k == K - 1 && j == np - 1) ph = zs[nz - 1];
+                if (proj) { double px, py; lcc_fwd(&LC, plat, plon, &px, &py); plon = px; plat = py; }
                 double vw, vh;
                 rgi2(ys, ny, xs, nx, zs, nz, wet, hyd, dtype, plat, plon, ph, &vw, &vh);
                 double wt = (j == 0 || j == np - 1) ? 0.5 : 1.0;
@@ -201,6 +228,13 @@ void orc_march(const double* lat, const double* lon, const double* los, int64_t 
         }
         out_w[i] = aw; out_h[i] = ah;
     }
+}
+
+void orc_march(const double* lat, const double* lon, const double* los, int64_t n, double ht,
+               const double* lo, const double* hi, int K, const int* nparts, int clamp_lo, int clamp_hi,
+               const double* ys, int ny, const double* xs, int nx, const double* zs, int nz, const void* wet, const void* hyd, int dtype,
+               double* out_w, double* out_h) {
+    orc_march_proj(lat, lon, los, n, ht, lo, hi, K, nparts, clamp_lo, clamp_hi, ys, ny, xs, nx, zs, nz, wet, hyd, dtype, NULL, out_w, out_h);
 }
 
 /* ---- per-ray origin heights (BASELINE configs' "c3b") ---------------------------------------------

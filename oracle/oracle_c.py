@@ -98,10 +98,11 @@ def nparts_of(maxlen, max_seg=1000.0):
     return np.ceil(np.asarray(maxlen) / max_seg).astype(int) + 1          # delay.py:283
 
 
-def build_cube_ray_slice(cube, xpts, ypts, ht, los, zref, max_seg=1000.0, nparts=None, clamp=None):
+def build_cube_ray_slice(cube, xpts, ypts, ht, los, zref, max_seg=1000.0, nparts=None, clamp=None, model_proj=None):
     """One height slice of _build_cube_ray (delay.py:256-323) on meshgrid(xpts, ypts) with look vectors los (ny,nx,3).
     cube: dict(xs, ys, zs, wet, hydro (z,y,x)).  Returns (wet, hydro, nparts).  nparts / clamp: the whole slice's partition and
-    z-clamp decisions when these rays are only a block of it (default: this block's own)."""
+    z-clamp decisions when these rays are only a block of it (default: this block's own).  model_proj: None (lon/lat cube) or the
+    Lambert-conformal-conic parameters of the cube's CRS (dict with lat_1, lat_2, lat_0, lon_0, x_0, y_0, a, es; delay.py:253,295)."""
     L = lib()
     shape, lat, lon, los, lo, hi = _slice_inputs(cube, xpts, ypts, ht, los, zref)
     n = lat.size
@@ -119,8 +120,13 @@ def build_cube_ray_slice(cube, xpts, ypts, ht, los, zref, max_seg=1000.0, nparts
             clamp = (own[0], own[1])
     np32 = np.ascontiguousarray(nparts, dtype=np.int32)
     ow, oh = np.empty(n), np.empty(n)
-    L.orc_march(_p(lat), _p(lon), _p(los), C.c_int64(n), C.c_double(ht), _p(lo), _p(hi), C.c_int(K), _p(np32), C.c_int(clamp[0]), C.c_int(clamp[1]),
-                _p(ys), C.c_int(ys.size), _p(xs), C.c_int(xs.size), _p(zs), C.c_int(zs.size), _p(wet), _p(hyd), C.c_int(dtype), _p(ow), _p(oh))
+    proj = None
+    if model_proj is not None:
+        mp = dict(x_0=0.0, y_0=0.0, a=6371229.0, es=0.0); mp.update(model_proj)
+        proj = np.array([mp['a'], mp['es'], mp['lat_1'], mp['lat_2'], mp['lat_0'], mp['lon_0'], mp['x_0'], mp['y_0']], dtype=np.float64)
+    L.orc_march_proj(_p(lat), _p(lon), _p(los), C.c_int64(n), C.c_double(ht), _p(lo), _p(hi), C.c_int(K), _p(np32), C.c_int(clamp[0]), C.c_int(clamp[1]),
+                     _p(ys), C.c_int(ys.size), _p(xs), C.c_int(xs.size), _p(zs), C.c_int(zs.size), _p(wet), _p(hyd), C.c_int(dtype),
+                     _p(proj) if proj is not None else None, _p(ow), _p(oh))
     return ow.reshape(shape), oh.reshape(shape), np.asarray(nparts)
 
 

@@ -228,6 +228,17 @@ def test_config5_lcc_blend_stations_and_rays(R):
                                   nParts_override=[nparts], model_proj=HRRR)
         np.testing.assert_allclose(wet[r0:r0 + 12, c0:c0 + 12], ow[0], rtol=0, atol=TIGHT)
         np.testing.assert_allclose(hyd[r0:r0 + 12, c0:c0 + 12], oh[0], rtol=0, atol=TIGHT)
+    # ... and five 200 x 200 blocks (200 k rays) against the C oracle with the same projection
+    from oracle import oracle_c as OC
+    blended = dict(ys=ys, xs=xs, zs=zs, wet=bw, hydro=bh)
+    b = 200
+    for r0, c0 in ((0, 0), (0, cols - b), (rows - b, 0), (rows - b, cols - b), (901, 777)):
+        xx, yy = np.meshgrid(lonp[c0:c0 + b], latp[r0:r0 + b])
+        los = O.look_vectors_from_inc_hd(np.broadcast_to(inc_cols[c0:c0 + b], yy.shape), np.full(yy.shape, hd), yy, xx, 0.0)
+        ow, oh, _ = OC.build_cube_ray_slice(blended, lonp[c0:c0 + b], latp[r0:r0 + b], 0.0, los, zref, nparts=nparts, model_proj=HRRR)
+        assert np.isfinite(ow).all()
+        np.testing.assert_allclose(wet[r0:r0 + b, c0:c0 + b], ow, rtol=0, atol=TIGHT)
+        np.testing.assert_allclose(hyd[r0:r0 + b, c0:c0 + b], oh, rtol=0, atol=TIGHT)
 
 
 # ---- edge cases -----------------------------------------------------------------------------------------------

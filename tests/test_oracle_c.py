@@ -92,3 +92,33 @@ def test_per_pixel_heights_c_vs_numpy(c1):
     # a different partition than any single slice would give: the per-level maximum comes from the rays that REACH the level
     lo_only = OC.build_cube_ray_per_pixel(c1, lat[6:], lon[6:], np.full(n - 6, hts[6:].min()), los[6:], zref)[2]
     assert (npc >= 0).all() and npc.max() >= 2 and lo_only.shape == npc.shape
+
+
+@pytest.mark.parametrize('proj', [dict(lat_1=38.5, lat_2=38.5, lat_0=38.5, lon_0=262.5 - 360.0, x_0=0.0, y_0=0.0, a=6371229.0, es=0.0),
+                                  dict(lat_1=33.0, lat_2=45.0, lat_0=38.5, lon_0=-97.5, x_0=1000.0, y_0=-2000.0, a=6378137.0, es=0.0066943799901413165)])
+def test_c_oracle_on_a_lambert_cube_vs_numpy(proj):
+    """A weather cube on a Lambert-conformal-conic grid (HRRR's spherical cone; a two-parallel ellipsoidal one): every sample is projected
+    to the model's x / y metres before the interpolation (delay.py:253,295).  C restatement == NumPy restatement (which the GPU
+    parity tests of the conic path are written against), partition handed over and own."""
+    rng = np.random.default_rng(4)
+    lat = np.linspace(38.4, 37.6, 14); lon = np.linspace(-106.5, -104.9, 17)
+    cx, cy = O.lcc_forward(*np.meshgrid(lat, lon, indexing='ij'), **proj)
+    ny, nx, nz = 90, 110, 24
+    ys = cy.min() - 60e3 + 3000.0 * np.arange(ny); xs = cx.min() - 60e3 + 3000.0 * np.arange(nx)
+    assert ys[-1] > cy.max() + 30e3 and xs[-1] > cx.max() + 30e3
+    zs = np.round(-100 + 26100 * np.linspace(0, 1, nz) ** 2, 3)
+    z3 = zs[:, None, None]
+    c = dict(ys=ys, xs=xs, zs=zs, wet=(60 * np.exp(-z3 / 2000) * (1 + 0.1 * rng.standard_normal((ny, nx))[None])).astype(np.float32),
+             hydro=(270 * np.exp(-z3 / 8000) * (1 + 0.01 * rng.standard_normal((ny, nx))[None])).astype(np.float32))
+    zref = float(zs.max() - 1)
+    ip = list(O.getInterpolators(xs, ys, zs, c['wet'], c['hydro']))
+    look = lambda ht, llh, xyz, yy: O.look_vectors_from_inc_hd(np.full(yy.shape, 36.0), np.full(yy.shape, -167.9), llh[1], llh[0], llh[2])
+    for ht in (0.0, 1500.0):
+        (rw, rh), onp = O.build_cube_ray(lon, lat, np.array([ht]), look, ip, MAX_TROPO_HEIGHT=zref, return_nparts=True, model_proj=proj)
+        assert np.isfinite(rw).all()
+        w, h, npn = OC.build_cube_ray_slice(c, lon, lat, ht, _los(lon, lat, 36.0, -167.9, ht), zref, model_proj=proj)
+        assert np.array_equal(npn, onp[0])
+        np.testing.assert_allclose(w, rw[0], rtol=0, atol=1e-11); np.testing.assert_allclose(h, rh[0], rtol=0, atol=1e-11)
+    # outside the grid: NaN in both
+    w, h, _ = OC.build_cube_ray_slice(c, lon - 5.0, lat, 0.0, _los(lon - 5.0, lat, 36.0, -167.9, 0.0), zref, model_proj=proj)
+    assert np.isnan(w).all() and np.isnan(h).all()
