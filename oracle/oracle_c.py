@@ -130,27 +130,52 @@ def build_cube_ray_slice(cube, xpts, ypts, ht, los, zref, max_seg=1000.0, nparts
     return ow.reshape(shape), oh.reshape(shape), np.asarray(nparts)
 
 
-def build_cube_ray_per_pixel(cube, lat, lon, hts, los, zref, max_seg=1000.0, nparts=None):
-    """Rays with their OWN origin heights (no reference semantics; rule in oracle_c.c / DESIGN.md 5c): lat, lon, hts of one shape,
-    los (..., 3).  Returns (wet, hydro, nparts[nz-1]) with nparts indexed by model interval (0 where no ray passes)."""
-    L = lib()
+def _pp_inputs(cube, lat, lon, hts, los):
     shape = np.shape(lat)
     lat = np.ascontiguousarray(np.asarray(lat, dtype=np.float64).ravel()); lon = np.ascontiguousarray(np.asarray(lon, dtype=np.float64).ravel())
     hts = np.ascontiguousarray(np.broadcast_to(np.asarray(hts, dtype=np.float64), shape).ravel())
     los = np.ascontiguousarray(np.asarray(los, dtype=np.float64).reshape(-1, 3))
+    return shape, lat, lon, hts, los
+
+
+def per_pixel_prepass(cube, lat, lon, hts, los, zref):
+    """Pass 1 of the per-ray-height rule alone: (maxlen[nz-1] by model interval, (clamp_lo, clamp_hi)).  Blocks of one batch combine
+    as element-wise max / logical AND."""
+    L = lib()
+    _, lat, lon, hts, los = _pp_inputs(cube, lat, lon, hts, los)
+    zs = np.ascontiguousarray(cube['zs'], dtype=np.float64)
+    maxlen = np.zeros(zs.size - 1); clamp = (C.c_int * 2)(); anyl = C.c_int()
+    L.orc_prepass_pp(_p(lat), _p(lon), _p(hts), _p(los), C.c_int64(lat.size), _p(zs), C.c_int(zs.size), C.c_double(zref), C.c_double(zs.min()),
+                     C.c_double(zs.max()), _p(maxlen), clamp, C.byref(anyl))
+    return maxlen, (int(clamp[0]), int(clamp[1]))
+
+
+def per_pixel_nparts(maxlen, max_seg=1000.0):
+    with np.errstate(invalid='ignore'):
+        return np.where(maxlen > 0, np.ceil(maxlen / max_seg) + 1, 0).astype(np.int32)
+
+
+def build_cube_ray_per_pixel(cube, lat, lon, hts, los, zref, max_seg=1000.0, nparts=None, clamp=None):
+    """Rays with their OWN origin heights (no reference semantics; rule in oracle_c.c / DESIGN.md 5c): lat, lon, hts of one shape,
+    los (..., 3).  Returns (wet, hydro, nparts[nz-1]) with nparts indexed by model interval (0 where no ray passes).  nparts / clamp:
+    the whole batch's when these rays are only a block of it."""
+    L = lib()
+    shape, lat, lon, hts, los = _pp_inputs(cube, lat, lon, hts, los)
     n = lat.size
     ys, xs, zs = (np.ascontiguousarray(cube[k], dtype=np.float64) for k in ('ys', 'xs', 'zs'))
     wet, hyd = _yxz(cube)
     dtype = 0 if wet.dtype == np.float32 else 1
-    M = zs.size - 1
-    maxlen = np.zeros(M); clamp = (C.c_int * 2)(); anyl = C.c_int()
-    L.orc_prepass_pp(_p(lat), _p(lon), _p(hts), _p(los), C.c_int64(n), _p(zs), C.c_int(zs.size), C.c_double(zref), C.c_double(zs.min()),
-                     C.c_double(zs.max()), _p(maxlen), clamp, C.byref(anyl))
-    if nparts is None:
-        with np.errstate(invalid='ignore'):
-            nparts = np.where(maxlen > 0, np.ceil(maxlen / max_seg) + 1, 0)
-        if np.isnan(maxlen).any():
-            raise ValueError('some ray lengths are NaN: the number of integration parts (delay.py:283) is undefined')
+    if nparts is None or clamp is None:
+        M = zs.size - 1
+        maxlen = np.zeros(M); own = (C.c_int * 2)(); anyl = C.c_int()
+        L.orc_prepass_pp(_p(lat), _p(lon), _p(hts), _p(los), C.c_int64(n), _p(zs), C.c_int(zs.size), C.c_double(zref), C.c_double(zs.min()),
+                         C.c_double(zs.max()), _p(maxlen), own, C.byref(anyl))
+        if nparts is None:
+            if np.isnan(maxlen).any():
+                raise ValueError('some ray lengths are NaN: the number of integration parts (delay.py:283) is undefined')
+            nparts = per_pixel_nparts(maxlen, max_seg)
+        if clamp is None:
+            clamp = (own[0], own[1])
     np32 = np.ascontiguousarray(nparts, dtype=np.int32)
     ow, oh = np.empty(n), np.empty(n)
     L.orc_march_pp(_p(lat), _p(lon), _p(hts), _p(los), C.c_int64(n), _p(zs), C.c_double(zref), _p(np32), C.c_int(clamp[0]), C.c_int(clamp[1]),

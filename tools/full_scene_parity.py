@@ -3,7 +3,9 @@
 the whole scene once, the oracle re-traces it in row blocks driven with the whole-slice partition (delay.py:283), and the tool
 records the largest |difference| of both delays, the NaN-mask agreement and the nParts agreement.  Not part of the suite (the
 oracle needs 30 s for 16 M rays and 3 min for 100 M on the GPU box's 16 usable cores).
-usage: full_scene_parity.py [rows=4000] [cols=4000] [out.json] [c5]
+usage: full_scene_parity.py [rows=4000] [cols=4000] [out.json] [c5|c3b]
+c3b: SURVEY 8(d)'s secondary workload - every pixel starts at its own height, rng(2).uniform(0, 3000) - against the oracle's per-ray
+restatement of the rule in DESIGN.md 5c (no reference semantics).
 c5: the ray scene of BASELINE configs[4] instead - an HRRR-like 1000 x 1000 x 50 cube on the 3-km Lambert-conformal-conic grid, two
 epochs blended (0.25, 0.75) on the device (f32), lon / lat scene over the central US; the oracle projects every sample as delay.py:253,295."""
 import json
@@ -24,6 +26,7 @@ rows = int(sys.argv[1]) if len(sys.argv) > 1 else 4000
 cols = int(sys.argv[2]) if len(sys.argv) > 2 else 4000
 out_path = sys.argv[3] if len(sys.argv) > 3 else ''
 C5 = len(sys.argv) > 4 and sys.argv[4] == 'c5'
+PP = len(sys.argv) > 4 and sys.argv[4] == 'c3b'
 HRRR = dict(lat_1=38.5, lat_2=38.5, lat_0=38.5, lon_0=262.5 - 360.0, x_0=0.0, y_0=0.0, a=6371229.0, es=0.0)       # models/hrrr.py:248-259
 
 import torch                                # noqa: E402
@@ -50,10 +53,11 @@ zref = float(c['zs'].max() - 1.0)
 proj = HRRR if C5 else None
 xt, yt = torch.from_numpy(xpts).to(dev), torch.from_numpy(ypts).to(dev)
 inc = torch.from_numpy(np.ascontiguousarray(np.broadcast_to(inc_cols, (rows, cols)))).to(dev)
-rays = R.Rays.grid(xt, yt, inc=inc, hd=hd)
+hts_np = np.random.default_rng(2).uniform(0.0, 3000.0, (rows, cols)) if PP else None
+rays = R.Rays.grid(xt, yt, inc=inc, hd=hd, hts=torch.from_numpy(hts_np).to(dev) if PP else None)
 wet = torch.empty((rows, cols), dtype=torch.float64, device=dev); hyd = torch.empty_like(wet)
 t0 = time.perf_counter()
-_, _, nparts, flags = cube.raytrace(rays, 0.0, zref, out=(wet, hyd))
+_, _, nparts, flags = cube.raytrace(rays, None if PP else 0.0, zref, out=(wet, hyd))
 torch.cuda.synchronize()
 t_gpu = time.perf_counter() - t0
 wn, hn = wet.cpu().numpy(), hyd.cpu().numpy()
@@ -68,25 +72,38 @@ nan_mismatch = 0
 sum_w = sum_h = 0.0
 los_of = lambda r0, r1: O.look_vectors_from_inc_hd(np.broadcast_to(inc_cols, (r1 - r0, cols)), np.full((r1 - r0, cols), hd),
                                                    *np.meshgrid(ypts[r0:r1], xpts, indexing='ij'), 0.0)
+ll_of = lambda r0, r1: np.meshgrid(ypts[r0:r1], xpts, indexing='ij')
 for r0 in range(0, rows, block):            # pass 1: per-level maxima / clamp predicates of every block -> the scene's
     r1 = min(rows, r0 + block)
-    ml, cl = OC.ray_prepass(c, xpts, ypts[r0:r1], 0.0, los_of(r0, r1), zref)
+    if PP:
+        ml, cl = OC.per_pixel_prepass(c, *ll_of(r0, r1), hts_np[r0:r1], los_of(r0, r1), zref)
+    else:
+        ml, cl = OC.ray_prepass(c, xpts, ypts[r0:r1], 0.0, los_of(r0, r1), zref)
     maxlen = ml if maxlen is None else np.maximum(maxlen, ml)
     clamp = cl if clamp is None else (clamp[0] & cl[0], clamp[1] & cl[1])
-onp = OC.nparts_of(maxlen)
 t_pass1 = time.perf_counter() - t0
-nparts_equal = bool(np.array_equal(onp, nparts))
+if PP:          # the oracle's partition is indexed by model interval, the library's by entry of the batch's level table
+    onp = OC.per_pixel_nparts(maxlen)
+    kz = cube.ray_levels(float(hts_np.min()), zref)[2]
+    mask = np.zeros(onp.size, bool); mask[kz] = True
+    nparts_equal = bool(np.array_equal(onp[kz], nparts) and not onp[~mask].any())
+else:
+    onp = OC.nparts_of(maxlen)
+    nparts_equal = bool(np.array_equal(onp, nparts))
 t0 = time.perf_counter()
 for r0 in range(0, rows, block):
     r1 = min(rows, r0 + block)
-    ow, oh, _ = OC.build_cube_ray_slice(c, xpts, ypts[r0:r1], 0.0, los_of(r0, r1), zref, nparts=onp, clamp=clamp, model_proj=proj)
+    if PP:
+        ow, oh, _ = OC.build_cube_ray_per_pixel(c, *ll_of(r0, r1), hts_np[r0:r1], los_of(r0, r1), zref, nparts=onp, clamp=clamp)
+    else:
+        ow, oh, _ = OC.build_cube_ray_slice(c, xpts, ypts[r0:r1], 0.0, los_of(r0, r1), zref, nparts=onp, clamp=clamp, model_proj=proj)
     gw, gh = wn[r0:r1], hn[r0:r1]
     nan_mismatch += int((np.isnan(ow) != np.isnan(gw)).sum() + (np.isnan(oh) != np.isnan(gh)).sum())
     with np.errstate(invalid='ignore'):
         worst_w = max(worst_w, float(np.nanmax(np.abs(gw - ow)))); worst_h = max(worst_h, float(np.nanmax(np.abs(gh - oh))))
     sum_w += float(np.nansum(ow)); sum_h += float(np.nansum(oh))
 t_march = time.perf_counter() - t0
-res = dict(scene=f'{rows}x{cols}', rays=rows * cols, cube='1000x1000x50 f32 LCC, two epochs blended (configs[4])' if C5 else '300x300x80 f32 (SURVEY 8d, seed 0)', S=int(np.sum(nparts)), K=int(len(nparts)),
+res = dict(scene=f'{rows}x{cols}' + (' on a DEM: per-pixel origin heights rng(2).uniform(0, 3000) (c3b)' if PP else ''), rays=rows * cols, cube='1000x1000x50 f32 LCC, two epochs blended (configs[4])' if C5 else '300x300x80 f32 (SURVEY 8d, seed 0)', S=int(np.sum(nparts)), K=int(len(nparts)),
            nparts_equal=nparts_equal, max_abs_wet_m=worst_w, max_abs_hydro_m=worst_h, nan_mask_mismatches=nan_mismatch,
            gpu_mean_wet_m=float(np.nanmean(wn)), gpu_mean_hydro_m=float(np.nanmean(hn)), oracle_mean_wet_m=sum_w / (rows * cols),
            oracle_mean_hydro_m=sum_h / (rows * cols), gpu_call_s=t_gpu, oracle_pass1_s=t_pass1, oracle_march_s=t_march,
