@@ -105,6 +105,7 @@ def main():
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         self_launch(args)
 
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # (before the HSA runtime starts: this pool's driver only has dmabuf IPC, RCCL needs it)
     import torch
     import torch.distributed as dist
     import raider_amd as R
