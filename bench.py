@@ -106,6 +106,11 @@ def main():
         self_launch(args)
 
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # (before the HSA runtime starts: this pool's driver only has dmabuf IPC, RCCL needs it)
+    # stdout carries ONE line, the result: whatever libraries print there (RCCL's version banner goes to the C stdout and comes out
+    # when the process exits, i.e. AFTER a Python print) is sent to stderr; the JSON line is written to the saved descriptor
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
     import raider_amd as R
@@ -347,7 +352,7 @@ def main():
         if world == 1 and args.cpu_sample > 0:
             pp = (hts_np, cube.ray_levels(rays.ht_min, zref)[2]) if args.per_pixel_ht else None
             res['cpu_baseline'] = cpu_baseline(args, rows, cols, xpts, ypts, inc_cols, hd, nparts, zref, out_w, out_h, pp)
-        print(json.dumps(res), flush=True)
+        os.write(result_fd, (json.dumps(res) + '\n').encode())
     if dist_on:
         dist.destroy_process_group()
 
