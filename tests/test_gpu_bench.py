@@ -15,8 +15,8 @@ def _bench(*args):
     out = subprocess.run([sys.executable, str(ROOT / 'bench.py'), '--steps', '3', '--warmup', '1', '--rows', '640', '--cols', '704', '--cpu-sample', '96'] + list(args),
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-4000:])
-    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
-    assert len(lines) == 1, out.stdout[-2000:]
+    lines = out.stdout.splitlines()          # the contract: stdout is ONE line, the JSON (library banners and logs go to stderr)
+    assert len(lines) == 1 and lines[0].startswith('{'), out.stdout[-2000:]
     return json.loads(lines[0])
 
 

@@ -105,8 +105,8 @@ def _bench(tmp_path, tag, *args):
     out = subprocess.run([sys.executable, str(ROOT / 'bench.py'), '--steps', '2', '--warmup', '1', '--cpu-sample', '0', '--no-e2e',
                           '--dump', str(tmp_path / tag)] + list(args), capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-4000:])
-    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
-    assert len(lines) == 1, out.stdout[-2000:]
+    lines = out.stdout.splitlines()          # the contract: stdout is ONE line, the JSON (library banners and logs go to stderr)
+    assert len(lines) == 1 and lines[0].startswith('{'), out.stdout[-2000:]
     return json.loads(lines[0])
 
 
