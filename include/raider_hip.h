@@ -16,6 +16,10 @@
  *   - all floating point arrays are float64 unless a dtype argument says otherwise; angles in degrees,
  *     lengths in metres; NaN is the in-band missing value exactly as in the reference.
  *   - one ctx = one device + one stream; a ctx is not thread-safe, distinct ctxs are.
+ *   - argument errors never reach the device: a NULL pointer where an array is needed, a negative count, an unknown mode /
+ *     dtype / direction is RDR_ERR_INVALID with the reason in rdr_last_error; a count of 0 is an empty batch (RDR_OK, nothing
+ *     touched).  A HIP failure the library reports (RDR_ERR_HIP, e.g. out of memory) leaves no error state behind: the
+ *     next call starts clean.  rdr_last_error(ctx) is the context's last message, rdr_last_error(NULL) the calling thread's.
  */
 #ifndef RAIDER_HIP_H
 #define RAIDER_HIP_H
