@@ -8,11 +8,13 @@ exactly that subset of the published HDF5 file format (HDF5 File Format Specific
 
   * superblock versions 0-3; version-2 object headers (what libhdf5 >= 1.8 writes for NetCDF-4 files) and version-1
     object headers; header continuation blocks;
-  * groups: compact links (link messages), dense links (fractal heap + version-2 B-tree name index) and old-style
-    symbol tables (B-tree v1 + local heap);
+  * groups: compact links (link messages), dense links (fractal heap, objects located through the version-2 B-tree name index - a heap
+    keeps the bytes of removed or renamed entries, only the index says which objects are live) and old-style symbol tables
+    (B-tree v1 + local heap);
   * datasets: contiguous, compact, and chunked (version-3 layout, B-tree v1 chunk index) with the deflate and shuffle
     filters; fixed-point and IEEE floating-point element types of either byte order;
-  * attributes: compact (attribute messages) and dense (fractal heap), numeric or string (fixed or variable length).
+  * attributes: compact (attribute messages) and dense (fractal heap through its version-2 B-tree name index), numeric or string
+    (fixed or variable length).
 
 Anything else (compound / reference types, version-4 chunk indices, external storage, ...) raises
 `UnsupportedHDF5Feature` - loudly, never a silent wrong answer.
@@ -22,7 +24,10 @@ superblock v2, v2 object headers, dense links and attributes, contiguous dataset
 tests/test_ref_files.py checks what is read against physics identities and against the reference's own results.  The
 version-0 superblock and symbol-table groups are exercised by the files of raider_amd.h5write (tests/test_h5write.py), the
 chunked / deflate / shuffle / fletcher32 branches by libhdf5's own re-layouts of those files and of a reference cube (h5repack
-1.10.6 of the build image, same test): arrays come back bit for bit.
+1.10.6 of the build image, same test): arrays come back bit for bit.  tests/test_h5py_cross.py: files written by h5py (libhdf5
+through an independent binding, when the image has one) under five file-format bounds - every layout, element type, byte order and
+attribute storage above - are read back bit for bit or refused by name (the version-4 chunk indices of the >= v110 bounds), and
+h5py reads what raider_amd.h5write writes.
 """
 import zlib
 
@@ -240,9 +245,10 @@ class Group:
                 elif t == 0x02:       # link info -> dense storage
                     flags = body[1]
                     p = 2 + (8 if flags & 1 else 0)
-                    heap = _u(body, p, 8)
+                    heap, index = _u(body, p, 8), _u(body, p + 8, 8)
                     if heap != UNDEF:
-                        for obj in f._fractal_heap_objects(heap):
+                        objs = f._heap_objects_by_index(heap, index, 4, 7) if index != UNDEF else f._fractal_heap_objects(heap)
+                        for obj in objs:                  # (type-5 records: name hash (4), heap ID (7))
                             nm, addr = _link_message(obj)
                             if addr is not None:
                                 links[nm] = addr
@@ -390,17 +396,15 @@ class File(Group):
         return self._cache[addr]
 
     # -- fractal heap (dense links / dense attributes) ---------------------------------------------------------------
-    def _fractal_heap_objects(self, addr):
-        """Every managed object of the heap, in heap order.  Objects are located through the heap's doubling table; inside
-        a direct block they are laid out back to back, which is how this reader walks them (it does not need the B-tree
-        index because the messages stored here - links, attributes - are self-delimiting)."""
+    def _fractal_heap(self, addr):
+        """(direct blocks as (file position, heap offset, size), header fields) of a fractal heap."""
         b = self.buf
         a = self.base + addr
         if b[a:a + 4] != b'FRHP':
             raise ValueError('corrupt fractal heap header')
-        idlen = _u(b, a + 5, 2)
         filt = _u(b, a + 7, 2)
         flags = b[a + 9]
+        maxman = _u(b, a + 10, 4)
         p = a + 10 + 4 + 8 + 8 + 8 + 8 + 8 + 8 + 8
         nman = _u(b, p, 8); p += 8
         p += 8 * 4
@@ -415,13 +419,13 @@ class File(Group):
             raise UnsupportedHDF5Feature('filtered fractal heap')
         offbytes = (maxheapbits + 7) // 8
         hdr = 5 + 8 + offbytes + (4 if flags & 2 else 0)
-        objs = []
+        blocks = []
 
         def direct(addr_, size):
             q = self.base + addr_
             if b[q:q + 4] != b'FHDB':
                 raise ValueError('corrupt fractal heap direct block')
-            objs.append((q + hdr, q + size))
+            blocks.append((q, _u(b, q + 13, offbytes), size))
 
         def indirect(addr_, rows):
             q = self.base + addr_
@@ -441,20 +445,92 @@ class File(Group):
                         crow = (size // start).bit_length() - 1 - (width.bit_length() - 1) + 1
                         indirect(child, crow)
 
-        if root == UNDEF:
-            return []
-        if nrows == 0:
-            direct(root, start)
-        else:
-            indirect(root, nrows)
+        if root != UNDEF:
+            if nrows == 0:
+                direct(root, start)
+            else:
+                indirect(root, nrows)
+        enc = lambda x: (max(int(x), 1).bit_length() - 1) // 8 + 1                # H5VM_limit_enc_size
+        lenbytes = min((maxdirect.bit_length() - 1 + 7) // 8, enc(maxman))
+        return blocks, dict(nman=nman, hdr=hdr, offbytes=offbytes, lenbytes=lenbytes)
+
+    def _fractal_heap_objects(self, addr):
+        """Every managed object of the heap, in heap order, found by walking the direct blocks back to back (links and attributes are
+        self-delimiting).  Only right for a heap nothing was ever removed from - the fallback when the object has no name index."""
+        b = self.buf
+        blocks, info = self._fractal_heap(addr)
         out = []
-        for lo, hi in objs:
-            p = lo
-            while p < hi and len(out) < nman:
+        for q, _off, size in blocks:
+            p, hi = q + info['hdr'], q + size
+            while p < hi and len(out) < info['nman']:
                 n = self._self_delimited(b, p, hi)
                 if n is None:
                     break
                 out.append(b[p:p + n]); p += n
+        return out
+
+    def _heap_objects_by_index(self, heap_addr, btree_addr, id_off, id_len):
+        """The LIVE objects of a fractal heap: the version-2 B-tree that indexes them (links by name hash: type 5, attributes by name: type 8)
+        holds one record per object with its heap ID at record bytes [id_off, id_off + id_len) - offset and length inside the heap's
+        address space.  Space freed by a deleted or renamed attribute / link still holds its old bytes, which a walk of the blocks would
+        take for an object (h5py writes every attribute under a temporary name first)."""
+        b = self.buf
+        blocks, info = self._fractal_heap(heap_addr)
+        out = []
+        for rec in self._btree2_records(btree_addr):
+            hid = rec[id_off:id_off + id_len]
+            kind = (hid[0] >> 4) & 3
+            if kind != 0:
+                raise UnsupportedHDF5Feature('huge / tiny fractal-heap object')
+            off = _u(hid, 1, info['offbytes']); ln = _u(hid, 1 + info['offbytes'], info['lenbytes'])
+            for q, boff, size in blocks:
+                if boff <= off < boff + size:
+                    out.append(b[q + off - boff:q + off - boff + ln])
+                    break
+            else:
+                raise ValueError('fractal heap ID outside every direct block')
+        return out
+
+    def _btree2_records(self, addr):
+        """All records of a version-2 B-tree (HDF5 spec III.A.2), as raw bytes."""
+        b = self.buf
+        a = self.base + addr
+        if b[a:a + 4] != b'BTHD':
+            raise ValueError('corrupt version-2 B-tree header')
+        nodesize, recsize, depth = _u(b, a + 6, 4), _u(b, a + 10, 2), _u(b, a + 12, 2)
+        root, nroot = _u(b, a + 16, 8), _u(b, a + 24, 2)
+        if root == UNDEF or nroot == 0:
+            return []
+        enc = lambda x: (max(int(x), 1).bit_length() - 1) // 8 + 1                # H5VM_limit_enc_size
+        max_leaf = (nodesize - 10) // recsize
+        nrec_size = enc(max_leaf)
+        cum = [max_leaf]; cum_size = [0]                                           # per level: cumulative max records, and its field width
+        for u in range(1, depth + 1):
+            ptr = 8 + nrec_size + cum_size[u - 1]
+            mx = (nodesize - (10 + ptr)) // (recsize + ptr)
+            cum.append((mx + 1) * cum[u - 1] + mx); cum_size.append(enc(cum[u]))
+        out = []
+
+        def node(addr_, nrec, level):
+            q = self.base + addr_
+            sig = b'BTLF' if level == 0 else b'BTIN'
+            if b[q:q + 4] != sig:
+                raise ValueError('corrupt version-2 B-tree node')
+            p = q + 6
+            recs = [bytes(b[p + i * recsize:p + (i + 1) * recsize]) for i in range(nrec)]
+            p += nrec * recsize
+            if level == 0:
+                out.extend(recs)
+                return
+            for i in range(nrec + 1):
+                caddr = _u(b, p, 8); p += 8
+                cn = _u(b, p, nrec_size); p += nrec_size
+                p += cum_size[level - 1]
+                node(caddr, cn, level - 1)
+                if i < nrec:
+                    out.append(recs[i])
+
+        node(root, nroot, depth)
         return out
 
     @staticmethod
@@ -499,9 +575,9 @@ class File(Group):
         if info is not None:
             flags = info[1]
             p = 2 + (2 if flags & 1 else 0)
-            heap = _u(info, p, 8)
-            if heap != UNDEF:
-                bodies.extend(self._fractal_heap_objects(heap))
+            heap, index = _u(info, p, 8), _u(info, p + 8, 8)
+            if heap != UNDEF:       # (type-8 records: heap ID (8), message flags (1), creation order (4), name hash (4))
+                bodies.extend(self._heap_objects_by_index(heap, index, 0, 8) if index != UNDEF else self._fractal_heap_objects(heap))
         for body in bodies:
             try:
                 k, v = self._attribute(body)

@@ -113,3 +113,45 @@ def test_conic_projections_against_40_digit_arithmetic():
         for k in range(la.size):
             ex, ey = stere_north(float(la[k]), float(lo[k]), kw['lat_ts'], kw['lon_0'], kw['a'], kw['es'])
             assert abs(float(mp.mpf(float(x[k])) - ex)) < 2e-8 and abs(float(mp.mpf(float(y[k])) - ey)) < 2e-8
+
+
+ERFA_PY = '/opt/conda/bin/python3.9'          # an Anaconda interpreter in the image carries pyerfa (the IAU SOFA routines, with astropy)
+
+
+def test_geodetic_ecef_conversions_against_erfa(tmp_path):
+    """A THIRD party's code for the same conversions: ERFA / SOFA `gd2gc` and `gc2gd` (Fukushima's closed-form inverse, no truncation)
+    on 200 000 points over the range the delay path uses - the 40-digit test above covers 65.  Forward: rounding only.  Inverse: the
+    oracle restates PROJ's ONE Bowring step, so its height departs from ERFA's by that step's truncation (~h^2; same envelope as
+    above), its latitude by < 1e-9 degrees."""
+    import os
+    import subprocess
+    if not os.path.exists(ERFA_PY):
+        pytest.skip('no interpreter with pyerfa in this image')
+    script = (
+        "import sys, numpy as np\n"
+        "try:\n    import erfa\nexcept Exception:\n    sys.exit(77)\n"
+        "d = np.load(sys.argv[1])\n"
+        "xyz = erfa.gd2gc(1, np.radians(d['lon']), np.radians(d['lat']), d['h'])\n"          # 1 = WGS84
+        "elong, phi, height = erfa.gc2gd(1, d['xyz'])\n"
+        "np.savez(sys.argv[2], xyz=xyz, lon=np.degrees(elong), lat=np.degrees(phi), h=height)\n")
+    rng = np.random.default_rng(5)
+    n = 200000
+    lat = rng.uniform(-90, 90, n); lon = rng.uniform(-180, 180, n); h = rng.uniform(-500, 85000, n)
+    x, y, z = O.lla2ecef(lat, lon, h)
+    np.savez(tmp_path / 'in.npz', lat=lat, lon=lon, h=h, xyz=np.stack([x, y, z], -1))
+    r = subprocess.run([ERFA_PY, '-c', script, str(tmp_path / 'in.npz'), str(tmp_path / 'out.npz')], capture_output=True, text=True, timeout=600,
+                       env={k: v for k, v in os.environ.items() if not k.startswith('PYTHON')})
+    if r.returncode == 77:
+        pytest.skip('pyerfa is not importable')
+    assert r.returncode == 0, r.stderr[-2000:]
+    e = np.load(tmp_path / 'out.npz')
+    assert np.abs(np.stack([x, y, z], -1) - e['xyz']).max() < 5e-9                      # forward: a few ulp of 6.4e6 m
+    lo2, la2, h2 = O.ecef2lla(x, y, z)
+    dh = np.abs(h2 - e['h'])
+    for top, bound in ((1000.0, 3e-8), (10000.0, 2e-6), (40000.0, 3e-5), (85000.0, 1e-4)):
+        assert dh[h <= top].max() < bound, (top, dh[h <= top].max())
+    assert np.abs(la2 - e['lat']).max() < 1e-9
+    dlon = np.abs(((lo2 - e['lon'] + 180.0) % 360.0) - 180.0)
+    assert dlon[np.abs(lat) < 89.99].max() < 1e-12
+    # and ERFA's own inverse returns the inputs: the two authorities (40 digits, SOFA) agree with each other through the oracle's forward
+    assert np.abs(e['h'] - h).max() < 2e-8 and np.abs(e['lat'] - lat).max() < 1e-12

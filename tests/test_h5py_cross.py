@@ -1,0 +1,146 @@
+"""CPU: the built-in HDF5 reader / writer against h5py (libhdf5 through an independent binding), when the image has one - the
+Anaconda interpreter /opt/conda/bin/python3.9 does.  Two directions:
+  * h5py WRITES files in the layouts real NetCDF-4 / HDF5 producers choose (contiguous, compact-sized, chunked with shuffle + deflate +
+    fletcher32, either byte order, integer and float element types, old and new file-format bounds, dense and compact attribute storage,
+    fixed- and variable-length string attributes, nested groups) and raider_amd.h5lite must read every array and attribute back bit for
+    bit - or refuse by name (UnsupportedHDF5Feature), never return different numbers;
+  * raider_amd.h5write WRITES the delay cube and the processed model, and h5py must read them back bit for bit, with the
+    dimension scales attached the NetCDF-4 way."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+PY = '/opt/conda/bin/python3.9'
+ENV = {k: v for k, v in os.environ.items() if not k.startswith('PYTHON')}
+
+
+def _run(script, *args):
+    if not os.path.exists(PY):
+        pytest.skip('no interpreter with h5py in this image')
+    r = subprocess.run([PY, '-c', "import sys\ntry:\n    import h5py\nexcept Exception:\n    sys.exit(77)\n" + script] + [str(a) for a in args],
+                       capture_output=True, text=True, timeout=600, env=ENV)
+    if r.returncode == 77:
+        pytest.skip('h5py is not importable')
+    assert r.returncode == 0, r.stderr[-3000:]
+    return r.stdout
+
+
+WRITER = r'''
+import numpy as np
+out, libver = sys.argv[1], sys.argv[2]
+rng = np.random.default_rng(0)
+kw = {} if libver == 'default' else dict(libver=tuple(libver.split('-')))
+with h5py.File(out, 'w', **kw) as f:
+    f.attrs['title'] = 'written by h5py'
+    f.attrs['fixed'] = np.bytes_('fixed-length text')
+    f.attrs['number'] = np.float64(2.5)
+    f.attrs['vector'] = np.arange(5, dtype=np.int32)
+    a = rng.standard_normal((7, 11, 13))
+    f.create_dataset('contig_f64', data=a)
+    f.create_dataset('contig_f32', data=a.astype('f4'))
+    f.create_dataset('big_endian_f64', data=a.astype('>f8'))
+    f.create_dataset('big_endian_i16', data=(1000 * a).astype('>i2'))
+    f.create_dataset('i32', data=(1000 * a).astype('i4'))
+    f.create_dataset('u8', data=(np.abs(a) * 50).astype('u1'))
+    f.create_dataset('i64_scalar', data=np.int64(-2147483647))
+    f.create_dataset('chunk_plain', data=a, chunks=(3, 4, 5))
+    f.create_dataset('chunk_gzip', data=a, chunks=(7, 6, 13), compression='gzip', compression_opts=4)
+    f.create_dataset('chunk_shuffle_gzip', data=a.astype('f4'), chunks=(2, 11, 13), compression='gzip', shuffle=True)
+    f.create_dataset('chunk_fletcher', data=a, chunks=(4, 4, 4), fletcher32=True)
+    f.create_dataset('chunk_all', data=a, chunks=(5, 5, 5), compression='gzip', shuffle=True, fletcher32=True)
+    f.create_dataset('one_chunk', data=a, chunks=a.shape)
+    f.create_dataset('vector_1d', data=np.linspace(0, 1, 1001), chunks=(100,), compression='gzip')
+    f.create_dataset('tiny', data=np.arange(6.0))
+    d = f['contig_f64']
+    d.attrs['units'] = 'm'
+    d.attrs['scale_factor'] = np.float32(0.5)
+    for k in range(12):                         # enough attributes for dense storage under the 'latest' bounds
+        d.attrs[f'attr_{k:02d}'] = 'value %d' % k
+    g = f.create_group('group').create_group('nested')
+    g.create_dataset('inside', data=a[0])
+    g.attrs['where'] = 'two levels down'
+    for k in range(20):                         # many links in one group: dense link storage / several symbol-table nodes
+        f['group'].create_dataset(f'member_{k:02d}', data=np.full(3, float(k)))
+np.save(out + '.npy', a)
+'''
+
+
+@pytest.mark.parametrize('libver', ['default', 'earliest-v108', 'v108-v108', 'v110-v110', 'latest-latest'])
+def test_h5lite_reads_what_h5py_writes(tmp_path, libver):
+    from raider_amd import h5lite
+    path = tmp_path / f'h5py_{libver}.h5'
+    _run(WRITER, path, libver)
+    a = np.load(str(path) + '.npy')
+    want = {'contig_f64': a, 'contig_f32': a.astype('f4'), 'big_endian_f64': a, 'big_endian_i16': (1000 * a).astype('i2'), 'i32': (1000 * a).astype('i4'),
+            'u8': (np.abs(a) * 50).astype('u1'), 'chunk_plain': a, 'chunk_gzip': a, 'chunk_shuffle_gzip': a.astype('f4'), 'chunk_fletcher': a,
+            'chunk_all': a, 'one_chunk': a, 'vector_1d': np.linspace(0, 1, 1001), 'tiny': np.arange(6.0)}
+    refused = []
+    with h5lite.File(str(path)) as f:
+        assert set(want) <= set(f.keys()) and 'group' in f
+        for name, arr in want.items():
+            try:
+                got = np.asarray(f[name][:])
+            except h5lite.UnsupportedHDF5Feature as e:          # allowed: refused BY NAME
+                refused.append((name, str(e)))
+                continue
+            assert got.shape == arr.shape and np.array_equal(got.astype(arr.dtype), arr), name
+            assert got.dtype.itemsize == arr.dtype.itemsize and got.dtype.kind == arr.dtype.kind, name
+        assert int(np.asarray(f['i64_scalar'][()] if hasattr(f['i64_scalar'], '__getitem__') else f['i64_scalar'].read())) == -2147483647
+        at = f.attrs
+        assert at['title'] == 'written by h5py' and at['fixed'] == 'fixed-length text' and float(at['number']) == 2.5
+        assert np.array_equal(np.asarray(at['vector']), np.arange(5))
+        da = f['contig_f64'].attrs
+        assert da['units'] == 'm' and float(da['scale_factor']) == 0.5 and all(da[f'attr_{k:02d}'] == f'value {k}' for k in range(12))
+        g = f['group']
+        assert len([k for k in g.keys() if k.startswith('member_')]) == 20
+        assert np.array_equal(np.asarray(g['member_07'][:]), np.full(3, 7.0))
+        n = g['nested']
+        assert n.attrs['where'] == 'two levels down' and np.array_equal(np.asarray(n['inside'][:]), a[0])
+    # what may be refused: only the version-4 chunk indices of the newest format bounds (h5lite.py header)
+    assert all('version-4' in msg or 'layout' in msg.lower() for _, msg in refused), refused
+    if libver in ('default', 'earliest-v108', 'v108-v108'):
+        assert refused == [], refused
+
+
+READER = r'''
+import json, numpy as np
+path = sys.argv[1]
+out = {}
+with h5py.File(path, 'r') as f:
+    out['root_attrs'] = {k: (v.decode() if isinstance(v, bytes) else (v if isinstance(v, str) else np.asarray(v).tolist())) for k, v in f.attrs.items()}
+    out['vars'] = {}
+    for name, d in f.items():
+        if not isinstance(d, h5py.Dataset):
+            continue
+        a = d[()]
+        np.save(path + '.' + name + '.npy', np.asarray(a))
+        info = dict(shape=list(d.shape), dtype=str(d.dtype), is_scale=bool(h5py.h5ds.is_scale(d.id)), attrs=sorted(d.attrs.keys()))
+        info['dims'] = [[s.name.lstrip('/') for s in dim.values()] for dim in d.dims] if d.shape else []
+        out['vars'][name] = info
+print(json.dumps(out))
+'''
+
+
+def test_h5py_reads_what_h5write_writes(tmp_path):
+    from raider_amd.delay import DelayCube
+    rng = np.random.default_rng(1)
+    z = np.array([0.0, 500.0, 1500.0]); y = np.linspace(34.0, 33.0, 9); x = np.linspace(-118.0, -117.0, 11)
+    wet = rng.standard_normal((3, 9, 11)); hyd = rng.standard_normal((3, 9, 11)); wet[1, 2, 3] = np.nan
+    dc = DelayCube(dict(x=x, y=y, z=z, wet=wet, hydro=hyd), dict(Conventions='CF-1.7', title='RAiDER geo cube', source='unit test',
+                                                                  description='RAiDER geo cube - slant - raytracing', reference_time='20200130T13:52:45'))
+    path = tmp_path / 'delay_cube.nc'
+    dc.to_netcdf(path)
+    info = json.loads(_run(READER, path).strip().splitlines()[-1])
+    v = info['vars']
+    assert {'x', 'y', 'z', 'wet', 'hydro', 'crs'} <= set(v)
+    for name, arr in (('x', x), ('y', y), ('z', z), ('wet', wet), ('hydro', hyd)):
+        got = np.load(f'{path}.{name}.npy')
+        assert got.dtype == np.float64 and np.array_equal(got, arr, equal_nan=True), name
+    assert v['wet']['shape'] == [3, 9, 11] and v['wet']['dims'] == [['z'], ['y'], ['x']] and v['hydro']['dims'] == [['z'], ['y'], ['x']]   # H5DS, as netCDF-4 attaches them
+    assert v['x']['is_scale'] and v['y']['is_scale'] and v['z']['is_scale'] and not v['wet']['is_scale']
+    assert 'units' in v['wet']['attrs'] and 'grid_mapping' in v['wet']['attrs']
+    assert info['root_attrs']['title'] == 'RAiDER geo cube' and info['root_attrs']['Conventions'] == 'CF-1.7'
+    assert int(np.load(f'{path}.crs.npy')) == -2147483647
