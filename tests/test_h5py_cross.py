@@ -144,3 +144,66 @@ def test_h5py_reads_what_h5write_writes(tmp_path):
     assert 'units' in v['wet']['attrs'] and 'grid_mapping' in v['wet']['attrs']
     assert info['root_attrs']['title'] == 'RAiDER geo cube' and info['root_attrs']['Conventions'] == 'CF-1.7'
     assert int(np.load(f'{path}.crs.npy')) == -2147483647
+
+
+DUMP = r'''
+import json, numpy as np
+path, outdir = sys.argv[1], sys.argv[2]
+meta = {}
+def norm(v):
+    if isinstance(v, bytes):
+        return v.decode('utf-8', 'replace')
+    if isinstance(v, str):
+        return v
+    a = np.asarray(v)
+    if a.dtype.kind in 'OSU':
+        return [x.decode() if isinstance(x, bytes) else str(x) for x in a.ravel().tolist()]
+    return a.ravel().tolist()
+n = [0]
+def visit(name, obj):
+    ent = dict(attrs={k: norm(v) for k, v in obj.attrs.items() if k not in ('DIMENSION_LIST', 'REFERENCE_LIST')})
+    if isinstance(obj, h5py.Dataset):
+        a = np.asarray(obj[()])
+        if a.dtype.kind in 'fiu':
+            np.save(f'{outdir}/{n[0]}.npy', a); ent['file'] = n[0]; n[0] += 1
+            ent['dtype'] = a.dtype.str.lstrip('<>=|'); ent['shape'] = list(a.shape)
+    meta[name] = ent
+with h5py.File(path, 'r') as f:
+    meta['/'] = dict(attrs={k: norm(v) for k, v in f.attrs.items()})
+    f.visititems(visit)
+print(json.dumps(meta))
+'''
+
+
+def test_h5lite_equals_h5py_on_the_files_the_real_raider_wrote(tmp_path):
+    """The NetCDF-4 files under tests/golden/ref_files were written by the real RAiDER (xarray -> netCDF4 -> libhdf5): every dataset and
+    every attribute h5py finds in them, h5lite must return identically."""
+    from pathlib import Path
+    from raider_amd import h5lite
+    files = [p for p in sorted((Path(__file__).parent / 'golden' / 'ref_files').rglob('*.nc')) if p.read_bytes()[:8] == b'\x89HDF\r\n\x1a\n']
+    assert len(files) >= 2
+    for k, path in enumerate(files):
+        out = tmp_path / str(k); out.mkdir()
+        meta = json.loads(_run(DUMP, path, out).strip().splitlines()[-1])
+        with h5lite.File(str(path)) as f:
+            for name, ent in meta.items():
+                obj = f if name == '/' else f
+                if name != '/':
+                    for part in name.split('/'):
+                        obj = obj[part]
+                mine = obj.attrs
+                for an, want in ent['attrs'].items():
+                    assert an in mine, (path.name, name, an)
+                    got = mine[an]
+                    if isinstance(want, str):
+                        assert got == want, (path.name, name, an, got, want)
+                    elif want and isinstance(want[0], str):
+                        assert list(np.ravel(got)) == want, (path.name, name, an)
+                    else:
+                        assert np.array_equal(np.ravel(np.asarray(got, dtype=np.float64)), np.asarray(want, dtype=np.float64), equal_nan=True), (path.name, name, an)
+                assert set(mine) - {'DIMENSION_LIST', 'REFERENCE_LIST'} == set(ent['attrs']), (path.name, name, set(mine) ^ set(ent['attrs']))
+                if 'file' in ent:
+                    want = np.load(out / f"{ent['file']}.npy")
+                    got = np.asarray(obj[()] if want.ndim == 0 else obj[:])
+                    assert got.shape == want.shape and got.dtype.kind == want.dtype.kind and got.dtype.itemsize == want.dtype.itemsize, (path.name, name)
+                    assert np.array_equal(got, want, equal_nan=True), (path.name, name)
