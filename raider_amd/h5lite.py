@@ -11,12 +11,14 @@ exactly that subset of the published HDF5 file format (HDF5 File Format Specific
   * groups: compact links (link messages), dense links (fractal heap, objects located through the version-2 B-tree name index - a heap
     keeps the bytes of removed or renamed entries, only the index says which objects are live) and old-style symbol tables
     (B-tree v1 + local heap);
-  * datasets: contiguous, compact, and chunked (version-3 layout, B-tree v1 chunk index) with the deflate and shuffle
-    filters; fixed-point and IEEE floating-point element types of either byte order;
+  * datasets: contiguous, compact, and chunked - version-3 layout with its B-tree v1 chunk index, version-4 layout with a
+    single-chunk, implicit or (paged) fixed-array index - with the deflate, shuffle and fletcher32 filters; fixed-point and IEEE
+    floating-point element types of either byte order;
   * attributes: compact (attribute messages) and dense (fractal heap through its version-2 B-tree name index), numeric or string
     (fixed or variable length).
 
-Anything else (compound / reference types, version-4 chunk indices, external storage, ...) raises
+Anything else (compound / reference types, the extensible-array and B-tree v2 chunk indices that datasets with unlimited dimensions get
+under the >= v110 format bounds, external storage, ...) raises
 `UnsupportedHDF5Feature` - loudly, never a silent wrong answer.
 
 Test status: exercised on the NetCDF-4 files the reference's test suite holds (written by netCDF4 4.9 / libhdf5 1.12-1.14:
@@ -26,7 +28,7 @@ version-0 superblock and symbol-table groups are exercised by the files of raide
 chunked / deflate / shuffle / fletcher32 branches by libhdf5's own re-layouts of those files and of a reference cube (h5repack
 1.10.6 of the build image, same test): arrays come back bit for bit.  tests/test_h5py_cross.py: files written by h5py (libhdf5
 through an independent binding, when the image has one) under five file-format bounds - every layout, element type, byte order and
-attribute storage above - are read back bit for bit or refused by name (the version-4 chunk indices of the >= v110 bounds), and
+attribute storage above - are read back bit for bit or refused by name (an unlimited dimension under the >= v110 bounds), and
 h5py reads what raider_amd.h5write writes.
 """
 import zlib
@@ -160,23 +162,102 @@ class Dataset:
             raw = f.buf[f.base + addr:f.base + addr + count * self.dtype.itemsize]
             return np.frombuffer(raw, dtype=self.dtype, count=count).reshape(shape).astype(self.dtype.newbyteorder('='))
         if cls == 2:
-            if ver != 3:
-                raise UnsupportedHDF5Feature('version-4 chunked layout (fixed/extensible array, B-tree v2 chunk index)')
             return self._read_chunked(lay, shape)
         raise UnsupportedHDF5Feature(f'data layout class {cls}')
 
+    def _chunks(self, lay, shape):
+        """(chunk shape, iterator of (offsets, stored size, filter mask, address, may be filtered)) of a chunked dataset: the version-3
+        layout with its version-1 B-tree, or a version-4 layout with a single-chunk, implicit or fixed-array index (what libhdf5 picks
+        for fixed-shape datasets under the >= v110 format bounds)."""
+        f = self.file
+        es = self.dtype.itemsize
+        if lay[0] == 3:
+            nd = lay[2] - 1
+            btree = _u(lay, 3, 8)
+            chunk = tuple(_u(lay, 11 + 4 * i, 4) for i in range(nd))
+            return chunk, (() if btree == UNDEF else ((o, sz, m, a, True) for o, sz, m, a in f._chunk_btree(btree, nd)))
+        flags, nd1, enc = lay[2], lay[3], lay[4]
+        nd = nd1 - 1
+        chunk = tuple(_u(lay, 5 + enc * i, enc) for i in range(nd))
+        p = 5 + enc * nd1
+        itype = lay[p]; p += 1
+        grid = [-(-s // c) for s, c in zip(shape, chunk)]
+        nchunks = int(np.prod(grid)) if grid else 1
+        plain = int(np.prod(chunk)) * es
+
+        def offsets(i):
+            idx = np.unravel_index(i, grid) if grid else ()
+            return tuple(int(k) * c for k, c in zip(idx, chunk))
+
+        partial = lambda offs: any(o + c > s for o, c, s in zip(offs, chunk, shape))
+        edge_plain = bool(flags & 1)             # DONT_FILTER_PARTIAL_BOUND_CHUNKS
+        if itype == 1:                           # single chunk
+            size, mask = plain, 0
+            if flags & 2:
+                size, mask = _u(lay, p, 8), _u(lay, p + 8, 4); p += 12
+            addr = _u(lay, p, 8)
+            return chunk, (() if addr == UNDEF else [(offsets(0), size, mask, addr, bool(flags & 2))])
+        if itype == 2:                           # implicit: every chunk allocated, back to back, never filtered
+            addr = _u(lay, p, 8)
+            return chunk, (() if addr == UNDEF else ((offsets(i), plain, 0, addr + i * plain, False) for i in range(nchunks)))
+        if itype == 3:                           # fixed array
+            addr = _u(lay, p + 1, 8)
+            if addr == UNDEF:
+                return chunk, ()
+            b = f.buf
+            a = f.base + addr
+            if b[a:a + 4] != b'FAHD':
+                raise ValueError('corrupt fixed-array header')
+            client, esize, pbits = b[a + 5], b[a + 6], b[a + 7]
+            nel, dblk = _u(b, a + 8, 8), _u(b, a + 16, 8)
+            if dblk == UNDEF:
+                return chunk, ()
+            q = f.base + dblk
+            if b[q:q + 4] != b'FADB':
+                raise ValueError('corrupt fixed-array data block')
+            q += 6 + 8
+            per_page = 1 << pbits
+            pages = []                           # (file position of the page's first element, number of elements)
+            if nel > per_page:
+                npages = -(-nel // per_page)
+                bitmap = b[q:q + (npages + 7) // 8]
+                q += (npages + 7) // 8 + 4
+                for pg in range(npages):
+                    cnt = min(per_page, nel - pg * per_page)
+                    init = (bitmap[pg // 8] >> (7 - pg % 8)) & 1
+                    pages.append((q if init else None, cnt))
+                    q += cnt * esize + 4
+            else:
+                pages.append((q, nel))
+
+            def elements():
+                i = 0
+                for pos, cnt in pages:
+                    for k in range(cnt):
+                        if pos is not None and i < nchunks:
+                            e = pos + k * esize
+                            caddr = _u(b, e, 8)
+                            if caddr != UNDEF:
+                                offs = offsets(i)
+                                if client == 1:
+                                    size, mask = _u(b, e + 8, esize - 12), _u(b, e + esize - 4, 4)
+                                    yield offs, size, mask, caddr, not (edge_plain and partial(offs))
+                                else:
+                                    yield offs, plain, 0, caddr, False
+                        i += 1
+            return chunk, elements()
+        raise UnsupportedHDF5Feature({4: 'version-4 chunked layout with an extensible-array chunk index (unlimited dimension)',
+                                      5: 'version-4 chunked layout with a version-2 B-tree chunk index (several unlimited dimensions)'}
+                                     .get(itype, f'version-4 chunked layout, chunk index type {itype}'))
+
     def _read_chunked(self, lay, shape):
         f = self.file
-        nd = lay[2] - 1
-        btree = _u(lay, 3, 8)
-        chunk = tuple(_u(lay, 11 + 4 * i, 4) for i in range(nd))
+        chunk, entries = self._chunks(lay, shape)
         out = np.zeros(shape, dtype=self.dtype.newbyteorder('='))
-        if btree == UNDEF:
-            return out
-        for offs, size, mask, addr in f._chunk_btree(btree, nd):
+        for offs, size, mask, addr, filtered in entries:
             raw = f.buf[f.base + addr:f.base + addr + size]
             for i, (fid, _) in reversed(list(enumerate(self.filters))):
-                if mask & (1 << i):
+                if not filtered or mask & (1 << i):
                     continue
                 if fid == 1:
                     raw = zlib.decompress(raw)

@@ -3,7 +3,8 @@ Anaconda interpreter /opt/conda/bin/python3.9 does.  Two directions:
   * h5py WRITES files in the layouts real NetCDF-4 / HDF5 producers choose (contiguous, compact-sized, chunked with shuffle + deflate +
     fletcher32, either byte order, integer and float element types, old and new file-format bounds, dense and compact attribute storage,
     fixed- and variable-length string attributes, nested groups) and raider_amd.h5lite must read every array and attribute back bit for
-    bit - or refuse by name (UnsupportedHDF5Feature), never return different numbers;
+    bit - or refuse by name (UnsupportedHDF5Feature: the extensible-array chunk index of a dataset with an unlimited dimension under
+    the >= v110 bounds), never return different numbers;
   * raider_amd.h5write WRITES the delay cube and the processed model, and h5py must read them back bit for bit, with the
     dimension scales attached the NetCDF-4 way."""
 import json
@@ -54,6 +55,18 @@ with h5py.File(out, 'w', **kw) as f:
     f.create_dataset('one_chunk', data=a, chunks=a.shape)
     f.create_dataset('vector_1d', data=np.linspace(0, 1, 1001), chunks=(100,), compression='gzip')
     f.create_dataset('tiny', data=np.arange(6.0))
+    many = rng.standard_normal((64, 66))
+    f.create_dataset('many_chunks', data=many, chunks=(1, 2))                       # 2112 chunks: a paged fixed array under the new bounds
+    f.create_dataset('many_chunks_gzip', data=many, chunks=(2, 4), compression='gzip')
+    part = f.create_dataset('partly_written', shape=(40, 50), dtype='f8', chunks=(8, 8))
+    part[8:24, 16:40] = many[:16, :24]                                               # the other chunks are never allocated: fill value 0
+    dcpl = h5py.h5p.create(h5py.h5p.DATASET_CREATE)
+    dcpl.set_chunk((5, 7)); dcpl.set_alloc_time(h5py.h5d.ALLOC_TIME_EARLY)         # early allocation, no filter: the implicit index
+    sid = h5py.h5s.create_simple((23, 31))
+    did = h5py.h5d.create(f.id, b'early_alloc', h5py.h5t.NATIVE_DOUBLE, sid, dcpl=dcpl)
+    did.write(h5py.h5s.ALL, h5py.h5s.ALL, np.ascontiguousarray(many[:23, :31]))
+    f.create_dataset('unlimited', data=many, chunks=(8, 8), maxshape=(None, 66))     # extensible-array index under the new bounds
+    np.save(out + '.many.npy', many)
     d = f['contig_f64']
     d.attrs['units'] = 'm'
     d.attrs['scale_factor'] = np.float32(0.5)
@@ -77,6 +90,9 @@ def test_h5lite_reads_what_h5py_writes(tmp_path, libver):
     want = {'contig_f64': a, 'contig_f32': a.astype('f4'), 'big_endian_f64': a, 'big_endian_i16': (1000 * a).astype('i2'), 'i32': (1000 * a).astype('i4'),
             'u8': (np.abs(a) * 50).astype('u1'), 'chunk_plain': a, 'chunk_gzip': a, 'chunk_shuffle_gzip': a.astype('f4'), 'chunk_fletcher': a,
             'chunk_all': a, 'one_chunk': a, 'vector_1d': np.linspace(0, 1, 1001), 'tiny': np.arange(6.0)}
+    many = np.load(str(path) + '.many.npy')
+    part = np.zeros((40, 50)); part[8:24, 16:40] = many[:16, :24]
+    want.update(many_chunks=many, many_chunks_gzip=many, partly_written=part, early_alloc=many[:23, :31], unlimited=many)
     refused = []
     with h5lite.File(str(path)) as f:
         assert set(want) <= set(f.keys()) and 'group' in f
@@ -99,10 +115,10 @@ def test_h5lite_reads_what_h5py_writes(tmp_path, libver):
         assert np.array_equal(np.asarray(g['member_07'][:]), np.full(3, 7.0))
         n = g['nested']
         assert n.attrs['where'] == 'two levels down' and np.array_equal(np.asarray(n['inside'][:]), a[0])
-    # what may be refused: only the version-4 chunk indices of the newest format bounds (h5lite.py header)
-    assert all('version-4' in msg or 'layout' in msg.lower() for _, msg in refused), refused
-    if libver in ('default', 'earliest-v108', 'v108-v108'):
-        assert refused == [], refused
+    # what may be refused: only the chunk index of a dataset with an unlimited dimension under the >= v110 format bounds
+    # (an extensible array; netCDF-C writes the version-1 B-tree there) - single-chunk, implicit and fixed-array indices are read
+    assert [n for n, _ in refused] == (['unlimited'] if libver in ('v110-v110', 'latest-latest') else []), refused
+    assert all('extensible-array' in msg for _, msg in refused), refused
 
 
 READER = r'''
