@@ -158,9 +158,12 @@ def test_h5repack_rewrites_the_file_and_h5lite_reads_libhdf5s_chunked_layouts(tm
             if tag != 'plain':
                 hdr = subprocess.run([H5DUMP, '-H', '-p', '-d', '/wet', str(out)], capture_output=True, text=True).stdout
                 assert 'CHUNKED' in hdr, hdr[:600]
-    # the version-4 chunk indices (libver latest) are refused by name, not misread
-    out = tmp_path / 'latest.nc'
-    r = subprocess.run([H5REPACK, '--latest', '-f', f'{big}:GZIP=1', '-l', f'{big}:CHUNK=2x3x2', str(p), str(out)], capture_output=True, text=True)
-    assert r.returncode == 0
-    with pytest.raises(h5lite.UnsupportedHDF5Feature):
-        h5lite.File(out)['wet'].read()
+    # libhdf5's newest file format (version-4 layouts: fixed-array chunk index; version-2 B-tree group index) of both files
+    for k, (src, want) in enumerate(((p, {n: t[1] for n, t in v.items()}), (ref, ref_vars))):
+        out = tmp_path / f'latest_{src.name}'
+        r = subprocess.run([H5REPACK, '--latest', '-f', f'{big}:GZIP=1', '-l', f"{big}:CHUNK={('2x3x2', '40x5x6')[k]}", str(src), str(out)], capture_output=True, text=True)
+        assert r.returncode == 0
+        f = h5lite.File(out)
+        for name, arr in want.items():
+            got = f[name].read()
+            assert got.dtype == np.asarray(arr).dtype and np.array_equal(got, arr, equal_nan=True), ('latest', src.name, name)
