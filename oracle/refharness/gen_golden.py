@@ -44,9 +44,14 @@ import RAiDER.delay as rdelay  # noqa: E402
 import RAiDER.delayFcns as rdelayFcns  # noqa: E402
 import RAiDER.losreader as rlos  # noqa: E402
 import RAiDER.utilFcns as rutil  # noqa: E402
-from RAiDER.interpolate import interpolate as r_interpolate  # noqa: E402
-from RAiDER.interpolate import interpolate_along_axis as r_interp_axis  # noqa: E402
-from RAiDER import makePoints as r_mp  # noqa: E402
+try:
+    from RAiDER.interpolate import interpolate as r_interpolate  # noqa: E402
+    from RAiDER.interpolate import interpolate_along_axis as r_interp_axis  # noqa: E402
+    from RAiDER import makePoints as r_mp  # noqa: E402
+    HAVE_NATIVES = True
+except ImportError:      # (oracle/_ref is built for ONE interpreter; live_check.py under another one checks the Python path only)
+    r_interpolate = r_interp_axis = r_mp = None
+    HAVE_NATIVES = False
 from pyproj import CRS  # noqa: E402  (stub)
 
 from oracle.raider_oracle import synthetic_cube  # noqa: E402  (input generator only)

@@ -42,6 +42,11 @@ ow, oh = O.build_cube(xpts, ypts, zpts, list(O.getInterpolators(cube['xs'], cube
 assert np.array_equal(np.isnan(ow), np.isnan(wet)) and np.isnan(wet).any()
 m = np.isfinite(wet)
 out['zenith_max_rel'] = float(max(np.abs(ow - wet)[m].max() / np.abs(wet[m]).max(), np.abs(oh - hydro)[m].max() / np.abs(hydro[m]).max()))     # of the field maximum
+import scipy          # noqa: E402
+out['python'] = '.'.join(str(v) for v in sys.version_info[:3]); out['numpy'] = np.__version__; out['scipy'] = scipy.__version__
+if not H.HAVE_NATIVES:          # (another interpreter than the one oracle/_ref was built for: the Python path only)
+    print(json.dumps(out))
+    sys.exit(0)
 grids = (np.sort(rng.uniform(0, 5, 9)), np.linspace(-1, 1, 7), np.sort(rng.uniform(10, 20, 5)))
 vals = rng.standard_normal((9, 7, 5)); q = np.stack([rng.uniform(-0.5, 5.5, 500), rng.uniform(-1.2, 1.2, 500), rng.uniform(9, 21, 500)], -1)
 out['natives_bit_exact'] = all(np.array_equal(O.native_interpolate(grids, vals, q, fill_value=f), H.r_interpolate(grids, vals, q, fill_value=f), equal_nan=True)

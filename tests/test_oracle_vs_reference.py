@@ -20,3 +20,22 @@ def test_oracle_against_the_live_reference():
     assert out.returncode == 0, out.stderr[-3000:]
     res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
     assert res['ray_max_abs_m'] < 1e-11 and res['zenith_max_rel'] < 1e-15 and res['natives_bit_exact'] and res['makepoints_bit_exact'], res
+
+
+OLD_PY = '/opt/conda/bin/python3.9'
+
+
+@pytest.mark.skipif(not Path('/root/reference/tools/RAiDER').is_dir() or not Path(OLD_PY).exists(), reason='the reference tree / a second interpreter are not here')
+def test_the_reference_in_its_own_generation_of_libraries_gives_the_same_numbers():
+    """The reference pins numpy < 2 (environment.yml) and no scipy; the goldens were made under numpy 2.2 / scipy 1.15.  The image's
+    Anaconda interpreter (python 3.9, numpy 1.26, scipy 1.7.1 - the generation of libraries a RAiDER installation has) runs the SAME live
+    check of the reference's Python path against the oracle: delays to 1e-14 m (observed: one ulp), zenith bit for bit.  So neither the
+    goldens nor the parity target depend on which side of the numpy-2 / compiled-RGI changes an installation is."""
+    import os
+    env = {k: v for k, v in os.environ.items() if not k.startswith('PYTHON')}
+    out = subprocess.run([OLD_PY, '-W', 'ignore', str(ROOT / 'oracle' / 'refharness' / 'live_check.py')], capture_output=True, text=True, timeout=900, env=env)
+    if out.returncode != 0 and ('ModuleNotFoundError' in out.stderr or 'ImportError' in out.stderr):
+        pytest.skip('the second interpreter lacks a module: ' + out.stderr.strip().splitlines()[-1])
+    assert out.returncode == 0, out.stderr[-3000:]
+    res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
+    assert res['numpy'].startswith('1.') and res['ray_max_abs_m'] < 1e-14 and res['zenith_max_rel'] < 1e-15, res
