@@ -37,6 +37,7 @@ extern "C" {
 #define RDR_ERR_ALL_NAN (-4)    /* every ray length is NaN     -> ValueError('geo2rdr did not converge...') delay.py:279-280 */
 #define RDR_ERR_NO_LEVELS (-5)  /* no model interval contributes: build_ray returns (None,None,None) losreader.py:832-833 */
 #define RDR_ERR_NAN_LENGTH (-6) /* some (not all) ray lengths NaN: the reference's nParts (delay.py:283) is undefined there */
+#define RDR_ERR_OOM (-7)        /* the device could not hold an allocation (hipErrorOutOfMemory) -> MemoryError; the caller may retry with a smaller batch */
 
 #define RDR_F32 0
 #define RDR_F64 1
@@ -211,8 +212,19 @@ int rdr_cube_read(rdr_ctx* ctx, const rdr_cube* cube, void* wet, void* hydro);
 
 /* ---- zenith / projected path -----------------------------------------------------------------
  * scipy RegularGridInterpolator.__call__ on both fields (delay.py:214,120-121): pts[n,3] = (y,x,z). */
+/* Either of wet / hydro may be NULL: that field is then neither stored nor downloaded (a caller that evaluates the two interpolators one
+ * after the other - `for intp in interpolators: intp(pts)`, delay.py:213-214 - moves 8 B per point and call instead of 16). */
 int rdr_interp3(rdr_ctx* ctx, const rdr_cube* cube, const double* pts, int64_t n, double* wet,
                 double* hydro, int loc);
+/* The second stage of tropo_delay's point branch (delay.py:110-128) in one call: the gather of rdr_interp3 on the intermediate delay
+ * cube and, for a projected line of sight, the division of Conventional.__call__ (losreader.py:130-133) before the values leave the
+ * device - 24-32 B per point up, 16 B down, nothing in between.
+ * Points: three arrays y[n], x[n], z[n] (what aoi.readLL() / readZ() hand out: no packed copy on the host), or y = packed pts[n,3]
+ * with x = z = NULL.  proj_mode 0: no projection; 1: proj[n] = incidence angles (deg), delay / cosd(inc) (inc_hd_to_enu(...)[..., -1],
+ * losreader.py:374-396); 2: one incidence inc0 for every point (proj unused); 3: proj[n] = the divisor itself (the cosine of the look
+ * angle state_to_los returns for an orbit file, losreader.py:122-128).  Either output may be NULL. */
+int rdr_interp3_project(rdr_ctx* ctx, const rdr_cube* cube, const double* y, const double* x, const double* z, int64_t n, int proj_mode,
+                        const double* proj, double inc0, double* wet, double* hydro, int loc);
 /* Large random point sets on a cube beyond the caches (BASELINE configs[4]: 5 M stations on a 1000 x 1000 x 50 cube): rdr_interp3
  * then reads four 128 B lines per point for 16 B each.  The cube can carry a second, cell-column-major copy ("corner quads",
  * 5.3 x its bytes for f32, 8 x for f64) from which a point's eight corners are ONE line - same values, same arithmetic, 3.3 x less
@@ -227,8 +239,17 @@ int rdr_build_cube(rdr_ctx* ctx, const rdr_cube* cube, const double* xpts, int64
 /* 1 / 0: the result of the last rdr_build_cube call with HOST arrays on this ctx holds / does not hold a NaN - the scan the caller
  * runs over the result (delay.py:187) done on the device before the download; -1: unknown (no such call yet, or device arrays). */
 int rdr_last_nan_output(rdr_ctx* ctx);
-/* Conventional.__call__ tail (losreader.py:130-133) with inc/heading rasters: out = delay / cos(inc) */
+/* _build_cube whose result STAYS on the device as a new float64 cube with axes (ypts, xpts, zpts) - the intermediate delay cube of
+ * tropo_delay's point branch (delay.py:96-121: _get_delays_on_cube -> writeResultsToXarray -> getInterpolators(ds, 'ztd')), ready
+ * for rdr_interp3_project.  Nothing crosses PCIe but the three axes.  rdr_cube_has_nan(*out) answers the scan of delay.py:187
+ * ("There are missing delay values").  Needs two nodes per axis (scipy's grid rule), nz <= 512. */
+int rdr_build_cube_to_cube(rdr_ctx* ctx, const rdr_cube* cube, const double* xpts, int64_t nx, const double* ypts, int64_t ny,
+                           const double* zpts, int64_t nz, int loc, rdr_cube** out);
+/* Conventional.__call__ tail (losreader.py:130-133): delay / cosd(inc) in place, inc[n] in degrees (what inc_hd_to_enu(...)[..., -1]
+ * holds for an incidence raster).  The reference projects wet and hydro in two calls: either pointer may be NULL. */
 int rdr_project_cosinc(rdr_ctx* ctx, double* wet, double* hydro, const double* inc, int64_t n, int loc);
+/* The same with the divisor given (losreader.py:130-131: LOS_enu from an orbit file is cos(look angle), same shape as the delays). */
+int rdr_project_divide(rdr_ctx* ctx, double* wet, double* hydro, const double* divisor, int64_t n, int loc);
 
 /* ---- ray-traced path --------------------------------------------------------------------------
  * rdr_ray_levels: the slice-uniform part of build_ray (losreader.py:785-808).  lo/hi/kz need room for
@@ -274,6 +295,13 @@ int rdr_raytrace(rdr_ctx* ctx, const rdr_cube* cube, const rdr_rays* rays, doubl
 int rdr_raytrace_slices(rdr_ctx* ctx, const rdr_cube* cube, const rdr_rays* rays, const double* hts, int32_t nslices,
                         int32_t los_per_slice, double zref, double max_seg, double* wet, double* hydro, int32_t* K_out,
                         int32_t* nparts_out, int32_t ld, int32_t* flags_out);
+
+/* rdr_raytrace_slices whose delays STAY on the device as a new float64 cube with axes (rays->ypts, rays->xpts, hts): the intermediate
+ * cube of tropo_delay's point branch for a ray-traced line of sight (delay.py:96-121).  GRID batches, >= 2 nodes per axis, strictly
+ * monotonic hts; the partition outputs are as for rdr_raytrace_slices. */
+int rdr_raytrace_slices_to_cube(rdr_ctx* ctx, const rdr_cube* cube, const rdr_rays* rays, const double* hts, int32_t nslices,
+                                int32_t los_per_slice, double zref, double max_seg, int32_t* K_out, int32_t* nparts_out, int32_t ld,
+                                int32_t* flags_out, rdr_cube** out);
 
 /* Materialising variants for API parity on small inputs:
  * getTopOfAtmosphere (losreader.py:706-733): factor==NULL -> 10 iterations with factor 1, else 3 */

@@ -14,7 +14,7 @@ _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get('RAIDER_HIP_LIB', _HERE / 'libraider_hip.so'))
 
 RDR_OK = 0
-RDR_ERR_INVALID, RDR_ERR_HIP, RDR_ERR_NODEVICE, RDR_ERR_ALL_NAN, RDR_ERR_NO_LEVELS, RDR_ERR_NAN_LENGTH = -1, -2, -3, -4, -5, -6
+RDR_ERR_INVALID, RDR_ERR_HIP, RDR_ERR_NODEVICE, RDR_ERR_ALL_NAN, RDR_ERR_NO_LEVELS, RDR_ERR_NAN_LENGTH, RDR_ERR_OOM = -1, -2, -3, -4, -5, -6, -7
 RDR_F32, RDR_F64 = 0, 1
 RDR_BYTESWAPPED = 0x100
 RDR_HOST, RDR_DEVICE = 0, 1
@@ -40,6 +40,10 @@ class RdrRays(C.Structure):
 
 class NoLevels(Exception):
     """build_ray would return (None, None, None) (losreader.py:832-833)."""
+
+
+class DeviceOutOfMemory(MemoryError):
+    """RDR_ERR_OOM: the GPU could not hold an allocation of the call (the caller may retry with a smaller batch)."""
 
 
 _lib = None
@@ -79,15 +83,20 @@ SYMBOLS = [
     ('rdr_cube_point_index', C.c_int, [_VP, _VP, C.c_int]),
     ('rdr_cube_point_index_bytes', C.c_int64, [_VP]),
     ('rdr_interp3', C.c_int, [_VP, _VP, _VP, C.c_int64, _VP, _VP, C.c_int]),
+    ('rdr_interp3_project', C.c_int, [_VP, _VP, _VP, _VP, _VP, C.c_int64, C.c_int, _VP, C.c_double, _VP, _VP, C.c_int]),
     ('rdr_build_cube', C.c_int, [_VP, _VP, _VP, C.c_int64, _VP, C.c_int64, _VP, C.c_int64, _VP, _VP, C.c_int]),
+    ('rdr_build_cube_to_cube', C.c_int, [_VP, _VP, _VP, C.c_int64, _VP, C.c_int64, _VP, C.c_int64, C.c_int, C.POINTER(_VP)]),
     ('rdr_last_nan_output', C.c_int, [_VP]),
     ('rdr_project_cosinc', C.c_int, [_VP, _VP, _VP, _VP, C.c_int64, C.c_int]),
+    ('rdr_project_divide', C.c_int, [_VP, _VP, _VP, _VP, C.c_int64, C.c_int]),
     ('rdr_ray_levels', C.c_int, [_VP, C.c_double, C.c_double, c_ip, _VP, _VP, _VP]),
     ('rdr_ray_prepass', C.c_int, [_VP, _VP, C.POINTER(RdrRays), C.c_double, C.c_double, _VP, c_ip]),
     ('rdr_nparts', C.c_int, [_VP, C.c_int32, C.c_double, _VP]),
     ('rdr_ray_march', C.c_int, [_VP, _VP, C.POINTER(RdrRays), C.c_double, C.c_double, _VP, C.c_int32, _VP, _VP]),
     ('rdr_raytrace', C.c_int, [_VP, _VP, C.POINTER(RdrRays), C.c_double, C.c_double, C.c_double, _VP, _VP, _VP, c_ip]),
     ('rdr_raytrace_slices', C.c_int, [_VP, _VP, C.POINTER(RdrRays), _VP, C.c_int32, C.c_int32, C.c_double, C.c_double, _VP, _VP, _VP, _VP, C.c_int32, _VP]),
+    ('rdr_raytrace_slices_to_cube', C.c_int, [_VP, _VP, C.POINTER(RdrRays), _VP, C.c_int32, C.c_int32, C.c_double, C.c_double, _VP, _VP, C.c_int32, _VP,
+                                              C.POINTER(_VP)]),
     ('rdr_top_of_atmosphere', C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_double, _VP, _VP, C.c_int]),
     ('rdr_build_ray', C.c_int, [_VP, _VP, C.c_int64, C.c_double, _VP, _VP, C.c_int64, C.c_double, c_ip, _VP, _VP, _VP, C.c_int]),
     ('rdr_lla2ecef', C.c_int, [_VP, _VP, _VP, _VP, C.c_int64, _VP, C.c_int]),
@@ -203,6 +212,8 @@ def check(rc, ctx=None, exc_invalid=ValueError):
         raise ValueError(msg)                      # delay.py:283 -> np.linspace(num<0) ValueError in the reference
     if rc == RDR_ERR_NO_LEVELS:
         raise NoLevels(msg)
+    if rc == RDR_ERR_OOM:
+        raise DeviceOutOfMemory(f'raider_amd HIP engine: out of device memory: {msg}')
     raise RuntimeError(f'raider_amd HIP engine error {rc}: {msg}')
 
 

@@ -167,9 +167,35 @@ __global__ void blend_weighted_kernel(CubeSet S, const double* __restrict__ w, i
     }
 }
 
+// A point query = scipy RGI __call__ on both fields (delay.py:120-121,214) and, optionally, the second stage of tropo_delay's point
+// branch fused behind it (delay.py:110-128): the points as the caller's THREE arrays (x != NULL; no packed (n,3) copy on the host) or
+// packed (y = pts[n,3], x = z = NULL), and - for a projected line of sight - the division of Conventional.__call__
+// (losreader.py:130-133) before the two values leave the device.  Either output may be NULL.
+//   pmode 0: none; 1: proj[i] = incidence (deg), delay / cosd(inc) as inc_hd_to_enu(...)[..., -1] gives it; 2: one incidence inc0;
+//   3: proj[i] = the divisor itself (cos of the look angle from state_to_los, losreader.py:122-128)
+__device__ __forceinline__ double project_divisor(int pmode, const double* __restrict__ proj, double inc0, int64_t i) {
+    if (pmode == 1) return cos(proj[i] * DEG_TO_RAD);
+    if (pmode == 2) return cos(inc0 * DEG_TO_RAD);
+    return proj[i];
+}
+
+struct PointQuery {
+    const double *y, *x, *z;      // x == NULL: y is the packed (n,3) array
+    int pmode; const double* proj; double inc0;
+    __device__ __forceinline__ void point(int64_t i, double& py, double& px, double& pz) const {
+        if (x) { py = y[i]; px = x[i]; pz = z[i]; }
+        else { py = y[3 * i]; px = y[3 * i + 1]; pz = y[3 * i + 2]; }
+    }
+    __device__ __forceinline__ void store(int64_t i, double w, double h, double* __restrict__ wet, double* __restrict__ hyd) const {
+        if (pmode) { const double up = project_divisor(pmode, proj, inc0, i); w = w / up; h = h / up; }
+        if (wet) wet[i] = w;
+        if (hyd) hyd[i] = h;
+    }
+};
+
 // A4/A5: scipy RGI at packed points (n,3) = (y,x,z)
 template <typename T2>
-__global__ __launch_bounds__(256) void interp_points_kernel(CubeView<T2> c, const double* __restrict__ pts, int64_t n,
+__global__ __launch_bounds__(256) void interp_points_kernel(CubeView<T2> c, PointQuery Q, int64_t n,
                                                             double* __restrict__ wet, double* __restrict__ hyd, int axes_in_lds) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const double* s_y = c.axes;                       // very long axes stay in global memory (L1 / L2 hits)
@@ -182,10 +208,11 @@ __global__ __launch_bounds__(256) void interp_points_kernel(CubeView<T2> c, cons
     const double* s_x = s_y + c.ny;
     const double* s_z = s_x + c.nx;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const double y = pts[3 * i], x = pts[3 * i + 1], z = pts[3 * i + 2];
+        double y, x, z;
+        Q.point(i, y, x, z);
         double w, h;
         trilinear(c, s_y, s_x, s_z, y, x, z, w, h);
-        wet[i] = w; hyd[i] = h;
+        Q.store(i, w, h, wet, hyd);
     }
 }
 
@@ -266,7 +293,7 @@ __global__ __launch_bounds__(256) void quad_build_kernel(const T2* __restrict__ 
 // the same interpolant as interp_points_kernel / trilinear<> (cell search, weights, summation order: bit-identical results), corners
 // from the quad copy: 64 contiguous bytes of one block for an f32 cube, the whole 128 B block for an f64 one
 template <typename T2>
-__global__ __launch_bounds__(256) void interp_points_quad_kernel(CubeView<T2> c, const uint4* __restrict__ q, int nblk, const double* __restrict__ pts,
+__global__ __launch_bounds__(256) void interp_points_quad_kernel(CubeView<T2> c, const uint4* __restrict__ q, int nblk, PointQuery Q,
                                                                  int64_t n, double* __restrict__ wet, double* __restrict__ hyd, int axes_in_lds) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const double* s_y = c.axes;
@@ -279,7 +306,8 @@ __global__ __launch_bounds__(256) void interp_points_quad_kernel(CubeView<T2> c,
     const double* s_x = s_y + c.ny;
     const double* s_z = s_x + c.nx;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const double y = pts[3 * i], x = pts[3 * i + 1], z = pts[3 * i + 2];
+        double y, x, z;
+        Q.point(i, y, x, z);
         double sw = qnan(), sh = qnan();
         const bool inside = (y >= c.y_lo) && (y <= c.y_hi) && (x >= c.x_lo) && (x <= c.x_hi) && (z >= c.z_lo) && (z <= c.z_hi);
         if (inside) {
@@ -322,7 +350,7 @@ __global__ __launch_bounds__(256) void interp_points_quad_kernel(CubeView<T2> c,
             sw += w[6] * k6; sh += h[6] * k6;
             sw += w[7] * k7; sh += h[7] * k7;
         }
-        wet[i] = sw; hyd[i] = sh;
+        Q.store(i, sw, sh, wet, hyd);
     }
 }
 
@@ -517,10 +545,13 @@ __global__ __launch_bounds__(256) void build_cube_kernel(const T2* __restrict__ 
 
 constexpr int BUILD_ZCHUNK_MAX = 1024;
 
-__global__ void project_kernel(double* wet, double* hyd, const double* __restrict__ inc, int64_t n) {
+// Conventional.__call__ tail (losreader.py:130-133): delay / LOS_enu[..., -1].  pmode as in project_divisor (1: inc[i] deg, 2: inc0, 3:
+// the divisor itself); either field may be absent (the reference projects wet and hydro in two calls).
+__global__ void project_kernel(double* wet, double* hyd, int pmode, const double* __restrict__ proj, double inc0, int64_t n) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const double up = cos(inc[i] * DEG_TO_RAD);   // inc_hd_to_enu(...)[..., -1] = cosd(inc)
-        wet[i] = wet[i] / up; hyd[i] = hyd[i] / up;
+        const double up = project_divisor(pmode, proj, inc0, i);   // inc_hd_to_enu(...)[..., -1] = cosd(inc)
+        if (wet) wet[i] = wet[i] / up;
+        if (hyd) hyd[i] = hyd[i] / up;
     }
 }
 

@@ -136,7 +136,9 @@ __global__ __launch_bounds__(256) void producer_kernel(ProducerParams P) {
         // instructions).  (NumPy's own summation is pairwise, not sequential: either order agrees with it to a few ulp.)
         {
             double carry_w = 0.0, carry_h = 0.0;
-            for (int s0 = ((nzo - 1 + 63) / 64 - 1) * 64; s0 >= 0; s0 -= 64) {
+            // (strips over the nzo OUTPUT levels, not the nzo-1 terms: with (nzo-1) % 64 == 0 - 65, 129, ... levels - the top level
+            // would otherwise belong to no strip and its total stay unwritten; it has no term: the empty sum, 0)
+            for (int s0 = ((nzo + 63) / 64 - 1) * 64; s0 >= 0; s0 -= 64) {
                 const int k = s0 + lane;
                 double tw = 0.0, th = 0.0;
                 if (k < nzo - 1) {

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <utility>
 #include <vector>
@@ -77,6 +78,7 @@ struct rdr_cube {
     mutable size_t quad_bytes = 0;
     mutable int quad_nblk = 0;
     mutable int big_point_calls = 0;             // rdr_interp3 calls that would have profited
+    mutable std::mutex quad_mutex;               // one builder of the quad copy per cube
     bool has_nan = false;                        // a NaN among the fields (seen while packing; blends: unknown -> false)
 };
 
@@ -91,7 +93,7 @@ static int fail(rdr_ctx* ctx, int code, const std::string& msg) {
         hipError_t _e = (expr);                                                                     \
         if (_e != hipSuccess) {                                                                     \
             (void)hipGetLastError();   /* reported here: a later launch check must not find it again */ \
-            return fail(ctx, RDR_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));      \
+            return fail(ctx, _e == hipErrorOutOfMemory ? RDR_ERR_OOM : RDR_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
         }                                                                                           \
     } while (0)
 
@@ -730,31 +732,42 @@ static size_t quad_need_bytes(const rdr_cube* q, int* nblk) {
 }
 
 static int quad_build(rdr_ctx* c, const rdr_cube* q) {
+    // (one builder per cube: two contexts sharing a cube must not both allocate and publish a copy)
+    std::lock_guard<std::mutex> guard(q->quad_mutex);
     if (q->d_quad) return RDR_OK;
     int nblk = 0;
     const size_t need = quad_need_bytes(q, &nblk);
-    HIPCHECK(c, hipMalloc(&q->d_quad, need));
-    q->quad_bytes = need; q->quad_nblk = nblk;
+    void* dq = nullptr;
+    HIPCHECK(c, hipMalloc(&dq, need));
+    struct Pub { const rdr_cube* q; void* p; size_t need; int nblk; bool ok = false;
+                 ~Pub() { if (ok) { q->quad_bytes = need; q->quad_nblk = nblk; q->d_quad = p; } else (void)hipFree(p); } } pub{q, dq, need, nblk};
     const int64_t parts = (int64_t)(need / 16);
     const int g = (grid_for(parts, 256, c->num_cus * 32) + 7) / 8 * 8;       // a multiple of 8: one share of the ranges per XCD (quad_build_kernel)
-    if (q->dtype == RDR_F32) hipLaunchKernelGGL((quad_build_kernel<float2>), dim3(g), dim3(256), 0, c->stream, (const float2*)q->d_vals, (int)q->ny, (int)q->nx, (int)q->nz, nblk, (uint4*)q->d_quad);
-    else hipLaunchKernelGGL((quad_build_kernel<double2>), dim3(g), dim3(256), 0, c->stream, (const double2*)q->d_vals, (int)q->ny, (int)q->nx, (int)q->nz, nblk, (uint4*)q->d_quad);
+    if (q->dtype == RDR_F32) hipLaunchKernelGGL((quad_build_kernel<float2>), dim3(g), dim3(256), 0, c->stream, (const float2*)q->d_vals, (int)q->ny, (int)q->nx, (int)q->nz, nblk, (uint4*)dq);
+    else hipLaunchKernelGGL((quad_build_kernel<double2>), dim3(g), dim3(256), 0, c->stream, (const double2*)q->d_vals, (int)q->ny, (int)q->nx, (int)q->nz, nblk, (uint4*)dq);
     HIPCHECK(c, hipGetLastError());
+    // one-time, like rdr_cube_create: the copy must be complete before it is PUBLISHED - any other stream (a context switched to
+    // torch's stream, a second context sharing the cube) may read it from then on.  0.7 ms of a build that happens once per cube.
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    pub.ok = true;
     return RDR_OK;
 }
 
 // Policy of the automatic build: only for point sets and cubes large enough that the four-lines-per-point gather is what bounds
 // the call (>= 256 k points, a cube beyond 32 MB - smaller ones live in L2 / the Infinity Cache), only when the copy fits a quarter
-// of the free memory, and only from the SECOND such call on a cube: building costs about one query of 5 M points (one pass over
-// the cube, 5-8 x its bytes written), so a cube queried once never pays for it.  RAIDER_HIP_POINT_INDEX=0 never, =1 at the first call.
+// of the free memory.  When: at the FIRST such call if the direct gather of THIS point set would already move 1.5 x the bytes the
+// build writes (572 B per point measured against 5.3-8 x the cube: 5 M stations on the 400 MB HRRR-sized cube, 2.9 GB against 2.2 GB
+// - round 4), else from the second call on the cube (a cube queried once with few points never pays for the copy).
+// RAIDER_HIP_POINT_INDEX=0 never, =1 at the first large call, =2 the round-3 rule (second call only).
 static bool quad_wanted(rdr_ctx* c, const rdr_cube* q, int64_t n) {
     if (q->d_quad) return true;
     static const int env = []() { const char* e = std::getenv("RAIDER_HIP_POINT_INDEX"); return e ? std::atoi(e) : -1; }();
     if (env == 0) return false;
     const size_t cube_bytes = (size_t)q->ny * q->nx * q->nz * (q->dtype == RDR_F32 ? 8 : 16);
     if (n < (1 << 18) || cube_bytes < ((size_t)32 << 20) || q->ny < 2 || q->nx < 2 || q->nz < 2) return false;
-    if (++q->big_point_calls < 2 && env != 1) return false;
     int nblk; const size_t need = quad_need_bytes(q, &nblk);
+    const bool pays_now = env != 2 && (double)n * 572.0 > 1.5 * (double)need;
+    if (++q->big_point_calls < 2 && env != 1 && !pays_now) return false;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || need > free_b / 4) return false;
     (void)c;
@@ -765,6 +778,7 @@ int rdr_cube_point_index(rdr_ctx* c, rdr_cube* q, int mode) {
     if (!c || !q) return fail(c, RDR_ERR_INVALID, "rdr_cube_point_index: NULL argument");
     HIPCHECK(c, hipSetDevice(c->device));
     if (mode == 0) {
+        std::lock_guard<std::mutex> guard(q->quad_mutex);
         if (q->d_quad) { HIPCHECK(c, hipStreamSynchronize(c->stream)); HIPCHECK(c, hipFree(q->d_quad)); q->d_quad = nullptr; q->quad_bytes = 0; q->quad_nblk = 0; }
         q->big_point_calls = 0;
         return RDR_OK;
@@ -776,15 +790,28 @@ int rdr_cube_point_index(rdr_ctx* c, rdr_cube* q, int mode) {
 
 int64_t rdr_cube_point_index_bytes(const rdr_cube* q) { return q ? (int64_t)q->quad_bytes : -1; }
 
-int rdr_interp3(rdr_ctx* c, const rdr_cube* q, const double* pts, int64_t n, double* wet, double* hydro, int loc) {
-    if (!c || !q || (n > 0 && (!pts || !wet || !hydro))) return fail(c, RDR_ERR_INVALID, "rdr_interp3: NULL argument");
-    if (n < 0) return fail(c, RDR_ERR_INVALID, "rdr_interp3: negative count");
+// the point query behind rdr_interp3 / rdr_interp3_project: y/x/z three arrays (x != NULL) or y = packed (n,3); pmode / proj / inc0 as
+// PointQuery (cube_kernels.h); either output may be NULL (it is then neither written nor downloaded)
+static int interp3_impl(rdr_ctx* c, const char* who, const rdr_cube* q, const double* y, const double* x, const double* z, int64_t n, int pmode,
+                        const double* proj, double inc0, double* wet, double* hydro, int loc) {
+    if (!c || !q) return fail(c, RDR_ERR_INVALID, std::string(who) + ": NULL argument");
+    if (n < 0) return fail(c, RDR_ERR_INVALID, std::string(who) + ": negative count");
+    if (n > 0 && (!y || (x && !z) || (!x && z) || (!wet && !hydro))) return fail(c, RDR_ERR_INVALID, std::string(who) + ": NULL argument");
+    if (pmode < 0 || pmode > 3) return fail(c, RDR_ERR_INVALID, std::string(who) + ": proj_mode is 0 (none), 1 (incidence array), 2 (one incidence) or 3 (divisor array)");
+    if (n > 0 && (pmode == 1 || pmode == 3) && !proj) return fail(c, RDR_ERR_INVALID, std::string(who) + ": proj_mode 1 / 3 need the proj array");
     if (n == 0) return RDR_OK;
     HIPCHECK(c, hipSetDevice(c->device));
-    const void* dp; void *dw, *dh;
-    int rc = stage_in(c, SLOT_IN0, pts, (size_t)n * 24, loc, &dp); if (rc) return rc;
-    rc = stage_out(c, SLOT_OUT0, wet, (size_t)n * 8, loc, &dw); if (rc) return rc;
-    rc = stage_out(c, SLOT_OUT1, hydro, (size_t)n * 8, loc, &dh); if (rc) return rc;
+    PointQuery Q; std::memset(&Q, 0, sizeof(Q));
+    Q.pmode = pmode; Q.inc0 = inc0;
+    const void* d; void *dw = nullptr, *dh = nullptr;
+    int rc = stage_in(c, SLOT_IN0, y, (size_t)n * (x ? 8 : 24), loc, &d); if (rc) return rc; Q.y = (const double*)d;
+    if (x) {
+        rc = stage_in(c, SLOT_IN1, x, (size_t)n * 8, loc, &d); if (rc) return rc; Q.x = (const double*)d;
+        rc = stage_in(c, SLOT_IN2, z, (size_t)n * 8, loc, &d); if (rc) return rc; Q.z = (const double*)d;
+    }
+    if (pmode == 1 || pmode == 3) { rc = stage_in(c, SLOT_IN3, proj, (size_t)n * 8, loc, &d); if (rc) return rc; Q.proj = (const double*)d; }
+    if (wet) { rc = stage_out(c, SLOT_OUT0, wet, (size_t)n * 8, loc, &dw); if (rc) return rc; }
+    if (hydro) { rc = stage_out(c, SLOT_OUT1, hydro, (size_t)n * 8, loc, &dh); if (rc) return rc; }
     const int g = grid_for(n, 256, c->num_cus * 8);
     const bool quad = quad_wanted(c, q, n);
     if (quad) { rc = quad_build(c, q); if (rc) return rc; }
@@ -793,16 +820,16 @@ int rdr_interp3(rdr_ctx* c, const rdr_cube* q, const double* pts, int64_t n, dou
         if (quad) {
             if (q->dtype == RDR_F32)
                 hipLaunchKernelGGL((interp_points_quad_kernel<float2>), dim3(g), dim3(256), axes_smem(q), c->stream, make_view<float2>(q),
-                                   (const uint4*)q->d_quad, q->quad_nblk, (const double*)dp, n, (double*)dw, (double*)dh, (int)axes_fit_lds(q));
+                                   (const uint4*)q->d_quad, q->quad_nblk, Q, n, (double*)dw, (double*)dh, (int)axes_fit_lds(q));
             else
                 hipLaunchKernelGGL((interp_points_quad_kernel<double2>), dim3(g), dim3(256), axes_smem(q), c->stream, make_view<double2>(q),
-                                   (const uint4*)q->d_quad, q->quad_nblk, (const double*)dp, n, (double*)dw, (double*)dh, (int)axes_fit_lds(q));
+                                   (const uint4*)q->d_quad, q->quad_nblk, Q, n, (double*)dw, (double*)dh, (int)axes_fit_lds(q));
         } else if (q->dtype == RDR_F32)
             hipLaunchKernelGGL((interp_points_kernel<float2>), dim3(g), dim3(256), axes_smem(q), c->stream, make_view<float2>(q),
-                               (const double*)dp, n, (double*)dw, (double*)dh, (int)axes_fit_lds(q));
+                               Q, n, (double*)dw, (double*)dh, (int)axes_fit_lds(q));
         else
             hipLaunchKernelGGL((interp_points_kernel<double2>), dim3(g), dim3(256), axes_smem(q), c->stream, make_view<double2>(q),
-                               (const double*)dp, n, (double*)dw, (double*)dh, (int)axes_fit_lds(q));
+                               Q, n, (double*)dw, (double*)dh, (int)axes_fit_lds(q));
     }
     HIPCHECK(c, hipGetLastError());
     rc = finish_out(c, wet, dw, (size_t)n * 8, loc); if (rc) return rc;
@@ -811,19 +838,31 @@ int rdr_interp3(rdr_ctx* c, const rdr_cube* q, const double* pts, int64_t n, dou
     return RDR_OK;
 }
 
-int rdr_build_cube(rdr_ctx* c, const rdr_cube* q, const double* xpts, int64_t nx, const double* ypts, int64_t ny,
-                   const double* zpts, int64_t nz, double* wet, double* hydro, int loc) {
-    if (!c || !q || !xpts || !ypts || !zpts || !wet || !hydro) return fail(c, RDR_ERR_INVALID, "rdr_build_cube: NULL argument");
+int rdr_interp3(rdr_ctx* c, const rdr_cube* q, const double* pts, int64_t n, double* wet, double* hydro, int loc) {
+    return interp3_impl(c, "rdr_interp3", q, pts, nullptr, nullptr, n, 0, nullptr, 0.0, wet, hydro, loc);
+}
+
+int rdr_interp3_project(rdr_ctx* c, const rdr_cube* q, const double* y, const double* x, const double* z, int64_t n, int proj_mode,
+                        const double* proj, double inc0, double* wet, double* hydro, int loc) {
+    return interp3_impl(c, "rdr_interp3_project", q, y, x, z, n, proj_mode, proj, inc0, wet, hydro, loc);
+}
+
+// _build_cube (delay.py:196-216).  keep == NULL: the public entry (results to the caller's wet / hydro at `loc`); keep != NULL: the results
+// stay in the context's scratch (planar (z,y,x), keep[0] = wet, keep[1] = hydro) for rdr_build_cube_to_cube, nothing is downloaded.
+static int build_cube_impl(rdr_ctx* c, const rdr_cube* q, const double* xpts, int64_t nx, const double* ypts, int64_t ny,
+                           const double* zpts, int64_t nz, double* wet, double* hydro, int loc, double** keep) {
+    if (!c || !q || !xpts || !ypts || !zpts || (!keep && (!wet || !hydro))) return fail(c, RDR_ERR_INVALID, "rdr_build_cube: NULL argument");
     if (nx < 0 || ny < 0 || nz < 0) return fail(c, RDR_ERR_INVALID, "rdr_build_cube: negative count");
     const int64_t n = nx * ny * nz;
+    c->last_nan_output = -1;                  // (also for an empty build: the previous call's verdict is not this one's)
     if (n == 0) return RDR_OK;
     HIPCHECK(c, hipSetDevice(c->device));
     const void *dx, *dy, *dz; void *dw, *dh;
     int rc = stage_in(c, SLOT_IN0, xpts, (size_t)nx * 8, loc, &dx); if (rc) return rc;
     rc = stage_in(c, SLOT_IN1, ypts, (size_t)ny * 8, loc, &dy); if (rc) return rc;
     rc = stage_in(c, SLOT_IN2, zpts, (size_t)nz * 8, loc, &dz); if (rc) return rc;
-    rc = stage_out(c, SLOT_OUT0, wet, (size_t)n * 8, loc, &dw); if (rc) return rc;
-    rc = stage_out(c, SLOT_OUT1, hydro, (size_t)n * 8, loc, &dh); if (rc) return rc;
+    rc = stage_out(c, SLOT_OUT0, wet, (size_t)n * 8, keep ? RDR_HOST : loc, &dw); if (rc) return rc;
+    rc = stage_out(c, SLOT_OUT1, hydro, (size_t)n * 8, keep ? RDR_HOST : loc, &dh); if (rc) return rc;
     // Setup kernel: per-node and per-height records (24 B / 16 B) into scratch; then the gather: 64 x 4-node tiles x chunks of
     // heights - enough chunks that a small grid still fills the chip, as few as possible otherwise.
     const int64_t nodes = nx * ny;
@@ -859,9 +898,9 @@ int rdr_build_cube(rdr_ctx* c, const rdr_cube* q, const double* xpts, int64_t nx
         }
         if (e != hipSuccess) return fail(c, RDR_ERR_HIP, std::string("build_cube_kernel launch: ") + hipGetErrorString(e));
     }
+    if (keep) { keep[0] = (double*)dw; keep[1] = (double*)dh; return RDR_OK; }
     // np.isnan(result).any() (delay.py:187) answered here, before the outputs leave the device (rdr_last_nan_output)
     int* const nf = c->d_flags + MAX_SLICES + 1;
-    c->last_nan_output = -1;
     if (loc == RDR_HOST) {
         HIPCHECK(c, hipMemsetAsync(nf, 0, sizeof(int), c->stream));
         hipLaunchKernelGGL(nan_scan_kernel, dim3(grid_for(n, 256, c->num_cus * 8)), dim3(256), 0, c->stream, (const double*)dw, (const double*)dh, n, n, nf);
@@ -878,25 +917,66 @@ int rdr_build_cube(rdr_ctx* c, const rdr_cube* q, const double* xpts, int64_t nx
     return RDR_OK;
 }
 
+int rdr_build_cube(rdr_ctx* c, const rdr_cube* q, const double* xpts, int64_t nx, const double* ypts, int64_t ny,
+                   const double* zpts, int64_t nz, double* wet, double* hydro, int loc) {
+    return build_cube_impl(c, q, xpts, nx, ypts, ny, zpts, nz, wet, hydro, loc, nullptr);
+}
+
 int rdr_last_nan_output(rdr_ctx* c) { return c ? c->last_nan_output : -1; }
 
+// host copy of an axis given at `loc` (the cube keeps its axes on the host as well)
+static int axis_to_host(rdr_ctx* c, const double* a, int64_t n, int loc, std::vector<double>& out) {
+    out.resize((size_t)std::max<int64_t>(n, 0));
+    if (n <= 0) return RDR_OK;
+    if (loc == RDR_DEVICE) {
+        HIPCHECK(c, hipMemcpyAsync(out.data(), a, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHECK(c, hipStreamSynchronize(c->stream));
+    } else std::copy(a, a + n, out.begin());
+    return RDR_OK;
+}
 
-int rdr_project_cosinc(rdr_ctx* c, double* wet, double* hydro, const double* inc, int64_t n, int loc) {
-    if (!c || !wet || !hydro || !inc) return fail(c, RDR_ERR_INVALID, "rdr_project_cosinc: NULL argument");
-    if (n < 0) return fail(c, RDR_ERR_INVALID, "rdr_project_cosinc: negative count");
+int rdr_build_cube_to_cube(rdr_ctx* c, const rdr_cube* q, const double* xpts, int64_t nx, const double* ypts, int64_t ny,
+                           const double* zpts, int64_t nz, int loc, rdr_cube** out) {
+    if (!c || !q || !xpts || !ypts || !zpts || !out) return fail(c, RDR_ERR_INVALID, "rdr_build_cube_to_cube: NULL argument");
+    if (nx < 2 || ny < 2 || nz < 2) return fail(c, RDR_ERR_INVALID, "rdr_build_cube_to_cube: the delay cube needs two nodes per axis");
+    HIPCHECK(c, hipSetDevice(c->device));
+    std::vector<double> hx, hy, hz;
+    int rc = axis_to_host(c, xpts, nx, loc, hx); if (rc) return rc;
+    rc = axis_to_host(c, ypts, ny, loc, hy); if (rc) return rc;
+    rc = axis_to_host(c, zpts, nz, loc, hz); if (rc) return rc;
+    double* planar[2] = {nullptr, nullptr};
+    rc = build_cube_impl(c, q, xpts, nx, ypts, ny, zpts, nz, nullptr, nullptr, loc, planar); if (rc) return rc;
+    // planar (z,y,x) results -> interleaved (y,x,z) cube with axes (ypts, xpts, zpts): what getInterpolators(ds, 'ztd') builds from the
+    // Dataset of writeResultsToXarray (delay.py:113, delayFcns.py:40-41), descending axes flipped as scipy does; its NaN scan
+    // (delayFcns.py:50-52 on this cube == np.isnan(result).any(), delay.py:187) comes with the packing
+    return rdr_cube_create(c, hy.data(), ny, hx.data(), nx, hz.data(), nz, planar[0], planar[1], RDR_F64, nx, 1, ny * nx, RDR_DEVICE, out);
+}
+
+
+static int project_impl(rdr_ctx* c, const char* who, double* wet, double* hydro, int pmode, const double* proj, int64_t n, int loc) {
+    if (!c || (!wet && !hydro) || !proj) return fail(c, RDR_ERR_INVALID, std::string(who) + ": NULL argument");
+    if (n < 0) return fail(c, RDR_ERR_INVALID, std::string(who) + ": negative count");
     if (n == 0) return RDR_OK;
     HIPCHECK(c, hipSetDevice(c->device));
-    const void *di, *dwi, *dhi;
-    int rc = stage_in(c, SLOT_IN0, inc, (size_t)n * 8, loc, &di); if (rc) return rc;
-    rc = stage_in(c, SLOT_OUT0, wet, (size_t)n * 8, loc, &dwi); if (rc) return rc;
-    rc = stage_in(c, SLOT_OUT1, hydro, (size_t)n * 8, loc, &dhi); if (rc) return rc;
-    hipLaunchKernelGGL(project_kernel, dim3(grid_for(n, 256, c->num_cus * 8)), dim3(256), 0, c->stream, (double*)dwi, (double*)dhi,
-                       (const double*)di, n);
+    const void *di, *dwi = nullptr, *dhi = nullptr;
+    int rc = stage_in(c, SLOT_IN0, proj, (size_t)n * 8, loc, &di); if (rc) return rc;
+    if (wet) { rc = stage_in(c, SLOT_OUT0, wet, (size_t)n * 8, loc, &dwi); if (rc) return rc; }
+    if (hydro) { rc = stage_in(c, SLOT_OUT1, hydro, (size_t)n * 8, loc, &dhi); if (rc) return rc; }
+    hipLaunchKernelGGL(project_kernel, dim3(grid_for(n, 256, c->num_cus * 8)), dim3(256), 0, c->stream, (double*)dwi, (double*)dhi, pmode,
+                       (const double*)di, 0.0, n);
     HIPCHECK(c, hipGetLastError());
     rc = finish_out(c, wet, dwi, (size_t)n * 8, loc); if (rc) return rc;
     rc = finish_out(c, hydro, dhi, (size_t)n * 8, loc); if (rc) return rc;
     if (loc == RDR_HOST) HIPCHECK(c, hipStreamSynchronize(c->stream));
     return RDR_OK;
+}
+
+int rdr_project_cosinc(rdr_ctx* c, double* wet, double* hydro, const double* inc, int64_t n, int loc) {
+    return project_impl(c, "rdr_project_cosinc", wet, hydro, 1, inc, n, loc);
+}
+
+int rdr_project_divide(rdr_ctx* c, double* wet, double* hydro, const double* divisor, int64_t n, int loc) {
+    return project_impl(c, "rdr_project_divide", wet, hydro, 3, divisor, n, loc);
 }
 
 // ---- rays -------------------------------------------------------------------------------------------
@@ -1460,10 +1540,12 @@ int rdr_raytrace(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, double ht, do
 // job is ~20 heights x 1e4-1e5 rays (aria/prepFromGUNW.py:173,180), and one such slice fills a fraction of the chip.  Tiles are
 // numbered slice-major; per-level maxima / flags / nParts stay per slice (RayParams), so the result is what slice-by-slice
 // calls give, bit for bit.
-int rdr_raytrace_slices(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, const double* hts, int32_t nslices, int32_t los_per_slice,
-                        double zref, double max_seg, double* wet, double* hydro, int32_t* K_out, int32_t* nparts_out, int32_t ld,
-                        int32_t* flags_out) {
-    if (!c || !q || !hts || !wet || !hydro) return fail(c, RDR_ERR_INVALID, "rdr_raytrace_slices: NULL argument");
+// keep == NULL: the public entry; keep != NULL: the delays stay in the context's scratch (planar [nslices][n], keep[0] = wet, keep[1] = hydro)
+// for rdr_raytrace_slices_to_cube - nothing is downloaded, the partition outputs are still read back.
+static int raytrace_slices_impl(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, const double* hts, int32_t nslices, int32_t los_per_slice,
+                                double zref, double max_seg, double* wet, double* hydro, int32_t* K_out, int32_t* nparts_out, int32_t ld,
+                                int32_t* flags_out, double** keep) {
+    if (!c || !q || !hts || (!keep && (!wet || !hydro))) return fail(c, RDR_ERR_INVALID, "rdr_raytrace_slices: NULL argument");
     if (nslices < 1 || nslices > MAX_SLICES) return fail(c, RDR_ERR_INVALID, "rdr_raytrace_slices: 1..512 slices per call");
     if (!(max_seg > 0)) return fail(c, RDR_ERR_INVALID, "rdr_raytrace_slices: MAX_SEGMENT_LENGTH must be positive");
     if (nparts_out && ld < (int32_t)q->nz - 1) return fail(c, RDR_ERR_INVALID, "rdr_raytrace_slices: nparts_out needs a row length of at least nz-1");
@@ -1485,8 +1567,10 @@ int rdr_raytrace_slices(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, const 
     const int64_t per = P.ntiles;                                   // tiles of one slice
     const size_t nout = (size_t)r->n * nslices;
     void *dw, *dh;
-    rc = stage_out(c, SLOT_OUT0, wet, nout * 8, r->loc, &dw); if (rc) return rc;
-    rc = stage_out(c, SLOT_OUT1, hydro, nout * 8, r->loc, &dh); if (rc) return rc;
+    const int out_loc = keep ? RDR_DEVICE : r->loc;                 // where the delays end up
+    rc = stage_out(c, SLOT_OUT0, wet, nout * 8, keep ? RDR_HOST : r->loc, &dw); if (rc) return rc;
+    rc = stage_out(c, SLOT_OUT1, hydro, nout * 8, keep ? RDR_HOST : r->loc, &dh); if (rc) return rc;
+    if (keep) { keep[0] = (double*)dw; keep[1] = (double*)dh; }
     const void* dht;
     rc = stage_in(c, SLOT_AUX, hts, (size_t)nslices * 8, RDR_HOST, &dht); if (rc) return rc;
     HIPCHECK(c, hipStreamSynchronize(c->stream));                   // (hts is the caller's memory)
@@ -1501,7 +1585,7 @@ int rdr_raytrace_slices(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, const 
     // Host outputs of a large batch come down slice group by slice group on the copy stream while the next groups are integrated
     // (all kernels are enqueued first: a copy into pageable memory blocks the host thread, not the device).
     static const bool no_pipeline = std::getenv("RAIDER_HIP_NO_PIPELINE") != nullptr;
-    const bool pipe = r->loc == RDR_HOST && nslices >= 2 && nout * 16 >= ((size_t)32 << 20) && per <= fit && !no_pipeline;
+    const bool pipe = out_loc == RDR_HOST && nslices >= 2 && nout * 16 >= ((size_t)32 << 20) && per <= fit && !no_pipeline;
     struct EventList {                                   // (destroyed on every exit path)
         std::vector<hipEvent_t> v;
         ~EventList() { for (auto& e : v) if (e) (void)hipEventDestroy(e); }
@@ -1572,8 +1656,8 @@ int rdr_raytrace_slices(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, const 
                                (const double*)dh, (int64_t)nout, (int64_t)r->n, c->d_flags);
             HIPCHECK(c, hipGetLastError());
         }
-        rc = finish_out(c, wet, dw, nout * 8, r->loc); if (rc) return rc;
-        rc = finish_out(c, hydro, dh, nout * 8, r->loc); if (rc) return rc;
+        rc = finish_out(c, wet, dw, nout * 8, out_loc); if (rc) return rc;
+        rc = finish_out(c, hydro, dh, nout * 8, out_loc); if (rc) return rc;
     }
     const bool need_sync = r->loc == RDR_HOST || nparts_out || flags_out;
     if (need_sync) {
@@ -1591,6 +1675,28 @@ int rdr_raytrace_slices(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, const 
         }
     }
     return RDR_OK;
+}
+
+int rdr_raytrace_slices(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, const double* hts, int32_t nslices, int32_t los_per_slice,
+                        double zref, double max_seg, double* wet, double* hydro, int32_t* K_out, int32_t* nparts_out, int32_t ld,
+                        int32_t* flags_out) {
+    return raytrace_slices_impl(c, q, r, hts, nslices, los_per_slice, zref, max_seg, wet, hydro, K_out, nparts_out, ld, flags_out, nullptr);
+}
+
+int rdr_raytrace_slices_to_cube(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, const double* hts, int32_t nslices, int32_t los_per_slice,
+                                double zref, double max_seg, int32_t* K_out, int32_t* nparts_out, int32_t ld, int32_t* flags_out,
+                                rdr_cube** out) {
+    if (!c || !q || !r || !hts || !out) return fail(c, RDR_ERR_INVALID, "rdr_raytrace_slices_to_cube: NULL argument");
+    if (r->origin_mode != RDR_ORIGIN_GRID) return fail(c, RDR_ERR_INVALID, "rdr_raytrace_slices_to_cube: the delay cube is a GRID batch (xpts, ypts) x heights");
+    if (r->nx < 2 || r->ny < 2 || nslices < 2) return fail(c, RDR_ERR_INVALID, "rdr_raytrace_slices_to_cube: the delay cube needs two nodes per axis");
+    HIPCHECK(c, hipSetDevice(c->device));
+    std::vector<double> hx, hy;
+    int rc = axis_to_host(c, r->xpts, r->nx, r->loc, hx); if (rc) return rc;
+    rc = axis_to_host(c, r->ypts, r->ny, r->loc, hy); if (rc) return rc;
+    double* planar[2] = {nullptr, nullptr};
+    rc = raytrace_slices_impl(c, q, r, hts, nslices, los_per_slice, zref, max_seg, nullptr, nullptr, K_out, nparts_out, ld, flags_out, planar);
+    if (rc) return rc;
+    return rdr_cube_create(c, hy.data(), r->ny, hx.data(), r->nx, hts, nslices, planar[0], planar[1], RDR_F64, r->nx, 1, r->ny * r->nx, RDR_DEVICE, out);
 }
 
 int rdr_top_of_atmosphere(rdr_ctx* c, const double* xyz, const double* los, int64_t n, double h, const double* factor, double* pos, int loc) {

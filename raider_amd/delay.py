@@ -347,23 +347,37 @@ def tropo_delay(datetime, weather_model_file, aoi, los, height_levels=None, out_
         zref = toa
         logger.warning(f'Requested integration height (zref) is higher than top of weather model. Forcing to top ({toa}).')
 
-    ds = _get_delays_on_cube(datetime, weather_model_file, wm_proj, aoi, height_levels, los, crs, zref, _loaded=var)
     if _is_cube_aoi(aoi):
+        ds = _get_delays_on_cube(datetime, weather_model_file, wm_proj, aoi, height_levels, los, crs, zref, _loaded=var)
         return ds, None
 
-    # point branch (delay.py:101-128): interpolate the output cube to the query points
+    # point branch (delay.py:101-128): the intermediate cube, interpolated to the query points.  The cube never leaves the device:
+    # built as a device `Cube` (rdr_build_cube_to_cube / rdr_raytrace_slices_to_cube), gathered ONCE for both fields at the points
+    # and, for a projected line of sight, divided by cos(inc) in the same launch (Cube.interp_project) - the points go up, 2 x N
+    # doubles come down.  (Round 3 mirrored the reference's data flow literally: cube down, Dataset, cube up again, two gathers.)
+    dcube = _delay_cube_on_device(weather_model_file, wm_proj, aoi, height_levels, los, crs, zref, var)
     lats, lons = aoi.readLL()
     hgts = aoi.readZ()
-    pnts = transformPoints(lats, lons, hgts, 4326, out_proj)
-    try:
-        ifWet, ifHydro = getInterpolators(ds, 'ztd')
-    except RuntimeError:
-        raise RuntimeError(f'Failed to get weather model {weather_model_file} interpolators.')
-    wetDelay = ifWet(pnts)
-    hydroDelay = ifHydro(pnts)
+    if dcube is None:
+        # jobs the device route does not take (an output CRS that needs pyproj, a degenerate one-node grid, > 512 heights):
+        # the reference's own sequence
+        ds = _get_delays_on_cube(datetime, weather_model_file, wm_proj, aoi, height_levels, los, crs, zref, _loaded=var)
+        try:
+            ifWet, ifHydro = getInterpolators(ds, 'ztd')
+        except RuntimeError:
+            raise RuntimeError(f'Failed to get weather model {weather_model_file} interpolators.')
+        dcube = ifWet.cube
+    proj = None
     if los.is_Projected():
         los.setTime(datetime)
         los.setPoints(lats, lons, hgts)
+        proj = los._divisor_source() if hasattr(los, '_divisor_source') else False
+    kw = {} if not proj else ({'inc': proj[1]} if proj[0] == 'inc' else {'divisor': proj[1]})
+    if _is_4326(out_proj):
+        wetDelay, hydroDelay = dcube.interp_project(lats, lons, hgts, **kw)        # transformPoints(4326 -> 4326) is the identity stack
+    else:
+        wetDelay, hydroDelay = dcube.interp_project(transformPoints(lats, lons, hgts, 4326, out_proj), **kw)
+    if proj is False:                                  # a foreign projected LOS object: its own __call__ (losreader.py:110-133)
         wetDelay = los(wetDelay)
         hydroDelay = los(hydroDelay)
     return wetDelay, hydroDelay
@@ -372,21 +386,10 @@ def tropo_delay(datetime, weather_model_file, aoi, los, height_levels=None, out_
 getDelays = tropo_delay   # legacy name used by BASELINE.json's north_star
 
 
-_nan_hints = {}      # id(result array) -> (weak reference to it, "holds a NaN"): left by _build_cube* when the device already scanned the result
-
-
-def _hint_set(arr, flag):
-    import weakref
-    try:
-        _nan_hints[id(arr)] = (weakref.ref(arr), bool(flag))
-    except TypeError:            # (not weak-referenceable: no hint, the host scan decides)
-        pass
-
-
-def _hint_pop(arr):
-    """The device's verdict on exactly THIS array (an id recycled by a later array does not match the weak reference), else None."""
-    ent = _nan_hints.pop(id(arr), None)
-    return ent[1] if ent is not None and ent[0]() is arr else None
+class _Result(list):
+    """[wetDelay, hydroDelay] as the reference's _build_cube / _build_cube_ray return it, plus what the device already knows about it:
+    `has_nan` = np.isnan(...).any() over both arrays (delay.py:187), scanned before the download; None: unknown (the host scans)."""
+    has_nan = None
 
 
 def _has_nan(a):
@@ -399,13 +402,8 @@ def _has_nan(a):
     return bool(np.isnan(np.dot(flat, flat)))
 
 
-def _get_delays_on_cube(datetime, weather_model_file, wm_proj, aoi, heights, los, crs, zref, nproc=1, _loaded=None):
-    """delay.py:133-193.  `_loaded`: the already-opened variables of `weather_model_file` (tropo_delay opens the file once;
-    the reference loads it three times, delay.py:66,76 and delayFcns.py:36)."""
-    zpts = np.array(heights)
-    wm_source = weather_model_file
-    if _loaded is not None:
-        weather_model_file = _loaded
+def _ensure_output_grid(aoi, weather_model_file, crs):
+    """delay.py:142-151: an AOI without an output grid gets one at the weather model's own spacing."""
     try:
         aoi.xpts
     except AttributeError:
@@ -415,23 +413,90 @@ def _get_delays_on_cube(datetime, weather_model_file, wm_proj, aoi, heights, los
         aoi.set_output_spacing(ll_res=np.min([x_spacing, y_spacing]))
         aoi.set_output_xygrid(crs)
 
+
+def _raise_slice_failures(K, flags, zz, top):
+    """The reference's failure modes of one ray-traced slice batch (delay.py:276-283), in slice order."""
+    from ._lib import FLAG_ANY_FINITE, FLAG_ANY_NAN
+    for hh, ht in enumerate(zz):
+        if K[hh] == 0:
+            if ht == top:                                              # delay.py:276-277: the slice stays zero (the kernels wrote 0)
+                continue
+            raise TypeError("ufunc 'isnan' not supported for the input types (build_ray returned None)")   # delay.py:279
+        if not (flags[hh] & FLAG_ANY_FINITE):
+            raise ValueError('geo2rdr did not converge. Check orbit coverage')            # delay.py:279-280
+        if flags[hh] & FLAG_ANY_NAN:
+            raise ValueError('some ray lengths are NaN: the number of integration parts (delay.py:283) is undefined')
+        if flags[hh] & FLAG_DIVERGED:
+            raise ValueError('ray lengths diverged: a model level asks for fewer than 2 or more than 65536 integration parts '
+                             '(are the look vectors unit vectors?)')
+
+
+def _delay_cube_on_device(weather_model_file, wm_proj, aoi, heights, los, crs, zref, _loaded):
+    """_get_delays_on_cube (delay.py:133-193) for the point branch of tropo_delay, with the cube left ON THE DEVICE: a float64
+    `Cube` with axes (aoi.ypts, aoi.xpts, heights) - what getInterpolators(ds, 'ztd') would wrap (delay.py:113) - or None for the
+    jobs that need the host sequence (an output grid that is neither the model's CRS nor lon/lat, a one-node axis, > 512 heights).
+    Same kernels, same arithmetic as _build_cube / _build_cube_ray: the values are theirs bit for bit."""
+    zpts = np.array(heights, dtype=np.float64)
+    if _loaded is not None and not isinstance(weather_model_file, (str, os.PathLike)):
+        weather_model_file = _loaded
+    _ensure_output_grid(aoi, weather_model_file, crs)
+    xpts, ypts = np.asarray(aoi.xpts, dtype=np.float64), np.asarray(aoi.ypts, dtype=np.float64)
+    if zpts.ndim != 1 or min(xpts.size, ypts.size, zpts.size) < 2 or zpts.size > 512 or xpts.size + ypts.size + zpts.size > 100000:
+        return None
+    dz = np.diff(zpts)
+    if not (np.all(dz > 0) or np.all(dz < 0)):
+        return None                                                    # (scipy's grid rule: the host sequence raises what it raises)
+    if los.is_Zenith() or los.is_Projected():
+        ifWet, ifHydro = getInterpolators(weather_model_file, 'total')
+        cube = ifWet.cube
+        if _is_4326(wm_proj) and cube.projection is not None:
+            cube.clear_projection()
+        if not ((_same_crs(wm_proj, crs) and cube.projection is None) or (_is_4326(crs) and _apply_model_crs(cube, wm_proj))):
+            return None
+        dcube = cube.build_delay_cube(xpts, ypts, zpts)
+    else:
+        if not (_is_4326(crs) and hasattr(los, 'ray_batch_slices')):
+            return None
+        ifWet, ifHydro = getInterpolators(weather_model_file, kind='pointwise')
+        cube = ifWet.cube
+        if _is_4326(wm_proj):
+            if cube.projection is not None:
+                cube.clear_projection()
+        elif not _apply_model_crs(cube, wm_proj):
+            return None
+        rays = los.ray_batch_slices(xpts, ypts, zpts)
+        dcube, K, _nparts, flags = cube.raytrace_slices_to_cube(rays, zpts, zref, 1000.0)
+        _raise_slice_failures(K, flags, zpts, zpts[-1])
+    if dcube.has_nan():                                                # delay.py:187, answered while the cube was packed
+        logger.critical('There are missing delay values. Check your inputs.')
+    return dcube
+
+
+def _get_delays_on_cube(datetime, weather_model_file, wm_proj, aoi, heights, los, crs, zref, nproc=1, _loaded=None):
+    """delay.py:133-193.  `_loaded`: the already-opened variables of `weather_model_file` (tropo_delay opens the file once;
+    the reference loads it three times, delay.py:66,76 and delayFcns.py:36)."""
+    zpts = np.array(heights)
+    wm_source = weather_model_file
+    if _loaded is not None and not isinstance(weather_model_file, (str, os.PathLike)):
+        weather_model_file = _loaded          # (a path goes on as a path: the opened file and its device cubes are cached by file identity)
+    _ensure_output_grid(aoi, weather_model_file, crs)
+
     if los.is_Zenith() or los.is_Projected():
         # NB: a projected LOS on a cube AOI yields ZENITH delays, exactly like the reference (SURVEY.md §0.8)
         out_type = 'zenith' if los.is_Zenith() else 'slant - projected'
         ifWet, ifHydro = getInterpolators(weather_model_file, 'total')
-        wetDelay, hydroDelay = _build_cube(aoi.xpts, aoi.ypts, zpts, wm_proj, crs, [ifWet, ifHydro])
+        res = _build_cube(aoi.xpts, aoi.ypts, zpts, wm_proj, crs, [ifWet, ifHydro])
     else:
         out_type = 'slant - raytracing'
         ifWet, ifHydro = getInterpolators(weather_model_file, kind='pointwise', shared=(nproc > 1))
         if nproc == 1:
-            wetDelay, hydroDelay = _build_cube_ray(aoi.xpts, aoi.ypts, zpts, los, wm_proj, crs, [ifWet, ifHydro],
-                                                   MAX_TROPO_HEIGHT=zref)
+            res = _build_cube_ray(aoi.xpts, aoi.ypts, zpts, los, wm_proj, crs, [ifWet, ifHydro], MAX_TROPO_HEIGHT=zref)
         else:
             raise NotImplementedError     # delay.py:178-185 (multi-GPU: see raider_amd.distributed)
+    wetDelay, hydroDelay = res
 
-    hw, hh = _hint_pop(wetDelay), _hint_pop(hydroDelay)
-    _nan_hints.clear()
-    if (hw if hw is not None else _has_nan(wetDelay)) or (hh if hh is not None else _has_nan(hydroDelay)):
+    known = getattr(res, 'has_nan', None)           # the device's scan of exactly these arrays, carried by the result itself
+    if known if known is not None else (_has_nan(wetDelay) or _has_nan(hydroDelay)):
         logger.critical('There are missing delay values. Check your inputs.')
 
     return writeResultsToXarray(datetime, aoi.xpts, aoi.ypts, zpts, crs, wetDelay, hydroDelay, wm_source, out_type)
@@ -444,10 +509,9 @@ def _build_cube(xpts, ypts, zpts, model_crs, pts_crs, interpolators):
     if _is_4326(model_crs) and cube.projection is not None:
         cube.clear_projection()                            # (a cached cube that served a projected model before)
     def hinted(res):
-        out = [res[f] for f in fields]
-        h = getattr(cube, 'last_build_cube_has_nan', None)
-        if h is not None and len(out) == 2:               # what np.isnan(result).any() would find (delay.py:187): known from the device scan
-            _hint_set(out[0], h); _hint_set(out[1], h)
+        out = _Result(res[f] for f in fields)
+        if len(out) == 2:                                 # what np.isnan(result).any() would find (delay.py:187): known from the device scan
+            out.has_nan = getattr(cube, 'last_build_cube_has_nan', None)
         return out
     if _same_crs(model_crs, pts_crs) and cube.projection is None:
         return hinted(cube.build_cube(xpts, ypts, zpts))   # points generated on the fly in the kernel
@@ -490,7 +554,6 @@ def _build_cube_ray(xpts, ypts, zpts, los, model_crs, pts_crs, interpolators, ou
     if direct and grid_is_ll and hasattr(los, 'ray_batch_slices') and zpts.size > 0:
         # the whole height loop as one batched launch pair per <= 512 slices (Cube.raytrace_slices): bit-identical to the slice
         # loop below, but a production job (20 heights x 1e4-1e5 rays) fills the GPU instead of a tenth of it
-        from ._lib import FLAG_ANY_FINITE, FLAG_ANY_NAN
         any_nan = False
         # slices per call from a byte budget, not a fixed count: a batch holds per ray and slice its look vector (orbit-based ones
         # depend on the height: 24 B, plus the 24 B target they were solved from) and 16 B of delays on the device, next to the 232 B
@@ -515,27 +578,19 @@ def _build_cube_ray(xpts, ypts, zpts, los, model_crs, pts_crs, interpolators, ou
                     any_nan = any_nan or bool(cube.last_nan_output.any())
                     torch.from_numpy(outputArrs[0][s0:s0 + zz.size]).copy_(dw); torch.from_numpy(outputArrs[1][s0:s0 + zz.size]).copy_(dh)
                     del dw, dh
-            except (RuntimeError, MemoryError) as exc:
-                if chunk == 1 or 'memory' not in str(exc).lower():
+            except (MemoryError, RuntimeError) as exc:
+                # out of DEVICE memory, told by status / class, not by the wording of a message: RDR_ERR_OOM arrives as
+                # _lib.DeviceOutOfMemory (a MemoryError), torch's allocator raises torch.OutOfMemoryError (a RuntimeError)
+                if chunk == 1 or not (isinstance(exc, MemoryError) or type(exc).__name__ == 'OutOfMemoryError'):
                     raise
                 chunk = max(1, chunk // 2)                                 # the device could not hold the batch: smaller ones
                 logger.info(f'slice batch did not fit the device ({exc}); continuing with {chunk} slices per call')
                 continue
             s0 += zz.size
-            for hh, ht in enumerate(zz):                                   # the reference's failure modes, in slice order
-                if K[hh] == 0:
-                    if ht == zpts[-1]:                                     # delay.py:276-277: the slice stays zero (the kernels wrote 0)
-                        continue
-                    raise TypeError("ufunc 'isnan' not supported for the input types (build_ray returned None)")   # delay.py:279
-                if not (flags[hh] & FLAG_ANY_FINITE):
-                    raise ValueError('geo2rdr did not converge. Check orbit coverage')            # delay.py:279-280
-                if flags[hh] & FLAG_ANY_NAN:
-                    raise ValueError('some ray lengths are NaN: the number of integration parts (delay.py:283) is undefined')
-                if flags[hh] & FLAG_DIVERGED:
-                    raise ValueError('ray lengths diverged: a model level asks for fewer than 2 or more than 65536 integration parts '
-                                     '(are the look vectors unit vectors?)')
+            _raise_slice_failures(K, flags, zz, zpts[-1])
         # what np.isnan(result).any() would find (delay.py:187), already known from the device-side scan of every slice
-        _hint_set(outputArrs[0], any_nan); _hint_set(outputArrs[1], any_nan)
+        outputArrs = _Result(outputArrs)
+        outputArrs.has_nan = any_nan
         return outputArrs
     for hh, ht in enumerate(zpts):
         logger.info(f'Processing slice {hh + 1} / {len(zpts)}: {ht}')

@@ -3,11 +3,59 @@
 Returns two interpolator objects with scipy's `RegularGridInterpolator` call semantics (linear,
 bounds_error=False, fill_value=nan) and a `.grid` attribute (delay.py:239 reads `interpolators[0].grid[2]`),
 both views of ONE device-resident `Cube` (wet and hydro interleaved, gathered together)."""
+import os
+import threading
+from collections import OrderedDict
 from pathlib import Path
 
 import numpy as np
 
 from .engine import Cube
+
+# A processed weather-model file is opened by tropo_delay up to three times per call (delay.py:66,76, delayFcns.py:36) and by every
+# call of a job that evaluates several AOIs / line-of-sight types on one model epoch.  Both the opened file (its variables, mapped)
+# and the device cubes made from it are kept, keyed by the file's identity - resolved path, size, modification time (ns) and inode,
+# so a file that was rewritten is read again - for the last RAIDER_HIP_FILE_CACHE files (default 4; 0 switches the cache off).
+_CACHE_LOCK = threading.Lock()
+_FILE_CACHE = OrderedDict()        # file key -> opened dataset
+_CUBE_CACHE = OrderedDict()        # (file key, kind, id(ctx)) -> Cube
+
+
+def _cache_size():
+    try:
+        return max(0, int(os.environ.get('RAIDER_HIP_FILE_CACHE', '4')))
+    except ValueError:
+        return 4
+
+
+def _file_key(path):
+    try:
+        st = os.stat(path)
+    except OSError:
+        return None
+    return (os.path.realpath(path), st.st_size, st.st_mtime_ns, st.st_ino)
+
+
+def _cache_get(cache, key):
+    with _CACHE_LOCK:
+        if key in cache:
+            cache.move_to_end(key)
+            return cache[key]
+    return None
+
+
+def _cache_put(cache, key, value, limit):
+    with _CACHE_LOCK:
+        cache[key] = value
+        cache.move_to_end(key)
+        while len(cache) > limit:
+            cache.popitem(last=False)
+
+
+def clear_file_cache():
+    """Forget every cached weather-model file and the device cubes made from them."""
+    with _CACHE_LOCK:
+        _FILE_CACHE.clear(); _CUBE_CACHE.clear()
 
 
 class FieldInterpolator:
@@ -20,42 +68,20 @@ class FieldInterpolator:
         self.fill_value = np.nan
         self.bounds_error = False
         self.method = 'linear'
-        self._sibling = None
-        self._cache = None
 
     @property
     def values(self):
         return self.cube.read()[self.field]
 
-    @staticmethod
-    def _sig(pts):
-        """Content key of a point set: shape, dtype and a 128-bit digest of ALL its bytes - a caller who edits the array in place
-        (or hands over a different one) between the wet and the hydro call is never served the other call's result."""
-        flat = np.ascontiguousarray(pts).reshape(-1).view(np.uint8)
-        try:                                   # 128-bit XXH3: 10 GB/s (5 M stations: 12 ms); BLAKE2b (0.7 GB/s) where xxhash is not installed
-            import xxhash
-            digest = xxhash.xxh3_128_digest(flat)
-        except ImportError:
-            import hashlib
-            digest = hashlib.blake2b(flat, digest_size=16).digest()
-        return (pts.shape, pts.dtype.str, digest)
-
     def __call__(self, xi):
-        """Both fields are gathered in one kernel launch; the sibling interpolator reuses the result when it
-        is called next with the same points (the reference loops `for intp in interpolators: intp(pts)`,
-        delay.py:213-214,318-319).  The hand-over entry is consumed (or dropped) by the sibling's next call, so neither the
-        caller's array nor the spare result outlives it."""
+        """One gather of THIS field at xi[..., 3] = (y, x, z).  Stateless: the wet and the hydro call of the reference's
+        `for intp in interpolators: intp(pts)` (delay.py:213-214,318-319) each upload the points and download their own 8 B per point
+        (rdr_interp3 with the other output NULL) - no hand-over between the two objects, so an array edited in place between the calls
+        can never be served the other call's result, and nothing is hashed (round 3 hashed all of xi on both calls: 12 ms per
+        5 M stations, 80 x the gather).  tropo_delay itself does not come through here: its point branch gathers both fields in one
+        launch (Cube.interp_project)."""
         pts = np.asarray(xi, dtype=np.float64)
-        cache, self._cache = self._cache, None
-        sig = None
-        if cache is not None:
-            sig = self._sig(pts)
-            if cache[0] == sig:
-                return cache[1]
-        wet, hyd = self.cube.interp(pts)
-        if self._sibling is not None:
-            self._sibling._cache = (sig if sig is not None else self._sig(pts), hyd if self.field == 0 else wet)
-        return wet if self.field == 0 else hyd
+        return self.cube.interp(pts, field=self.field)[self.field]
 
 
 class _Var:
@@ -128,11 +154,17 @@ def _read_cube_file(path):
 def _load_fields(wm_file):
     """Pull x, y, z and the four fields out of a path / xarray.Dataset / mapping."""
     if isinstance(wm_file, (str, Path)):
-        try:
-            import xarray as xr
-            ds = xr.load_dataset(wm_file)
-        except ImportError:
-            ds = _read_cube_file(wm_file)
+        limit = _cache_size()
+        key = _file_key(wm_file) if limit else None
+        ds = _cache_get(_FILE_CACHE, key) if key is not None else None
+        if ds is None:
+            try:
+                import xarray as xr
+                ds = xr.load_dataset(wm_file)
+            except ImportError:
+                ds = _read_cube_file(wm_file)
+            if key is not None:
+                _cache_put(_FILE_CACHE, key, ds, limit)
     else:
         ds = wm_file
     var = ds.variables if hasattr(ds, 'variables') else ds
@@ -146,6 +178,17 @@ def getInterpolators(wm_file, kind='pointwise', shared=False, ctx=None):
     order (z, y, x).  `shared` is accepted and ignored (device memory is shared by construction)."""
     if hasattr(wm_file, 'interpolators') and hasattr(wm_file, 'pointwise'):
         return wm_file.interpolators('total' if kind == 'total' else 'pointwise')    # weather.ProcessedModel: already on the device
+    ckey = None
+    if isinstance(wm_file, (str, Path)) and _cache_size():
+        fkey = _file_key(wm_file)
+        if fkey is not None:
+            ckey = (fkey, 'total' if kind == 'total' else 'pointwise', id(ctx) if ctx is not None else None)
+            cube = _cache_get(_CUBE_CACHE, ckey)
+            if cube is not None:                                       # the same file, still on the device
+                if cube.has_nan():
+                    from .logger import logger
+                    logger.critical('Weather model contains NaNs!')
+                return FieldInterpolator(cube, 0), FieldInterpolator(cube, 1)
     var, get = _load_fields(wm_file)
     xs, ys, zs = get('x'), get('y'), get('z')
 
@@ -161,13 +204,11 @@ def getInterpolators(wm_file, kind='pointwise', shared=False, ctx=None):
     if cube.has_nan():                                             # delayFcns.py:50-52, answered by the packing kernel
         from .logger import logger
         logger.critical('Weather model contains NaNs!')
-    ifWet, ifHydro = FieldInterpolator(cube, 0), FieldInterpolator(cube, 1)
-    ifWet._sibling, ifHydro._sibling = ifHydro, ifWet
-    return ifWet, ifHydro
+    if ckey is not None:
+        _cache_put(_CUBE_CACHE, ckey, cube, 2 * _cache_size())     # (two kinds per file)
+    return FieldInterpolator(cube, 0), FieldInterpolator(cube, 1)
 
 
 def interpolators_from_cube(cube):
     """Wrap an existing device `Cube` (e.g. a blended one) as the (ifWet, ifHydro) pair."""
-    a, b = FieldInterpolator(cube, 0), FieldInterpolator(cube, 1)
-    a._sibling, b._sibling = b, a
-    return a, b
+    return FieldInterpolator(cube, 0), FieldInterpolator(cube, 1)

@@ -154,8 +154,9 @@ class Cube:
         check(self.ctx.lib.rdr_cube_point_index(self.ctx.handle, self.handle, 1 if build else 0), self.ctx.handle)
         return int(self.ctx.lib.rdr_cube_point_index_bytes(self.handle))
 
-    def interp(self, pts):
-        """scipy RGI __call__ on both fields; pts[...,3] = (y,x,z).  Returns (wet, hydro) f64."""
+    def interp(self, pts, field=None):
+        """scipy RGI __call__ on both fields; pts[...,3] = (y,x,z).  Returns (wet, hydro) f64.
+        field=0 / 1 (host arrays): only that field is stored and downloaded, the other entry of the pair is None."""
         if _is_dev(pts):
             import torch
             if pts.shape[-1] != 3:
@@ -173,9 +174,53 @@ class Cube:
             raise ValueError(f'The requested sample points xi have dimension {pts.shape[-1]} but this '
                              'RegularGridInterpolator has dimension 3')
         p = f64(pts).reshape(-1, 3)
-        wet = _pinned.empty((p.shape[0],)); hyd = _pinned.empty((p.shape[0],))          # (large point sets: recycled page-locked results)
+        # (large point sets: recycled page-locked results)
+        wet = _pinned.empty((p.shape[0],)) if field in (None, 0) else None
+        hyd = _pinned.empty((p.shape[0],)) if field in (None, 1) else None
         check(self.ctx.lib.rdr_interp3(self.ctx.handle, self.handle, ptr(p), p.shape[0], ptr(wet), ptr(hyd), L.RDR_HOST), self.ctx.handle)
-        return wet.reshape(pts.shape[:-1]), hyd.reshape(pts.shape[:-1])
+        return (None if wet is None else wet.reshape(pts.shape[:-1])), (None if hyd is None else hyd.reshape(pts.shape[:-1]))
+
+    def interp_project(self, y, x=None, z=None, inc=None, divisor=None):
+        """The second stage of tropo_delay's point branch (delay.py:110-128) in one launch: both fields at the points given as three
+        arrays y, x, z of one shape (or y = packed pts[..., 3], x = z = None) and, for a projected line of sight, delay / cosd(inc)
+        (`inc`: a scalar or an array of the points' shape, degrees) or delay / `divisor` (an array: cos of the look angle) -
+        losreader.py:130-133 - before the values leave the device.  Returns (wet, hydro) f64 of the points' shape."""
+        if inc is not None and divisor is not None:
+            raise ValueError('give inc= or divisor=, not both')
+        if x is None:
+            y = np.asarray(y)
+            if y.shape[-1] != 3:
+                raise ValueError(f'The requested sample points xi have dimension {y.shape[-1]} but this RegularGridInterpolator has dimension 3')
+            shape = y.shape[:-1]
+            ya, xa, za = f64(y).reshape(-1, 3), None, None
+            n = ya.shape[0]
+        else:
+            y, x, z = np.broadcast_arrays(np.asarray(y), np.asarray(x), np.asarray(z))
+            shape = y.shape
+            ya, xa, za = f64(y).reshape(-1), f64(x).reshape(-1), f64(z).reshape(-1)
+            n = ya.size
+        mode, parr, inc0 = 0, None, 0.0
+        if inc is not None:
+            if np.ndim(inc) == 0:
+                mode, inc0 = 2, float(inc)
+            else:
+                mode, parr = 1, f64(np.broadcast_to(np.asarray(inc, dtype=np.float64), shape)).reshape(-1)
+        elif divisor is not None:
+            mode, parr = 3, f64(np.broadcast_to(np.asarray(divisor, dtype=np.float64), shape)).reshape(-1)
+        wet = _pinned.empty((n,)); hyd = _pinned.empty((n,))
+        check(self.ctx.lib.rdr_interp3_project(self.ctx.handle, self.handle, ptr(ya), ptr(xa), ptr(za), n, mode, ptr(parr), inc0, ptr(wet), ptr(hyd),
+                                               L.RDR_HOST), self.ctx.handle)
+        return wet.reshape(shape), hyd.reshape(shape)
+
+    def build_delay_cube(self, xpts, ypts, zpts):
+        """_build_cube (delay.py:196-216) whose result stays on the device: a float64 `Cube` with axes (ypts, xpts, zpts) - the
+        intermediate delay cube of tropo_delay's point branch (delay.py:96-121), ready for interp_project().  Its has_nan() is the
+        np.isnan(...).any() of delay.py:187."""
+        x, y, z = f64(xpts).ravel(), f64(ypts).ravel(), f64(np.atleast_1d(zpts)).ravel()
+        h = C.c_void_p()
+        check(self.ctx.lib.rdr_build_cube_to_cube(self.ctx.handle, self.handle, ptr(x), x.size, ptr(y), y.size, ptr(z), z.size, L.RDR_HOST, C.byref(h)),
+              self.ctx.handle)
+        return Cube._from_handle(self.ctx, h)
 
     def build_cube(self, xpts, ypts, zpts, out=None):
         """_build_cube (delay.py:196-216): (wet, hydro) of shape (nz, ny, nx)."""
@@ -195,9 +240,10 @@ class Cube:
         # (large cubes in recycled page-locked memory: the 640 MB of a 1000 x 1000 x 40 zenith cube come down in 12 ms instead of 40-120 ms
         # into freshly mapped pageable pages - _pinned.py)
         wet = _pinned.empty((z.size, y.size, x.size)); hyd = _pinned.empty((z.size, y.size, x.size))
-        check(self.ctx.lib.rdr_build_cube(self.ctx.handle, self.handle, ptr(x), x.size, ptr(y), y.size, ptr(z), z.size,
-                                          ptr(wet), ptr(hyd), L.RDR_HOST), self.ctx.handle)
-        f = self.ctx.lib.rdr_last_nan_output(self.ctx.handle)
+        with self.ctx.lock:          # (the verdict is context state: read it before another thread's build on this context replaces it)
+            check(self.ctx.lib.rdr_build_cube(self.ctx.handle, self.handle, ptr(x), x.size, ptr(y), y.size, ptr(z), z.size,
+                                              ptr(wet), ptr(hyd), L.RDR_HOST), self.ctx.handle)
+            f = self.ctx.lib.rdr_last_nan_output(self.ctx.handle)
         self.last_build_cube_has_nan = None if f < 0 else bool(f)       # np.isnan(result).any(), scanned on the device
         return wet, hyd
 
@@ -319,6 +365,24 @@ class Cube:
         check(self.ctx.lib.rdr_raytrace_slices(self.ctx.handle, self.handle, C.byref(rays.struct), ptr(hts), S, int(rays.slices > 0), float(zref),
                                                float(max_seg), ptr(wet), ptr(hyd), None, None, ld, None), self.ctx.handle)
         return wet, hyd, None, None, None
+
+    def raytrace_slices_to_cube(self, rays, hts, zref, max_seg=1000.0):
+        """raytrace_slices() whose delays stay on the device: (Cube with axes (ypts, xpts, hts), K[S], nparts[S, nz-1], flags[S]) -
+        the intermediate cube of tropo_delay's point branch for a ray-traced line of sight.  GRID batches only."""
+        rays.adopt_stream(self.ctx)
+        if rays.ht_min is not None:
+            raise ValueError('a batch with per-ray heights is ONE slice: use raytrace()')
+        hts = f64(np.atleast_1d(hts)).ravel()
+        S = hts.size
+        if rays.slices not in (0, S):
+            raise ValueError(f'the ray batch carries look vectors for {rays.slices} slices, {S} heights were given')
+        ld = self.shape[2] - 1
+        K = np.zeros(S, dtype=np.int32); nparts = np.zeros((S, ld), dtype=np.int32); flags = np.zeros(S, dtype=np.int32)
+        h = C.c_void_p()
+        check(self.ctx.lib.rdr_raytrace_slices_to_cube(self.ctx.handle, self.handle, C.byref(rays.struct), ptr(hts), S, int(rays.slices > 0), float(zref),
+                                                       float(max_seg), ptr(K), ptr(nparts), ld, ptr(flags), C.byref(h)), self.ctx.handle)
+        flags &= ~np.int32(L.FLAG_NAN_OUTPUT)
+        return Cube._from_handle(self.ctx, h), K, nparts, flags
 
     def __del__(self):
         try:

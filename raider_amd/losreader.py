@@ -91,6 +91,38 @@ class Conventional(LOS):
         self._hd = None if heading is None else np.asarray(heading, dtype=np.float64)
         if self._convention.lower() != 'isce':
             raise NotImplementedError()
+        if self._inc is not None and np.any(self._inc < 0):           # inc_hd_to_enu's check (losreader.py:386-387), once
+            raise ValueError('inc_hd_to_enu: Incidence angle cannot be less than 0')
+        self._raster = None
+
+    def _divisor_source(self):
+        """What `delays` are divided by (losreader.py:116-133), in the form the device kernels take it:
+        ('inc', incidence in degrees - scalar or array; LOS_enu[..., -1] = cosd(inc) is evaluated on the device) for incidence /
+        heading given as arrays or read from an ISCE-style two-band raster, or ('div', cos(look angle) array) from an orbit /
+        state-vector file (state_to_los: the zero-Doppler geometry, solved on the GPU)."""
+        if self._inc is not None:
+            return 'inc', self._inc
+        if self._file is None:
+            raise ValueError('LOS file not set')
+        if self._raster is not None:
+            return 'inc', self._raster
+        from .rawraster import rio_open
+        raster_error = None
+        try:
+            data, _ = rio_open(self._file)
+            inc = np.asarray(data[0], dtype=np.float64)
+            if np.any(inc < 0):
+                raise ValueError('inc_hd_to_enu: Incidence angle cannot be less than 0')
+            self._raster = inc
+            return 'inc', inc
+        except (OSError, TypeError) as e:
+            raster_error = e
+        from .orbits import get_sv
+        try:
+            svs = np.stack(get_sv(self._file, self._time, self._pad), axis=-1)
+        except ValueError as e:
+            raise ValueError(f'{e}; as a line-of-sight raster it could not be read either: {raster_error}') from e
+        return 'div', state_to_los(svs, [self._lats, self._lons, self._heights])
 
     def _enu(self):
         if self._inc is not None:
@@ -121,11 +153,17 @@ class Conventional(LOS):
             raise ValueError('Target points not set')
         if self._file is None and self._inc is None:
             raise ValueError('LOS file not set')
-        LOS_enu = self._enu()
+        kind, arr = self._divisor_source()
         delays = np.asarray(delays)
-        if delays.shape == LOS_enu.shape:
-            return delays / LOS_enu
-        return delays / LOS_enu[..., -1]
+        ctx = Context.default()
+        if kind == 'inc' and delays.shape == np.shape(arr) + (3,):
+            kind, arr = 'div', self._enu()                             # losreader.py:130-131 with a (..., 3) delay array: delays / LOS_enu
+        shape = np.broadcast_shapes(delays.shape, np.shape(arr))
+        out = np.array(np.broadcast_to(delays, shape), dtype=np.float64, order='C')            # (a fresh array: the kernel divides in place)
+        d = f64(np.broadcast_to(np.asarray(arr, dtype=np.float64), shape))
+        fn = ctx.lib.rdr_project_cosinc if kind == 'inc' else ctx.lib.rdr_project_divide
+        check(fn(ctx.handle, ptr(out), None, ptr(d), out.size, L.RDR_HOST), ctx.handle)
+        return out
 
 
 class Raytracing(LOS):

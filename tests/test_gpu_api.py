@@ -613,7 +613,7 @@ def test_large_result_cubes_pinned_pipelined_and_nan_scanned():
     import gc
     import raider_amd as R
     from raider_amd import _pinned
-    from raider_amd.delay import _build_cube_ray, _nan_hints
+    from raider_amd.delay import _build_cube_ray
     from raider_amd.delayFcns import interpolators_from_cube
     from raider_amd.losreader import Raytracing
     from raider_amd.synthetic import synthetic_cube
@@ -627,9 +627,11 @@ def test_large_result_cubes_pinned_pipelined_and_nan_scanned():
     zpts = np.array([0.0, 250.0, 700.0, 1500.0, 2600.0, 4000.0])                      # 6 slices x 420 k rays: 20 MB per field
     los = Raytracing(inc=inc, heading=-167.9)
     _pinned.trim()
-    wet, hyd = _build_cube_ray(xpts, ypts, zpts, los, 4326, 4326, list(ip), MAX_TROPO_HEIGHT=zref)
+    res = _build_cube_ray(xpts, ypts, zpts, los, 4326, 4326, list(ip), MAX_TROPO_HEIGHT=zref)
+    wet, hyd = res
     assert _pinned.is_pinned(wet) and _pinned.is_pinned(hyd) and wet.shape == (6, ny, nx)
-    assert _nan_hints.get(id(wet), (None, None))[1] is False
+    assert isinstance(res, list) and res.has_nan is False       # the device's scan travels with the result (no module-global hint table)
+    del res
     # reference: every slice alone, plain NumPy outputs
     for i, ht in enumerate(zpts):
         w1, h1, _, _ = cube.raytrace(R.Rays.grid(xpts, ypts, inc=inc, hd=-167.9), float(ht), zref)
@@ -651,8 +653,9 @@ def test_large_result_cubes_pinned_pipelined_and_nan_scanned():
     assert np.isfinite(v).all()
     # a scene partly outside the cube: NaNs, found by the device scan (and only there)
     xo = np.linspace(-121.5, -113.5, nx)
-    wn, hn = _build_cube_ray(xo, ypts, zpts, los, 4326, 4326, list(ip), MAX_TROPO_HEIGHT=zref)
-    assert _nan_hints.get(id(wn), (None, None))[1] is True and np.isnan(wn).any() and np.isfinite(wn).any()
+    resn = _build_cube_ray(xo, ypts, zpts, los, 4326, 4326, list(ip), MAX_TROPO_HEIGHT=zref)
+    wn, hn = resn
+    assert resn.has_nan is True and np.isnan(wn).any() and np.isfinite(wn).any()
     for i in (0, 5):
         w1, h1, _, _ = cube.raytrace(R.Rays.grid(xo, ypts, inc=inc, hd=-167.9), float(zpts[i]), zref)
         assert np.array_equal(w1, wn[i], equal_nan=True) and np.array_equal(h1, hn[i], equal_nan=True)
@@ -806,24 +809,26 @@ def test_zenith_cube_nan_scan_on_the_device_and_pinned_result():
     100 ms ones) - right in both directions."""
     import raider_amd as R
     from raider_amd import _pinned
-    from raider_amd.delay import _build_cube, _nan_hints
+    from raider_amd.delay import _build_cube
     from raider_amd.delayFcns import interpolators_from_cube
     c = O.synthetic_cube(50, 50, 40, seed=0)
     cube = R.Cube(c['ys'], c['xs'], c['zs'], c['wet_total'], c['hydro_total'], order='zyx')
     ip = list(interpolators_from_cube(cube))
     xp = np.linspace(-119.5, -115.5, 700); yp = np.linspace(34.5, 31.5, 600); zp = np.array([0.0, 500.0, 2000.0])
-    w, h = _build_cube(xp, yp, zp, 4326, 4326, ip)
-    assert _pinned.is_pinned(w) and _nan_hints.get(id(w), (None, None))[1] is False and _nan_hints.get(id(h), (None, None))[1] is False and np.isfinite(w).all()
+    r = _build_cube(xp, yp, zp, 4326, 4326, ip)
+    w, h = r
+    assert _pinned.is_pinned(w) and r.has_nan is False and np.isfinite(w).all()
     it = list(O.getInterpolators(c['xs'], c['ys'], c['zs'], c['wet_total'], c['hydro_total']))
     ow, oh = O.build_cube(xp[::50], yp[::50], zp, it)
     np.testing.assert_allclose(w[:, ::50, ::50], ow, rtol=0, atol=1e-13)
     xo = np.linspace(-122.0, -115.5, 700)                                    # partly west of the cube: fill values
-    w2, h2 = _build_cube(xo, yp, zp, 4326, 4326, ip)
-    assert _nan_hints.get(id(w2), (None, None))[1] is True and np.isnan(w2).any() and np.isfinite(w2).any()
+    r2 = _build_cube(xo, yp, zp, 4326, 4326, ip)
+    w2, h2 = r2
+    assert r2.has_nan is True and np.isnan(w2).any() and np.isfinite(w2).any()
     zo = np.array([0.0, 50000.0])                                            # a height above the model: that whole level is NaN
-    w3, _ = _build_cube(xp, yp, zo, 4326, 4326, ip)
-    assert _nan_hints.get(id(w3), (None, None))[1] is True and np.isnan(w3[1]).all() and np.isfinite(w3[0]).all()
-    _nan_hints.clear()
+    r3 = _build_cube(xp, yp, zo, 4326, 4326, ip)
+    w3 = r3[0]
+    assert r3.has_nan is True and np.isnan(w3[1]).all() and np.isfinite(w3[0]).all()
 
 
 def test_array_layouts_and_dtypes_do_not_change_results(c1):

@@ -63,6 +63,27 @@ def test_producer_vs_oracle_with_missing_data():
     np.testing.assert_allclose(wt, r['wet_total'], rtol=2 * E_RTOL, atol=1e-18)
 
 
+@pytest.mark.parametrize('nzo', [64, 65, 66, 129, 193])
+def test_producer_top_level_total_is_zero_at_strip_boundaries(nzo):
+    """the suffix scan of _getZTD walks the output levels in strips of 64; with (nzo - 1) % 64 == 0 (65, 129, 193 levels)
+    the top level used to belong to no strip and its total stayed unwritten LDS.  Its value is the empty sum: exactly 0 - and every
+    other level agrees with the oracle."""
+    from oracle import raider_oracle as O
+    rng = np.random.default_rng(nzo)
+    A, B, nl = 5, 6, 30
+    base = np.sort(rng.uniform(0, 1, (A, B, nl)), axis=2)
+    zs = -50.0 + 200.0 * rng.uniform(0, 1, (A, B, 1)) + 40000.0 * base ** 1.4
+    t = np.maximum(288.0 - 0.0063 * zs, 205.0); p = 101000.0 * np.exp(-zs / 7700.0); q = 0.010 * np.exp(-zs / 2500.0)
+    newz = np.linspace(-100.0, 38000.0, nzo)
+    for _ in range(2):                                     # (twice: the second run sees the LDS the first one left behind)
+        m = _run(zs, p, t, q, 'q', newz)
+        r = O.cube_from_model_levels(zs, p, t, q, 'q', newz)
+        wt, ht = m.total.read()
+        assert wt.shape[2] == nzo and np.all(wt[..., -1] == 0.0) and np.all(ht[..., -1] == 0.0)
+        np.testing.assert_allclose(ht, r['hydro_total'], rtol=1e-13, atol=1e-18)
+        np.testing.assert_allclose(wt, r['wet_total'], rtol=2 * E_RTOL, atol=1e-18)
+
+
 def test_producer_with_many_levels_needs_large_lds():
     """500 model levels resampled to 300 heights: the per-wavefront column buffers are 98 KB per workgroup, past the 64 KB a launch
     gets by default.  Same parity as above; a level count whose buffers exceed the device's LDS is refused by name."""

@@ -87,12 +87,7 @@ def test_vrt_raw_bands_and_simple_sources(tmp_path):
         rio_open(tmp_path / 'missing.rdr')
 
 
-def test_conventional_los_from_a_raster_file(tmp_path):
-    """losreader.py:110-133 with an ISCE-style 2-band LOS raster: delays / cos(incidence) - the reference reads the file through
-    rasterio; here through the built-in reader.  A 2-D delay array is divided by the up component; an (.., 3)-shaped one by the
-    ENU vector itself (the reference's shape rule)."""
-    from raider_amd.losreader import Conventional, inc_hd_to_enu
-    rng = np.random.default_rng(2)
+def _los_raster(tmp_path, rng):
     inc = rng.uniform(30, 45, (6, 8)).astype(np.float32); hd = rng.uniform(-170, -165, (6, 8)).astype(np.float32)
     (tmp_path / 'los.rdr').write_bytes(np.ascontiguousarray(np.stack([inc, hd], -1)).tobytes())
     (tmp_path / 'los.rdr.vrt').write_text('''<VRTDataset rasterXSize="8" rasterYSize="6">
@@ -101,13 +96,36 @@ def test_conventional_los_from_a_raster_file(tmp_path):
     <VRTRasterBand band="2" dataType="Float32" subClass="VRTRawRasterBand"><SourceFilename relativeToVRT="1">los.rdr</SourceFilename>
         <ByteOrder>LSB</ByteOrder><ImageOffset>4</ImageOffset><PixelOffset>8</PixelOffset><LineOffset>64</LineOffset></VRTRasterBand>
 </VRTDataset>''')
+    return inc, hd
+
+
+@pytest.mark.gpu
+def test_conventional_los_from_a_raster_file(tmp_path):
+    """losreader.py:110-133 with an ISCE-style 2-band LOS raster: delays / cos(incidence) - the reference reads the file through
+    rasterio; here through the built-in reader, and the division runs on the device (rdr_project_cosinc; round 3 divided on the
+    host).  A 2-D delay array is divided by the up component; an (.., 3)-shaped one by the ENU vector itself (the reference's
+    shape rule).  Tolerance 2 ulp: the device's cos against libm's."""
+    from raider_amd.losreader import Conventional, inc_hd_to_enu
+    rng = np.random.default_rng(2)
+    inc, hd = _los_raster(tmp_path, rng)
     los = Conventional(filename=str(tmp_path / 'los.rdr'))
     lats = rng.uniform(30, 31, (6, 8)); lons = rng.uniform(-118, -117, (6, 8))
     los.setPoints(lats, lons, np.zeros((6, 8)))
     ztd = rng.uniform(2.0, 2.5, (6, 8))
+    keep = ztd.copy()
     out = los(ztd)
-    np.testing.assert_allclose(out, ztd / np.cos(np.radians(inc.astype(np.float64))), rtol=1e-6)
-    assert np.array_equal(out, ztd / inc_hd_to_enu(inc, hd)[..., -1])
+    assert np.array_equal(ztd, keep) and out.shape == ztd.shape            # (the caller's array is not divided in place)
+    np.testing.assert_allclose(out, ztd / inc_hd_to_enu(inc, hd)[..., -1], rtol=5e-16, atol=0)
+    enu = inc_hd_to_enu(inc, hd)
+    d3 = rng.uniform(2.0, 2.5, (6, 8, 3))
+    assert np.array_equal(los(d3), d3 / enu)                               # losreader.py:130-131: same shape -> delays / LOS_enu
+
+
+def test_conventional_los_from_an_unreadable_file(tmp_path):
+    from raider_amd.losreader import Conventional
+    rng = np.random.default_rng(2)
+    lats = rng.uniform(30, 31, (6, 8)); lons = rng.uniform(-118, -117, (6, 8))
+    ztd = rng.uniform(2.0, 2.5, (6, 8))
     # a file that is neither a raster nor an orbit file: one error naming both attempts
     bad = tmp_path / 'junk.bin'
     bad.write_bytes(b'\x01\x02\x03')
