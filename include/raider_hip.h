@@ -245,6 +245,14 @@ int rdr_last_nan_output(rdr_ctx* ctx);
  * ("There are missing delay values").  Needs two nodes per axis (scipy's grid rule), nz <= 512. */
 int rdr_build_cube_to_cube(rdr_ctx* ctx, const rdr_cube* cube, const double* xpts, int64_t nx, const double* ypts, int64_t ny,
                            const double* zpts, int64_t nz, int loc, rdr_cube** out);
+/* tropo_delay's point branch for a zenith / projected line of sight (delay.py:96-128) in ONE call, host arrays in, host arrays out:
+ * rdr_build_cube_to_cube on the output grid (xpts[nx], ypts[ny], zpts[nz]) + rdr_interp3_project at the query points, with the
+ * intermediate cube in the context's scratch (no allocation per call) and the upload of the points running under its build.  Same
+ * kernels and arithmetic as the two separate entries: the same bits.  Points / projection / outputs as rdr_interp3_project;
+ * *cube_has_nan (may be NULL): the intermediate cube holds a NaN - the scan of delay.py:187 ("There are missing delay values"). */
+int rdr_point_delays(rdr_ctx* ctx, const rdr_cube* cube, const double* xpts, int64_t nx, const double* ypts, int64_t ny, const double* zpts,
+                     int64_t nz, const double* y, const double* x, const double* z, int64_t n, int proj_mode, const double* proj, double inc0,
+                     double* wet, double* hydro, int32_t* cube_has_nan);
 /* Conventional.__call__ tail (losreader.py:130-133): delay / cosd(inc) in place, inc[n] in degrees (what inc_hd_to_enu(...)[..., -1]
  * holds for an incidence raster).  The reference projects wet and hydro in two calls: either pointer may be NULL. */
 int rdr_project_cosinc(rdr_ctx* ctx, double* wet, double* hydro, const double* inc, int64_t n, int loc);

@@ -87,6 +87,8 @@ SYMBOLS = [
     ('rdr_build_cube', C.c_int, [_VP, _VP, _VP, C.c_int64, _VP, C.c_int64, _VP, C.c_int64, _VP, _VP, C.c_int]),
     ('rdr_build_cube_to_cube', C.c_int, [_VP, _VP, _VP, C.c_int64, _VP, C.c_int64, _VP, C.c_int64, C.c_int, C.POINTER(_VP)]),
     ('rdr_last_nan_output', C.c_int, [_VP]),
+    ('rdr_point_delays', C.c_int, [_VP, _VP, _VP, C.c_int64, _VP, C.c_int64, _VP, C.c_int64, _VP, _VP, _VP, C.c_int64, C.c_int, _VP, C.c_double, _VP, _VP,
+                                   c_ip]),
     ('rdr_project_cosinc', C.c_int, [_VP, _VP, _VP, _VP, C.c_int64, C.c_int]),
     ('rdr_project_divide', C.c_int, [_VP, _VP, _VP, _VP, C.c_int64, C.c_int]),
     ('rdr_ray_levels', C.c_int, [_VP, C.c_double, C.c_double, c_ip, _VP, _VP, _VP]),

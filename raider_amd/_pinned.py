@@ -19,7 +19,7 @@ import numpy as np
 from . import _lib as L
 
 _GRAN = 2 << 20                      # blocks are multiples of 2 MiB: a slightly different cube shape still finds a block
-_MIN_BYTES = 8 << 20                 # smaller results are not worth a page-locked block
+_MIN_BYTES = 1 << 20                 # smaller results are not worth a page-locked block (10^6 station delays are 8 MB: they are)
 _lock = threading.Lock()
 _free = {}                           # rounded size -> [pointers]
 _free_bytes = 0

@@ -29,12 +29,15 @@ struct DevBuf {
 
 constexpr int MAX_SLICES = 512;   // height slices per rdr_raytrace_slices call
 
-enum { SLOT_IN0 = 0, SLOT_IN1, SLOT_IN2, SLOT_IN3, SLOT_IN4, SLOT_IN5, SLOT_IN6, SLOT_OUT0, SLOT_OUT1, SLOT_OUT2, SLOT_AUX, NSLOT };
+enum { SLOT_IN0 = 0, SLOT_IN1, SLOT_IN2, SLOT_IN3, SLOT_IN4, SLOT_IN5, SLOT_IN6, SLOT_OUT0, SLOT_OUT1, SLOT_OUT2, SLOT_AUX,
+       SLOT_PT0, SLOT_PT1, SLOT_PT2, SLOT_PT3, SLOT_PT4, SLOT_PT5, SLOT_TMPCUBE, SLOT_TMPAXES,      // rdr_point_delays: points, delays, the intermediate cube
+       NSLOT };
 
 struct rdr_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t copy_stream = nullptr;      // host<->device transfers of the pipelined host-buffer ray tracing
+    hipStream_t down_stream = nullptr;      // downloads that run under the uploads of the next chunk (rdr_point_delays)
     hipStream_t stream = nullptr;
     int num_cus = 256;
     size_t lds_max = 64u << 10;             // largest dynamic LDS allocation of one workgroup
@@ -53,6 +56,7 @@ struct rdr_ctx {
     DevBuf side;                              // level crossings of the generic rays (compact columns of K+1 doubles)
     int64_t side_cap = 0;                     // columns of `side` in the current layout
     int* d_sidectr = nullptr;                 // [1] next free column
+    int* h_word = nullptr;                    // [4] page-locked host words: flags read back WITHOUT stalling the host before the final sync
     int64_t side_forced = -1;                 // rdr_set_side_capacity
     int64_t last_nslow = 0;                   // generic rays seen by the last pass 1 whose count the host happened to read back
     int last_nan_output = -1;                 // rdr_build_cube (host arrays): 1 / 0 = its last result holds / does not hold a NaN; -1 unknown
@@ -215,6 +219,7 @@ int rdr_create(int device, rdr_ctx** out) {
         if (c->name.empty()) c->name = std::string("AMD ") + prop.gcnArchName;   // amdgpu.ids may be absent on the box
         HIPCHECK(nullptr, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
         HIPCHECK(nullptr, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        HIPCHECK(nullptr, hipStreamCreateWithFlags(&c->down_stream, hipStreamNonBlocking));
         c->stream = c->own_stream;
         HIPCHECK(nullptr, hipMalloc((void**)&c->d_maxlen, (size_t)MAX_SLICES * MAX_LEVELS * sizeof(unsigned long long)));
         HIPCHECK(nullptr, hipMalloc((void**)&c->d_flags, (MAX_SLICES + 4) * sizeof(int)));      // (+ the cube packer's NaN word)
@@ -223,6 +228,7 @@ int rdr_create(int device, rdr_ctx** out) {
         HIPCHECK(nullptr, hipMalloc((void**)&c->d_tilectr, 32 * sizeof(int)));
         HIPCHECK(nullptr, hipMalloc((void**)&c->d_sidectr, sizeof(int)));
         HIPCHECK(nullptr, hipMemset(c->d_sidectr, 0, sizeof(int)));
+        HIPCHECK(nullptr, hipHostMalloc((void**)&c->h_word, 4 * sizeof(int), hipHostMallocDefault));
         HIPCHECK(nullptr, hipMemset(c->d_nslow, 0, sizeof(int)));
         return RDR_OK;
     }();
@@ -245,9 +251,11 @@ void rdr_destroy(rdr_ctx* c) {
     if (c->ws.p) (void)hipFree(c->ws.p);
     if (c->side.p) (void)hipFree(c->side.p);
     if (c->d_sidectr) (void)hipFree(c->d_sidectr);
+    if (c->h_word) (void)hipHostFree(c->h_word);
     for (auto& v : c->evs) for (auto& pr : v) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    if (c->down_stream) (void)hipStreamDestroy(c->down_stream);
     delete c;
 }
 
@@ -790,47 +798,111 @@ int rdr_cube_point_index(rdr_ctx* c, rdr_cube* q, int mode) {
 
 int64_t rdr_cube_point_index_bytes(const rdr_cube* q) { return q ? (int64_t)q->quad_bytes : -1; }
 
+static void launch_interp(rdr_ctx* c, const rdr_cube* q, const PointQuery& Qk, int64_t cnt, double* dwk, double* dhk, bool quad) {
+    const int g = grid_for(cnt, 256, c->num_cus * 8);
+    KTimer t(c, 2);
+    if (quad) {
+        if (q->dtype == RDR_F32)
+            hipLaunchKernelGGL((interp_points_quad_kernel<float2>), dim3(g), dim3(256), axes_smem(q), c->stream, make_view<float2>(q),
+                               (const uint4*)q->d_quad, q->quad_nblk, Qk, cnt, dwk, dhk, (int)axes_fit_lds(q));
+        else
+            hipLaunchKernelGGL((interp_points_quad_kernel<double2>), dim3(g), dim3(256), axes_smem(q), c->stream, make_view<double2>(q),
+                               (const uint4*)q->d_quad, q->quad_nblk, Qk, cnt, dwk, dhk, (int)axes_fit_lds(q));
+    } else if (q->dtype == RDR_F32)
+        hipLaunchKernelGGL((interp_points_kernel<float2>), dim3(g), dim3(256), axes_smem(q), c->stream, make_view<float2>(q), Qk, cnt, dwk, dhk,
+                           (int)axes_fit_lds(q));
+    else
+        hipLaunchKernelGGL((interp_points_kernel<double2>), dim3(g), dim3(256), axes_smem(q), c->stream, make_view<double2>(q), Qk, cnt, dwk, dhk,
+                           (int)axes_fit_lds(q));
+}
+
+// Large HOST point sets: the points go up (copy stream) and the delays come down (download stream) in chunks, the download of chunk k
+// under the upload of chunk k+1 (PCIe is full duplex), the gathers on the ctx stream in between - 40-48 B per point cross the link,
+// which is all such a call costs (the gather itself: 0.03 ms per 10^6 points).  Uploads on their OWN stream also run under whatever
+// the ctx stream is still doing (rdr_point_delays: the build of the intermediate cube).  `slots`: device scratch for y, x, z, proj,
+// wet, hydro.  Synchronises all three streams before it returns.  (A download into pageable memory blocks the host thread instead of
+// overlapping: still correct.)
+static int interp_pipeline(rdr_ctx* c, const char* who, const rdr_cube* q, bool quad, const double* y, const double* x, const double* z, int64_t n,
+                           PointQuery Q, const double* proj, double* wet, double* hydro, const int* slots) {
+    const bool has_proj = Q.pmode == 1 || Q.pmode == 3;
+    const size_t ystride = x ? 1 : 3;
+    void *dy, *dx = nullptr, *dz = nullptr, *dp = nullptr, *dw = nullptr, *dh = nullptr;
+    int rc = ensure(c, slots[0], (size_t)n * ystride * 8, &dy); if (rc) return rc;
+    if (x) { rc = ensure(c, slots[1], (size_t)n * 8, &dx); if (rc) return rc; rc = ensure(c, slots[2], (size_t)n * 8, &dz); if (rc) return rc; }
+    if (has_proj) { rc = ensure(c, slots[3], (size_t)n * 8, &dp); if (rc) return rc; }
+    if (wet) { rc = ensure(c, slots[4], (size_t)n * 8, &dw); if (rc) return rc; }
+    if (hydro) { rc = ensure(c, slots[5], (size_t)n * 8, &dh); if (rc) return rc; }
+    // chunks of >= 512 k points (a copy call costs 10-20 us: 1 MB copies would spend as long on calls as on bytes), at most 8
+    const int nchunk = (int)std::max<int64_t>(1, std::min<int64_t>(8, n >> 19));
+    struct EventList { std::vector<hipEvent_t> v; ~EventList() { for (auto& e : v) if (e) (void)hipEventDestroy(e); } } evs;
+    evs.v.assign((size_t)2 * nchunk, nullptr);
+    for (auto& e : evs.v)
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return fail(c, RDR_ERR_HIP, std::string(who) + ": event creation failed");
+    for (int k = 0; k < nchunk; ++k) {
+        const int64_t o = n * k / nchunk, cnt = n * (k + 1) / nchunk - o;
+        HIPCHECK(c, hipMemcpyAsync((double*)dy + o * ystride, y + o * ystride, (size_t)cnt * ystride * 8, hipMemcpyHostToDevice, c->copy_stream));
+        if (x) {
+            HIPCHECK(c, hipMemcpyAsync((double*)dx + o, x + o, (size_t)cnt * 8, hipMemcpyHostToDevice, c->copy_stream));
+            HIPCHECK(c, hipMemcpyAsync((double*)dz + o, z + o, (size_t)cnt * 8, hipMemcpyHostToDevice, c->copy_stream));
+        }
+        if (has_proj) HIPCHECK(c, hipMemcpyAsync((double*)dp + o, proj + o, (size_t)cnt * 8, hipMemcpyHostToDevice, c->copy_stream));
+        HIPCHECK(c, hipEventRecord(evs.v[2 * k], c->copy_stream));
+        HIPCHECK(c, hipStreamWaitEvent(c->stream, evs.v[2 * k], 0));
+        PointQuery Qk = Q;
+        Qk.y = (const double*)dy + o * ystride;
+        Qk.x = x ? (const double*)dx + o : nullptr; Qk.z = x ? (const double*)dz + o : nullptr;
+        Qk.proj = has_proj ? (const double*)dp + o : nullptr;
+        launch_interp(c, q, Qk, cnt, dw ? (double*)dw + o : nullptr, dh ? (double*)dh + o : nullptr, quad);
+        HIPCHECK(c, hipGetLastError());
+        HIPCHECK(c, hipEventRecord(evs.v[2 * k + 1], c->stream));
+        HIPCHECK(c, hipStreamWaitEvent(c->down_stream, evs.v[2 * k + 1], 0));
+        if (wet) HIPCHECK(c, hipMemcpyAsync(wet + o, (double*)dw + o, (size_t)cnt * 8, hipMemcpyDeviceToHost, c->down_stream));
+        if (hydro) HIPCHECK(c, hipMemcpyAsync(hydro + o, (double*)dh + o, (size_t)cnt * 8, hipMemcpyDeviceToHost, c->down_stream));
+    }
+    HIPCHECK(c, hipStreamSynchronize(c->down_stream));
+    HIPCHECK(c, hipStreamSynchronize(c->copy_stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    return RDR_OK;
+}
+
+static int point_query_args(rdr_ctx* c, const char* who, const double* y, const double* x, const double* z, int64_t n, int pmode, const double* proj,
+                            const double* wet, const double* hydro) {
+    if (n < 0) return fail(c, RDR_ERR_INVALID, std::string(who) + ": negative count");
+    if (n > 0 && (!y || (x && !z) || (!x && z) || (!wet && !hydro))) return fail(c, RDR_ERR_INVALID, std::string(who) + ": NULL argument");
+    if (pmode < 0 || pmode > 3) return fail(c, RDR_ERR_INVALID, std::string(who) + ": proj_mode is 0 (none), 1 (incidence array), 2 (one incidence) or 3 (divisor array)");
+    if (n > 0 && (pmode == 1 || pmode == 3) && !proj) return fail(c, RDR_ERR_INVALID, std::string(who) + ": proj_mode 1 / 3 need the proj array");
+    return RDR_OK;
+}
+
 // the point query behind rdr_interp3 / rdr_interp3_project: y/x/z three arrays (x != NULL) or y = packed (n,3); pmode / proj / inc0 as
 // PointQuery (cube_kernels.h); either output may be NULL (it is then neither written nor downloaded)
 static int interp3_impl(rdr_ctx* c, const char* who, const rdr_cube* q, const double* y, const double* x, const double* z, int64_t n, int pmode,
                         const double* proj, double inc0, double* wet, double* hydro, int loc) {
     if (!c || !q) return fail(c, RDR_ERR_INVALID, std::string(who) + ": NULL argument");
-    if (n < 0) return fail(c, RDR_ERR_INVALID, std::string(who) + ": negative count");
-    if (n > 0 && (!y || (x && !z) || (!x && z) || (!wet && !hydro))) return fail(c, RDR_ERR_INVALID, std::string(who) + ": NULL argument");
-    if (pmode < 0 || pmode > 3) return fail(c, RDR_ERR_INVALID, std::string(who) + ": proj_mode is 0 (none), 1 (incidence array), 2 (one incidence) or 3 (divisor array)");
-    if (n > 0 && (pmode == 1 || pmode == 3) && !proj) return fail(c, RDR_ERR_INVALID, std::string(who) + ": proj_mode 1 / 3 need the proj array");
+    int rc = point_query_args(c, who, y, x, z, n, pmode, proj, wet, hydro); if (rc) return rc;
     if (n == 0) return RDR_OK;
     HIPCHECK(c, hipSetDevice(c->device));
     PointQuery Q; std::memset(&Q, 0, sizeof(Q));
     Q.pmode = pmode; Q.inc0 = inc0;
+    const bool has_proj = pmode == 1 || pmode == 3;
+    const size_t ystride = x ? 1 : 3;                                  // doubles per point behind `y`
+    const bool quad = quad_wanted(c, q, n);
+    if (quad) { rc = quad_build(c, q); if (rc) return rc; }
+    static const bool no_pipeline = std::getenv("RAIDER_HIP_NO_PIPELINE") != nullptr;
+    if (loc == RDR_HOST && n >= (1 << 18) && !no_pipeline) {
+        static const int slots[6] = {SLOT_IN0, SLOT_IN1, SLOT_IN2, SLOT_IN3, SLOT_OUT0, SLOT_OUT1};
+        return interp_pipeline(c, who, q, quad, y, x, z, n, Q, proj, wet, hydro, slots);
+    }
     const void* d; void *dw = nullptr, *dh = nullptr;
-    int rc = stage_in(c, SLOT_IN0, y, (size_t)n * (x ? 8 : 24), loc, &d); if (rc) return rc; Q.y = (const double*)d;
+    rc = stage_in(c, SLOT_IN0, y, (size_t)n * ystride * 8, loc, &d); if (rc) return rc; Q.y = (const double*)d;
     if (x) {
         rc = stage_in(c, SLOT_IN1, x, (size_t)n * 8, loc, &d); if (rc) return rc; Q.x = (const double*)d;
         rc = stage_in(c, SLOT_IN2, z, (size_t)n * 8, loc, &d); if (rc) return rc; Q.z = (const double*)d;
     }
-    if (pmode == 1 || pmode == 3) { rc = stage_in(c, SLOT_IN3, proj, (size_t)n * 8, loc, &d); if (rc) return rc; Q.proj = (const double*)d; }
+    if (has_proj) { rc = stage_in(c, SLOT_IN3, proj, (size_t)n * 8, loc, &d); if (rc) return rc; Q.proj = (const double*)d; }
     if (wet) { rc = stage_out(c, SLOT_OUT0, wet, (size_t)n * 8, loc, &dw); if (rc) return rc; }
     if (hydro) { rc = stage_out(c, SLOT_OUT1, hydro, (size_t)n * 8, loc, &dh); if (rc) return rc; }
-    const int g = grid_for(n, 256, c->num_cus * 8);
-    const bool quad = quad_wanted(c, q, n);
-    if (quad) { rc = quad_build(c, q); if (rc) return rc; }
-    {
-        KTimer t(c, 2);
-        if (quad) {
-            if (q->dtype == RDR_F32)
-                hipLaunchKernelGGL((interp_points_quad_kernel<float2>), dim3(g), dim3(256), axes_smem(q), c->stream, make_view<float2>(q),
-                                   (const uint4*)q->d_quad, q->quad_nblk, Q, n, (double*)dw, (double*)dh, (int)axes_fit_lds(q));
-            else
-                hipLaunchKernelGGL((interp_points_quad_kernel<double2>), dim3(g), dim3(256), axes_smem(q), c->stream, make_view<double2>(q),
-                                   (const uint4*)q->d_quad, q->quad_nblk, Q, n, (double*)dw, (double*)dh, (int)axes_fit_lds(q));
-        } else if (q->dtype == RDR_F32)
-            hipLaunchKernelGGL((interp_points_kernel<float2>), dim3(g), dim3(256), axes_smem(q), c->stream, make_view<float2>(q),
-                               Q, n, (double*)dw, (double*)dh, (int)axes_fit_lds(q));
-        else
-            hipLaunchKernelGGL((interp_points_kernel<double2>), dim3(g), dim3(256), axes_smem(q), c->stream, make_view<double2>(q),
-                               Q, n, (double*)dw, (double*)dh, (int)axes_fit_lds(q));
-    }
+    launch_interp(c, q, Q, n, (double*)dw, (double*)dh, quad);
     HIPCHECK(c, hipGetLastError());
     rc = finish_out(c, wet, dw, (size_t)n * 8, loc); if (rc) return rc;
     rc = finish_out(c, hydro, dh, (size_t)n * 8, loc); if (rc) return rc;
@@ -952,6 +1024,62 @@ int rdr_build_cube_to_cube(rdr_ctx* c, const rdr_cube* q, const double* xpts, in
     return rdr_cube_create(c, hy.data(), ny, hx.data(), nx, hz.data(), nz, planar[0], planar[1], RDR_F64, nx, 1, ny * nx, RDR_DEVICE, out);
 }
 
+
+// tropo_delay's point branch for a zenith / projected line of sight (delay.py:96-128) in ONE call: _build_cube on the output grid
+// (xpts, ypts, zpts) -> the intermediate cube packed as getInterpolators(ds, 'ztd') would wrap it -> trilinear gather at the query
+// points -> delay / cos(inc).  Everything is enqueued before anything is waited for: the points travel up (copy stream) while the
+// intermediate cube is built (ctx stream), the cube lives in the context's scratch (no allocation per call), its NaN verdict
+// (delay.py:187) comes back with the final synchronisation.  Same kernels, same arithmetic as the separate entries: same bits.
+int rdr_point_delays(rdr_ctx* c, const rdr_cube* q, const double* xpts, int64_t nx, const double* ypts, int64_t ny, const double* zpts, int64_t nz,
+                     const double* y, const double* x, const double* z, int64_t n, int proj_mode, const double* proj, double inc0,
+                     double* wet, double* hydro, int32_t* cube_has_nan) {
+    if (!c || !q || !xpts || !ypts || !zpts) return fail(c, RDR_ERR_INVALID, "rdr_point_delays: NULL argument");
+    if (nx < 2 || ny < 2 || nz < 2) return fail(c, RDR_ERR_INVALID, "rdr_point_delays: the delay cube needs two nodes per axis");
+    if (nz > MAX_LEVELS) return fail(c, RDR_ERR_INVALID, "rdr_point_delays: more than 512 height levels");
+    if (ny + nx + nz > 100000) return fail(c, RDR_ERR_INVALID, "rdr_point_delays: axes too long");
+    int rc = point_query_args(c, "rdr_point_delays", y, x, z, n, proj_mode, proj, wet, hydro); if (rc) return rc;
+    int fy, fx, fz;
+    if (axis_check(ypts, ny, &fy) || axis_check(xpts, nx, &fx) || axis_check(zpts, nz, &fz))
+        return fail(c, RDR_ERR_INVALID, "The points in each dimension must be strictly ascending or descending (and >= 2)");
+    HIPCHECK(c, hipSetDevice(c->device));
+    // the intermediate cube: a scratch object (values and axes in context slots), never destroyed
+    rdr_cube tmp;
+    tmp.ctx = c; tmp.ny = ny; tmp.nx = nx; tmp.nz = nz; tmp.dtype = RDR_F64;
+    tmp.ys.assign(ypts, ypts + ny); tmp.xs.assign(xpts, xpts + nx); tmp.zs.assign(zpts, zpts + nz);
+    if (fy) std::reverse(tmp.ys.begin(), tmp.ys.end());
+    if (fx) std::reverse(tmp.xs.begin(), tmp.xs.end());
+    if (fz) std::reverse(tmp.zs.begin(), tmp.zs.end());
+    axis_uniformity(tmp.ys, &tmp.uni[0], &tmp.inv_d[0], &tmp.exact[0]);
+    axis_uniformity(tmp.xs, &tmp.uni[1], &tmp.inv_d[1], &tmp.exact[1]);
+    axis_uniformity(tmp.zs, &tmp.uni[2], &tmp.inv_d[2]);
+    const size_t total = (size_t)ny * nx * nz;
+    void *dvals, *daxes;
+    rc = ensure(c, SLOT_TMPCUBE, total * sizeof(double2), &dvals); if (rc) return rc;
+    rc = ensure(c, SLOT_TMPAXES, (size_t)(ny + nx + nz) * 8, &daxes); if (rc) return rc;
+    tmp.d_vals = dvals; tmp.d_axes = (double*)daxes;
+    std::vector<double> ax;
+    ax.insert(ax.end(), tmp.ys.begin(), tmp.ys.end()); ax.insert(ax.end(), tmp.xs.begin(), tmp.xs.end()); ax.insert(ax.end(), tmp.zs.begin(), tmp.zs.end());
+    HIPCHECK(c, hipMemcpyAsync(daxes, ax.data(), ax.size() * 8, hipMemcpyHostToDevice, c->stream));
+    double* planar[2] = {nullptr, nullptr};
+    rc = build_cube_impl(c, q, xpts, nx, ypts, ny, zpts, nz, nullptr, nullptr, RDR_HOST, planar); if (rc) return rc;
+    int* const nf = c->d_flags + MAX_SLICES + 2;
+    HIPCHECK(c, hipMemsetAsync(nf, 0, sizeof(int), c->stream));
+    hipLaunchKernelGGL((pack_cube_kernel<double, double2, false>), dim3(grid_for((int64_t)total, 256, c->num_cus * 8)), dim3(256), 0, c->stream,
+                       (const double*)planar[0], (const double*)planar[1], (double2*)dvals, ny, nx, nz, nx, (int64_t)1, ny * nx, fy, fx, fz, nf);
+    HIPCHECK(c, hipGetLastError());
+    // (into a page-locked word: a pageable destination would stall the host here until the cube is built - and the upload of the
+    // points, which is to run UNDER that build, with it)
+    c->h_word[0] = 0;
+    HIPCHECK(c, hipMemcpyAsync(&c->h_word[0], nf, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    if (n > 0) {
+        PointQuery Q; std::memset(&Q, 0, sizeof(Q));
+        Q.pmode = proj_mode; Q.inc0 = inc0;
+        static const int slots[6] = {SLOT_PT0, SLOT_PT1, SLOT_PT2, SLOT_PT3, SLOT_PT4, SLOT_PT5};
+        rc = interp_pipeline(c, "rdr_point_delays", &tmp, false, y, x, z, n, Q, proj, wet, hydro, slots); if (rc) return rc;
+    } else HIPCHECK(c, hipStreamSynchronize(c->stream));
+    if (cube_has_nan) *cube_has_nan = c->h_word[0] != 0;
+    return RDR_OK;
+}
 
 static int project_impl(rdr_ctx* c, const char* who, double* wet, double* hydro, int pmode, const double* proj, int64_t n, int loc) {
     if (!c || (!wet && !hydro) || !proj) return fail(c, RDR_ERR_INVALID, std::string(who) + ": NULL argument");

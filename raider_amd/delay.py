@@ -352,31 +352,31 @@ def tropo_delay(datetime, weather_model_file, aoi, los, height_levels=None, out_
         return ds, None
 
     # point branch (delay.py:101-128): the intermediate cube, interpolated to the query points.  The cube never leaves the device:
-    # built as a device `Cube` (rdr_build_cube_to_cube / rdr_raytrace_slices_to_cube), gathered ONCE for both fields at the points
-    # and, for a projected line of sight, divided by cos(inc) in the same launch (Cube.interp_project) - the points go up, 2 x N
-    # doubles come down.  (Round 3 mirrored the reference's data flow literally: cube down, Dataset, cube up again, two gathers.)
-    dcube = _delay_cube_on_device(weather_model_file, wm_proj, aoi, height_levels, los, crs, zref, var)
+    # zenith / projected lines of sight run the whole branch in ONE library call (rdr_point_delays: _build_cube into device scratch,
+    # one gather of both fields at the points, the division by cos(inc) in the same launch, the points travelling up while the cube
+    # is built); ray-traced ones keep the cube as a device `Cube` (rdr_raytrace_slices_to_cube) and gather from it.  The points go
+    # up, 2 x N doubles come down.  (Round 3 mirrored the reference's data flow literally: cube down, Dataset, cube up, two gathers.)
     lats, lons = aoi.readLL()
     hgts = aoi.readZ()
-    if dcube is None:
-        # jobs the device route does not take (an output CRS that needs pyproj, a degenerate one-node grid, > 512 heights):
-        # the reference's own sequence
-        ds = _get_delays_on_cube(datetime, weather_model_file, wm_proj, aoi, height_levels, los, crs, zref, _loaded=var)
-        try:
-            ifWet, ifHydro = getInterpolators(ds, 'ztd')
-        except RuntimeError:
-            raise RuntimeError(f'Failed to get weather model {weather_model_file} interpolators.')
-        dcube = ifWet.cube
     proj = None
     if los.is_Projected():
         los.setTime(datetime)
         los.setPoints(lats, lons, hgts)
         proj = los._divisor_source() if hasattr(los, '_divisor_source') else False
     kw = {} if not proj else ({'inc': proj[1]} if proj[0] == 'inc' else {'divisor': proj[1]})
-    if _is_4326(out_proj):
-        wetDelay, hydroDelay = dcube.interp_project(lats, lons, hgts, **kw)        # transformPoints(4326 -> 4326) is the identity stack
-    else:
-        wetDelay, hydroDelay = dcube.interp_project(transformPoints(lats, lons, hgts, 4326, out_proj), **kw)
+    # transformPoints(4326 -> 4326) is the identity stack: the three arrays go up as they are
+    pts = (lats, lons, hgts) if _is_4326(out_proj) else (transformPoints(lats, lons, hgts, 4326, out_proj),)
+    res = _point_branch_on_device(weather_model_file, wm_proj, aoi, height_levels, los, crs, zref, var, pts, kw)
+    if res is None:
+        # jobs the device route does not take (an output CRS that is neither the model's nor lon/lat, a one-node grid axis, > 512
+        # heights): the reference's own sequence
+        ds = _get_delays_on_cube(datetime, weather_model_file, wm_proj, aoi, height_levels, los, crs, zref, _loaded=var)
+        try:
+            ifWet, ifHydro = getInterpolators(ds, 'ztd')
+        except RuntimeError:
+            raise RuntimeError(f'Failed to get weather model {weather_model_file} interpolators.')
+        res = ifWet.cube.interp_project(*pts, **kw)
+    wetDelay, hydroDelay = res
     if proj is False:                                  # a foreign projected LOS object: its own __call__ (losreader.py:110-133)
         wetDelay = los(wetDelay)
         hydroDelay = los(hydroDelay)
@@ -431,11 +431,12 @@ def _raise_slice_failures(K, flags, zz, top):
                              '(are the look vectors unit vectors?)')
 
 
-def _delay_cube_on_device(weather_model_file, wm_proj, aoi, heights, los, crs, zref, _loaded):
-    """_get_delays_on_cube (delay.py:133-193) for the point branch of tropo_delay, with the cube left ON THE DEVICE: a float64
-    `Cube` with axes (aoi.ypts, aoi.xpts, heights) - what getInterpolators(ds, 'ztd') would wrap (delay.py:113) - or None for the
-    jobs that need the host sequence (an output grid that is neither the model's CRS nor lon/lat, a one-node axis, > 512 heights).
-    Same kernels, same arithmetic as _build_cube / _build_cube_ray: the values are theirs bit for bit."""
+def _point_branch_on_device(weather_model_file, wm_proj, aoi, heights, los, crs, zref, _loaded, pts, kw):
+    """_get_delays_on_cube (delay.py:133-193) + the second-stage interpolation (delay.py:110-128) with the intermediate cube - what
+    getInterpolators(ds, 'ztd') would wrap, axes (aoi.ypts, aoi.xpts, heights) - left ON THE DEVICE.  `pts`: (y, x, z) arrays or one
+    packed array, in the output CRS; `kw`: inc= / divisor= of a projected line of sight.  Returns (wetDelay, hydroDelay), or None for
+    the jobs that need the host sequence (an output grid that is neither the model's CRS nor lon/lat, a one-node axis, > 512
+    heights).  Same kernels, same arithmetic as _build_cube / _build_cube_ray + the interpolators: the values are theirs bit for bit."""
     zpts = np.array(heights, dtype=np.float64)
     if _loaded is not None and not isinstance(weather_model_file, (str, os.PathLike)):
         weather_model_file = _loaded
@@ -453,7 +454,7 @@ def _delay_cube_on_device(weather_model_file, wm_proj, aoi, heights, los, crs, z
             cube.clear_projection()
         if not ((_same_crs(wm_proj, crs) and cube.projection is None) or (_is_4326(crs) and _apply_model_crs(cube, wm_proj))):
             return None
-        dcube = cube.build_delay_cube(xpts, ypts, zpts)
+        wet, hyd, has_nan = cube.point_delays(xpts, ypts, zpts, *pts, **kw)
     else:
         if not (_is_4326(crs) and hasattr(los, 'ray_batch_slices')):
             return None
@@ -467,9 +468,11 @@ def _delay_cube_on_device(weather_model_file, wm_proj, aoi, heights, los, crs, z
         rays = los.ray_batch_slices(xpts, ypts, zpts)
         dcube, K, _nparts, flags = cube.raytrace_slices_to_cube(rays, zpts, zref, 1000.0)
         _raise_slice_failures(K, flags, zpts, zpts[-1])
-    if dcube.has_nan():                                                # delay.py:187, answered while the cube was packed
+        has_nan = dcube.has_nan()
+        wet, hyd = dcube.interp_project(*pts, **kw)
+    if has_nan:                                                        # delay.py:187, answered while the cube was packed
         logger.critical('There are missing delay values. Check your inputs.')
-    return dcube
+    return wet, hyd
 
 
 def _get_delays_on_cube(datetime, weather_model_file, wm_proj, aoi, heights, los, crs, zref, nproc=1, _loaded=None):

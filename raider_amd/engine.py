@@ -185,6 +185,15 @@ class Cube:
         arrays y, x, z of one shape (or y = packed pts[..., 3], x = z = None) and, for a projected line of sight, delay / cosd(inc)
         (`inc`: a scalar or an array of the points' shape, degrees) or delay / `divisor` (an array: cos of the look angle) -
         losreader.py:130-133 - before the values leave the device.  Returns (wet, hydro) f64 of the points' shape."""
+        ya, xa, za, n, shape, mode, parr, inc0 = self._point_args(y, x, z, inc, divisor)
+        wet = _pinned.empty((n,)); hyd = _pinned.empty((n,))
+        check(self.ctx.lib.rdr_interp3_project(self.ctx.handle, self.handle, ptr(ya), ptr(xa), ptr(za), n, mode, ptr(parr), inc0, ptr(wet), ptr(hyd),
+                                               L.RDR_HOST), self.ctx.handle)
+        return wet.reshape(shape), hyd.reshape(shape)
+
+    @staticmethod
+    def _point_args(y, x, z, inc, divisor):
+        """(y, x, z as flat arrays - or y packed (n, 3), x = z = None -, n, shape, proj_mode, proj array, inc0) of a point query."""
         if inc is not None and divisor is not None:
             raise ValueError('give inc= or divisor=, not both')
         if x is None:
@@ -207,10 +216,20 @@ class Cube:
                 mode, parr = 1, f64(np.broadcast_to(np.asarray(inc, dtype=np.float64), shape)).reshape(-1)
         elif divisor is not None:
             mode, parr = 3, f64(np.broadcast_to(np.asarray(divisor, dtype=np.float64), shape)).reshape(-1)
+        return ya, xa, za, n, shape, mode, parr, inc0
+
+    def point_delays(self, xpts, ypts, zpts, y, x=None, z=None, inc=None, divisor=None):
+        """tropo_delay's point branch for a zenith / projected line of sight in ONE library call (rdr_point_delays): _build_cube of THIS
+        (total-delay) cube on the output grid (xpts, ypts, zpts), the intermediate cube kept in device scratch, both fields gathered
+        at the points (y, x, z: three arrays, or y = packed [..., 3]) and divided by cosd(inc) / `divisor` - delay.py:96-128,
+        losreader.py:130-133.  Returns (wet, hydro, has_nan): has_nan = the intermediate cube holds a NaN (delay.py:187)."""
+        gx, gy, gz = f64(xpts).ravel(), f64(ypts).ravel(), f64(np.atleast_1d(zpts)).ravel()
+        ya, xa, za, n, shape, mode, parr, inc0 = self._point_args(y, x, z, inc, divisor)
         wet = _pinned.empty((n,)); hyd = _pinned.empty((n,))
-        check(self.ctx.lib.rdr_interp3_project(self.ctx.handle, self.handle, ptr(ya), ptr(xa), ptr(za), n, mode, ptr(parr), inc0, ptr(wet), ptr(hyd),
-                                               L.RDR_HOST), self.ctx.handle)
-        return wet.reshape(shape), hyd.reshape(shape)
+        flag = C.c_int32(0)
+        check(self.ctx.lib.rdr_point_delays(self.ctx.handle, self.handle, ptr(gx), gx.size, ptr(gy), gy.size, ptr(gz), gz.size, ptr(ya), ptr(xa), ptr(za), n,
+                                            mode, ptr(parr), inc0, ptr(wet), ptr(hyd), C.byref(flag)), self.ctx.handle)
+        return wet.reshape(shape), hyd.reshape(shape), bool(flag.value)
 
     def build_delay_cube(self, xpts, ypts, zpts):
         """_build_cube (delay.py:196-216) whose result stays on the device: a float64 `Cube` with axes (ypts, xpts, zpts) - the

@@ -105,16 +105,19 @@ class Conventional(LOS):
         if self._file is None:
             raise ValueError('LOS file not set')
         if self._raster is not None:
-            return 'inc', self._raster
+            return self._raster
         from .rawraster import rio_open
         raster_error = None
         try:
             data, _ = rio_open(self._file)
-            inc = np.asarray(data[0], dtype=np.float64)
+            inc = np.asarray(data[0])
             if np.any(inc < 0):
                 raise ValueError('inc_hd_to_enu: Incidence angle cannot be less than 0')
-            self._raster = inc
-            return 'inc', inc
+            # A float64 raster: cosd(inc) on the device.  Any other dtype (ISCE's los.rdr is float32): the reference's inc_hd_to_enu
+            # evaluates cosd IN THAT DTYPE (losreader.py:393, NumPy keeps float32) and divides the float64 delays by the float32
+            # cosine - reproduced by taking the cosine here, in the raster's dtype, once per file, and dividing on the device.
+            self._raster = ('inc', inc) if inc.dtype == np.float64 else ('div', cosd(inc).astype(np.float64))
+            return self._raster
         except (OSError, TypeError) as e:
             raster_error = e
         from .orbits import get_sv
@@ -156,8 +159,12 @@ class Conventional(LOS):
         kind, arr = self._divisor_source()
         delays = np.asarray(delays)
         ctx = Context.default()
-        if kind == 'inc' and delays.shape == np.shape(arr) + (3,):
-            kind, arr = 'div', self._enu()                             # losreader.py:130-131 with a (..., 3) delay array: delays / LOS_enu
+        # losreader.py:130-133: `delays / LOS_enu` when the shapes agree, else `delays / LOS_enu[..., -1]`
+        if self._inc is not None or self._raster is not None:          # LOS_enu = (..., 3) ENU vectors; `arr` stands for their last component
+            if delays.shape == np.shape(arr) + (3,):
+                kind, arr = 'div', self._enu()
+        elif delays.shape != np.shape(arr):                            # LOS_enu = cos(look angle) per target (an orbit file)
+            arr = np.asarray(arr)[..., -1]
         shape = np.broadcast_shapes(delays.shape, np.shape(arr))
         out = np.array(np.broadcast_to(delays, shape), dtype=np.float64, order='C')            # (a fresh array: the kernel divides in place)
         d = f64(np.broadcast_to(np.asarray(arr, dtype=np.float64), shape))

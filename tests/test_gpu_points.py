@@ -121,8 +121,8 @@ def test_point_branch_device_route_equals_the_reference_sequence(golden, c1, cap
     wm = _wm(c1)
     lats, lons, hgts = g['lats'], g['lons'], g['hgts']
     calls = []
-    real = D._delay_cube_on_device
-    D._delay_cube_on_device = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    real = D._point_branch_on_device
+    D._point_branch_on_device = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
     try:
         # zenith: golden g8 (the reference itself) and the host sequence, bit for bit
         wz, hz = tropo_delay(WHEN, wm, PointsAOI(lats, lons, hgts, g['xpts'], g['ypts']), Zenith(), hl, 4326, None)
@@ -159,7 +159,7 @@ def test_point_branch_device_route_equals_the_reference_sequence(golden, c1, cap
         with pytest.raises(ValueError, match='strictly ascending or descending'):
             tropo_delay(WHEN, wm, PointsAOI(lats, lons, np.full(lats.shape, hl[0]), g['xpts'], g['ypts']), Zenith(), hl[:1], 4326, None)
     finally:
-        D._delay_cube_on_device = real
+        D._point_branch_on_device = real
 
 
 def test_point_branch_projected_model_and_other_output_crs(c1):
@@ -194,6 +194,34 @@ def test_point_branch_projected_model_and_other_output_crs(c1):
     iw, ih = getInterpolators(ds, 'ztd')
     pn = transformPoints(la, lo, hg, 4326, 32611)
     assert np.array_equal(wu, iw(pn), equal_nan=True) and np.array_equal(hu, ih(pn), equal_nan=True) and np.isfinite(wu).mean() > 0.9
+
+
+def test_point_delays_is_the_two_entries_in_one(c1):
+    """rdr_point_delays = rdr_build_cube_to_cube + rdr_interp3_project with the cube in scratch and the uploads under the build: the
+    same bits, for point sets on both sides of the chunked-transfer threshold, every projection mode, descending grid axes, NaNs."""
+    import raider_amd as R
+    tot = R.Cube(c1['ys'], c1['xs'], c1['zs'], c1['wet_total'], c1['hydro_total'], order='zyx')
+    xp = np.linspace(-119.5, -115.5, 61); yp = np.linspace(34.5, 31.5, 47); zp = np.array([-50.0, 0.0, 300.0, 1000.0, 5000.0, 9000.0])
+    d = tot.build_delay_cube(xp, yp, zp)
+    rng = np.random.default_rng(5)
+    for n in (1000, 700_000):
+        y = rng.uniform(31.4, 34.6, n); x = rng.uniform(-119.6, -115.4, n); z = rng.uniform(-100, 9500, n)
+        inc = rng.uniform(20, 50, n)
+        for kw in ({}, {'inc': inc}, {'inc': 33.0}, {'divisor': np.cos(np.radians(inc))}):
+            a = d.interp_project(y, x, z, **kw)
+            b = tot.point_delays(xp, yp, zp, y, x, z, **kw)
+            assert np.array_equal(a[0], b[0], equal_nan=True) and np.array_equal(a[1], b[1], equal_nan=True) and b[2] is False
+            assert np.isnan(a[0]).any() and np.isfinite(a[0]).mean() > 0.8
+        p = tot.point_delays(xp, yp, zp, np.stack([y, x, z], -1), inc=inc)
+        assert np.array_equal(p[0], b[0] * 0 + d.interp_project(y, x, z, inc=inc)[0], equal_nan=True)
+    # a grid leaving the model: NaN nodes in the intermediate cube, reported
+    w, h, nan = tot.point_delays(np.linspace(-125.0, -115.5, 61), yp, zp, y[:100], x[:100], z[:100])
+    assert nan is True
+    # no points: the cube is still built and scanned
+    w0, h0, nan0 = tot.point_delays(xp, yp, zp, np.zeros(0), np.zeros(0), np.zeros(0))
+    assert w0.size == 0 and nan0 is False
+    with pytest.raises(ValueError):
+        tot.point_delays(xp, yp, np.array([0.0, 0.0]), y, x, z)
 
 
 def test_interp3_one_field_soa_and_projection_modes(c1):
@@ -274,10 +302,12 @@ def test_delay_cube_on_device_is_the_downloaded_cube(c1):
     assert np.array_equal(rw, w2.transpose(1, 2, 0)[::-1]) and np.array_equal(rh, h2.transpose(1, 2, 0)[::-1])
     assert np.array_equal(K, K2) and np.array_equal(nparts, np2) and np.array_equal(flags, fl2)
     import torch                                                            # a device-resident ray batch takes the same entry
-    lv = torch.from_numpy(np.ascontiguousarray(R.Rays.grid(xp, yp, inc=39.0, hd=-167.9).look_vectors())).cuda()
-    dc3, _, _, _ = pw.raytrace_slices_to_cube(R.Rays.grid(torch.from_numpy(xp).cuda(), torch.from_numpy(yp).cuda(), los=lv), zp, zref)
+    lv = np.ascontiguousarray(R.Rays.grid(xp, yp, inc=39.0, hd=-167.9).look_vectors())
+    dc2, _, _, _ = pw.raytrace_slices_to_cube(R.Rays.grid(xp, yp, los=lv), zp, zref)
+    np.testing.assert_allclose(dc2.read()[1], rh, rtol=0, atol=1e-11)       # (look vectors as an array / made in the kernel: last bits)
+    dc3, _, _, _ = pw.raytrace_slices_to_cube(R.Rays.grid(torch.from_numpy(xp).cuda(), torch.from_numpy(yp).cuda(), los=torch.from_numpy(lv).cuda()), zp, zref)
     torch.cuda.synchronize()
-    assert np.array_equal(dc3.read()[1], rh)
+    assert np.array_equal(dc3.read()[1], dc2.read()[1]) and np.array_equal(dc3.read()[0], dc2.read()[0])
 
 
 def test_weather_file_is_opened_and_uploaded_once(tmp_path, c1):

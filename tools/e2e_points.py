@@ -63,9 +63,27 @@ if mode == 'c2':
     lats = rng.uniform(31.5, 34.5, n); lons = rng.uniform(-119.5, -115.5, n); hgts = rng.uniform(0.0, 3000.0, n)
     inc = rng.uniform(30.0, 46.0, n)
     res.update(points=n, cube='300x300x80 (NetCDF-3 file on disk)')
-    wz, hz = timed_calls('zenith', lambda: tropo_delay(WHEN, str(tmp), PointsAOI(lats, lons, hgts), Zenith(), None, 4326, None), n)
+    # the AOI object of a job is made once and serves every date (cli/raider.py:347-355 loops over the dates with one aoi; its output
+    # grid is laid out by the first call, delay.py:142-151): the timed calls reuse it.  `*_fresh_aoi`: a new AOI per call as well
+    # (four min / max passes over the points to find their bounding box - host work of the AOI provider, outside the path).
+    aoi = PointsAOI(lats, lons, hgts)
+    wz, hz = timed_calls('zenith', lambda: tropo_delay(WHEN, str(tmp), aoi, Zenith(), None, 4326, None), n)
     los = Conventional(inc=inc, heading=np.full(n, -167.9))
-    wc, hc = timed_calls('conventional', lambda: tropo_delay(WHEN, str(tmp), PointsAOI(lats, lons, hgts), los, None, 4326, None), n)
+    wc, hc = timed_calls('conventional', lambda: tropo_delay(WHEN, str(tmp), aoi, los, None, 4326, None), n)
+    timed_calls('conventional_fresh_aoi', lambda: tropo_delay(WHEN, str(tmp), PointsAOI(lats, lons, hgts), los, None, 4326, None), n)
+    # where the time goes: the two library calls of the branch by themselves
+    from raider_amd.delayFcns import getInterpolators
+    cube = getInterpolators(str(tmp), 'total')[0].cube
+    zl = np.asarray(c['zs'], dtype=np.float64)
+    def best(fn, reps=6):
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter(); r = fn(); ts.append(time.perf_counter() - t0)
+        return min(ts[1:]) * 1e3, r
+    res['piece_build_delay_cube_ms'], dcube = best(lambda: cube.build_delay_cube(aoi.xpts, aoi.ypts, zl))
+    res['piece_interp_project_ms'], _ = best(lambda: dcube.interp_project(lats, lons, hgts, inc=inc))
+    res['piece_interp_ms'], _ = best(lambda: dcube.interp_project(lats, lons, hgts))
+    res['intermediate_grid'] = [int(zl.size), int(aoi.ypts.size), int(aoi.xpts.size)]
     up = np.cos(np.radians(inc))
     res['conventional_vs_zenith_over_cos_max_rel'] = float(np.nanmax(np.abs(hc * up / hz - 1.0)))
     # the same job with the file cache off: every call opens the file and uploads the 115 MB of f64 totals again
@@ -117,7 +135,7 @@ else:
     hl = list(zs[zs <= 6000.0]) + [8000.0]                                       # station heights end at 4 km
     res.update(points=n, cube='blend(0.25, 0.75) of two 1000x1000x50 epochs, 3-km LCC grid, device-resident', intermediate_grid=[len(hl), yg.size, xg.size])
     import logging
-    logging.getLogger('raider_amd').setLevel(logging.CRITICAL + 1)               # (the lon/lat bounding grid leaves the LCC cube at its corners: NaN nodes, logged per call)
+    logging.getLogger('RAiDER').setLevel(logging.CRITICAL + 1)               # (the lon/lat bounding grid leaves the LCC cube at its corners: NaN nodes, logged per call)
     wz, hz = timed_calls('zenith', lambda: tropo_delay(WHEN, model, PointsAOI(lats, lons, hgts, xg, yg), Zenith(), hl, 4326, None), n)
     prof = lambda: tropo_delay(WHEN, model, PointsAOI(lats, lons, hgts, xg, yg), Zenith(), hl, 4326, None)
 
