@@ -30,6 +30,8 @@ sys.path.insert(0, str(REPO))
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s HBM3E spec
 # vector-ALU issue peak: 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction (fp64 FMA is full rate on CDNA4)
 VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4
+FP64_VECTOR_PEAK = 256 * 4 * 16 * 2 * 2.4e9      # flop/s: 78.6 TFLOP/s fp64 vector (MI355X_MICROARCH.md), an FMA = 2 flop per lane and 4-cycle pass
+FLOP_PER_REFERENCE_SAMPLE = 110.0               # ~1.1e2 fp64 operations per (ray, sample) of the reference's algorithm
 
 
 def kernel_source_hash():
@@ -55,6 +57,24 @@ def load_counters(cube, rows, cols):
             continue
         if d.get('cube') != cube:
             why = f'{f.name}: profiled on cube {d.get("cube")}, this run uses {cube}'
+            continue
+        return d, str(f.relative_to(REPO))
+    return None, why
+
+
+def load_parity(tag):
+    """The newest profiles/r*_full_scene_parity_<tag>.json (tools/full_scene_parity.py: EVERY ray of the scene against the C oracle)
+    made with the CURRENT kernels; (dict, path) or (None, reason).  A record of an earlier source version is not cited."""
+    cands = sorted((REPO / 'profiles').glob(f'r*_full_scene_parity_{tag}.json'), reverse=True)
+    want = kernel_source_hash()
+    why = f'no profiles/r*_full_scene_parity_{tag}.json'
+    for f in cands:
+        try:
+            d = json.loads(f.read_text())
+        except (OSError, ValueError):
+            continue
+        if d.get('source_hash') != want:
+            why = f'{f.name}: source hash {d.get("source_hash")} != current {want} (stale parity record: not cited)'
             continue
         return d, str(f.relative_to(REPO))
     return None, why
@@ -97,6 +117,12 @@ def main():
                                                                 'its own GPU, else gloo with device-resident collective tensors (ranks sharing a GPU: RCCL refuses duplicates)')
     ap.add_argument('--dump', type=str, default='', help='write this rank\'s slab of the hydrostatic / wet delays to <dump>.rank<r>.npz (tests)')
     ap.add_argument('--cpu-sample', type=int, default=640, help='edge of the square ray block timed on the CPU oracle (0 = skip)')
+    ap.add_argument('--workload', choices=('rays', 'c5'), default='rays',
+                    help='rays (default): the ray-traced scene the metric is quoted on (configs[2] / configs[3]).  c5: BASELINE configs[4] - two HRRR-sized '
+                         '1000x1000x50 f32 epochs on the 3-km LCC grid, blended (0.25, 0.75), --stations GNSS station points gathered from the blend; '
+                         'N > 1: the epochs go out in two packed broadcasts, every rank blends and gathers its block of the stations (no data-path collective); '
+                         'value = stations/s')
+    ap.add_argument('--stations', type=int, default=5_000_000, help='--workload c5: station points of the whole job')
     args = ap.parse_args()
     if args.scaling == 'auto':
         args.scaling = 'strong' if (args.gpus > 1 and args.rows is None) else 'weak'
@@ -147,6 +173,8 @@ def main():
 
     ctx = R.Context(local)
     # (raider_amd launches on torch's current stream whenever it is handed device tensors)
+    if args.workload == 'c5':
+        return run_c5(args, ctx, dev, coll_dev, dist_on, rank, world, ndev, result_fd)
 
     # ---- weather cube: generated on rank 0, sent to every rank in ONE packed broadcast (RCCL over xGMI), packed (y,x,z) on device
     ny, nx, nz = (int(v) for v in args.cube.split('x'))
@@ -228,8 +256,15 @@ def main():
     torch.cuda.synchronize()
     if dist_on:
         dist.barrier()
+    # the shader clock DURING the timed steps (one sleeping wave on another stream reads the cycle and the wall counter, rdr_clock_sample_*):
+    # sized from one untimed step so that it ends inside the timed region
+    torch.cuda.synchronize()
+    tw = time.perf_counter(); step(); torch.cuda.synchronize(); tw = time.perf_counter() - tw
+    if dist_on:
+        dist.barrier()
     ctx.set_profiling(True)                                      # HIP event pairs around every kernel launch
     torch.cuda.synchronize()
+    clock_end = ctx.clock_sample(max(0.2, 0.8 * tw * args.steps * 1e3)) if rank == 0 else None
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -237,6 +272,7 @@ def main():
     if dist_on:
         dist.barrier()
     dt = time.perf_counter() - t0
+    clock_ghz = clock_end() if clock_end is not None else None
     n_pre, ms_pre = ctx.profile_get(0)
     n_march, ms_march = ctx.profile_get(1)
     ctx.set_profiling(False)
@@ -292,6 +328,11 @@ def main():
         pr_ = 2 if args.per_pixel_ht else 0
         ka_m, ka_c = cube.ray_kernel_attributes(1 + pr_), cube.ray_kernel_attributes(0 + pr_)      # from the loaded code object
         frac_valu = valu_rate / VALU_ISSUE_PEAK if valu_rate else None
+        # how GOOD the kernel is, beside how busy: the reference's arithmetic (SURVEY 8d flop model: 110 fp64 flop per ray and
+        # REFERENCE sample, S of them per ray) per second of march time against the fp64 vector peak - a kernel that issues more
+        # instructions for the same rays scores lower here and the same in `frac`
+        useful_flops = FLOP_PER_REFERENCE_SAMPLE * S * n_rays / (march_ms * 1e-3)
+        parity, parity_src = load_parity('c3b' if args.per_pixel_ht else ('c3' if (rows, cols) == (4000, 4000) else 'c4' if (total_rows, cols) == (10000, 10000) else 'none'))
         frac_hbm = (traffic / (march_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic is not None else None
         if args.per_pixel_ht:
             wl = (f'c3b (SURVEY 8d secondary workload, no reference semantics): Raytracing LOS, {total_rows}x{cols} scene on a DEM - per-pixel origin heights '
@@ -325,6 +366,15 @@ def main():
             'roofline': {'bound': 'valu_fp64_issue', 'kernel': 'march_kernel<float2,false,1,true>' if args.per_pixel_ht else 'march_kernel<float2,false,1>',
                          'achieved': valu_rate / 1e9 if valu_rate else None, 'peak': VALU_ISSUE_PEAK / 1e9, 'unit': 'G wave64-instr/s',
                          'frac': frac_valu, 'frac_valu': frac_valu, 'frac_hbm_measured': frac_hbm,
+                         # frac prices every VALU instruction at the fp64 rate and the 2.4 GHz data-sheet clock: it says how BUSY the issue
+                         # ports are.  useful_flops_frac (the headline for kernel quality) says how much of the chip's fp64
+                         # vector peak goes into the reference's own arithmetic; the clock the chip really ran at is beside it.
+                         'useful_flops_frac': useful_flops / FP64_VECTOR_PEAK, 'useful_TFLOPs': useful_flops / 1e12, 'fp64_vector_peak_TFLOPs': FP64_VECTOR_PEAK / 1e12,
+                         'flop_model': f'{FLOP_PER_REFERENCE_SAMPLE:.0f} fp64 flop x S = {S} reference samples per ray (SURVEY 8d)',
+                         'valu_per_reference_sample': (valu_rw / S) if valu_rw else None,
+                         'clock_GHz_measured': clock_ghz, 'clock_GHz_assumed_by_peak': 2.4,
+                         'frac_at_measured_clock': (valu_rate / (256 * 4 * clock_ghz * 1e9 / 4)) if (valu_rate and clock_ghz) else None,
+                         'useful_flops_frac_at_measured_clock': (useful_flops / (FP64_VECTOR_PEAK * clock_ghz / 2.4)) if clock_ghz else None,
                          'traffic': traffic, 'traffic_unit': 'HBM bytes per march_kernel launch (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE, separate passes)',
                          'traffic_over_compulsory': (step_traffic / (compulsory * n_rays)) if step_traffic is not None else None,
                          'valu_instr_per_raywave': valu_rw, 'valu_busy_frac': km.get('valu_busy_frac'),
@@ -347,12 +397,143 @@ def main():
                                  'gather_model_note': '(64*S+64) B/ray of SURVEY 8d x rays / march time: an ALGORITHMIC rate above the HBM peak because the '
                                                       'gathers are L2/MALL hits - not a utilisation'}},
         }
+        res['parity'] = ({'record': parity_src, 'rays_compared': parity.get('rays'), 'max_abs_wet_m': parity.get('max_abs_wet_m'),
+                          'max_abs_hydro_m': parity.get('max_abs_hydro_m'), 'nan_mask_mismatches': parity.get('nan_mask_mismatches'),
+                          'nparts_equal': parity.get('nparts_equal'), 'tolerance_m': parity.get('tolerance_m'), 'source_hash': parity.get('source_hash'),
+                          'what': 'every ray of this scene against the C oracle (tools/full_scene_parity.py), made with the kernels of this source hash'}
+                         if parity is not None else {'record': None, 'note': parity_src})
         if e2e is not None:
             res['end_to_end'] = e2e
         if world == 1 and args.cpu_sample > 0:
             pp = (hts_np, cube.ray_levels(rays.ht_min, zref)[2]) if args.per_pixel_ht else None
             res['cpu_baseline'] = cpu_baseline(args, rows, cols, xpts, ypts, inc_cols, hd, nparts, zref, out_w, out_h, pp)
         os.write(result_fd, (json.dumps(res) + '\n').encode())
+    if dist_on:
+        dist.destroy_process_group()
+
+
+def run_c5(args, ctx, dev, coll_dev, dist_on, rank, world, ndev, result_fd):
+    """BASELINE configs[4]: HRRR 3-km cube (1000x1000x50, f32), two-epoch temporal interpolation (cli/raider.py:817-819), 5 M GNSS
+    station-height points.  Synthetic epochs per SURVEY 8(d) (seeds 0 and 1, weights 0.25 / 0.75) on the LCC lattice; stations
+    rng(3) uniform in the cube interior, h ~ U(0, 4000).  One step = blend the two resident epochs on this rank + gather this rank's
+    contiguous block of the station list (distributed.interp_points_sharded): station work shards with NO data-path collective,
+    the blend is replicated (every rank needs the whole blended cube)."""
+    import torch
+    import torch.distributed as dist
+    import raider_amd as R
+    from raider_amd import distributed as D
+    ny = nx = 1000; nz = 50
+    header = (ny, nx, nz, 0, nz, ny, nx)
+    xs = -1.5e6 + 3000.0 * np.arange(nx); ys = -1.5e6 + 3000.0 * np.arange(ny)
+    zs = np.round(-100.0 + 26100.0 * np.linspace(0, 1, nz) ** 2, 3)
+
+    def epoch(seed):
+        rng = np.random.default_rng(seed)
+        gh = rng.standard_normal((ny, nx)).astype(np.float32); gw = rng.standard_normal((ny, nx)).astype(np.float32)
+        z3 = zs[:, None, None]
+        hyd = (np.float32(270.0) * np.exp(-z3 / 8000.0).astype(np.float32) * (1 + np.float32(0.01) * gh[None])).astype(np.float32)
+        wet = (np.float32(60.0) * np.exp(-z3 / 2000.0).astype(np.float32) * (1 + np.float32(0.1) * gw[None])).astype(np.float32)
+        return dict(ys=ys, xs=xs, zs=zs, wet=wet, hydro=hyd)
+    epochs = [epoch(0), epoch(1)] if rank == 0 else None
+    w1, w2 = 0.25, 0.75
+    t_bcast = 0.0
+    if dist_on:
+        torch.cuda.synchronize(); dist.barrier()
+        t0 = time.perf_counter()
+        cubes = []
+        for k in range(2):                      # one packed broadcast per epoch (RCCL over xGMI), packed (y,x,z) on every rank's device
+            axes, wet, hyd = D.broadcast_cube_packed(epochs[k] if rank == 0 else None, src=0, device=coll_dev, header=header)
+            if coll_dev is None:
+                wet, hyd = wet.to(dev), hyd.to(dev)
+            cubes.append(R.Cube(ys, xs, zs, wet, hyd, order='zyx', ctx=ctx))
+        torch.cuda.synchronize()
+        t_bcast = time.perf_counter() - t0
+    else:
+        cubes = [R.Cube(ys, xs, zs, torch.from_numpy(e['wet']).to(dev), torch.from_numpy(e['hydro']).to(dev), order='zyx', ctx=ctx) for e in epochs]
+    a, b = cubes
+    n_all = int(args.stations)
+    rng = np.random.default_rng(3)
+    pts_all = np.stack([rng.uniform(-1.4e6, 1.4e6, n_all), rng.uniform(-1.4e6, 1.4e6, n_all), rng.uniform(0.0, 4000.0, n_all)], -1)   # (y, x, z), every rank the same list
+    p0, cnt = D.shard_rows(n_all, world, rank)
+    pts = torch.from_numpy(np.ascontiguousarray(pts_all[p0:p0 + cnt])).to(dev)
+    out = [None, None]
+
+    def step():
+        m = a.blend(w1, b, w2)
+        out[0], out[1] = m.interp(pts)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist_on:
+        dist.barrier()
+    ctx.set_profiling(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist_on:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    n_int, ms_int = ctx.profile_get(2)
+    ctx.set_profiling(False)
+    if dist_on:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=coll_dev if coll_dev is not None else 'cpu')
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    # the blend's own time: HIP events on the stream the kernels run on (torch's current stream here)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); keep = [a.blend(w1, b, w2) for _ in range(3)]; e1.record(); torch.cuda.synchronize()
+    blend_ms = e0.elapsed_time(e1) / 3.0
+    del keep
+    wet_t, hyd_t = out
+    if args.dump:
+        np.savez(f'{args.dump}.rank{rank}.npz', wet=wet_t.cpu().numpy(), hydro=hyd_t.cpu().numpy(), p0=p0, cnt=cnt)
+    if rank != 0:
+        if dist_on:
+            dist.destroy_process_group()
+        return
+    cells = ny * nx * nz
+    interp_ms = ms_int / args.steps
+    step_ms = dt / args.steps * 1e3
+    # algorithmic bytes of one rank's step (SURVEY 8d): blend 24 B per f32 cell (two reads, one write, both fields = 2 x 12), gather 104 B per point
+    alg_bytes = 24.0 * cells + 104.0 * cnt
+    res = {
+        'metric': 'GNSS station points/sec (two-epoch blend + wet/hydro gather) through HRRR cube; achieved HBM GB/s',
+        'value': n_all * args.steps / dt, 'unit': 'points/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': step_ms,
+        'higher_is_better': True, 'scaling': 'strong' if world > 1 else 'weak', 'vs_baseline': None, 'dtype': 'f32 blend / f64 interpolation', 'data': 'synthetic',
+        'config': {'workload': f'configs[4]: HRRR-sized 1000x1000x50 f32 cube on the 3-km LCC grid, two epochs blended ({w1}, {w2}) on every rank, {n_all} station points '
+                               f'(rng(3), h ~ U(0, 4000) m) sharded into {world} contiguous blocks, wet + hydro at every point',
+                   'stations_all_gpus': n_all, 'stations_this_rank': cnt, 'cube': '1000x1000x50 x 2 epochs',
+                   'parallelism': (f'stations sharded x{world} ({args.backend}, {ndev} device(s) visible), epochs: two packed broadcasts ({t_bcast*1e3:.1f} ms), blend replicated '
+                                   f'per rank, no data-path collective') if dist_on else 'single GPU',
+                   'ranks': world, 'backend': (dist.get_backend() if dist_on else None), 'world_size_seen_by_backend': (dist.get_world_size() if dist_on else 1),
+                   'mean_hydro': float(torch.nanmean(hyd_t).item()), 'mean_wet': float(torch.nanmean(wet_t).item()), 'nan_fraction': float(torch.isnan(hyd_t).double().mean().item())},
+        'roofline': {'bound': 'hbm', 'kernel': 'blend_kernel<float> + interp_points_kernel<float2> (one step of one rank)',
+                     'achieved': alg_bytes / ((blend_ms + interp_ms) * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                     'frac': alg_bytes / ((blend_ms + interp_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 'traffic': None,
+                     'algorithmic_bytes_per_step': alg_bytes, 'blend_ms': blend_ms, 'interp_ms_per_step': interp_ms, 'interp_launches_timed': n_int,
+                     'note': 'algorithmic bytes (24 B per cell of the blend + 104 B per station, SURVEY 8d) over the two kernels\' HIP-event time; the one-shot gather on a '
+                             'FRESH blended cube reads 4 x 128 B lines per point (572 B measured, profiles/r04_secondary.json) - the corner-quad copy only pays from the '
+                             'second query of a cube on (raider_hip.hip quad_wanted)',
+                     'source_hash': kernel_source_hash(), 'library_source_hash': R.load_library().rdr_source_hash().decode()},
+    }
+    if world == 1 and args.cpu_sample > 0:
+        from oracle import raider_oracle as O
+        t0 = time.perf_counter()
+        bw = O.blend_cubes(w1, epochs[0]['wet'], w2, epochs[1]['wet']); bh = O.blend_cubes(w1, epochs[0]['hydro'], w2, epochs[1]['hydro'])
+        t_blend = time.perf_counter() - t0
+        ns = min(cnt, 400_000)
+        ip = list(O.getInterpolators(xs, ys, zs, bw, bh))
+        t0 = time.perf_counter()
+        ow, oh = ip[0](pts_all[:ns]), ip[1](pts_all[:ns])
+        t_int = time.perf_counter() - t0
+        err = float(max(np.nanmax(np.abs(ow - wet_t[:ns].cpu().numpy())), np.nanmax(np.abs(oh - hyd_t[:ns].cpu().numpy()))))
+        res['cpu_baseline'] = {'value': ns / (t_blend * ns / n_all + t_int), 'unit': 'points/s', 'cores': 1, 'kind': 'port',
+                               'sample': f'NumPy oracle (oracle/raider_oracle.py: blend_cubes + scipy-RGI restatement), one thread: the blend of the two epochs ({t_blend:.2f} s, '
+                                         f'charged pro rata) + {ns} of the stations ({t_int:.2f} s)', 'gpu_vs_oracle_max_abs': err}
+    os.write(result_fd, (json.dumps(res) + '\n').encode())
     if dist_on:
         dist.destroy_process_group()
 

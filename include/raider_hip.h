@@ -140,6 +140,12 @@ int rdr_set_workspace_limit(rdr_ctx* ctx, int64_t bytes);
 /* Columns of the generic-ray side buffer: >= 0 fixes the capacity (0: always recompute), -1 restores the automatic sizing. */
 int rdr_set_side_capacity(rdr_ctx* ctx, int64_t columns);
 int rdr_profile_get(rdr_ctx* ctx, int which, int* count, float* total_ms);
+/* diagnostics: the shader clock the chip ACTUALLY runs at while the ctx's kernels execute (it is managed by power: fp64-dense kernels
+ * run near 2.0 GHz, not at the data sheet's 2.4).  _begin puts one sleeping wave on the ctx's copy stream for `ms` of wall time; it
+ * reads the shader-clock counter and the 100 MHz wall counter before and after.  _end waits for it and returns cycles / wall time
+ * in GHz.  Launch the kernels to be observed between the two calls. */
+int rdr_clock_sample_begin(rdr_ctx* ctx, double ms);
+int rdr_clock_sample_end(rdr_ctx* ctx, double* ghz);
 /* diagnostics: resources of the light ray kernel a GRID + look-vector batch on `cube` launches (which 0: pass 1 crossings_kernel,
  * 1: pass 2 march_kernel; 2 / 3: their per-ray-height instantiations, rdr_rays.hts), read from the loaded code object (hipFuncGetAttributes): vector registers per lane, static LDS bytes,
  * dynamic LDS bytes of the launch (axis / level tables), scratch bytes per lane, max threads per block.  Any output may be NULL. */
@@ -229,8 +235,9 @@ int rdr_interp3_project(rdr_ctx* ctx, const rdr_cube* cube, const double* y, con
  * then reads four 128 B lines per point for 16 B each.  The cube can carry a second, cell-column-major copy ("corner quads",
  * 5.3 x its bytes for f32, 8 x for f64) from which a point's eight corners are ONE line - same values, same arithmetic, 3.3 x less
  * HBM traffic.  mode 1: build it now; mode 0: free it.  Without this call rdr_interp3 builds it by itself from the second call with
- * >= 262144 points on a cube beyond 32 MB, if it fits a quarter of the free memory (env RAIDER_HIP_POINT_INDEX=0 never, =1 at the
- * first such call).  rdr_cube_point_index_bytes: bytes the copy holds now (0: none). */
+ * >= 262144 points on a cube beyond 32 MB - or at the first, when the point set is large enough that the build pays for itself within
+ * that call (n x 175 B > the copy's bytes, from the measured rates) - if it fits a quarter of the free memory (env
+ * RAIDER_HIP_POINT_INDEX=0 never, =1 at the first such call, =2 second call only).  rdr_cube_point_index_bytes: bytes the copy holds now (0: none). */
 int rdr_cube_point_index(rdr_ctx* ctx, rdr_cube* cube, int mode);
 int64_t rdr_cube_point_index_bytes(const rdr_cube* cube);
 /* _build_cube (delay.py:196-216) for model_crs == pts_crs: out[(iz*ny+iy)*nx+ix] = f(ypts[iy],xpts[ix],zpts[iz]) */

@@ -67,6 +67,8 @@ SYMBOLS = [
     ('rdr_set_side_capacity', C.c_int, [_VP, C.c_int64]),
     ('rdr_generic_ray_count', C.c_int64, [_VP]),
     ('rdr_profile_get', C.c_int, [_VP, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_float)]),
+    ('rdr_clock_sample_begin', C.c_int, [_VP, C.c_double]),
+    ('rdr_clock_sample_end', C.c_int, [_VP, c_dp]),
     ('rdr_ray_kernel_attributes', C.c_int, [_VP, _VP, C.c_int, c_ip, c_ip, c_ip, c_ip, c_ip]),
     ('rdr_cube_create', C.c_int, [_VP, _VP, C.c_int64, _VP, C.c_int64, _VP, C.c_int64, _VP, _VP, C.c_int,
                                   C.c_int64, C.c_int64, C.c_int64, C.c_int, C.POINTER(_VP)]),
@@ -302,6 +304,17 @@ class Context:
     def generic_ray_count(self):
         """Rays the last synchronising ray pass 1 left to the generic-geodesy kernels (diagnostics)."""
         return int(self.lib.rdr_generic_ray_count(self.handle))
+
+    def clock_sample(self, ms):
+        """Start sampling the shader clock for `ms` milliseconds of wall time (one sleeping wave on the copy stream); returns a
+        function that waits for the sample and gives the clock in GHz - call it after the kernels to be observed."""
+        check(self.lib.rdr_clock_sample_begin(self.handle, float(ms)), self.handle)
+
+        def end():
+            g = C.c_double()
+            check(self.lib.rdr_clock_sample_end(self.handle, C.byref(g)), self.handle)
+            return float(g.value)
+        return end
 
     def profile_get(self, which):
         """(launch count, total ms) of kernel kind `which` since set_profiling(True)."""

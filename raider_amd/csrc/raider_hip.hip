@@ -56,9 +56,10 @@ struct rdr_ctx {
     DevBuf side;                              // level crossings of the generic rays (compact columns of K+1 doubles)
     int64_t side_cap = 0;                     // columns of `side` in the current layout
     int* d_sidectr = nullptr;                 // [1] next free column
-    int* h_word = nullptr;                    // [4] page-locked host words: flags read back WITHOUT stalling the host before the final sync
+    int* h_word = nullptr;                    // [16] page-locked host words: flags read back WITHOUT stalling the host before the final sync
     int64_t side_forced = -1;                 // rdr_set_side_capacity
     int64_t last_nslow = 0;                   // generic rays seen by the last pass 1 whose count the host happened to read back
+    int wall_khz = 0;                         // rate of the wall counter (rdr_clock_sample_begin)
     int last_nan_output = -1;                 // rdr_build_cube (host arrays): 1 / 0 = its last result holds / does not hold a NaN; -1 unknown
     size_t ws_limit = (size_t)48 << 30;       // cap on that workspace; bigger batches are marched in chunks
     // which ray batch the stored records belong to (a later rdr_ray_march reuses them only for the identical batch)
@@ -228,7 +229,7 @@ int rdr_create(int device, rdr_ctx** out) {
         HIPCHECK(nullptr, hipMalloc((void**)&c->d_tilectr, 32 * sizeof(int)));
         HIPCHECK(nullptr, hipMalloc((void**)&c->d_sidectr, sizeof(int)));
         HIPCHECK(nullptr, hipMemset(c->d_sidectr, 0, sizeof(int)));
-        HIPCHECK(nullptr, hipHostMalloc((void**)&c->h_word, 4 * sizeof(int), hipHostMallocDefault));
+        HIPCHECK(nullptr, hipHostMalloc((void**)&c->h_word, 16 * sizeof(int), hipHostMallocDefault));
         HIPCHECK(nullptr, hipMemset(c->d_nslow, 0, sizeof(int)));
         return RDR_OK;
     }();
@@ -321,6 +322,41 @@ int rdr_set_profiling(rdr_ctx* c, int on) {
     if (!c) return fail(nullptr, RDR_ERR_INVALID, "ctx is NULL");
     c->profiling = on != 0;
     for (auto& u : c->ev_used) u = 0;
+    return RDR_OK;
+}
+
+// Shader clock while other kernels run: ONE wave on the copy stream sleeps for `ms` of wall time and reads the shader-clock counter
+// (s_memtime) and the 100 MHz wall counter (s_memrealtime) before and after - cycles per wall tick = the clock the chip actually ran
+// at during those milliseconds (under fp64-dense kernels it sits near 2.0 GHz, not at the 2.4 GHz of the data sheet).
+__global__ void clock_sample_kernel(long long wall_ticks, long long* out) {
+    if (threadIdx.x != 0) return;
+    const long long c0 = clock64(), w0 = wall_clock64();
+    while (wall_clock64() - w0 < wall_ticks) __builtin_amdgcn_s_sleep(127);
+    const long long c1 = clock64(), w1 = wall_clock64();
+    out[0] = c1 - c0; out[1] = w1 - w0;
+}
+
+int rdr_clock_sample_begin(rdr_ctx* c, double ms) {
+    if (!c || !(ms > 0) || ms > 60000.0) return fail(c, RDR_ERR_INVALID, "rdr_clock_sample_begin: NULL context or a duration outside (0, 60000] ms");
+    HIPCHECK(c, hipSetDevice(c->device));
+    int khz = 0;
+    HIPCHECK(c, hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device));
+    if (khz <= 0) return fail(c, RDR_ERR_HIP, "rdr_clock_sample_begin: the device reports no wall-clock rate");
+    long long* out = reinterpret_cast<long long*>(c->h_word + 4);      // (page-locked and device-visible: the wave writes it directly)
+    out[0] = 0; out[1] = 0;
+    c->wall_khz = khz;
+    hipLaunchKernelGGL(clock_sample_kernel, dim3(1), dim3(64), 0, c->copy_stream, (long long)(ms * khz), out);
+    HIPCHECK(c, hipGetLastError());
+    return RDR_OK;
+}
+
+int rdr_clock_sample_end(rdr_ctx* c, double* ghz) {
+    if (!c || !ghz) return fail(c, RDR_ERR_INVALID, "rdr_clock_sample_end: NULL argument");
+    HIPCHECK(c, hipSetDevice(c->device));
+    HIPCHECK(c, hipStreamSynchronize(c->copy_stream));
+    const long long* out = reinterpret_cast<const long long*>(c->h_word + 4);
+    if (out[1] <= 0 || c->wall_khz <= 0) return fail(c, RDR_ERR_INVALID, "rdr_clock_sample_end: no sample was started on this context");
+    *ghz = (double)out[0] / ((double)out[1] / (c->wall_khz * 1e3)) / 1e9;
     return RDR_OK;
 }
 
@@ -763,10 +799,12 @@ static int quad_build(rdr_ctx* c, const rdr_cube* q) {
 
 // Policy of the automatic build: only for point sets and cubes large enough that the four-lines-per-point gather is what bounds
 // the call (>= 256 k points, a cube beyond 32 MB - smaller ones live in L2 / the Infinity Cache), only when the copy fits a quarter
-// of the free memory.  When: at the FIRST such call if the direct gather of THIS point set would already move 1.5 x the bytes the
-// build writes (572 B per point measured against 5.3-8 x the cube: 5 M stations on the 400 MB HRRR-sized cube, 2.9 GB against 2.2 GB
-// - round 4), else from the second call on the cube (a cube queried once with few points never pays for the copy).
-// RAIDER_HIP_POINT_INDEX=0 never, =1 at the first large call, =2 the round-3 rule (second call only).
+// of the free memory.  When: by TIME, from the measured rates (profiles/r03_secondary.json, r04_secondary.json: 5 M stations on the
+// 400 MB HRRR-sized cube) - the direct gather moves 572 B per point at 6.5 TB/s (88 ps), the quad gather 168 B at 5.65 TB/s (30 ps),
+// the build writes the copy at 3.0 TB/s: building at the FIRST large call pays when n x 58 ps > bytes / 3.0 TB/s, i.e. n x 175 B >
+// the copy's bytes (12 M points for that cube; a 5 M-station one-shot is FASTER from the (y,x,z) cube: 0.43 ms against 0.72 + 0.15 -
+// fewer HBM bytes per point is not the goal, time is), else from the second large call on the cube (then the copy has paid for itself
+// by the end of that call).  RAIDER_HIP_POINT_INDEX=0 never, =1 at the first large call, =2 second call only.
 static bool quad_wanted(rdr_ctx* c, const rdr_cube* q, int64_t n) {
     if (q->d_quad) return true;
     static const int env = []() { const char* e = std::getenv("RAIDER_HIP_POINT_INDEX"); return e ? std::atoi(e) : -1; }();
@@ -774,7 +812,7 @@ static bool quad_wanted(rdr_ctx* c, const rdr_cube* q, int64_t n) {
     const size_t cube_bytes = (size_t)q->ny * q->nx * q->nz * (q->dtype == RDR_F32 ? 8 : 16);
     if (n < (1 << 18) || cube_bytes < ((size_t)32 << 20) || q->ny < 2 || q->nx < 2 || q->nz < 2) return false;
     int nblk; const size_t need = quad_need_bytes(q, &nblk);
-    const bool pays_now = env != 2 && (double)n * 572.0 > 1.5 * (double)need;
+    const bool pays_now = env != 2 && (double)n * 175.0 > (double)need;
     if (++q->big_point_calls < 2 && env != 1 && !pays_now) return false;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || need > free_b / 4) return false;

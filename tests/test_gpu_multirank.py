@@ -66,3 +66,27 @@ def test_per_pixel_heights_across_two_ranks(tmp_path):
     assert np.array_equal(a['nparts'], b0['nparts']) and np.array_equal(a['nparts'], b1['nparts'])
     assert np.array_equal(a['hydro'], np.concatenate([b0['hydro'], b1['hydro']])) and np.array_equal(a['wet'], np.concatenate([b0['wet'], b1['wet']]))
     assert np.isfinite(a['hydro']).all()
+
+
+def test_c5_station_workload_across_two_ranks(tmp_path):
+    """`bench.py --workload c5 --gpus 2` = BASELINE configs[4] launched as the driver would launch it: the two epochs go out in two
+    packed broadcasts, every rank blends them and gathers its contiguous block of the station list - no data-path collective.  The
+    two blocks together equal the one-rank result bit for bit; `value` counts the job's stations once (strong scaling)."""
+    def run(tag, *args):
+        out = subprocess.run([sys.executable, str(ROOT / 'bench.py'), '--workload', 'c5', '--stations', '400001', '--steps', '2', '--warmup', '1', '--cpu-sample', '0',
+                              '--dump', str(tmp_path / tag)] + list(args), capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-4000:])
+        lines = out.stdout.splitlines()
+        assert len(lines) == 1 and lines[0].startswith('{'), out.stdout[-2000:]
+        return json.loads(lines[0])
+    one = run('one', '--gpus', '1')
+    two = run('two', '--gpus', '2')
+    assert one['unit'] == 'points/s' and one['n_gpus'] == 1 and two['n_gpus'] == 2 and two['scaling'] == 'strong'
+    assert 'configs[4]' in two['config']['workload'] and two['config']['stations_all_gpus'] == 400001 and two['config']['stations_this_rank'] == 200001
+    assert two['config']['world_size_seen_by_backend'] == 2 and abs(two['value'] * two['ms_per_step'] * 1e-3 - 400001) < 1.0
+    assert two['roofline']['bound'] == 'hbm' and 0 < two['roofline']['frac'] < 1 and two['roofline']['unit'] == 'GB/s'
+    a = np.load(tmp_path / 'one.rank0.npz')
+    b0, b1 = np.load(tmp_path / 'two.rank0.npz'), np.load(tmp_path / 'two.rank1.npz')
+    assert int(b0['cnt']) == 200001 and int(b1['p0']) == 200001 and int(b1['cnt']) == 200000
+    assert np.array_equal(a['wet'], np.concatenate([b0['wet'], b1['wet']])) and np.array_equal(a['hydro'], np.concatenate([b0['hydro'], b1['hydro']]))
+    assert np.isfinite(a['hydro']).all() and a['hydro'].mean() > 50.0          # (refractivities, not delays: N units)

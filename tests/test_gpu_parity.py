@@ -432,11 +432,11 @@ def test_point_index_is_built_by_the_second_large_call(R):
     r3 = cube.interp(small)
     torch.cuda.synchronize()
     assert torch.equal(r1[0], r2[0]) and torch.equal(r1[1], r2[1]) and torch.isfinite(r3[0]).all()
-    # round 4: a point set whose direct gather would already move 1.5 x the bytes the copy costs builds it at the FIRST call
-    # (572 B per point against (ny-1)(nx-1) nblk 128 B: 197 MB here -> from 517 k points on); same bits as the direct gather
+    # round 4: a point set so large that the build pays for itself WITHIN the call (by time, from the measured rates: n x 175 B > the
+    # copy's 197 MB here -> from 1.13 M points on) builds it at the FIRST call; same bits as the direct gather
     cube2 = R.Cube(ys, xs, zs, w, h, order='yxz')
     held2 = lambda: cube2.ctx.lib.rdr_cube_point_index_bytes(cube2.handle)
-    n2 = 600000
+    n2 = 1300000
     huge = torch.from_numpy(np.stack([rng.uniform(30, 40, n2), rng.uniform(-120, -110, n2), rng.uniform(0, 9000, n2)], -1)).to(dev)
     direct = cube2.interp(huge[:200000].contiguous())
     assert held2() == 0

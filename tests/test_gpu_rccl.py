@@ -122,6 +122,26 @@ def test_bench_n1_through_rccl_equals_plain_run(tmp_path):
     assert rccl['value'] > 0.5 * plain['value']        # a one-rank all-reduce between the passes must not serialise the step
 
 
+def test_bench_c5_through_one_rank_rccl_group(tmp_path):
+    """BASELINE configs[4] (`bench.py --workload c5`) through the nccl backend on the one GPU of this box: two packed epoch broadcasts
+    over RCCL, per-rank blend, sharded station gather - the line the first 8-GPU SCALE run can use - equals the plain run bit for bit,
+    and the oracle (blend_cubes + the scipy-RGI restatement) on a sample of the stations."""
+    def run(tag, *args):
+        out = subprocess.run([sys.executable, str(ROOT / 'bench.py'), '--workload', 'c5', '--stations', '300000', '--steps', '2', '--warmup', '1',
+                              '--dump', str(tmp_path / tag)] + list(args), capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-4000:])
+        lines = out.stdout.splitlines()
+        assert len(lines) == 1 and lines[0].startswith('{'), out.stdout[-2000:]
+        return json.loads(lines[0])
+    plain = run('plain', '--cpu-sample', '1')
+    rccl = run('rccl', '--force-dist', '--backend', 'nccl', '--cpu-sample', '0')
+    assert plain['config']['backend'] is None and rccl['config']['backend'] == 'nccl' and rccl['config']['world_size_seen_by_backend'] == 1
+    assert plain['cpu_baseline']['kind'] == 'port' and plain['cpu_baseline']['gpu_vs_oracle_max_abs'] < 1e-9      # N units: 1e-9 of ~300
+    assert plain['metric'].startswith('GNSS station points/sec') and plain['roofline']['source_hash'] == plain['roofline']['library_source_hash']
+    a, b = np.load(tmp_path / 'plain.rank0.npz'), np.load(tmp_path / 'rccl.rank0.npz')
+    assert np.array_equal(a['wet'], b['wet']) and np.array_equal(a['hydro'], b['hydro']) and np.isfinite(a['wet']).all()
+
+
 def test_loaded_library_was_built_from_this_tree():
     """The binary the tests run carries the digest of the sources it was compiled from; it must be the tree's."""
     sys.path.insert(0, str(ROOT))

@@ -72,6 +72,24 @@ res['quad_build_kernel'] = dict(what='corner-quad copy of the 1000x1000x50 f32 c
 t = timed(lambda: m.interp(pts))
 res['interp_points_quad_kernel'] = dict(what='configs[4]: the same 5 M points gathered from the corner-quad copy (one 128 B line per point)', units=npt, unit='points', bytes_per_unit=104,
                                         wall_ms=t * 1e3, reps=REPS + 1)
+# ---- the FIRST large call on a fresh cube, both ways: device time from HIP events around the calls -----------
+def first_call(env_mode):
+    m2 = a.blend(0.25, b, 0.75)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    if env_mode == 'build':
+        m2.point_index()
+    r = m2.interp(pts)
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1), r
+fd = min(first_call('direct')[0] for _ in range(3))
+fb = min(first_call('build')[0] for _ in range(3))
+rd, rb = first_call('direct')[1], first_call('build')[1]
+res['first_call_5M_stations'] = dict(what='ONE rdr_interp3 call of 5 M stations on a FRESH blended 1000x1000x50 f32 cube (device events, best of 3): gathered from the (y,x,z) '
+                                          'cube, against building the corner-quad copy first', direct_ms=fd, build_then_quad_ms=fb,
+                                     same_bits=bool(torch.equal(rd[0], rb[0]) and torch.equal(rd[1], rb[1])),
+                                     policy='time-based (raider_hip.hip quad_wanted): build at the first call only when n x 175 B > the copy\'s bytes (12 M points here)')
 del a, b, m, pts
 # ---- cube producer: 300 x 300 columns, 137 model levels -> 145 levels -------------------------------------------------------------
 from raider_amd.weather import cubes_from_model_levels, MODEL_LEVEL_HEIGHTS  # noqa: E402

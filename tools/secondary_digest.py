@@ -9,14 +9,17 @@ import sys
 from pathlib import Path
 
 REPO = Path(__file__).resolve().parent.parent
+TAG = sys.argv[1] if len(sys.argv) > 1 else 'r04'        # round prefix of the files written under profiles/
 src = REPO / 'gpurun_out' / 'secondary'
 line = [ln for ln in (src / 'bench.json').read_text().splitlines() if ln.startswith('{')][-1]
 res = json.loads(line)
 stats = max(glob.glob(str(src / 'kt') + '/**/*kernel_stats.csv', recursive=True), key=lambda f: Path(f).stat().st_mtime)   # (gpurun merges runs: newest)
-subprocess.run([sys.executable, str(REPO / 'tools' / 'rocprof_summary.py'), stats, str(REPO / 'profiles' / 'r03_secondary_kernel_stats.txt'),
+subprocess.run([sys.executable, str(REPO / 'tools' / 'rocprof_summary.py'), stats, str(REPO / 'profiles' / f'{TAG}_secondary_kernel_stats.txt'),
                 'tools/secondary_bench.py: configs 2 / 5 sizes, producer, orbit look vectors'], check=True, stdout=subprocess.DEVNULL)
 rows = list(csv.DictReader(open(stats)))
 for k, d in res.items():
+    if 'units' not in d:
+        continue
     cand = [r for r in rows if k in r['Name']]
     if not cand:
         continue
@@ -38,6 +41,8 @@ def pmc(sub, counter):
 
 fetch, write = pmc('fetch', 'FETCH_SIZE'), pmc('write', 'WRITE_SIZE')
 for k, d in res.items():
+    if 'units' not in d:
+        continue
     fr = [v for name, vals in fetch.items() if k in name for v in vals]
     wr = [v for name, vals in write.items() if k in name for v in vals]
     if fr and wr and 'rocprof_avg_us' in d:
@@ -64,6 +69,8 @@ for sub in ('sq1', 'sq2'):
     for (name, cn), vals in sq(sub).items():
         sqc.setdefault(name, {})[cn] = sorted(vals)[len(vals) // 2]
 for k, d in res.items():
+    if 'units' not in d:
+        continue
     hit = [v for name, v in sqc.items() if k in name]
     if not hit or 'rocprof_avg_us' not in d:
         continue
@@ -81,6 +88,11 @@ for k, d in res.items():
             d[key] = v[cn]
     if 'hbm_read_bytes' in d:
         d['hbm_bytes_per_unit'] = (d['hbm_read_bytes'] + d['hbm_write_bytes']) / d['units']
-(REPO / 'profiles' / 'r03_secondary.json').write_text(json.dumps(res, indent=1) + '\n')
+sys.path.insert(0, str(REPO))
+from raider_amd import _lib                                   # noqa: E402
+res['source_hash'] = _lib.source_hash()
+(REPO / 'profiles' / f'{TAG}_secondary.json').write_text(json.dumps(res, indent=1) + '\n')
 for k, d in res.items():
+    if not isinstance(d, dict) or 'unit' not in d:
+        continue
     print(f"{k:24s} {d.get('rocprof_avg_us', float('nan')):10.1f} us  {d.get('units_per_s', 0)/1e9:8.2f} G {d['unit']}/s  {d.get('algorithmic_GBps', 0):9.1f} GB/s  = {d.get('frac_of_hbm_peak_8TBps', 0):.3f} of 8 TB/s;  measured HBM {d.get('hbm_measured_GBps', float('nan')):8.1f} GB/s = {d.get('hbm_measured_frac', float('nan')):.3f} ({d.get('hbm_bytes_per_unit', float('nan')):.1f} B/{d['unit'][:-1]});  VALU issue {d.get('valu_issue_frac', float('nan')):.3f} ({d.get('valu_instr_per_unit', float('nan')):.0f} lane-instr/{d['unit'][:-1]})")
