@@ -1375,6 +1375,8 @@ static int launch_crossings(rdr_ctx* c, const rdr_cube* q, RayParams P, int64_t 
 
 static int launch_march(rdr_ctx* c, const rdr_cube* q, RayParams P, int64_t tb, int64_t tc, int64_t nslots_total = 0) {
     P.tile_begin = tb; P.tile_count = tc; P.nslots = nslots_total > 0 ? nslots_total : tc * BLOCK;
+    static const int stage_f64 = []() { const char* e = std::getenv("RAIDER_HIP_F64_STAGE"); return e ? std::atoi(e) : 1; }();
+    P.stage_f64 = stage_f64;
     const int g = ray_grid(c, tc, 8);
     HIPCHECK(c, hipMemsetAsync(c->d_tilectr + 16, 0, 16 * sizeof(int), c->stream));
     P.tile_ctr = c->d_tilectr + 16;

@@ -442,6 +442,7 @@ struct RayParams {
     double* wet; double* hyd;
     // tiling of the whole batch
     int64_t ntiles; int tiles_x;
+    int stage_f64;                     // light march on f64 cubes: stage every level's footprint of a wave in LDS (0: the direct gathers)
 };
 
 // The slice-uniform level table of build_ray (losreader.py:785-808), computed by one thread into LDS from the LDS z table.
@@ -974,6 +975,11 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
     if (GRID == 2) { c.exact_y = 0; c.exact_x = 0; c.uni_y = 1; c.uni_x = 1; c.small = 1; }
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const RaySmem m = carve_smem(smem_raw, c.ny, c.nx, c.nz, c.exact_y, c.exact_x);
+    // f64 cubes on exactly uniform axes (round 4): a wave's footprint of one model level - 4 x 4 cube columns x 3 z entries of 16 B -
+    // staged in LDS, the eight corners of every sample of the level read from there (STAGED below)
+    constexpr bool STAGED = !SLOW && !PR && REGULAR && sizeof(T2) == 16;
+    constexpr int STAGE_N = 48;                        // [z 0..2][y 0..3][x 0..3]
+    __shared__ T2 s_stage[STAGED ? (BLOCK / 64) * STAGE_N : 1];
     fill_axes(c, m);
     const int tid = threadIdx.x;
     int K = 0, slice = -1;
@@ -1210,7 +1216,132 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
                 for (int n = 0; n < PX; ++n) xs += fabs(xc[n]);
                 lane_safe = (mine || !active) && (fabs(u0r) <= 1.001) && (fabs(u1r) <= 1.001) && (xs <= 1.001) && inside(q.lat, c.ny) && inside(q.lon, c.nx);
             }
-            if (REGULAR && __all(lane_safe)) run(std::integral_constant<bool, true>{});
+            // ---- f64 cubes: the level's footprint through LDS --------------------------------------------------------------------
+            // An f64 cube doubles the bytes of every gather (4 x 32 B per lane and sample): the instantiation is bound by the vector L1's
+            // 64 B/clk return path, not by instruction issue (6.8 against 5.0 ms per 16 M rays, round 3).  But the 64 rays of a wave
+            // (4 x 16 neighbouring pixels) sit in one or two cube cells at any given level: per level the wave loads the 4 x 4 columns
+            // around lane 0's cell, z entries zb .. zb+2 (48 lanes, ONE 16 B load each), into LDS and every sample of the level reads
+            // its eight corners from there (128 B/clk, broadcast) - same operands, same arithmetic: the same bits.  A sample whose
+            // cell leaves the staged block for ANY lane of the wave (coarse scenes, large look-angle gradients) takes the direct
+            // gathers, wave-uniformly.  Only for waves with the no-check proof above (cells inside the cube by construction).
+            auto run_staged = [&]() {
+                T2* const st = s_stage + (tl >> 6) * STAGE_N;
+                const int lane = tl & 63;
+                unsigned lane_off = ((unsigned)((lane >> 2) & 3) * (unsigned)c.nx + (unsigned)(lane & 3)) * (unsigned)c.nz + (unsigned)(lane >> 4);
+                asm volatile("" : "+v"(lane_off));        // (opaque: the block's base below stays ONE scalar product, not two vector multiplies per level)
+                const bool loader = lane < STAGE_N;
+                bool stage_on = true;                     // wave-uniform: off for the rest of the tile once a level's cells leave the block
+                                                          // (the footprint is set by scene spacing / cube spacing: a coarse scene never fits)
+                const char* const vb = reinterpret_cast<const char*>(c.v);
+                const size_t rowx = (size_t)c.nz * sizeof(T2), rowy = (size_t)c.nx * rowx;
+                int fy0 = 0, fx0 = 0, zb = 0;
+                // the eight corners of the sample in cell (iy, ix, iz): from the staged block when every lane's cell is in it
+                auto fetch = [&](int iy, int ix, int iz, PendingSample<T2>& sm) {
+                    const unsigned ry = (unsigned)(iy - fy0), rx = (unsigned)(ix - fx0), rz = (unsigned)(iz - zb);
+                    bool staged_here = false;
+                    if (stage_on) {
+                        const bool out = active & (max(max(ry, rx), rz + 1u) > 2u);
+                        staged_here = __builtin_amdgcn_ballot_w64(out) == 0;
+                        stage_on = staged_here;
+                    }
+                    if (staged_here) {
+                        // (an LDS-address-space pointer, and a fence: left as a generic pointer the two branches' loads are merged into
+                        // ONE set of flat loads behind a pointer select - LDS data through the flat path, slower than the gathers)
+                        typedef decltype(T2().x) S1;
+                        typedef S1 S2 __attribute__((ext_vector_type(2)));
+                        typedef __attribute__((address_space(3))) S2 LdsS2;
+                        const LdsS2* p = (const LdsS2*)st + (active ? (rz * 16u + ry * 4u + rx) : 0u);
+                        auto get = [&](int i_, int o_) { const S2 t_ = p[o_]; sm.v[i_].x = t_.x; sm.v[i_].y = t_.y; };
+                        get(0, 0); get(1, 16); get(2, 1); get(3, 17); get(4, 4); get(5, 20); get(6, 5); get(7, 21);
+                        asm volatile("" ::: "memory");
+                    } else {
+                        const unsigned off = (__umul24(__umul24((unsigned)iy, (unsigned)c.nx) + (unsigned)ix, (unsigned)c.nz) + (unsigned)iz) * (unsigned)sizeof(T2);
+                        const T2* p00 = reinterpret_cast<const T2*>(vb + off);
+                        const T2* p01 = reinterpret_cast<const T2*>(vb + rowx + off);
+                        const T2* p10 = reinterpret_cast<const T2*>(vb + rowy + off);
+                        const T2* p11 = reinterpret_cast<const T2*>(vb + rowy + rowx + off);
+                        sm.v[0] = p00[0]; sm.v[1] = p00[1]; sm.v[2] = p01[0]; sm.v[3] = p01[1];
+                        sm.v[4] = p10[0]; sm.v[5] = p10[1]; sm.v[6] = p11[0]; sm.v[7] = p11[1];
+                    }
+                };
+                auto finish = [&](const PendingSample<T2>& sm, double wv) {
+                    double vw, vh;
+                    sample_finish_lerp(sm, vw, vh);
+                    acc_w = fma(wv, vw, acc_w); acc_h = fma(wv, vh, acc_h);
+                };
+                int np = __builtin_amdgcn_readfirstlane(m.np[0]);
+                int kz = __builtin_amdgcn_readfirstlane(m.kz[0]);
+                double step = m.step[0], hs = m.hs[0];
+                double u_k = w[(int64_t)WS_U0 * ns];
+                double u_last = w[(int64_t)WS_U1 * ns];
+                double du = u_last - u_k;
+                if (K > 0) {                              // the ray's very first sample: direct gathers (its z window may start one interval lower)
+                    PendingSample<T2> s0;
+                    double ph = poly5(q.h, fma(0.0 * step, du, u_k));
+                    const double plat = poly5(q.lat, fma(0.0 * step, du, u_k)), plon = poly5(q.lon, fma(0.0 * step, du, u_k));
+                    if (clamp_lo) { asm volatile("" ::: "memory"); ph = fmax(ph, c.z_lo); }
+                    sample_issue<T2, 1, true>(c, m.ax, plat, plon, ph, window2_base(c.nz, kz - ((m.lo[0] <= m.ax.ez[kz].x) ? 1 : 0)), s0);
+                    finish(s0, hs * du);
+                }
+#pragma unroll 1
+                for (int k = 0; k < K; ++k) {
+                    zb = window2_base(c.nz, kz);
+                    const bool more = k + 1 < K;
+                    const double w_mid = (2.0 * hs) * du;
+                    // the level's TOP sample first: its cell places the staged block
+                    PendingSample<T2> top;
+                    double ph = poly5(q.h, u_k + du);
+                    const double plat = poly5(q.lat, u_k + du), plon = poly5(q.lon, u_k + du);
+                    if (clamp_hi && !more) { asm volatile("" ::: "memory"); ph = fmin(ph, c.z_hi); }
+                    int iy, ix, iz;
+                    cell_xy<true, true>(m.ax.ey, c.ny, plat, c.y_lo, c.y_hi, c.inv_dy, true, true, iy, top.ty);
+                    cell_xy<true, true>(m.ax.ex, c.nx, plon, c.x_lo, c.x_hi, c.inv_dx, true, true, ix, top.tx);
+                    window2_cell(m.ax.ez, c.nz, ph, zb, c.nz >= 4, iz, top.tz);
+                    if (stage_on) {
+                        fy0 = min(max(__builtin_amdgcn_readfirstlane(iy) - 1, 0), c.ny - 4);
+                        fx0 = min(max(__builtin_amdgcn_readfirstlane(ix) - 1, 0), c.nx - 4);
+                        const unsigned base = (unsigned)__builtin_amdgcn_readfirstlane((fy0 * c.nx + fx0) * c.nz + zb);
+                        __builtin_amdgcn_wave_barrier();          // (the previous level's readers are done: same wave, program order)
+                        if (loader) st[lane] = c.v[base + lane_off];
+                        __builtin_amdgcn_wave_barrier();
+                    }
+#pragma unroll 1
+                    for (int j = 1; j < np - 1; ++j) {
+                        PendingSample<T2> sm;
+                        const double us = fma((double)j * step, du, u_k);
+                        const double mh = poly5(q.h, us), mlat = poly5(q.lat, us), mlon = poly5(q.lon, us);
+                        int my, mx, mz = kz;
+                        cell_xy<true, true>(m.ax.ey, c.ny, mlat, c.y_lo, c.y_hi, c.inv_dy, true, true, my, sm.ty);
+                        cell_xy<true, true>(m.ax.ex, c.nx, mlon, c.x_lo, c.x_hi, c.inv_dx, true, true, mx, sm.tx);
+                        const double2 e0 = m.ax.ez[kz];
+                        sm.tz = (mh - e0.x) * e0.y;
+                        if (!(sm.tz >= 0.0) || !(sm.tz <= 1.0)) cell_exact(m.ax.ez, c.nz, mh, mz, sm.tz);   // rare
+                        fetch(my, mx, mz, sm);
+                        finish(sm, w_mid);
+                    }
+                    fetch(iy, ix, iz, top);
+                    double du1 = 0.0, hs1 = 0.0;
+                    double w_top = hs * du;
+                    if (more) {
+                        const double t2 = poly7(xc, m.xv[k + 1]);
+                        du1 = t2 - u_last; u_last = t2; hs1 = m.hs[k + 1];
+                        w_top = fma(hs1, du1, w_top);
+                    }
+                    finish(top, w_top);
+                    u_k += du; du = du1; hs = hs1;
+                    if (more) {
+                        np = __builtin_amdgcn_readfirstlane(m.np[k + 1]);
+                        kz = __builtin_amdgcn_readfirstlane(m.kz[k + 1]);
+                        step = m.step[k + 1];
+                    }
+                }
+            };
+            if (REGULAR && __all(lane_safe)) {
+                if constexpr (STAGED) {
+                    if (P.stage_f64 && c.ny >= 4 && c.nx >= 4) run_staged();
+                    else run(std::integral_constant<bool, true>{});
+                } else run(std::integral_constant<bool, true>{});
+            }
             else run(std::integral_constant<bool, false>{});
             acc_w *= scale; acc_h *= scale;
         } else {

@@ -444,3 +444,34 @@ def test_point_index_is_built_by_the_second_large_call(R):
     assert held2() == held()
     torch.cuda.synchronize()
     assert torch.equal(q1[0][:200000], direct[0]) and torch.equal(q1[1][:200000], direct[1])
+
+
+def test_f64_cube_marcher_lds_staging_gives_the_f32_kernels_bits(R):
+    """Round 4: on f64 cubes the light marcher stages every level's footprint of a wave (4 x 4 columns x 3 z entries) in LDS and reads
+    the samples' corners from there; samples whose cells leave the block take the direct gathers.  An f64 cube holding f32 values
+    widened gives the f32 kernel the SAME operands (its f32 -> f64 conversions are exact), so the two instantiations must agree
+    bit for bit - on a fine scene (staging engaged everywhere), a scene hugging the cube's corner (block origin clamped at the
+    first / last columns), a coarse scene (a wave spans several cells: staging switches itself off) and across the level count."""
+    import torch
+    from raider_amd.synthetic import synthetic_cube
+    dev = torch.device('cuda:0')
+    c = synthetic_cube(60, 64, 48, seed=5)
+    w32 = torch.from_numpy(c['wet']).to(dev); h32 = torch.from_numpy(c['hydro']).to(dev)
+    c32 = R.Cube(c['ys'], c['xs'], c['zs'], w32, h32, order='zyx')
+    c64 = R.Cube(c['ys'], c['xs'], c['zs'], w32.double(), h32.double(), order='zyx')
+    assert c64.dtype == np.float64 and c32.dtype == np.float32
+    zref = float(c['zs'].max() - 1)
+    dy = c['ys'][1] - c['ys'][0]; dx = c['xs'][1] - c['xs'][0]
+    scenes = {
+        'fine': (np.linspace(-118.0, -117.6, 400), np.linspace(33.4, 33.1, 320)),                                   # 0.001 deg pixels: a wave sits in 1-2 cells
+        'corner': (np.linspace(c['xs'][0] + 0.02 * dx, c['xs'][0] + 1.9 * dx, 256), np.linspace(c['ys'][-1] - 0.03 * dy, c['ys'][-1] - 2.2 * dy, 192)),
+        'coarse': (np.linspace(-119.5, -115.5, 300), np.linspace(34.5, 31.5, 280)),                                   # 0.013 deg pixels: several cells per wave
+    }
+    for name, (xp, yp) in scenes.items():
+        for inc, hd in ((39.0, -167.9), (20.0, 12.0)):
+            for ht in (0.0, 1500.0):
+                a = c32.raytrace(R.Rays.grid(xp, yp, inc=inc, hd=hd), ht, zref)
+                b = c64.raytrace(R.Rays.grid(xp, yp, inc=inc, hd=hd), ht, zref)
+                assert np.array_equal(a[2], b[2]), (name, inc, ht)
+                assert np.array_equal(a[0], b[0], equal_nan=True) and np.array_equal(a[1], b[1], equal_nan=True), (name, inc, ht)
+                assert np.isfinite(a[1]).mean() > (0.3 if name == 'corner' else 0.9)
