@@ -52,6 +52,12 @@ struct rdr_ctx {
     int* d_nparts = nullptr;                  // [MAX_LEVELS] (rdr_ray_march's host-given partition)
     int* d_nslow = nullptr;                   // [1] rays sent to the generic kernels by the last pass 1
     int* d_tilectr = nullptr;                 // [4][8] per-XCD tile counters of the four ray-kernel launches of a step
+    // value buffers of destroyed cubes, kept for the next cube of the same size: a job that blends / builds a cube per date or per call
+    // (cli/raider.py:817-819, the intermediate cubes of the point branch) then allocates nothing - hipMalloc + hipFree of a 400 MB cube
+    // are 0.2 ms of host time AND a device-wide synchronisation.  A buffer is handed on with the event recorded when its cube died.
+    struct PoolEntry { void* p; size_t bytes; hipEvent_t ev; };
+    std::vector<PoolEntry> cube_pool;
+    size_t cube_pool_bytes = 0, cube_pool_limit = (size_t)4 << 30;
     DevBuf ws;                                // pass 1 -> pass 2 workspace (field-major ray records, 232 B per ray)
     DevBuf side;                              // level crossings of the generic rays (compact columns of K+1 doubles)
     int64_t side_cap = 0;                     // columns of `side` in the current layout
@@ -85,6 +91,7 @@ struct rdr_cube {
     mutable int big_point_calls = 0;             // rdr_interp3 calls that would have profited
     mutable std::mutex quad_mutex;               // one builder of the quad copy per cube
     bool has_nan = false;                        // a NaN among the fields (seen while packing; blends: unknown -> false)
+    size_t alloc_bytes = 0;                      // bytes of the ONE allocation behind d_vals (values | axes); 0: not owned (scratch cube)
 };
 
 static int fail(rdr_ctx* ctx, int code, const std::string& msg) {
@@ -235,6 +242,7 @@ int rdr_create(int device, rdr_ctx** out) {
     }();
     if (rc) { rdr_destroy(c); return rc; }
     if (const char* e = std::getenv("RAIDER_HIP_WORKSPACE_BYTES")) c->ws_limit = (size_t)std::strtoull(e, nullptr, 10);
+    if (const char* e = std::getenv("RAIDER_HIP_CUBE_POOL_BYTES")) c->cube_pool_limit = (size_t)std::strtoull(e, nullptr, 10);
     *out = c;
     return RDR_OK;
 }
@@ -244,6 +252,7 @@ void rdr_destroy(rdr_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto& b : c->slot) if (b.p) (void)hipFree(b.p);
+    for (auto& e : c->cube_pool) { if (e.ev) (void)hipEventDestroy(e.ev); (void)hipFree(e.p); }
     if (c->d_maxlen) (void)hipFree(c->d_maxlen);
     if (c->d_flags) (void)hipFree(c->d_flags);
     if (c->d_nparts) (void)hipFree(c->d_nparts);
@@ -421,13 +430,31 @@ static size_t axes_smem(const rdr_cube* q) { return axes_fit_lds(q) ? (size_t)(q
 static int cube_alloc(rdr_ctx* c, rdr_cube* q) {
     const size_t esz = q->dtype == RDR_F32 ? 8 : 16;
     const size_t total = (size_t)q->ny * q->nx * q->nz;
-    HIPCHECK(c, hipMalloc(&q->d_vals, total * esz));
-    HIPCHECK(c, hipMalloc((void**)&q->d_axes, (size_t)(q->ny + q->nx + q->nz) * sizeof(double)));
+    // ONE allocation: the values, then (256 B aligned) the three axes
+    const size_t vbytes = (total * esz + 255) / 256 * 256;
+    const size_t bytes = vbytes + (size_t)(q->ny + q->nx + q->nz) * sizeof(double);
+    q->alloc_bytes = bytes;
+    for (size_t i = 0; i < c->cube_pool.size(); ++i) {
+        if (c->cube_pool[i].bytes != bytes) continue;
+        const rdr_ctx::PoolEntry e = c->cube_pool[i];
+        c->cube_pool.erase(c->cube_pool.begin() + (long)i);
+        c->cube_pool_bytes -= bytes;
+        // (its previous cube's last work was enqueued before this event: whatever stream builds the new cube waits for it)
+        hipError_t w = e.ev ? hipStreamWaitEvent(c->stream, e.ev, 0) : hipSuccess;
+        if (e.ev) (void)hipEventDestroy(e.ev);
+        if (w != hipSuccess) { (void)hipFree(e.p); (void)hipGetLastError(); break; }
+        q->d_vals = e.p;
+        break;
+    }
+    if (!q->d_vals) HIPCHECK(c, hipMalloc(&q->d_vals, bytes));
+    q->d_axes = reinterpret_cast<double*>(static_cast<char*>(q->d_vals) + vbytes);
     std::vector<double> ax;
     ax.insert(ax.end(), q->ys.begin(), q->ys.end());
     ax.insert(ax.end(), q->xs.begin(), q->xs.end());
     ax.insert(ax.end(), q->zs.begin(), q->zs.end());
-    HIPCHECK(c, hipMemcpy(q->d_axes, ax.data(), ax.size() * sizeof(double), hipMemcpyHostToDevice));
+    // (stream-ordered: a pooled buffer may still be read by work enqueued before the event above; pageable source: the call returns
+    // once the bytes are staged)
+    HIPCHECK(c, hipMemcpyAsync(q->d_axes, ax.data(), ax.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
     axis_uniformity(q->ys, &q->uni[0], &q->inv_d[0], &q->exact[0]);
     axis_uniformity(q->xs, &q->uni[1], &q->inv_d[1], &q->exact[1]);
     axis_uniformity(q->zs, &q->uni[2], &q->inv_d[2]);
@@ -486,9 +513,20 @@ int rdr_cube_create(rdr_ctx* c, const double* ys, int64_t ny, const double* xs, 
 
 void rdr_cube_destroy(rdr_cube* q) {
     if (!q) return;
-    if (q->ctx) { (void)hipSetDevice(q->ctx->device); (void)hipStreamSynchronize(q->ctx->stream); }
-    if (q->d_vals) (void)hipFree(q->d_vals);
-    if (q->d_axes) (void)hipFree(q->d_axes);
+    rdr_ctx* c = q->ctx;
+    if (c) (void)hipSetDevice(c->device);
+    bool pooled = false;
+    if (c && q->d_vals && q->alloc_bytes > 0 && c->cube_pool.size() < 6 && c->cube_pool_bytes + q->alloc_bytes <= c->cube_pool_limit) {
+        // hand the buffer on instead of freeing it: no synchronisation - the event marks the end of everything enqueued on it so far
+        hipEvent_t ev = nullptr;
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess && hipEventRecord(ev, c->stream) == hipSuccess) {
+            c->cube_pool.push_back({q->d_vals, q->alloc_bytes, ev});
+            c->cube_pool_bytes += q->alloc_bytes;
+            pooled = true;
+        } else { if (ev) (void)hipEventDestroy(ev); (void)hipGetLastError(); }
+    }
+    if (!pooled || q->d_quad) { if (c) (void)hipStreamSynchronize(c->stream); }
+    if (!pooled && q->d_vals) (void)hipFree(q->d_vals);       // (the axes live in the same allocation)
     if (q->d_quad) (void)hipFree(q->d_quad);
     delete q;
 }
