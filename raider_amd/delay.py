@@ -201,8 +201,10 @@ class PointsAOI:
         self._spacing = ll_res
 
     def set_output_xygrid(self, dst_crs=4326):
-        S, N = np.nanmin(self._lats), np.nanmax(self._lats)
-        W, E = np.nanmin(self._lons), np.nanmax(self._lons)
+        def lohi(a):           # np.nanmin / np.nanmax (llreader.py:173-191) - the plain reductions first: 4x cheaper, and right unless a NaN is there
+            lo, hi = a.min(), a.max()
+            return (lo, hi) if (lo == lo and hi == hi) else (np.nanmin(a), np.nanmax(a))
+        (S, N), (W, E) = lohi(self._lats), lohi(self._lons)
         sp = self._spacing
         self.xpts = np.arange(W, E + sp, sp)
         self.ypts = np.arange(N, S - sp, -sp)

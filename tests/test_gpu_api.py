@@ -357,7 +357,12 @@ def test_integration_md_stub_runs_as_printed(c1):
         assert np.array_equal(cw[0], w) and np.array_equal(ch[0], h) and not cw[2].any()
         w1, h1 = raytrace_slice(pw, xp, yp, 750.0, LOS, zref)
         assert np.array_equal(cw[1], w1) and np.array_equal(ch[1], h1)
-        np.savez(OUT, zw=zw, zh=zh, w=w, h=h, LOS=LOS)
+        rng = np.random.default_rng(11)
+        la = rng.uniform(31.6, 34.4, 500); lo = rng.uniform(-119.4, -115.6, 500); hg = rng.uniform(0.0, 2400.0, 500); inc = rng.uniform(25.0, 45.0, 500)
+        zl = np.array([0.0, 500.0, 1500.0, 3000.0])
+        pz = point_delays(tot, xp, yp, zl, la, lo, hg)
+        pc = point_delays(tot, xp, yp, zl, la, lo, hg, inc=inc)
+        np.savez(OUT, zw=zw, zh=zh, w=w, h=h, LOS=LOS, la=la, lo=lo, hg=hg, inc=inc, zl=zl, pzw=pz[0], pzh=pz[1], pcw=pc[0], pch=pc[1])
     ''')
     import tempfile
     out = Path(tempfile.mkdtemp()) / 'stub.npz'
@@ -370,6 +375,15 @@ def test_integration_md_stub_runs_as_printed(c1):
     tot = R.Cube(c1['ys'], c1['xs'], c1['zs'], c1['wet_total'], c1['hydro_total'], order='zyx')
     zw, zh = tot.build_cube(xp, yp, np.array([0.0, 500.0]))
     assert np.array_equal(got['zw'], zw) and np.array_equal(got['zh'], zh)
+    # the stub's point branch == tropo_delay of the mirror package on the same stations (zenith, and Conventional with an incidence raster)
+    from raider_amd.delay import PointsAOI, tropo_delay
+    from raider_amd.losreader import Conventional, Zenith
+    wm = dict(x=c1['xs'], y=c1['ys'], z=c1['zs'], wet=c1['wet'], hydro=c1['hydro'], wet_total=c1['wet_total'], hydro_total=c1['hydro_total'])
+    aoi = lambda: PointsAOI(got['la'], got['lo'], got['hg'], xp, yp)
+    mz = tropo_delay(dt.datetime(2020, 1, 1), wm, aoi(), Zenith(), list(got['zl']), 4326, None)
+    mc = tropo_delay(dt.datetime(2020, 1, 1), wm, aoi(), Conventional(inc=got['inc'], heading=0 * got['inc']), list(got['zl']), 4326, None)
+    assert np.array_equal(got['pzw'], mz[0]) and np.array_equal(got['pzh'], mz[1]) and np.isfinite(mz[1]).all()
+    assert np.array_equal(got['pcw'], mc[0]) and np.array_equal(got['pch'], mc[1])
     pw = R.Cube(c1['ys'], c1['xs'], c1['zs'], c1['wet'], c1['hydro'], order='zyx')
     w, h, _, _ = pw.raytrace(R.Rays.grid(xp, yp, los=got['LOS']), 0.0, float(c1['zs'].max() - 1))
     assert np.array_equal(got['w'], w) and np.array_equal(got['h'], h) and np.isfinite(h).all()
