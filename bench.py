@@ -457,10 +457,16 @@ def run_c5(args, ctx, dev, coll_dev, dist_on, rank, world, ndev, result_fd):
     p0, cnt = D.shard_rows(n_all, world, rank)
     pts = torch.from_numpy(np.ascontiguousarray(pts_all[p0:p0 + cnt])).to(dev)
     out = [None, None]
+    # the blend as a cube (24 B per cell, replicated on every rank) + a 4-line gather, or applied at the corners of this rank's points
+    # (8 lines per point, no cube): whichever moves fewer bytes for THIS rank's block - the same bits either way
+    fly = D.blend_on_the_fly_pays(a, cnt)
 
     def step():
-        m = a.blend(w1, b, w2)
-        out[0], out[1] = m.interp(pts)
+        if fly:
+            out[0], out[1] = a.interp_blend(w1, b, w2, pts)
+        else:
+            m = a.blend(w1, b, w2)
+            out[0], out[1] = m.interp(pts)
 
     for _ in range(args.warmup):
         step()
@@ -484,9 +490,11 @@ def run_c5(args, ctx, dev, coll_dev, dist_on, rank, world, ndev, result_fd):
         dt = float(tmax.item())
     # the blend's own time: HIP events on the stream the kernels run on (torch's current stream here)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(); keep = [a.blend(w1, b, w2) for _ in range(3)]; e1.record(); torch.cuda.synchronize()
-    blend_ms = e0.elapsed_time(e1) / 3.0
-    del keep
+    blend_ms = 0.0
+    if not fly:
+        e0.record(); keep = [a.blend(w1, b, w2) for _ in range(3)]; e1.record(); torch.cuda.synchronize()
+        blend_ms = e0.elapsed_time(e1) / 3.0
+        del keep
     wet_t, hyd_t = out
     if args.dump:
         np.savez(f'{args.dump}.rank{rank}.npz', wet=wet_t.cpu().numpy(), hydro=hyd_t.cpu().numpy(), p0=p0, cnt=cnt)
@@ -498,25 +506,29 @@ def run_c5(args, ctx, dev, coll_dev, dist_on, rank, world, ndev, result_fd):
     interp_ms = ms_int / args.steps
     step_ms = dt / args.steps * 1e3
     # algorithmic bytes of one rank's step: blend 24 B per f32 cell (two reads, one write, both fields = 2 x 12), gather 104 B per point
-    alg_bytes = 24.0 * cells + 104.0 * cnt
+    # (on the fly: 8 corners x 2 epochs x 8 B + 24 B of point + 16 B of delays = 168 B per station, SURVEY 8d's two-epoch form for an f32 cube)
+    alg_bytes = (168.0 * cnt) if fly else (24.0 * cells + 104.0 * cnt)
     res = {
         'metric': 'GNSS station points/sec (two-epoch blend + wet/hydro gather) through HRRR cube; achieved HBM GB/s',
         'value': n_all * args.steps / dt, 'unit': 'points/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': step_ms,
         'higher_is_better': True, 'scaling': 'strong' if world > 1 else 'weak', 'vs_baseline': None, 'dtype': 'f32 blend / f64 interpolation', 'data': 'synthetic',
-        'config': {'workload': f'configs[4]: HRRR-sized 1000x1000x50 f32 cube on the 3-km LCC grid, two epochs blended ({w1}, {w2}) on every rank, {n_all} station points '
+        'config': {'workload': f'configs[4]: HRRR-sized 1000x1000x50 f32 cube on the 3-km LCC grid, two epochs blended ({w1}, {w2}), {n_all} station points '
                                f'(rng(3), h ~ U(0, 4000) m) sharded into {world} contiguous blocks, wet + hydro at every point',
                    'stations_all_gpus': n_all, 'stations_this_rank': cnt, 'cube': '1000x1000x50 x 2 epochs',
+                   'blend': 'at the corners of the rank\'s points (rdr_interp3_blend: no blended cube)' if fly else 'blended cube per step (rdr_cube_blend), then the gather',
                    'parallelism': (f'stations sharded x{world} ({args.backend}, {ndev} device(s) visible), epochs: two packed broadcasts ({t_bcast*1e3:.1f} ms), blend replicated '
                                    f'per rank, no data-path collective') if dist_on else 'single GPU',
                    'ranks': world, 'backend': (dist.get_backend() if dist_on else None), 'world_size_seen_by_backend': (dist.get_world_size() if dist_on else 1),
                    'mean_hydro': float(torch.nanmean(hyd_t).item()), 'mean_wet': float(torch.nanmean(wet_t).item()), 'nan_fraction': float(torch.isnan(hyd_t).double().mean().item())},
-        'roofline': {'bound': 'hbm', 'kernel': 'blend_kernel<float> + interp_points_kernel<float2> (one step of one rank)',
+        'roofline': {'bound': 'hbm', 'kernel': 'interp_points_blend_kernel<float2> (one step of one rank)' if fly else 'blend_kernel<float> + interp_points_kernel<float2> (one step of one rank)',
                      'achieved': alg_bytes / ((blend_ms + interp_ms) * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': alg_bytes / ((blend_ms + interp_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 'traffic': None,
                      'algorithmic_bytes_per_step': alg_bytes, 'blend_ms': blend_ms, 'interp_ms_per_step': interp_ms, 'interp_launches_timed': n_int,
-                     'note': 'algorithmic bytes (24 B per cell of the blend + 104 B per station, SURVEY 8d) over the two kernels\' HIP-event time; the one-shot gather on a '
-                             'FRESH blended cube reads 4 x 128 B lines per point (572 B measured, profiles/r04_secondary.json) - the corner-quad copy only pays from the '
-                             'second query of a cube on (raider_hip.hip quad_wanted)',
+                     'note': ('algorithmic bytes (168 B per station: 8 corners x 2 epochs x 8 B + the point + the two delays, SURVEY 8d) over the kernel\'s HIP-event time; a random '
+                              'point touches 8 x 128 B lines for them (4 per epoch)') if fly else
+                             ('algorithmic bytes (24 B per cell of the blend + 104 B per station, SURVEY 8d) over the two kernels\' HIP-event time; the one-shot gather on a '
+                              'FRESH blended cube reads 4 x 128 B lines per point (572 B measured, profiles/r04_secondary.json) - the corner-quad copy only pays from the '
+                              'second query of a cube on (raider_hip.hip quad_wanted)'),
                      'source_hash': kernel_source_hash(), 'library_source_hash': R.load_library().rdr_source_hash().decode()},
     }
     if world == 1 and args.cpu_sample > 0:

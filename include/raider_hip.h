@@ -252,6 +252,13 @@ int rdr_last_nan_output(rdr_ctx* ctx);
  * ("There are missing delay values").  Needs two nodes per axis (scipy's grid rule), nz <= 512. */
 int rdr_build_cube_to_cube(rdr_ctx* ctx, const rdr_cube* cube, const double* xpts, int64_t nx, const double* ypts, int64_t ny,
                            const double* zpts, int64_t nz, int loc, rdr_cube** out);
+/* rdr_interp3 on the two-epoch temporal blend w1 * a + w2 * b (cli/raider.py:817-819) WITHOUT making the blended cube: the blend is
+ * applied at the eight corners of every point, in the cubes' own dtype with blend_kernel's arithmetic - the same bits as rdr_cube_blend
+ * followed by rdr_interp3.  It reads eight lines per point instead of four and none of the blend's 24 B per cell: the better deal for a
+ * point set below ~5 % of the cube's cells - the station block of one rank of a multi-GPU job (BASELINE configs[4]), where a replicated
+ * blend is what stops the job from scaling.  Points as rdr_interp3_project (three arrays, or y = packed pts[n,3] with x = z = NULL). */
+int rdr_interp3_blend(rdr_ctx* ctx, const rdr_cube* a, double w1, const rdr_cube* b, double w2, const double* y, const double* x, const double* z,
+                      int64_t n, double* wet, double* hydro, int loc);
 /* tropo_delay's point branch for a zenith / projected line of sight (delay.py:96-128) in ONE call, host arrays in, host arrays out:
  * rdr_build_cube_to_cube on the output grid (xpts[nx], ypts[ny], zpts[nz]) + rdr_interp3_project at the query points, with the
  * intermediate cube in the context's scratch (no allocation per call) and the upload of the points running under its build.  Same

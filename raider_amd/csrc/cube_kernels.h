@@ -216,6 +216,69 @@ __global__ __launch_bounds__(256) void interp_points_kernel(CubeView<T2> c, Poin
     }
 }
 
+// The two-epoch temporal interpolation (cli/raider.py:817-819) applied ON THE FLY at the eight corners of every query point instead of
+// to the whole cube first: corner = w1 * a + w2 * b in the cube's own dtype, the two products rounded separately - exactly blend_kernel's
+// arithmetic - then the gather of trilinear<>: the same bits as blend-then-gather.  Reads eight lines per point instead of four but
+// never touches the 24 B per cell of a blend: it wins when a rank queries fewer points than ~5 % of the cube's cells - the station block of
+// one rank of an 8-GPU job (BASELINE configs[4]: 625 k of 5 M stations on a 50 M-cell cube), where the replicated blend is what stops
+// the job from scaling.
+template <typename T2>
+__global__ __launch_bounds__(256) void interp_points_blend_kernel(CubeView<T2> c, const T2* __restrict__ vb, double w1d, double w2d, PointQuery Q, int64_t n,
+                                                                  double* __restrict__ wet, double* __restrict__ hyd, int axes_in_lds) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    typedef decltype(T2().x) T;
+    const T w1 = (T)w1d, w2 = (T)w2d;
+    const double* s_y = c.axes;
+    if (axes_in_lds) {
+        double* t = reinterpret_cast<double*>(smem_raw);
+        for (int i = threadIdx.x; i < c.ny + c.nx + c.nz; i += blockDim.x) t[i] = c.axes[i];
+        __syncthreads();
+        s_y = t;
+    }
+    const double* s_x = s_y + c.ny;
+    const double* s_z = s_x + c.nx;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        double y, x, z;
+        Q.point(i, y, x, z);
+        double sw = qnan(), sh = qnan();
+        const bool inside = (y >= c.y_lo) && (y <= c.y_hi) && (x >= c.x_lo) && (x <= c.x_hi) && (z >= c.z_lo) && (z <= c.z_hi);
+        if (inside) {
+            const int iy = find_cell(s_y, c.ny, y, c.y_lo, c.inv_dy, c.uni_y);
+            const int ix = find_cell(s_x, c.nx, x, c.x_lo, c.inv_dx, c.uni_x);
+            const int iz = find_cell(s_z, c.nz, z, c.z_lo, c.inv_dz, c.uni_z);
+            const double ty = (y - s_y[iy]) / (s_y[iy + 1] - s_y[iy]);
+            const double tx = (x - s_x[ix]) / (s_x[ix + 1] - s_x[ix]);
+            const double tz = (z - s_z[iz]) / (s_z[iz + 1] - s_z[iz]);
+            const int64_t o00 = ((int64_t)iy * c.nx + ix) * c.nz + iz;
+            const int64_t off[4] = {o00, o00 + c.nz, o00 + (int64_t)c.nx * c.nz, o00 + (int64_t)c.nx * c.nz + c.nz};
+            T2 a[8], b[8];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { a[2 * k] = c.v[off[k]]; a[2 * k + 1] = c.v[off[k] + 1]; b[2 * k] = vb[off[k]]; b[2 * k + 1] = vb[off[k] + 1]; }
+            double w[8], h[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+#pragma clang fp contract(off)
+                const T pw = w1 * a[k].x, qw = w2 * b[k].x, ph = w1 * a[k].y, qh = w2 * b[k].y;
+                w[k] = (double)(T)(pw + qw); h[k] = (double)(T)(ph + qh);
+            }
+            const double wy0 = 1.0 - ty, wx0 = 1.0 - tx, wz0 = 1.0 - tz;
+            const double a00 = wy0 * wx0, a01 = wy0 * tx, a10 = ty * wx0, a11 = ty * tx;
+            const double k0 = a00 * wz0, k1 = a00 * tz, k2 = a01 * wz0, k3 = a01 * tz;
+            const double k4 = a10 * wz0, k5 = a10 * tz, k6 = a11 * wz0, k7 = a11 * tz;
+            sw = 0.0; sh = 0.0;
+            sw += w[0] * k0; sh += h[0] * k0;
+            sw += w[1] * k1; sh += h[1] * k1;
+            sw += w[2] * k2; sh += h[2] * k2;
+            sw += w[3] * k3; sh += h[3] * k3;
+            sw += w[4] * k4; sh += h[4] * k4;
+            sw += w[5] * k5; sh += h[5] * k5;
+            sw += w[6] * k6; sh += h[6] * k6;
+            sw += w[7] * k7; sh += h[7] * k7;
+        }
+        Q.store(i, sw, sh, wet, hyd);
+    }
+}
+
 // ---- station queries on a cube that fits no cache: the corner-quad copy ----------------------------------------------------
 // A random point's 2 x 2 x 2 corners sit in FOUR columns of the (y,x,z) cube, i.e. four 128 B lines for 16 B each: 5 M stations on
 // a 1000 x 1000 x 50 f32 cube move 2.78 GB (556 B per point) for 0.52 GB of algorithmic bytes - and the kernel runs at the HBM

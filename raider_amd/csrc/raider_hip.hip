@@ -874,10 +874,20 @@ int rdr_cube_point_index(rdr_ctx* c, rdr_cube* q, int mode) {
 
 int64_t rdr_cube_point_index_bytes(const rdr_cube* q) { return q ? (int64_t)q->quad_bytes : -1; }
 
-static void launch_interp(rdr_ctx* c, const rdr_cube* q, const PointQuery& Qk, int64_t cnt, double* dwk, double* dhk, bool quad) {
+// a second epoch blended in at the corners (rdr_interp3_blend): vb == NULL for an ordinary gather
+struct BlendSpec { const void* vb = nullptr; double w1 = 1.0, w2 = 0.0; };
+
+static void launch_interp(rdr_ctx* c, const rdr_cube* q, const PointQuery& Qk, int64_t cnt, double* dwk, double* dhk, bool quad, const BlendSpec& B = BlendSpec()) {
     const int g = grid_for(cnt, 256, c->num_cus * 8);
     KTimer t(c, 2);
-    if (quad) {
+    if (B.vb) {
+        if (q->dtype == RDR_F32)
+            hipLaunchKernelGGL((interp_points_blend_kernel<float2>), dim3(g), dim3(256), axes_smem(q), c->stream, make_view<float2>(q), (const float2*)B.vb, B.w1, B.w2,
+                               Qk, cnt, dwk, dhk, (int)axes_fit_lds(q));
+        else
+            hipLaunchKernelGGL((interp_points_blend_kernel<double2>), dim3(g), dim3(256), axes_smem(q), c->stream, make_view<double2>(q), (const double2*)B.vb, B.w1, B.w2,
+                               Qk, cnt, dwk, dhk, (int)axes_fit_lds(q));
+    } else if (quad) {
         if (q->dtype == RDR_F32)
             hipLaunchKernelGGL((interp_points_quad_kernel<float2>), dim3(g), dim3(256), axes_smem(q), c->stream, make_view<float2>(q),
                                (const uint4*)q->d_quad, q->quad_nblk, Qk, cnt, dwk, dhk, (int)axes_fit_lds(q));
@@ -899,7 +909,7 @@ static void launch_interp(rdr_ctx* c, const rdr_cube* q, const PointQuery& Qk, i
 // wet, hydro.  Synchronises all three streams before it returns.  (A download into pageable memory blocks the host thread instead of
 // overlapping: still correct.)
 static int interp_pipeline(rdr_ctx* c, const char* who, const rdr_cube* q, bool quad, const double* y, const double* x, const double* z, int64_t n,
-                           PointQuery Q, const double* proj, double* wet, double* hydro, const int* slots) {
+                           PointQuery Q, const double* proj, double* wet, double* hydro, const int* slots, const BlendSpec& B = BlendSpec()) {
     const bool has_proj = Q.pmode == 1 || Q.pmode == 3;
     const size_t ystride = x ? 1 : 3;
     void *dy, *dx = nullptr, *dz = nullptr, *dp = nullptr, *dw = nullptr, *dh = nullptr;
@@ -928,7 +938,7 @@ static int interp_pipeline(rdr_ctx* c, const char* who, const rdr_cube* q, bool 
         Qk.y = (const double*)dy + o * ystride;
         Qk.x = x ? (const double*)dx + o : nullptr; Qk.z = x ? (const double*)dz + o : nullptr;
         Qk.proj = has_proj ? (const double*)dp + o : nullptr;
-        launch_interp(c, q, Qk, cnt, dw ? (double*)dw + o : nullptr, dh ? (double*)dh + o : nullptr, quad);
+        launch_interp(c, q, Qk, cnt, dw ? (double*)dw + o : nullptr, dh ? (double*)dh + o : nullptr, quad, B);
         HIPCHECK(c, hipGetLastError());
         HIPCHECK(c, hipEventRecord(evs.v[2 * k + 1], c->stream));
         HIPCHECK(c, hipStreamWaitEvent(c->down_stream, evs.v[2 * k + 1], 0));
@@ -953,7 +963,7 @@ static int point_query_args(rdr_ctx* c, const char* who, const double* y, const 
 // the point query behind rdr_interp3 / rdr_interp3_project: y/x/z three arrays (x != NULL) or y = packed (n,3); pmode / proj / inc0 as
 // PointQuery (cube_kernels.h); either output may be NULL (it is then neither written nor downloaded)
 static int interp3_impl(rdr_ctx* c, const char* who, const rdr_cube* q, const double* y, const double* x, const double* z, int64_t n, int pmode,
-                        const double* proj, double inc0, double* wet, double* hydro, int loc) {
+                        const double* proj, double inc0, double* wet, double* hydro, int loc, const BlendSpec& B = BlendSpec()) {
     if (!c || !q) return fail(c, RDR_ERR_INVALID, std::string(who) + ": NULL argument");
     int rc = point_query_args(c, who, y, x, z, n, pmode, proj, wet, hydro); if (rc) return rc;
     if (n == 0) return RDR_OK;
@@ -962,12 +972,12 @@ static int interp3_impl(rdr_ctx* c, const char* who, const rdr_cube* q, const do
     Q.pmode = pmode; Q.inc0 = inc0;
     const bool has_proj = pmode == 1 || pmode == 3;
     const size_t ystride = x ? 1 : 3;                                  // doubles per point behind `y`
-    const bool quad = quad_wanted(c, q, n);
+    const bool quad = !B.vb && quad_wanted(c, q, n);
     if (quad) { rc = quad_build(c, q); if (rc) return rc; }
     static const bool no_pipeline = std::getenv("RAIDER_HIP_NO_PIPELINE") != nullptr;
     if (loc == RDR_HOST && n >= (1 << 18) && !no_pipeline) {
         static const int slots[6] = {SLOT_IN0, SLOT_IN1, SLOT_IN2, SLOT_IN3, SLOT_OUT0, SLOT_OUT1};
-        return interp_pipeline(c, who, q, quad, y, x, z, n, Q, proj, wet, hydro, slots);
+        return interp_pipeline(c, who, q, quad, y, x, z, n, Q, proj, wet, hydro, slots, B);
     }
     const void* d; void *dw = nullptr, *dh = nullptr;
     rc = stage_in(c, SLOT_IN0, y, (size_t)n * ystride * 8, loc, &d); if (rc) return rc; Q.y = (const double*)d;
@@ -978,7 +988,7 @@ static int interp3_impl(rdr_ctx* c, const char* who, const rdr_cube* q, const do
     if (has_proj) { rc = stage_in(c, SLOT_IN3, proj, (size_t)n * 8, loc, &d); if (rc) return rc; Q.proj = (const double*)d; }
     if (wet) { rc = stage_out(c, SLOT_OUT0, wet, (size_t)n * 8, loc, &dw); if (rc) return rc; }
     if (hydro) { rc = stage_out(c, SLOT_OUT1, hydro, (size_t)n * 8, loc, &dh); if (rc) return rc; }
-    launch_interp(c, q, Q, n, (double*)dw, (double*)dh, quad);
+    launch_interp(c, q, Q, n, (double*)dw, (double*)dh, quad, B);
     HIPCHECK(c, hipGetLastError());
     rc = finish_out(c, wet, dw, (size_t)n * 8, loc); if (rc) return rc;
     rc = finish_out(c, hydro, dh, (size_t)n * 8, loc); if (rc) return rc;
@@ -988,6 +998,15 @@ static int interp3_impl(rdr_ctx* c, const char* who, const rdr_cube* q, const do
 
 int rdr_interp3(rdr_ctx* c, const rdr_cube* q, const double* pts, int64_t n, double* wet, double* hydro, int loc) {
     return interp3_impl(c, "rdr_interp3", q, pts, nullptr, nullptr, n, 0, nullptr, 0.0, wet, hydro, loc);
+}
+
+int rdr_interp3_blend(rdr_ctx* c, const rdr_cube* a, double w1, const rdr_cube* b, double w2, const double* y, const double* x, const double* z, int64_t n,
+                      double* wet, double* hydro, int loc) {
+    if (!c || !a || !b) return fail(c, RDR_ERR_INVALID, "rdr_interp3_blend: NULL argument");
+    if (a->ny != b->ny || a->nx != b->nx || a->nz != b->nz || a->dtype != b->dtype || a->ys != b->ys || a->xs != b->xs || a->zs != b->zs)
+        return fail(c, RDR_ERR_INVALID, "rdr_interp3_blend: the two epochs are not on the same grid / dtype");
+    BlendSpec B; B.vb = b->d_vals; B.w1 = w1; B.w2 = w2;
+    return interp3_impl(c, "rdr_interp3_blend", a, y, x, z, n, 0, nullptr, 0.0, wet, hydro, loc, B);
 }
 
 int rdr_interp3_project(rdr_ctx* c, const rdr_cube* q, const double* y, const double* x, const double* z, int64_t n, int proj_mode,

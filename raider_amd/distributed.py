@@ -222,11 +222,21 @@ def raytrace_heights_sharded(cube, rays_for, hts, zref, max_seg=1000.0, world=No
     return h0, nh, wet, hyd, K, nparts, flags
 
 
-def interp_points_sharded(cube, pts, world=None, rank=None):
+def blend_on_the_fly_pays(cube, npoints):
+    """The two ways to interpolate the two-epoch blend at `npoints` points of one rank: make the blended cube (24 B per cell of HBM
+    traffic, the SAME on every rank) and gather from it (4 lines = 572 B per random point, measured), or blend at the corners
+    (Cube.interp_blend: 8 lines per point, no cube).  On the fly pays when the extra 572 B per point stay below the blend's bytes."""
+    ny, nx, nz = cube.shape
+    return 572.0 * npoints < 24.0 * ny * nx * nz * (1.0 if cube.dtype == np.float32 else 2.0)
+
+
+def interp_points_sharded(cube, pts, world=None, rank=None, blend=None):
     """Station / zenith queries (BASELINE configs[1], configs[4]: 5 M GNSS stations on 8 GPUs) shard with NO collective at all: every
     rank holds the (broadcast, possibly blended) cube and interpolates its contiguous block of the point list
     (delay.py:116-121 applied to rows [p0, p0 + np) of `pts[n, 3]` = (y, x, z)).  Returns (p0, np, wet, hydro); np == 0 when there are
-    more ranks than points."""
+    more ranks than points.
+    blend=(w1, other, w2): the temporal interpolation w1 * cube + w2 * other (cli/raider.py:817-819) is part of the query - made as a
+    cube first or applied at the corners of this rank's points, whichever moves fewer bytes (blend_on_the_fly_pays); same bits."""
     if world is None or rank is None:
         if is_distributed():
             dist = _dist()
@@ -237,7 +247,15 @@ def interp_points_sharded(cube, pts, world=None, rank=None):
     p0, cnt = shard_rows(n, world, rank)
     if cnt == 0:
         return p0, 0, None, None
-    wet, hyd = cube.interp(pts[p0:p0 + cnt])
+    mine = pts[p0:p0 + cnt]
+    if blend is None:
+        wet, hyd = cube.interp(mine)
+    else:
+        w1, other, w2 = blend
+        if blend_on_the_fly_pays(cube, cnt):
+            wet, hyd = cube.interp_blend(w1, other, w2, mine)
+        else:
+            wet, hyd = cube.blend(w1, other, w2).interp(mine)
     return p0, cnt, wet, hyd
 
 

@@ -346,3 +346,39 @@ def test_weather_file_is_opened_and_uploaded_once(tmp_path, c1):
     finally:
         del os.environ['RAIDER_HIP_FILE_CACHE']
     F.clear_file_cache()
+
+
+def test_interp_blend_is_blend_then_interp_bit_for_bit():
+    """rdr_interp3_blend: the two-epoch temporal interpolation applied at the corners of every query point == rdr_cube_blend followed by
+    rdr_interp3, bit for bit - f32 cubes (products and sum rounded in f32, as the blended cube holds them) and f64 cubes, host and device
+    point arrays, point sets on both sides of the chunked-transfer threshold, NaN / outside points; mismatched epochs are refused."""
+    import torch
+    import raider_amd as R
+    rng = np.random.default_rng(12)
+    ny, nx, nz = 37, 41, 19
+    ys = np.linspace(30.0, 36.0, ny)[::-1].copy(); xs = np.linspace(-121.0, -113.0, nx); zs = np.round(-100 + 30000 * np.linspace(0, 1, nz) ** 2, 3)
+    for dt_ in (np.float32, np.float64):
+        ea = [rng.normal(100, 30, (nz, ny, nx)).astype(dt_) for _ in range(2)]; eb = [rng.normal(100, 30, (nz, ny, nx)).astype(dt_) for _ in range(2)]
+        a = R.Cube(ys, xs, zs, ea[0], ea[1], order='zyx'); b = R.Cube(ys, xs, zs, eb[0], eb[1], order='zyx')
+        for w1, w2 in ((0.25, 0.75), (0.6041666666666667, 0.3958333333333333)):
+            m = a.blend(w1, b, w2)
+            for n in (3000, 300_000):
+                q = np.stack([rng.uniform(29.9, 36.1, n), rng.uniform(-121.0, -113.0, n), rng.uniform(-150, 30100, n)], -1)
+                q[0] = [np.nan, -117.0, 100.0]
+                r0 = m.interp(q)
+                r1 = a.interp_blend(w1, b, w2, q)
+                assert np.array_equal(r0[0], r1[0], equal_nan=True) and np.array_equal(r0[1], r1[1], equal_nan=True)
+                assert np.isnan(r1[0][0]) and 0.8 < np.isfinite(r1[0]).mean() < 1.0
+            qd = torch.from_numpy(q).cuda()
+            rd = a.interp_blend(w1, b, w2, qd)
+            torch.cuda.synchronize()
+            assert np.array_equal(rd[0].cpu().numpy(), r0[0], equal_nan=True) and np.array_equal(rd[1].cpu().numpy(), r0[1], equal_nan=True)
+    other = R.Cube(ys, xs[:-1], zs, ea[0][:, :, :-1].copy(), ea[1][:, :, :-1].copy(), order='zyx')
+    with pytest.raises(ValueError, match='same grid'):
+        a.interp_blend(0.5, other, 0.5, q)
+    # the sharded station query picks the cheaper of the two forms for the rank's block - same bits
+    from raider_amd import distributed as D
+    assert D.blend_on_the_fly_pays(a, 10) and not D.blend_on_the_fly_pays(a, 10_000_000)
+    p0, cnt, w, h = D.interp_points_sharded(a, q, world=3, rank=1, blend=(0.25, b, 0.75))
+    full = a.blend(0.25, b, 0.75).interp(q)
+    assert np.array_equal(w, full[0][p0:p0 + cnt], equal_nan=True) and np.array_equal(h, full[1][p0:p0 + cnt], equal_nan=True)
