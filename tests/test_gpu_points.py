@@ -382,3 +382,51 @@ def test_interp_blend_is_blend_then_interp_bit_for_bit():
     p0, cnt, w, h = D.interp_points_sharded(a, q, world=3, rank=1, blend=(0.25, b, 0.75))
     full = a.blend(0.25, b, 0.75).interp(q)
     assert np.array_equal(w, full[0][p0:p0 + cnt], equal_nan=True) and np.array_equal(h, full[1][p0:p0 + cnt], equal_nan=True)
+
+
+def test_point_branch_randomised_against_the_two_stage_host_sequence():
+    """40 random jobs: model cubes with exact / jittered / descending axes (f64 totals), AOI grids ascending or descending and partly outside
+    the model, height lists that leave the model's z range, query points inside / outside / NaN, every projection mode.  The fused call
+    (rdr_point_delays), the two-call form (rdr_build_cube_to_cube + rdr_interp3_project) and the reference's own sequence through the public
+    host-array entries (rdr_build_cube -> download -> rdr_cube_create from the (z,y,x) arrays -> rdr_interp3) must agree BIT FOR BIT, NaN
+    masks and the cube's NaN verdict included."""
+    import raider_amd as R
+    rng = np.random.default_rng(2024)
+    for trial in range(40):
+        ny, nx, nz = (int(v) for v in rng.integers(5, 40, 3))
+        ys = np.linspace(30.0, 30.0 + 0.2 * ny, ny); xs = np.linspace(-120.0, -120.0 + 0.25 * nx, nx); zs = np.sort(rng.uniform(-200, 30000, nz))
+        if trial % 3 == 1:
+            ys = ys + rng.uniform(-0.03, 0.03, ny); xs = xs + rng.uniform(-0.03, 0.03, nx)
+        if trial % 4 == 2:
+            ys = ys[::-1].copy()
+        shape = (nz, ny, nx)
+        wt = rng.uniform(0.0, 0.4, shape); ht = rng.uniform(1.0, 2.5, shape)
+        tot = R.Cube(ys, xs, zs, wt, ht, order='zyx')
+        # AOI grid: sometimes reaching beyond the model, either direction
+        gx = np.linspace(xs.min() - (0.3 if trial % 5 == 0 else -0.05), xs.max() - 0.05, int(rng.integers(2, 30)))
+        gy = np.linspace(ys.max() - 0.04, ys.min() + (-0.2 if trial % 7 == 0 else 0.04), int(rng.integers(2, 30)))
+        if trial % 2:
+            gx = gx[::-1].copy()
+        gz = np.sort(rng.uniform(zs.min() - (100 if trial % 6 == 0 else -1), zs.max() - 1, int(rng.integers(2, 12))))
+        n = int(rng.integers(1, 4000))
+        py = rng.uniform(gy.min() - 0.05, gy.max() + 0.05, n); px = rng.uniform(gx.min() - 0.05, gx.max() + 0.05, n); pz = rng.uniform(gz.min() - 20, gz.max() + 20, n)
+        if n > 3:
+            py[1] = np.nan
+        inc = rng.uniform(15, 55, n)
+        kw = ({}, {'inc': inc}, {'inc': 41.5}, {'divisor': np.cos(np.radians(inc))})[trial % 4]
+        fw, fh, fnan = tot.point_delays(gx, gy, gz, py, px, pz, **kw)
+        d = tot.build_delay_cube(gx, gy, gz)
+        tw, th = d.interp_project(py, px, pz, **kw)
+        bw, bh = tot.build_cube(gx, gy, gz)                                   # the reference's sequence: cube down ...
+        d2 = R.Cube(gy, gx, gz, np.asarray(bw), np.asarray(bh), order='zyx')     # ... Dataset -> getInterpolators(ds): cube up ...
+        hw, hh = d2.interp(np.stack([py, px, pz], -1))                        # ... the gather
+        if kw:
+            up = np.cos(np.radians(kw['inc'])) if 'inc' in kw else kw['divisor']
+            if 'inc' in kw:          # (the host cos against the device's: compare the un-projected values exactly, the projected to 2 ulp)
+                assert _ulp_close(fw, hw / up) and _ulp_close(fh, hh / up), trial
+            else:
+                assert np.array_equal(fw, hw / up, equal_nan=True) and np.array_equal(fh, hh / up, equal_nan=True), trial
+        else:
+            assert np.array_equal(fw, hw, equal_nan=True) and np.array_equal(fh, hh, equal_nan=True), trial
+        assert np.array_equal(fw, tw, equal_nan=True) and np.array_equal(fh, th, equal_nan=True), trial
+        assert fnan == d.has_nan() == bool(np.isnan(bw).any() or np.isnan(bh).any()), trial

@@ -1,6 +1,6 @@
 set -x
 cd $GRAFT_REPO_ROOT
-PROFILE_TAG=v28 bash tools/profile_round.sh > gpurun_out/v28_round.log 2>&1
+PROFILE_TAG=v29 bash tools/profile_round.sh > gpurun_out/v29_round.log 2>&1
 bash tools/profile_secondary.sh > gpurun_out/secondary_round.log 2>&1
 mkdir -p gpurun_out/parity
 python tools/full_scene_parity.py 4000 4000 gpurun_out/parity/c3.json > gpurun_out/parity/c3.log 2>&1
