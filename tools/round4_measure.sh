@@ -8,4 +8,4 @@ python tools/full_scene_parity.py 4000 4000 gpurun_out/parity/c3b.json c3b > gpu
 python tools/full_scene_parity.py 4000 4000 gpurun_out/parity/c5.json c5 > gpurun_out/parity/c5.log 2>&1
 python tools/full_scene_parity.py 10000 10000 gpurun_out/parity/c4.json > gpurun_out/parity/c4.log 2>&1
 python tools/full_batch_parity_points.py gpurun_out/parity/points.json > gpurun_out/parity/points.log 2>&1
-tail -2 gpurun_out/parity/*.log
+for f in gpurun_out/parity/*.log; do tail -n 2 $f; done
