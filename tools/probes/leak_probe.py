@@ -23,7 +23,12 @@ def cycle():
     tot = R.Cube(c['ys'], c['xs'], c['zs'], c['wet_total'], c['hydro_total'], order='zyx', ctx=ctx)
     zw, zh = tot.build_cube(xp, yp, np.array([0.0, 100.0, 1000.0]))
     m = cube.blend(0.25, cube, 0.75)
-    del cube, tot, m, ctx
+    # round 4: the point branch (fused / two-call / ray-traced), the on-the-fly blend
+    pw, ph, pn = tot.point_delays(xp, yp, np.array([0.0, 100.0, 1000.0, 4000.0]), pts[:, 0], pts[:, 1], pts[:, 2], inc=39.0)
+    d = tot.build_delay_cube(xp, yp, np.array([0.0, 100.0, 1000.0, 4000.0])); dw, dh = d.interp_project(pts)
+    rc, K2, n2, f2 = cube.raytrace_slices_to_cube(R.Rays.grid(xp, yp, inc=35.0, hd=-167.9), np.array([0.0, 500.0, 2000.0]), zref)
+    bw, bh = cube.interp_blend(0.25, cube, 0.75, pts)
+    del cube, tot, m, d, rc, ctx
 for i in range(3): cycle()
 gc.collect(); torch.cuda.synchronize()
 free0 = torch.cuda.mem_get_info()[0]
