@@ -300,3 +300,51 @@ def test_envi_header_names_the_rasters_own_crs(tmp_path):
     assert 'map info' not in (tmp_path / 'ps.hdr').read_text()
     writeArrayToRaster(a, tmp_path / 'll.envi', gt=(-118.0, 0.01, 0.0, 34.0, 0.0, -0.01))
     assert 'Geographic Lat/Lon' in (tmp_path / 'll.hdr').read_text()
+
+
+def test_round4_host_logic_without_a_gpu(tmp_path, monkeypatch):
+    """Host-side pieces of round 4 that need no device: the file-identity cache of opened model files (same file -> same object; a
+    rewritten file is read again; RAIDER_HIP_FILE_CACHE=0 switches it off), the byte model that picks on-the-fly blending for a rank's
+    station block, the pinned pool's per-rank limit, and the result list that carries the device's NaN verdict."""
+    import os
+    from scipy.io import netcdf_file
+    from raider_amd import delayFcns as F
+    from raider_amd import _pinned
+    from raider_amd.delay import _Result
+    from raider_amd.distributed import blend_on_the_fly_pays
+
+    def write(path, v):
+        with netcdf_file(str(path), 'w', version=2) as f:
+            f.createDimension('z', 3); f.createVariable('z', 'f8', ('z',))[:] = [0.0, 1.0, v]
+    p = tmp_path / 'm.nc'
+    write(p, 2.0)
+    F.clear_file_cache()
+    a, get = F._load_fields(str(p)); b, _ = F._load_fields(p)
+    assert a is b and np.array_equal(get('z'), [0.0, 1.0, 2.0])
+    write(p, 5.0)
+    os.utime(p, ns=(os.stat(p).st_atime_ns, os.stat(p).st_mtime_ns + 7_000_000))
+    c_, get2 = F._load_fields(str(p))
+    assert c_ is not a and np.array_equal(get2('z'), [0.0, 1.0, 5.0])
+    monkeypatch.setenv('RAIDER_HIP_FILE_CACHE', '0')
+    assert F._load_fields(str(p))[0] is not c_
+    monkeypatch.delenv('RAIDER_HIP_FILE_CACHE')
+    assert F._file_key(tmp_path / 'missing.nc') is None
+    F.clear_file_cache()
+
+    class _C:                                               # (what blend_on_the_fly_pays reads off a Cube)
+        shape = (1000, 1000, 50); dtype = np.float32
+    assert blend_on_the_fly_pays(_C, 625_000) and not blend_on_the_fly_pays(_C, 5_000_000)
+    _C.dtype = np.float64
+    assert blend_on_the_fly_pays(_C, 4_000_000)             # an f64 blend moves twice the bytes per cell
+
+    monkeypatch.delenv('RAIDER_HIP_PINNED_POOL_BYTES', raising=False)
+    monkeypatch.setenv('LOCAL_WORLD_SIZE', '8')
+    assert _pinned._limit() == (4 << 30) // 8               # eight ranks of a node page-lock together what one process would
+    monkeypatch.setenv('RAIDER_HIP_PINNED_POOL_BYTES', '123')
+    assert _pinned._limit() == 123
+
+    r = _Result([np.zeros(2), np.ones(2)])
+    w, h = r
+    assert isinstance(r, list) and r.has_nan is None and len(r) == 2 and h[0] == 1.0
+    r.has_nan = True
+    assert r.has_nan is True and _Result().has_nan is None  # (per instance, not shared)
