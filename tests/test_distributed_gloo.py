@@ -137,6 +137,19 @@ def _points_worker(rank, world, port, q):
                 return p[:, 0] * 2.0, p[:, 1] - 1.0
         pts = np.arange(3 * 1001, dtype=np.float64).reshape(1001, 3)
         p0, cnt, w, h = D.interp_points_sharded(FakeCube(), pts)
+        # the two-epoch blend as part of the query (round 4): the rank's block picks blend-at-the-corners or blended-cube-then-gather by the
+        # byte model; both stand-ins return the same numbers here, which route was taken is recorded
+        took = []
+
+        class FakeEpoch(FakeCube):
+            dtype = np.float32
+            def __init__(self, shape): self.shape = shape
+            def blend(self, w1, other, w2): took.append('cube'); return self
+            def interp_blend(self, w1, other, w2, p): took.append('corners'); return self.interp(p)
+        for shape in ((1000, 1000, 50), (10, 10, 5)):         # a big cube (the block is small against it), a tiny one
+            b0, bc, bw, bh = D.interp_points_sharded(FakeEpoch(shape), pts, blend=(0.25, FakeEpoch(shape), 0.75))
+            assert (b0, bc) == (p0, cnt) and np.array_equal(bw, w) and np.array_equal(bh, h)
+        assert took == ['corners', 'cube'], took
         q.put((rank, p0, cnt, float(w.sum()), float(h.sum())))
     finally:
         dist.destroy_process_group()
