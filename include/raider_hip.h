@@ -137,6 +137,12 @@ int rdr_host_free(void* p);
  * `bytes` caps records + side buffer (default 48 GiB of the 288 GB, and never more than half of the free memory); larger
  * batches are integrated in chunks.  Env override at rdr_create: RAIDER_HIP_WORKSPACE_BYTES. */
 int rdr_set_workspace_limit(rdr_ctx* ctx, int64_t bytes);
+/* Give device memory back: the context keeps its scratch (staging slots, the intermediate cube of rdr_point_delays, the ray-record
+ * workspace) and up to 4 GiB of value buffers of destroyed cubes for the next call of the same size.  rdr_trim waits for the
+ * context's streams, then frees every scratch buffer larger than `keep_bytes` and pooled buffers until at most `keep_bytes` remain
+ * (0: everything); *released (may be NULL) = bytes freed.  rdr_point_delays trims its own intermediates above
+ * RAIDER_HIP_SCRATCH_KEEP_BYTES (default 4 GiB) before it returns. */
+int rdr_trim(rdr_ctx* ctx, int64_t keep_bytes, int64_t* released);
 /* Columns of the generic-ray side buffer: >= 0 fixes the capacity (0: always recompute), -1 restores the automatic sizing. */
 int rdr_set_side_capacity(rdr_ctx* ctx, int64_t columns);
 int rdr_profile_get(rdr_ctx* ctx, int which, int* count, float* total_ms);
@@ -182,6 +188,13 @@ int rdr_cube_axes(const rdr_cube* cube, double* ys, double* xs, double* zs);
 #define RDR_PROJ_LCC 1
 #define RDR_PROJ_STERE 2   /* POLAR stereographic: params = {a, es, lat_0 (+-90), lat_ts (NaN: use k_0), k_0, lon_0, x_0, y_0} (HRRR-AK, models/hrrr.py:22-25) */
 int rdr_cube_set_projection(rdr_cube* cube, int kind, const double* params, int nparams);
+/* A VIEW of a cube: a second handle on the same device buffers (values, axes, corner-quad copy - nothing is copied or uploaded)
+ * that owns only its projection.  The reference builds its pyproj transformers afresh in every call (delay.py:196-216,238-253) and
+ * shares nothing between calls; a cube cached per weather-model file and handed to several callers (threads, model CRS arguments)
+ * must therefore never be re-projected in place - each call takes a view with the projection IT was given and destroys it afterwards.
+ * kind / params as rdr_cube_set_projection; kind -1: the source's own projection.  `ctx` = the context the view is used from (may
+ * differ from the source's).  The buffers live until the source AND every view are destroyed, in any order. */
+int rdr_cube_view(rdr_ctx* ctx, const rdr_cube* cube, int kind, const double* params, int nparams, rdr_cube** out);
 /* transformPoints (delay.py:404-436) for EPSG:4326 -> the cube's CRS: (lat, lon) deg -> (y, x) model coordinates */
 int rdr_project_points(rdr_ctx* ctx, const rdr_cube* cube, const double* lat, const double* lon, int64_t n, double* y, double* x, int loc);
 /* transformPoints (delay.py:404-436) between EPSG:4326 and a TRANSVERSE-MERCATOR CRS (every UTM zone, EPSG:326xx / 327xx; national

@@ -65,6 +65,7 @@ SYMBOLS = [
     ('rdr_host_free', C.c_int, [_VP]),
     ('rdr_set_workspace_limit', C.c_int, [_VP, C.c_int64]),
     ('rdr_set_side_capacity', C.c_int, [_VP, C.c_int64]),
+    ('rdr_trim', C.c_int, [_VP, C.c_int64, c_lp]),
     ('rdr_generic_ray_count', C.c_int64, [_VP]),
     ('rdr_profile_get', C.c_int, [_VP, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_float)]),
     ('rdr_clock_sample_begin', C.c_int, [_VP, C.c_double]),
@@ -77,6 +78,7 @@ SYMBOLS = [
     ('rdr_cube_shape', C.c_int, [_VP, c_lp, c_lp, c_lp, C.POINTER(C.c_int)]),
     ('rdr_cube_axes', C.c_int, [_VP, _VP, _VP, _VP]),
     ('rdr_cube_set_projection', C.c_int, [_VP, C.c_int, _VP, C.c_int]),
+    ('rdr_cube_view', C.c_int, [_VP, _VP, C.c_int, _VP, C.c_int, C.POINTER(_VP)]),
     ('rdr_project_points', C.c_int, [_VP, _VP, _VP, _VP, C.c_int64, _VP, _VP, C.c_int]),
     ('rdr_transform_tm', C.c_int, [_VP, _VP, C.c_int, C.c_int, _VP, _VP, C.c_int64, _VP, _VP, C.c_int]),
     ('rdr_transform_cone', C.c_int, [_VP, C.c_int, _VP, C.c_int, C.c_int, _VP, _VP, C.c_int64, _VP, _VP, C.c_int]),
@@ -250,9 +252,11 @@ class Context:
 
     _default = None
     _default_lock = threading.Lock()
+    _serials = __import__('itertools').count(1)
 
     def __init__(self, device=-1):
         lib = load()
+        self.serial = next(Context._serials)      # never reused (id() of a collected context can be): what caches key contexts by
         h = C.c_void_p()
         rc = lib.rdr_create(int(device), C.byref(h))
         if rc != RDR_OK:
@@ -297,6 +301,13 @@ class Context:
     def set_workspace_limit(self, nbytes):
         """Cap the HBM workspace that hands ray records from ray pass 1 to pass 2 (bigger batches run in chunks)."""
         check(self.lib.rdr_set_workspace_limit(self.handle, int(nbytes)), self.handle)
+
+    def trim(self, keep_bytes=0):
+        """Give device memory back (rdr_trim): scratch buffers larger than `keep_bytes` and pooled cube buffers beyond `keep_bytes` in
+        total are freed after the context's streams have drained.  Returns the bytes released."""
+        out = C.c_int64(0)
+        check(self.lib.rdr_trim(self.handle, int(keep_bytes), C.byref(out)), self.handle)
+        return int(out.value)
 
     def set_side_capacity(self, columns=-1):
         """Capacity (rays) of the side buffer holding the level crossings of generic-geodesy rays; -1 = automatic."""

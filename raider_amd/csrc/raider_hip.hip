@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -55,8 +56,10 @@ struct rdr_ctx {
     // value buffers of destroyed cubes, kept for the next cube of the same size: a job that blends / builds a cube per date or per call
     // (cli/raider.py:817-819, the intermediate cubes of the point branch) then allocates nothing - hipMalloc + hipFree of a 400 MB cube
     // are 0.2 ms of host time AND a device-wide synchronisation.  A buffer is handed on with the event recorded when its cube died.
-    struct PoolEntry { void* p; size_t bytes; hipEvent_t ev; };
+    struct PoolEntry { void* p; size_t bytes; std::vector<hipEvent_t> evs; };   // one event per stream the context has launched on
     std::vector<PoolEntry> cube_pool;
+    std::vector<hipStream_t> ext_streams;     // caller streams handed to rdr_set_stream so far (a cube may still be read on any of them)
+    bool ext_overflow = false;                // more than 8 of them: destroyed cubes are freed synchronously instead of pooled
     size_t cube_pool_bytes = 0, cube_pool_limit = (size_t)4 << 30;
     DevBuf ws;                                // pass 1 -> pass 2 workspace (field-major ray records, 232 B per ray)
     DevBuf side;                              // level crossings of the generic rays (compact columns of K+1 doubles)
@@ -69,7 +72,7 @@ struct rdr_ctx {
     int last_nan_output = -1;                 // rdr_build_cube (host arrays): 1 / 0 = its last result holds / does not hold a NaN; -1 unknown
     size_t ws_limit = (size_t)48 << 30;       // cap on that workspace; bigger batches are marched in chunks
     // which ray batch the stored records belong to (a later rdr_ray_march reuses them only for the identical batch)
-    struct { const void* cube = nullptr; int64_t n = -1; double ht = 0, zref = 0; const void* a = nullptr; const void* b = nullptr; const void* c = nullptr; const void* d = nullptr; int K = 0; bool valid = false; } wsig;
+    struct { const void* cube = nullptr; const void* vals = nullptr; LccParams proj = {0, 0, 0, 0, 0, 0, 0, 0}; int64_t n = -1; double ht = 0, zref = 0; const void* a = nullptr; const void* b = nullptr; const void* c = nullptr; const void* d = nullptr; int K = 0; bool valid = false; } wsig;
     std::string err;
 };
 
@@ -91,8 +94,17 @@ struct rdr_cube {
     mutable int big_point_calls = 0;             // rdr_interp3 calls that would have profited
     mutable std::mutex quad_mutex;               // one builder of the quad copy per cube
     bool has_nan = false;                        // a NaN among the fields (seen while packing; blends: unknown -> false)
-    size_t alloc_bytes = 0;                      // bytes of the ONE allocation behind d_vals (values | axes); 0: not owned (scratch cube)
+    size_t alloc_bytes = 0;                      // bytes of the ONE allocation behind d_vals (values | axes); 0: not owned (scratch cube, view)
+    // views (rdr_cube_view): `base` != NULL marks a handle that shares base's buffers and corner-quad copy and owns only its projection
+    const rdr_cube* base = nullptr;
+    mutable int views = 0;                       // live views of THIS cube (guarded by g_view_mutex)
+    mutable bool doomed = false;                 // destroyed while views were alive: the last view frees the buffers
+    mutable std::atomic<bool> foreign{false};    // used from a context other than its own: its buffers are freed synchronously, never pooled
 };
+static std::mutex g_view_mutex;
+static inline const rdr_cube* root(const rdr_cube* q) { return q->base ? q->base : q; }
+// every entry point that reads a cube says so: work enqueued by ANOTHER context is not covered by the events the owner records at destroy
+static inline void note_use(const rdr_ctx* c, const rdr_cube* q) { if (c && q && root(q)->ctx != c) root(q)->foreign.store(true, std::memory_order_relaxed); }
 
 static int fail(rdr_ctx* ctx, int code, const std::string& msg) {
     g_err = msg;
@@ -252,7 +264,7 @@ void rdr_destroy(rdr_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto& b : c->slot) if (b.p) (void)hipFree(b.p);
-    for (auto& e : c->cube_pool) { if (e.ev) (void)hipEventDestroy(e.ev); (void)hipFree(e.p); }
+    for (auto& e : c->cube_pool) { for (auto ev : e.evs) (void)hipEventDestroy(ev); (void)hipFree(e.p); }
     if (c->d_maxlen) (void)hipFree(c->d_maxlen);
     if (c->d_flags) (void)hipFree(c->d_flags);
     if (c->d_nparts) (void)hipFree(c->d_nparts);
@@ -274,7 +286,12 @@ int rdr_set_stream(rdr_ctx* c, void* s) {
     // NULL is HIP's legacy default stream (what torch.cuda.current_stream().cuda_stream is unless the caller
     // switched streams); (void*)-1 restores the ctx's private stream
     if (s == (void*)(intptr_t)-1) c->stream = c->own_stream;
-    else c->stream = (hipStream_t)s;
+    else {
+        c->stream = (hipStream_t)s;
+        if (std::find(c->ext_streams.begin(), c->ext_streams.end(), c->stream) == c->ext_streams.end()) {
+            if (c->ext_streams.size() < 8) c->ext_streams.push_back(c->stream); else c->ext_overflow = true;
+        }
+    }
     return RDR_OK;
 }
 
@@ -315,6 +332,32 @@ int rdr_set_workspace_limit(rdr_ctx* c, int64_t bytes) {
     if (!c || bytes < (int64_t)1 << 20) return fail(c, RDR_ERR_INVALID, "rdr_set_workspace_limit: need at least 1 MiB");
     c->ws_limit = (size_t)bytes;
     c->wsig.valid = false;
+    return RDR_OK;
+}
+
+int rdr_trim(rdr_ctx* c, int64_t keep_bytes, int64_t* released) {
+    if (!c || keep_bytes < 0) return fail(c, RDR_ERR_INVALID, "rdr_trim: NULL context or a negative size");
+    HIPCHECK(c, hipSetDevice(c->device));
+    HIPCHECK(c, hipStreamSynchronize(c->down_stream));
+    HIPCHECK(c, hipStreamSynchronize(c->copy_stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    if (c->stream != c->own_stream) HIPCHECK(c, hipStreamSynchronize(c->own_stream));
+    const size_t keep = (size_t)keep_bytes;
+    size_t freed = 0;
+    auto drop = [&](DevBuf& b) { if (b.p && b.cap > keep) { if (hipFree(b.p) == hipSuccess) freed += b.cap; b.p = nullptr; b.cap = 0; } };
+    for (auto& b : c->slot) drop(b);
+    if ((c->ws.p && c->ws.cap > keep) || (c->side.p && c->side.cap > keep)) c->wsig.valid = false;      // (the stored ray records go with them)
+    drop(c->ws);
+    if (c->side.p && c->side.cap > keep) { drop(c->side); c->side_cap = 0; }
+    while (!c->cube_pool.empty() && c->cube_pool_bytes > keep) {          // oldest first
+        rdr_ctx::PoolEntry e = c->cube_pool.front();
+        c->cube_pool.erase(c->cube_pool.begin());
+        c->cube_pool_bytes -= e.bytes;
+        for (auto ev : e.evs) { (void)hipEventSynchronize(ev); (void)hipEventDestroy(ev); }
+        if (hipFree(e.p) == hipSuccess) freed += e.bytes;
+    }
+    (void)hipGetLastError();
+    if (released) *released = (int64_t)freed;
     return RDR_OK;
 }
 
@@ -439,10 +482,11 @@ static int cube_alloc(rdr_ctx* c, rdr_cube* q) {
         const rdr_ctx::PoolEntry e = c->cube_pool[i];
         c->cube_pool.erase(c->cube_pool.begin() + (long)i);
         c->cube_pool_bytes -= bytes;
-        // (its previous cube's last work was enqueued before this event: whatever stream builds the new cube waits for it)
-        hipError_t w = e.ev ? hipStreamWaitEvent(c->stream, e.ev, 0) : hipSuccess;
-        if (e.ev) (void)hipEventDestroy(e.ev);
-        if (w != hipSuccess) { (void)hipFree(e.p); (void)hipGetLastError(); break; }
+        // (its previous cube's last work on every stream this context launches on was enqueued before these events: whatever stream
+        // builds the new cube waits for them)
+        hipError_t w = hipSuccess;
+        for (auto ev : e.evs) { if (w == hipSuccess) w = hipStreamWaitEvent(c->stream, ev, 0); (void)hipEventDestroy(ev); }
+        if (w != hipSuccess) { (void)hipDeviceSynchronize(); (void)hipFree(e.p); (void)hipGetLastError(); break; }
         q->d_vals = e.p;
         break;
     }
@@ -511,24 +555,76 @@ int rdr_cube_create(rdr_ctx* c, const double* ys, int64_t ny, const double* xs, 
     return RDR_OK;
 }
 
-void rdr_cube_destroy(rdr_cube* q) {
-    if (!q) return;
+static int cone_params(rdr_ctx* c, const char* who, int kind, const double* p, int np, LccParams& out);
+
+// The buffers of a dead cube.  Pooled (no synchronisation) with one event per stream the owning context has ever launched on - its own
+// three and every caller stream handed to rdr_set_stream (a torch stream adopted earlier may still be reading the cube) - or, when that
+// cannot be established (another context used the cube, more caller streams than are tracked, an event that cannot be recorded - e.g.
+// on a stream the caller has destroyed), freed after a device-wide synchronisation.
+static void cube_release(rdr_cube* q) {
     rdr_ctx* c = q->ctx;
     if (c) (void)hipSetDevice(c->device);
     bool pooled = false;
-    if (c && q->d_vals && q->alloc_bytes > 0 && c->cube_pool.size() < 6 && c->cube_pool_bytes + q->alloc_bytes <= c->cube_pool_limit) {
-        // hand the buffer on instead of freeing it: no synchronisation - the event marks the end of everything enqueued on it so far
-        hipEvent_t ev = nullptr;
-        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess && hipEventRecord(ev, c->stream) == hipSuccess) {
-            c->cube_pool.push_back({q->d_vals, q->alloc_bytes, ev});
+    const bool foreign = q->foreign.load(std::memory_order_relaxed);
+    if (c && q->d_vals && q->alloc_bytes > 0 && !foreign && !c->ext_overflow && c->cube_pool.size() < 6 &&
+        c->cube_pool_bytes + q->alloc_bytes <= c->cube_pool_limit) {
+        std::vector<hipStream_t> st = {c->own_stream, c->copy_stream, c->down_stream};
+        for (auto s_ : c->ext_streams) st.push_back(s_);
+        if (std::find(st.begin(), st.end(), c->stream) == st.end()) st.push_back(c->stream);
+        std::vector<hipEvent_t> evs;
+        bool ok = true;
+        for (auto s_ : st) {
+            hipEvent_t ev = nullptr;
+            if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { ok = false; break; }
+            evs.push_back(ev);
+            if (hipEventRecord(ev, s_) != hipSuccess) { ok = false; break; }
+        }
+        if (ok) {
+            c->cube_pool.push_back({q->d_vals, q->alloc_bytes, evs});
             c->cube_pool_bytes += q->alloc_bytes;
             pooled = true;
-        } else { if (ev) (void)hipEventDestroy(ev); (void)hipGetLastError(); }
+        } else { for (auto ev : evs) (void)hipEventDestroy(ev); (void)hipGetLastError(); }
     }
-    if (!pooled || q->d_quad) { if (c) (void)hipStreamSynchronize(c->stream); }
-    if (!pooled && q->d_vals) (void)hipFree(q->d_vals);       // (the axes live in the same allocation)
+    if (!pooled || q->d_quad) { if (foreign || !c || c->ext_overflow || !pooled) (void)hipDeviceSynchronize(); else (void)hipStreamSynchronize(c->stream); }
+    if (!pooled && q->d_vals && q->alloc_bytes > 0) (void)hipFree(q->d_vals);       // (the axes live in the same allocation)
     if (q->d_quad) (void)hipFree(q->d_quad);
     delete q;
+}
+
+void rdr_cube_destroy(rdr_cube* q) {
+    if (!q) return;
+    const rdr_cube* dead_root = nullptr;
+    {
+        std::lock_guard<std::mutex> guard(g_view_mutex);
+        if (q->base) {                                  // a view: only the handle goes; the last view of a destroyed source frees the buffers
+            const rdr_cube* r = q->base;
+            delete q;
+            if (--r->views == 0 && r->doomed) dead_root = r;
+            q = nullptr;
+        } else if (q->views > 0) { q->doomed = true; q = nullptr; }
+    }
+    if (dead_root) cube_release(const_cast<rdr_cube*>(dead_root));
+    if (q) cube_release(q);
+}
+
+int rdr_cube_view(rdr_ctx* c, const rdr_cube* src, int kind, const double* p, int np, rdr_cube** out) {
+    if (!c || !src || !out) return fail(c, RDR_ERR_INVALID, "rdr_cube_view: NULL argument");
+    *out = nullptr;
+    LccParams L = src->proj;
+    if (kind == RDR_PROJ_LONLAT) L = LccParams{0, 0, 0, 0, 0, 0, 0, 0};
+    else if (kind != -1) { const int rc = cone_params(c, "rdr_cube_view", kind, p, np, L); if (rc) return rc; }
+    const rdr_cube* r = root(src);
+    if (c->device != r->ctx->device) return fail(c, RDR_ERR_INVALID, "rdr_cube_view: the context is on another device than the cube");
+    rdr_cube* v = new rdr_cube();
+    v->ctx = c; v->ny = r->ny; v->nx = r->nx; v->nz = r->nz; v->dtype = r->dtype;
+    v->d_vals = r->d_vals; v->d_axes = r->d_axes; v->ys = r->ys; v->xs = r->xs; v->zs = r->zs;
+    for (int i = 0; i < 3; ++i) { v->uni[i] = r->uni[i]; v->inv_d[i] = r->inv_d[i]; }
+    v->exact[0] = r->exact[0]; v->exact[1] = r->exact[1];
+    v->proj = L; v->has_nan = r->has_nan; v->alloc_bytes = 0; v->base = r;
+    note_use(c, r);
+    { std::lock_guard<std::mutex> guard(g_view_mutex); ++r->views; }
+    *out = v;
+    return RDR_OK;
 }
 
 int rdr_cube_has_nan(const rdr_cube* q) { return q ? (q->has_nan ? 1 : 0) : -1; }
@@ -599,6 +695,7 @@ int rdr_transform_cone(rdr_ctx* c, int kind, const double* p, int np, int direct
 
 int rdr_project_points(rdr_ctx* c, const rdr_cube* q, const double* lat, const double* lon, int64_t n, double* y, double* x, int loc) {
     if (!c || !q || !lat || !lon || !y || !x) return fail(c, RDR_ERR_INVALID, "rdr_project_points: NULL argument");
+    note_use(c, q);
     if (n < 0) return fail(c, RDR_ERR_INVALID, "rdr_project_points: negative count");
     if (n == 0) return RDR_OK;
     HIPCHECK(c, hipSetDevice(c->device));
@@ -648,6 +745,7 @@ int rdr_transform_tm(rdr_ctx* c, const double* p, int np, int direction, const d
 
 int rdr_cube_blend(rdr_ctx* c, const rdr_cube* a, double w1, const rdr_cube* b, double w2, rdr_cube** out) {
     if (!c || !a || !b || !out) return fail(c, RDR_ERR_INVALID, "rdr_cube_blend: NULL argument");
+    note_use(c, a); note_use(c, b);
     if (a->ny != b->ny || a->nx != b->nx || a->nz != b->nz || a->dtype != b->dtype || a->ys != b->ys || a->xs != b->xs || a->zs != b->zs)
         return fail(c, RDR_ERR_INVALID, "rdr_cube_blend: cubes are not on the same grid / dtype");
     HIPCHECK(c, hipSetDevice(c->device));
@@ -718,6 +816,7 @@ int rdr_cube_blend_weighted(rdr_ctx* c, const rdr_cube* const* cubes, int32_t nd
     for (int i = 0; i < nd; ++i) {
         const rdr_cube* b = cubes[i];
         if (!b) return fail(c, RDR_ERR_INVALID, "rdr_cube_blend_weighted: NULL cube");
+        note_use(c, b);
         if (a->ny != b->ny || a->nx != b->nx || a->nz != b->nz || a->dtype != b->dtype || a->ys != b->ys || a->xs != b->xs || a->zs != b->zs)
             return fail(c, RDR_ERR_INVALID, "rdr_cube_blend_weighted: cubes are not on the same grid / dtype");
         S.v[i] = b->d_vals;
@@ -787,6 +886,7 @@ int rdr_delays_to_phase(rdr_ctx* c, const void* wet, const void* hydro, int64_t 
 
 int rdr_cube_read(rdr_ctx* c, const rdr_cube* q, void* wet, void* hydro) {
     if (!c || !q || !wet || !hydro) return fail(c, RDR_ERR_INVALID, "rdr_cube_read: NULL argument");
+    note_use(c, q);
     HIPCHECK(c, hipSetDevice(c->device));
     const int64_t total = q->ny * q->nx * q->nz;
     const size_t esz = q->dtype == RDR_F32 ? 4 : 8;
@@ -813,7 +913,8 @@ static size_t quad_need_bytes(const rdr_cube* q, int* nblk) {
     return (size_t)(q->ny - 1) * (size_t)(q->nx - 1) * (size_t)*nblk * 128;
 }
 
-static int quad_build(rdr_ctx* c, const rdr_cube* q) {
+static int quad_build(rdr_ctx* c, const rdr_cube* q_any) {
+    const rdr_cube* const q = root(q_any);              // (the copy belongs to the buffers, i.e. to the source of a view)
     // (one builder per cube: two contexts sharing a cube must not both allocate and publish a copy)
     std::lock_guard<std::mutex> guard(q->quad_mutex);
     if (q->d_quad) return RDR_OK;
@@ -843,7 +944,8 @@ static int quad_build(rdr_ctx* c, const rdr_cube* q) {
 // the copy's bytes (12 M points for that cube; a 5 M-station one-shot is FASTER from the (y,x,z) cube: 0.43 ms against 0.72 + 0.15 -
 // fewer HBM bytes per point is not the goal, time is), else from the second large call on the cube (then the copy has paid for itself
 // by the end of that call).  RAIDER_HIP_POINT_INDEX=0 never, =1 at the first large call, =2 second call only.
-static bool quad_wanted(rdr_ctx* c, const rdr_cube* q, int64_t n) {
+static bool quad_wanted(rdr_ctx* c, const rdr_cube* q_any, int64_t n) {
+    const rdr_cube* const q = root(q_any);
     if (q->d_quad) return true;
     static const int env = []() { const char* e = std::getenv("RAIDER_HIP_POINT_INDEX"); return e ? std::atoi(e) : -1; }();
     if (env == 0) return false;
@@ -858,12 +960,14 @@ static bool quad_wanted(rdr_ctx* c, const rdr_cube* q, int64_t n) {
     return true;
 }
 
-int rdr_cube_point_index(rdr_ctx* c, rdr_cube* q, int mode) {
-    if (!c || !q) return fail(c, RDR_ERR_INVALID, "rdr_cube_point_index: NULL argument");
+int rdr_cube_point_index(rdr_ctx* c, rdr_cube* q_any, int mode) {
+    if (!c || !q_any) return fail(c, RDR_ERR_INVALID, "rdr_cube_point_index: NULL argument");
+    const rdr_cube* const q = root(q_any);
+    note_use(c, q);
     HIPCHECK(c, hipSetDevice(c->device));
     if (mode == 0) {
         std::lock_guard<std::mutex> guard(q->quad_mutex);
-        if (q->d_quad) { HIPCHECK(c, hipStreamSynchronize(c->stream)); HIPCHECK(c, hipFree(q->d_quad)); q->d_quad = nullptr; q->quad_bytes = 0; q->quad_nblk = 0; }
+        if (q->d_quad) { HIPCHECK(c, q->foreign.load() ? hipDeviceSynchronize() : hipStreamSynchronize(c->stream)); HIPCHECK(c, hipFree(q->d_quad)); q->d_quad = nullptr; q->quad_bytes = 0; q->quad_nblk = 0; }
         q->big_point_calls = 0;
         return RDR_OK;
     }
@@ -872,7 +976,7 @@ int rdr_cube_point_index(rdr_ctx* c, rdr_cube* q, int mode) {
     return quad_build(c, q);
 }
 
-int64_t rdr_cube_point_index_bytes(const rdr_cube* q) { return q ? (int64_t)q->quad_bytes : -1; }
+int64_t rdr_cube_point_index_bytes(const rdr_cube* q) { return q ? (int64_t)root(q)->quad_bytes : -1; }
 
 // a second epoch blended in at the corners (rdr_interp3_blend): vb == NULL for an ordinary gather
 struct BlendSpec { const void* vb = nullptr; double w1 = 1.0, w2 = 0.0; };
@@ -890,10 +994,10 @@ static void launch_interp(rdr_ctx* c, const rdr_cube* q, const PointQuery& Qk, i
     } else if (quad) {
         if (q->dtype == RDR_F32)
             hipLaunchKernelGGL((interp_points_quad_kernel<float2>), dim3(g), dim3(256), axes_smem(q), c->stream, make_view<float2>(q),
-                               (const uint4*)q->d_quad, q->quad_nblk, Qk, cnt, dwk, dhk, (int)axes_fit_lds(q));
+                               (const uint4*)root(q)->d_quad, root(q)->quad_nblk, Qk, cnt, dwk, dhk, (int)axes_fit_lds(q));
         else
             hipLaunchKernelGGL((interp_points_quad_kernel<double2>), dim3(g), dim3(256), axes_smem(q), c->stream, make_view<double2>(q),
-                               (const uint4*)q->d_quad, q->quad_nblk, Qk, cnt, dwk, dhk, (int)axes_fit_lds(q));
+                               (const uint4*)root(q)->d_quad, root(q)->quad_nblk, Qk, cnt, dwk, dhk, (int)axes_fit_lds(q));
     } else if (q->dtype == RDR_F32)
         hipLaunchKernelGGL((interp_points_kernel<float2>), dim3(g), dim3(256), axes_smem(q), c->stream, make_view<float2>(q), Qk, cnt, dwk, dhk,
                            (int)axes_fit_lds(q));
@@ -901,6 +1005,18 @@ static void launch_interp(rdr_ctx* c, const rdr_cube* q, const PointQuery& Qk, i
         hipLaunchKernelGGL((interp_points_kernel<double2>), dim3(g), dim3(256), axes_smem(q), c->stream, make_view<double2>(q), Qk, cnt, dwk, dhk,
                            (int)axes_fit_lds(q));
 }
+
+// An error return must not leave asynchronous copies into (or out of) the caller's buffers in flight: whoever enqueued on the three
+// streams arms this; leaving the scope on any path but the disarmed one waits for all of them.
+struct StreamsQuiesce {
+    rdr_ctx* c; bool armed = true;
+    explicit StreamsQuiesce(rdr_ctx* ctx) : c(ctx) {}
+    ~StreamsQuiesce() {
+        if (!armed) return;
+        (void)hipStreamSynchronize(c->down_stream); (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamSynchronize(c->stream);
+        (void)hipGetLastError();
+    }
+};
 
 // Large HOST point sets: the points go up (copy stream) and the delays come down (download stream) in chunks, the download of chunk k
 // under the upload of chunk k+1 (PCIe is full duplex), the gathers on the ctx stream in between - 40-48 B per point cross the link,
@@ -924,6 +1040,7 @@ static int interp_pipeline(rdr_ctx* c, const char* who, const rdr_cube* q, bool 
     evs.v.assign((size_t)2 * nchunk, nullptr);
     for (auto& e : evs.v)
         if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return fail(c, RDR_ERR_HIP, std::string(who) + ": event creation failed");
+    StreamsQuiesce quiesce(c);                  // (declared after the events: they are destroyed only once the streams are idle)
     for (int k = 0; k < nchunk; ++k) {
         const int64_t o = n * k / nchunk, cnt = n * (k + 1) / nchunk - o;
         HIPCHECK(c, hipMemcpyAsync((double*)dy + o * ystride, y + o * ystride, (size_t)cnt * ystride * 8, hipMemcpyHostToDevice, c->copy_stream));
@@ -948,6 +1065,7 @@ static int interp_pipeline(rdr_ctx* c, const char* who, const rdr_cube* q, bool 
     HIPCHECK(c, hipStreamSynchronize(c->down_stream));
     HIPCHECK(c, hipStreamSynchronize(c->copy_stream));
     HIPCHECK(c, hipStreamSynchronize(c->stream));
+    quiesce.armed = false;
     return RDR_OK;
 }
 
@@ -965,6 +1083,7 @@ static int point_query_args(rdr_ctx* c, const char* who, const double* y, const 
 static int interp3_impl(rdr_ctx* c, const char* who, const rdr_cube* q, const double* y, const double* x, const double* z, int64_t n, int pmode,
                         const double* proj, double inc0, double* wet, double* hydro, int loc, const BlendSpec& B = BlendSpec()) {
     if (!c || !q) return fail(c, RDR_ERR_INVALID, std::string(who) + ": NULL argument");
+    note_use(c, q);
     int rc = point_query_args(c, who, y, x, z, n, pmode, proj, wet, hydro); if (rc) return rc;
     if (n == 0) return RDR_OK;
     HIPCHECK(c, hipSetDevice(c->device));
@@ -1003,6 +1122,7 @@ int rdr_interp3(rdr_ctx* c, const rdr_cube* q, const double* pts, int64_t n, dou
 int rdr_interp3_blend(rdr_ctx* c, const rdr_cube* a, double w1, const rdr_cube* b, double w2, const double* y, const double* x, const double* z, int64_t n,
                       double* wet, double* hydro, int loc) {
     if (!c || !a || !b) return fail(c, RDR_ERR_INVALID, "rdr_interp3_blend: NULL argument");
+    note_use(c, b);
     if (a->ny != b->ny || a->nx != b->nx || a->nz != b->nz || a->dtype != b->dtype || a->ys != b->ys || a->xs != b->xs || a->zs != b->zs)
         return fail(c, RDR_ERR_INVALID, "rdr_interp3_blend: the two epochs are not on the same grid / dtype");
     BlendSpec B; B.vb = b->d_vals; B.w1 = w1; B.w2 = w2;
@@ -1019,6 +1139,7 @@ int rdr_interp3_project(rdr_ctx* c, const rdr_cube* q, const double* y, const do
 static int build_cube_impl(rdr_ctx* c, const rdr_cube* q, const double* xpts, int64_t nx, const double* ypts, int64_t ny,
                            const double* zpts, int64_t nz, double* wet, double* hydro, int loc, double** keep) {
     if (!c || !q || !xpts || !ypts || !zpts || (!keep && (!wet || !hydro))) return fail(c, RDR_ERR_INVALID, "rdr_build_cube: NULL argument");
+    note_use(c, q);
     if (nx < 0 || ny < 0 || nz < 0) return fail(c, RDR_ERR_INVALID, "rdr_build_cube: negative count");
     const int64_t n = nx * ny * nz;
     c->last_nan_output = -1;                  // (also for an empty build: the previous call's verdict is not this one's)
@@ -1154,6 +1275,7 @@ int rdr_point_delays(rdr_ctx* c, const rdr_cube* q, const double* xpts, int64_t 
     tmp.d_vals = dvals; tmp.d_axes = (double*)daxes;
     std::vector<double> ax;
     ax.insert(ax.end(), tmp.ys.begin(), tmp.ys.end()); ax.insert(ax.end(), tmp.xs.begin(), tmp.xs.end()); ax.insert(ax.end(), tmp.zs.begin(), tmp.zs.end());
+    StreamsQuiesce quiesce(c);                  // (`ax`, the caller's points and outputs: nothing may still be copying when an error returns)
     HIPCHECK(c, hipMemcpyAsync(daxes, ax.data(), ax.size() * 8, hipMemcpyHostToDevice, c->stream));
     double* planar[2] = {nullptr, nullptr};
     rc = build_cube_impl(c, q, xpts, nx, ypts, ny, zpts, nz, nullptr, nullptr, RDR_HOST, planar); if (rc) return rc;
@@ -1172,7 +1294,14 @@ int rdr_point_delays(rdr_ctx* c, const rdr_cube* q, const double* xpts, int64_t 
         static const int slots[6] = {SLOT_PT0, SLOT_PT1, SLOT_PT2, SLOT_PT3, SLOT_PT4, SLOT_PT5};
         rc = interp_pipeline(c, "rdr_point_delays", &tmp, false, y, x, z, n, Q, proj, wet, hydro, slots); if (rc) return rc;
     } else HIPCHECK(c, hipStreamSynchronize(c->stream));
+    quiesce.armed = false;                      // (both branches have synchronised)
     if (cube_has_nan) *cube_has_nan = c->h_word[0] != 0;
+    // a large job's intermediates (16 B per cell of the cube + 16 B per cell of planar results) are not kept for the life of the context
+    static const size_t keep = []() { const char* e = std::getenv("RAIDER_HIP_SCRATCH_KEEP_BYTES"); return e ? (size_t)std::strtoull(e, nullptr, 10) : (size_t)4 << 30; }();
+    for (int s_ : {SLOT_TMPCUBE, SLOT_OUT0, SLOT_OUT1}) {
+        DevBuf& b = c->slot[s_];
+        if (b.p && b.cap > keep) { (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
+    }
     return RDR_OK;
 }
 
@@ -1300,6 +1429,8 @@ static int stage_rays(rdr_ctx* c, const rdr_rays* r, RayParams& P, int64_t los_m
 static size_t ray_smem(const rdr_cube* q) {
     return ray_smem_bytes(q->ny, q->nx, q->nz, q->exact[0], q->exact[1]);
 }
+// dynamic + the static LDS of the ray kernels (march_kernel's staging block for f64 cubes: 4 waves x 48 x 16 B): what must fit the CU
+static size_t ray_lds_total(const rdr_cube* q) { return ray_smem(q) + (q->dtype == RDR_F64 ? (size_t)(BLOCK / 64) * 48 * 16 : 16); }
 
 // Persistent grid of `per_cu` workgroups per CU; tiles are handed out dynamically (TileWalk: one device atomic per tile and
 // XCD band), so the grid only has to cover the resident workgroups (3-4 per CU) with a little slack.  Measured on the bench
@@ -1374,7 +1505,7 @@ static void ws_attach(rdr_ctx* c, RayParams& P) {
 }
 
 static void wsig_set(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, double ht, double zref, int K, bool valid) {
-    c->wsig.cube = q; c->wsig.n = r->n; c->wsig.ht = ht; c->wsig.zref = zref; c->wsig.K = K; c->wsig.valid = valid;
+    c->wsig.cube = q; c->wsig.vals = q->d_vals; c->wsig.proj = q->proj; c->wsig.n = r->n; c->wsig.ht = ht; c->wsig.zref = zref; c->wsig.K = K; c->wsig.valid = valid;
     c->wsig.a = r->origin_mode == RDR_ORIGIN_GRID ? (const void*)r->xpts : (r->origin_mode == RDR_ORIGIN_XYZ ? (const void*)r->xyz : (const void*)r->lat);
     c->wsig.b = r->origin_mode == RDR_ORIGIN_GRID ? (const void*)r->ypts : (const void*)r->lon;
     c->wsig.c = r->los_mode == RDR_LOS_VEC ? (const void*)r->los : (const void*)r->inc;
@@ -1382,7 +1513,7 @@ static void wsig_set(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, double ht
 }
 
 static bool wsig_match(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, double ht, double zref, int K) {
-    if (!c->wsig.valid || c->wsig.cube != q || c->wsig.n != r->n || c->wsig.ht != ht || c->wsig.zref != zref || c->wsig.K != K) return false;
+    if (!c->wsig.valid || c->wsig.cube != q || c->wsig.vals != q->d_vals || std::memcmp(&c->wsig.proj, &q->proj, sizeof(LccParams)) != 0 || c->wsig.n != r->n || c->wsig.ht != ht || c->wsig.zref != zref || c->wsig.K != K) return false;
     if (r->loc != RDR_DEVICE) return false;   // host arrays may have been rewritten in place between the two calls
     const void* a = r->origin_mode == RDR_ORIGIN_GRID ? (const void*)r->xpts : (r->origin_mode == RDR_ORIGIN_XYZ ? (const void*)r->xyz : (const void*)r->lat);
     const void* b = r->origin_mode == RDR_ORIGIN_GRID ? (const void*)r->ypts : (const void*)r->lon;
@@ -1396,8 +1527,8 @@ static bool wsig_match(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, double 
 static int launch_crossings(rdr_ctx* c, const rdr_cube* q, RayParams P, int64_t tb, int64_t tc, int64_t nslots_total = 0, bool reset_nslow = true) {
     P.tile_begin = tb; P.tile_count = tc; P.nslots = nslots_total > 0 ? nslots_total : tc * BLOCK;
     const int g = ray_grid(c, tc, 8);
-    if (ray_smem(q) > c->lds_max)
-        return fail(c, RDR_ERR_INVALID, "ray tracing: the cube's non-uniform horizontal axes and level tables need " + std::to_string(ray_smem(q)) +
+    if (ray_lds_total(q) > c->lds_max)
+        return fail(c, RDR_ERR_INVALID, "ray tracing: the cube's non-uniform horizontal axes and level tables need " + std::to_string(ray_lds_total(q)) +
                     " B of LDS per workgroup, the device offers " + std::to_string(c->lds_max) + " (resample the cube to uniform axes or crop it)");
     if (reset_nslow) {
         HIPCHECK(c, hipMemsetAsync(c->d_nslow, 0, sizeof(int), c->stream));
@@ -1575,6 +1706,7 @@ static int flags_to_status(rdr_ctx* c, int flags) {
 
 int rdr_ray_prepass(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, double ht, double zref, double* maxlen, int32_t* flags) {
     if (!c || !q || !maxlen) return fail(c, RDR_ERR_INVALID, "rdr_ray_prepass: NULL argument");
+    note_use(c, q);
     int rc = check_rays(c, r); if (rc) return rc;
     std::vector<double> lo, hi; std::vector<int> kz;
     const int K = levels_host(q->zs, ht, zref, lo, hi, kz);
@@ -1605,6 +1737,7 @@ int rdr_ray_prepass(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, double ht,
 
 int rdr_ray_prepass_device(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, double ht, double zref, double* partition) {
     if (!c || !q || !partition) return fail(c, RDR_ERR_INVALID, "rdr_ray_prepass_device: NULL argument");
+    note_use(c, q);
     int rc = check_rays(c, r); if (rc) return rc;
     if (r->loc != RDR_DEVICE) return fail(c, RDR_ERR_INVALID, "rdr_ray_prepass_device: rays must be device arrays");
     std::vector<double> lo, hi; std::vector<int> kz;
@@ -1631,6 +1764,7 @@ int rdr_ray_prepass_device(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, dou
 int rdr_ray_march_device(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, double ht, double zref, double max_seg, const double* partition,
                          double* wet, double* hydro) {
     if (!c || !q || !partition || !wet || !hydro) return fail(c, RDR_ERR_INVALID, "rdr_ray_march_device: NULL argument");
+    note_use(c, q);
     if (!(max_seg > 0)) return fail(c, RDR_ERR_INVALID, "rdr_ray_march_device: MAX_SEGMENT_LENGTH must be positive");
     int rc = check_rays(c, r); if (rc) return rc;
     if (r->loc != RDR_DEVICE) return fail(c, RDR_ERR_INVALID, "rdr_ray_march_device: rays and outputs must be device arrays");
@@ -1655,6 +1789,7 @@ int rdr_ray_march_device(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, doubl
 int rdr_ray_march(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, double ht, double zref, const int32_t* nparts, int32_t flags,
                   double* wet, double* hydro) {
     if (!c || !q || !nparts || !wet || !hydro) return fail(c, RDR_ERR_INVALID, "rdr_ray_march: NULL argument");
+    note_use(c, q);
     int rc = check_rays(c, r); if (rc) return rc;
     std::vector<double> lo, hi; std::vector<int> kz;
     const int K = levels_host(q->zs, ht, zref, lo, hi, kz);
@@ -1688,6 +1823,7 @@ int rdr_ray_march(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, double ht, d
 int rdr_raytrace(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r, double ht, double zref, double max_seg, double* wet,
                  double* hydro, int32_t* nparts_out, int32_t* flags_out) {
     if (!c || !q || !wet || !hydro) return fail(c, RDR_ERR_INVALID, "rdr_raytrace: NULL argument");
+    note_use(c, q);
     if (!(max_seg > 0)) return fail(c, RDR_ERR_INVALID, "rdr_raytrace: MAX_SEGMENT_LENGTH must be positive");
     int rc = check_rays(c, r); if (rc) return rc;
     std::vector<double> lo, hi; std::vector<int> kz;
@@ -1771,6 +1907,7 @@ static int raytrace_slices_impl(rdr_ctx* c, const rdr_cube* q, const rdr_rays* r
                                 double zref, double max_seg, double* wet, double* hydro, int32_t* K_out, int32_t* nparts_out, int32_t ld,
                                 int32_t* flags_out, double** keep) {
     if (!c || !q || !hts || (!keep && (!wet || !hydro))) return fail(c, RDR_ERR_INVALID, "rdr_raytrace_slices: NULL argument");
+    note_use(c, q);
     if (nslices < 1 || nslices > MAX_SLICES) return fail(c, RDR_ERR_INVALID, "rdr_raytrace_slices: 1..512 slices per call");
     if (!(max_seg > 0)) return fail(c, RDR_ERR_INVALID, "rdr_raytrace_slices: MAX_SEGMENT_LENGTH must be positive");
     if (nparts_out && ld < (int32_t)q->nz - 1) return fail(c, RDR_ERR_INVALID, "rdr_raytrace_slices: nparts_out needs a row length of at least nz-1");

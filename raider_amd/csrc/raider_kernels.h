@@ -1338,7 +1338,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
             };
             if (REGULAR && __all(lane_safe)) {
                 if constexpr (STAGED) {
-                    if (P.stage_f64 && c.ny >= 4 && c.nx >= 4) run_staged();
+                    if (P.stage_f64 && c.ny >= 4 && c.nx >= 4 && c.nz >= 3) run_staged();      // (the staged block holds z entries zb .. zb+2, zb >= 0)
                     else run(std::integral_constant<bool, true>{});
                 } else run(std::integral_constant<bool, true>{});
             }

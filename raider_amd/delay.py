@@ -141,23 +141,32 @@ def _tm_params(crs):
                 x_0=float(d.get('x_0', 0.0)), y_0=float(d.get('y_0', 0.0)))
 
 
-def _apply_model_crs(cube, model_crs):
-    """Make the device cube aware of the model CRS; returns True when the model is projected (queries must stay geodetic)."""
+def _model_projection(model_crs):
+    """The device-side description of a model CRS: None for lon/lat, a dict(proj='lcc' | 'stere', ...) for the conic grids the kernels
+    project to, False for anything else."""
     if _is_4326(model_crs):
-        if cube.projection is not None:
-            cube.clear_projection()             # (a cached cube that served a projected model before)
-        return False
+        return None
     lcc = _lcc_params(model_crs)
     if lcc is not None:
-        if cube.projection is None or cube.projection.get('proj') != 'lcc' or {k: cube.projection.get(k) for k in lcc} != lcc:
-            cube.set_projection_lcc(**lcc)
-        return True
+        return dict(lcc, proj='lcc')
     st = _stere_params(model_crs)
     if st is not None:
-        if cube.projection is None or cube.projection.get('proj') != 'stere' or {k: cube.projection.get(k) for k in st} != st:
-            cube.set_projection_stere(**st)
-        return True
+        return dict(st, proj='stere')
     return False
+
+
+def _with_model_crs(cube, model_crs):
+    """(the cube THIS call works on, model is projected).  The reference rebuilds its transformers in every call and shares nothing
+    (delay.py:196-216,238-253); here the device cube of a file is cached and shared between calls and threads, so it is NEVER
+    modified: a call whose model CRS differs from what the cube carries gets a view - a second handle on the same device buffers
+    with its own projection (Cube.view, rdr_cube_view; a few microseconds, no device work).  An unknown CRS: (cube, False)."""
+    want = _model_projection(model_crs)
+    if want is False:
+        return cube, False
+    have = cube.projection
+    same = (have is None and want is None) or (have is not None and want is not None and have.get('proj') == want['proj'] and
+                                               all(have.get(k) == v for k, v in want.items()))
+    return (cube if same else cube.view(want)), want is not None
 
 
 # ------------------------------------------------------------------------------------------------
@@ -296,22 +305,15 @@ def _cube_of(interpolators):
         return first.cube, [i.field for i in interpolators]
     if len(interpolators) > 2:
         raise ValueError('at most two interpolators (wet, hydro) are supported')
-    # cached upload, valid only for the SAME pair of interpolators still holding the SAME value arrays (an interpolator whose
-    # `.values` were replaced, or paired with a different partner, is uploaded again)
+    # Foreign interpolators are uploaded afresh on EVERY call: the reference reads `.values` at call time, so an array edited in place
+    # between two calls must give new results, and no identity / shape / sample check can see such an edit short of reading all of
+    # it - which costs what the upload costs (57 MB of an ERA5-sized pair: ~2 ms; the device buffer is recycled from the context's
+    # cube pool, nothing is allocated).  (Rounds 3-4 cached the upload on the first object, validated by identity of `.values` only.)
     last = interpolators[-1]
-    fv, lv = first.values, last.values
-    cached = getattr(first, '_raider_amd_cube', None)
-    # (the cache entry HOLDS the partner and the two value arrays it was made from, so `is` cannot be fooled by a recycled id())
-    if cached is not None and cached[0] is last and cached[1] is fv and cached[2] is lv and cached[3] == np.shape(fv):
-        return cached[4], list(range(len(interpolators)))
     grid = first.grid
-    a = np.asarray(fv)
-    b = np.asarray(lv)
+    a = np.asarray(first.values)
+    b = np.asarray(last.values)
     cube = Cube(grid[0], grid[1], grid[2], a, b.astype(a.dtype, copy=False), order='yxz')
-    try:
-        first._raider_amd_cube = (last, fv, lv, np.shape(fv), cube)
-    except AttributeError:
-        pass
     return cube, list(range(len(interpolators)))
 
 
@@ -449,29 +451,48 @@ def _point_branch_on_device(weather_model_file, wm_proj, aoi, heights, los, crs,
     dz = np.diff(zpts)
     if not (np.all(dz > 0) or np.all(dz < 0)):
         return None                                                    # (scipy's grid rule: the host sequence raises what it raises)
-    if los.is_Zenith() or los.is_Projected():
-        ifWet, ifHydro = getInterpolators(weather_model_file, 'total')
-        cube = ifWet.cube
-        if _is_4326(wm_proj) and cube.projection is not None:
-            cube.clear_projection()
-        if not ((_same_crs(wm_proj, crs) and cube.projection is None) or (_is_4326(crs) and _apply_model_crs(cube, wm_proj))):
-            return None
-        wet, hyd, has_nan = cube.point_delays(xpts, ypts, zpts, *pts, **kw)
-    else:
-        if not (_is_4326(crs) and hasattr(los, 'ray_batch_slices')):
-            return None
-        ifWet, ifHydro = getInterpolators(weather_model_file, kind='pointwise')
-        cube = ifWet.cube
-        if _is_4326(wm_proj):
-            if cube.projection is not None:
-                cube.clear_projection()
-        elif not _apply_model_crs(cube, wm_proj):
-            return None
-        rays = los.ray_batch_slices(xpts, ypts, zpts)
-        dcube, K, _nparts, flags = cube.raytrace_slices_to_cube(rays, zpts, zref, 1000.0)
-        _raise_slice_failures(K, flags, zpts, zpts[-1])
-        has_nan = dcube.has_nan()
-        wet, hyd = dcube.interp_project(*pts, **kw)
+    from ._lib import DeviceOutOfMemory
+    try:
+        if los.is_Zenith() or los.is_Projected():
+            ifWet, ifHydro = getInterpolators(weather_model_file, 'total')
+            cube = ifWet.cube
+            if _same_crs(wm_proj, crs) and (cube.projection is None or _is_4326(wm_proj)):
+                cube, _ = _with_model_crs(cube, 4326)                     # grid nodes already in the model's coordinates: nothing to project
+            elif _is_4326(crs):
+                cube, projected = _with_model_crs(cube, wm_proj)
+                if not projected:
+                    return None
+            else:
+                return None
+            wet, hyd, has_nan = cube.point_delays(xpts, ypts, zpts, *pts, **kw)
+        else:
+            if not (_is_4326(crs) and hasattr(los, 'ray_batch_slices')):
+                return None
+            ifWet, ifHydro = getInterpolators(weather_model_file, kind='pointwise')
+            cube, projected = _with_model_crs(ifWet.cube, wm_proj)
+            if not (projected or _is_4326(wm_proj)):
+                return None
+            # the whole intermediate cube in one batch only when it fits the slice budget of _build_cube_ray (64 B per ray and slice on
+            # the device next to the 16 B per cell of the cube itself); larger jobs take the chunked host sequence
+            if xpts.size * ypts.size * zpts.size * 80 > int(os.environ.get('RAIDER_HIP_SLICE_BUDGET_BYTES', 8 << 30)):
+                return None
+            rays = los.ray_batch_slices(xpts, ypts, zpts)
+            dcube, K, _nparts, flags = cube.raytrace_slices_to_cube(rays, zpts, zref, 1000.0)
+            _raise_slice_failures(K, flags, zpts, zpts[-1])
+            has_nan = dcube.has_nan()
+            wet, hyd = dcube.interp_project(*pts, **kw)
+    except (MemoryError, RuntimeError) as exc:
+        # out of DEVICE memory (RDR_ERR_OOM -> _lib.DeviceOutOfMemory, a MemoryError; torch's allocator: torch.OutOfMemoryError, a
+        # RuntimeError): the one-call route holds the whole intermediate cube; the host sequence builds it in chunks that are halved
+        # until they fit (_build_cube_ray), so the job still completes - as it did before the cube stayed on the device
+        if not (isinstance(exc, DeviceOutOfMemory) or type(exc).__name__ == 'OutOfMemoryError'):
+            raise
+        logger.info(f'the point branch did not fit the device in one piece ({exc}); continuing with the chunked sequence')
+        try:
+            cube.ctx.trim(0)
+        except Exception:
+            pass
+        return None
     if has_nan:                                                        # delay.py:187, answered while the cube was packed
         logger.critical('There are missing delay values. Check your inputs.')
     return wet, hyd
@@ -511,17 +532,20 @@ def _build_cube(xpts, ypts, zpts, model_crs, pts_crs, interpolators):
     """delay.py:196-216: zenith / projected cube, one trilinear gather of both fields per node."""
     cube, fields = _cube_of(interpolators)
     zpts = np.asarray(zpts)
-    if _is_4326(model_crs) and cube.projection is not None:
-        cube.clear_projection()                            # (a cached cube that served a projected model before)
-    def hinted(res):
+    if _is_4326(model_crs):
+        cube, _ = _with_model_crs(cube, 4326)              # (a cube that carries a projection: this call gets an unprojected view of it)
+    def hinted(c):
+        res = c.build_cube(xpts, ypts, zpts, want_nan=True)
         out = _Result(res[f] for f in fields)
         if len(out) == 2:                                 # what np.isnan(result).any() would find (delay.py:187): known from the device scan
-            out.has_nan = getattr(cube, 'last_build_cube_has_nan', None)
+            out.has_nan = res[2]                          # (part of the call's own result: the cube may be serving other threads)
         return out
     if _same_crs(model_crs, pts_crs) and cube.projection is None:
-        return hinted(cube.build_cube(xpts, ypts, zpts))   # points generated on the fly in the kernel
-    if _is_4326(pts_crs) and _apply_model_crs(cube, model_crs):
-        return hinted(cube.build_cube(xpts, ypts, zpts))   # lon/lat nodes projected to the model's LCC grid on the device
+        return hinted(cube)                                # points generated on the fly in the kernel
+    if _is_4326(pts_crs):
+        pcube, projected = _with_model_crs(cube, model_crs)
+        if projected:
+            return hinted(pcube)                           # lon/lat nodes projected to the model's LCC grid on the device
     xx, yy = np.meshgrid(xpts, ypts)
     outputArrs = [np.zeros((zpts.size, len(ypts), len(xpts))) for _ in interpolators]
     for ii, ht in enumerate(zpts):
@@ -538,10 +562,8 @@ def _build_cube_ray(xpts, ypts, zpts, los, model_crs, pts_crs, interpolators, ou
     pass 1 = build_ray's per-level ray lengths reduced to the slice maximum (-> nParts, delay.py:283),
     pass 2 = Newton level intersections + ECEF->geodetic + trilinear gather + trapezoid, per ray."""
     cube, fields = _cube_of(interpolators)
-    if _is_4326(model_crs):
-        if cube.projection is not None:
-            cube.clear_projection()                        # (a cached cube that served a projected model before)
-    elif not _apply_model_crs(cube, model_crs):
+    cube, projected = _with_model_crs(cube, model_crs)     # (never modifies a shared cube: a view with THIS call's model CRS)
+    if not (projected or _is_4326(model_crs)):
         raise NotImplementedError('ray tracing needs the weather cube on an EPSG:4326 lat/lon grid, a Lambert-conformal-conic grid '
                                   f'(HRRR) or a polar-stereographic grid (HRRR-AK); got {model_crs!r}')
     xpts = np.asarray(xpts, dtype=np.float64)
@@ -574,13 +596,13 @@ def _build_cube_ray(xpts, ypts, zpts, los, model_crs, pts_crs, interpolators, ou
             try:
                 rays = los.ray_batch_slices(xpts, ypts, zz)
                 if rays._torch_device is None:
-                    _, _, K, _nparts, flags = cube.raytrace_slices(rays, zz, MAX_TROPO_HEIGHT, MAX_SEGMENT_LENGTH,
-                                                                   out=(outputArrs[0][s0:s0 + zz.size], outputArrs[1][s0:s0 + zz.size]))
-                    any_nan = any_nan or bool(cube.last_nan_output.any())
+                    _, _, K, _nparts, flags, nan_out = cube.raytrace_slices(rays, zz, MAX_TROPO_HEIGHT, MAX_SEGMENT_LENGTH, want_nan=True,
+                                                                            out=(outputArrs[0][s0:s0 + zz.size], outputArrs[1][s0:s0 + zz.size]))
+                    any_nan = any_nan or bool(nan_out.any())
                 else:           # a device-resident batch (orbit-based look vectors made on the GPU): device outputs, one download per field
                     import torch
-                    dw, dh, K, _nparts, flags = cube.raytrace_slices(rays, zz, MAX_TROPO_HEIGHT, MAX_SEGMENT_LENGTH)
-                    any_nan = any_nan or bool(cube.last_nan_output.any())
+                    dw, dh, K, _nparts, flags, nan_out = cube.raytrace_slices(rays, zz, MAX_TROPO_HEIGHT, MAX_SEGMENT_LENGTH, want_nan=True)
+                    any_nan = any_nan or bool(nan_out.any())
                     torch.from_numpy(outputArrs[0][s0:s0 + zz.size]).copy_(dw); torch.from_numpy(outputArrs[1][s0:s0 + zz.size]).copy_(dh)
                     del dw, dh
             except (MemoryError, RuntimeError) as exc:

@@ -18,7 +18,7 @@ from .engine import Cube
 # so a file that was rewritten is read again - for the last RAIDER_HIP_FILE_CACHE files (default 4; 0 switches the cache off).
 _CACHE_LOCK = threading.Lock()
 _FILE_CACHE = OrderedDict()        # file key -> opened dataset
-_CUBE_CACHE = OrderedDict()        # (file key, kind, id(ctx)) -> Cube
+_CUBE_CACHE = OrderedDict()        # (file key, kind, context serial) -> Cube; a cached cube is shared and NEVER modified (delay._with_model_crs)
 
 
 def _cache_size():
@@ -182,7 +182,7 @@ def getInterpolators(wm_file, kind='pointwise', shared=False, ctx=None):
     if isinstance(wm_file, (str, Path)) and _cache_size():
         fkey = _file_key(wm_file)
         if fkey is not None:
-            ckey = (fkey, 'total' if kind == 'total' else 'pointwise', id(ctx) if ctx is not None else None)
+            ckey = (fkey, 'total' if kind == 'total' else 'pointwise', ctx.serial if ctx is not None else None)      # (a serial, not id(): never recycled)
             cube = _cache_get(_CUBE_CACHE, ckey)
             if cube is not None:                                       # the same file, still on the device
                 if cube.has_nan():

@@ -121,6 +121,34 @@ class Cube:
         self.projection = None
         return self
 
+    def view(self, projection='same', ctx=None):
+        """A second handle on the SAME device buffers (values, axes, corner-quad copy: nothing is copied) that owns only its projection
+        (rdr_cube_view) - how a cached cube serves callers with different model-CRS arguments without ever being modified.
+        projection: 'same' (this cube's), None (lon/lat) or a dict as `Cube.projection` holds it (proj='lcc' / 'stere' + parameters).
+        The view keeps this cube alive; the C side frees the buffers when the source and every view are gone, in any order."""
+        ctx = ctx or self.ctx
+        if projection == 'same':
+            projection = self.projection
+        if projection is None:
+            kind, p = 0, None
+        elif projection.get('proj') == 'lcc':
+            d = projection
+            kind, p = 1, np.array([d.get('a', 6371229.0), d.get('es', 0.0), d['lat_1'], d['lat_2'], d['lat_0'], d['lon_0'], d.get('x_0', 0.0), d.get('y_0', 0.0)], dtype=np.float64)
+        elif projection.get('proj') == 'stere':
+            d = projection
+            lat_ts = d.get('lat_ts')
+            kind, p = 2, np.array([d.get('a', 6371229.0), d.get('es', 0.0), d.get('lat_0', 90.0), np.nan if lat_ts is None else lat_ts, d.get('k_0', 1.0),
+                                   d.get('lon_0', 0.0), d.get('x_0', 0.0), d.get('y_0', 0.0)], dtype=np.float64)
+        else:
+            raise ValueError(f'Cube.view: unknown projection {projection!r}')
+        h = C.c_void_p()
+        check(ctx.lib.rdr_cube_view(ctx.handle, self.handle, kind, ptr(p), 0 if p is None else p.size, C.byref(h)), ctx.handle)
+        v = Cube.__new__(Cube)
+        v.ctx, v.handle, v.shape, v.dtype, v.grid = ctx, h, self.shape, self.dtype, self.grid
+        v.projection = None if projection is None else dict(projection)
+        v._source = self
+        return v
+
     def project(self, lats, lons):
         """EPSG:4326 (lat, lon) -> the cube's (y, x) coordinates (identity for lon/lat cubes)."""
         lats, lons = np.broadcast_arrays(np.asarray(lats, dtype=np.float64), np.asarray(lons, dtype=np.float64))
@@ -266,8 +294,10 @@ class Cube:
               self.ctx.handle)
         return Cube._from_handle(self.ctx, h)
 
-    def build_cube(self, xpts, ypts, zpts, out=None):
-        """_build_cube (delay.py:196-216): (wet, hydro) of shape (nz, ny, nx)."""
+    def build_cube(self, xpts, ypts, zpts, out=None, want_nan=False):
+        """_build_cube (delay.py:196-216): (wet, hydro) of shape (nz, ny, nx).  want_nan=True (host arrays): (wet, hydro, has_nan) with
+        has_nan = np.isnan(result).any() as scanned on the device (None: not scanned) - part of the RESULT, not state of this object:
+        a cached cube serves several threads."""
         if _is_dev(xpts):
             import torch
             self.ctx.adopt_torch_stream(xpts)
@@ -288,7 +318,8 @@ class Cube:
             check(self.ctx.lib.rdr_build_cube(self.ctx.handle, self.handle, ptr(x), x.size, ptr(y), y.size, ptr(z), z.size,
                                               ptr(wet), ptr(hyd), L.RDR_HOST), self.ctx.handle)
             f = self.ctx.lib.rdr_last_nan_output(self.ctx.handle)
-        self.last_build_cube_has_nan = None if f < 0 else bool(f)       # np.isnan(result).any(), scanned on the device
+        if want_nan:
+            return wet, hyd, (None if f < 0 else bool(f))             # np.isnan(result).any(), scanned on the device
         return wet, hyd
 
     # ---- rays ------------------------------------------------------------------------------------
@@ -374,12 +405,13 @@ class Cube:
                                         ptr(wet), ptr(hyd), None, None), self.ctx.handle)
         return wet, hyd, None, None
 
-    def raytrace_slices(self, rays, hts, zref, max_seg=1000.0, out=None, want_partition=True):
+    def raytrace_slices(self, rays, hts, zref, max_seg=1000.0, out=None, want_partition=True, want_nan=False):
         """The height loop of _build_cube_ray (delay.py:256-323) in one launch pair: every slice hts[s] of the same origins is
         integrated exactly as raytrace() would integrate it alone (own level table, slice maxima, nParts, z-clamp decision).
         `rays`: a GRID / LLH batch; when built with slices=S its look-vector / incidence arrays hold one block per slice.
         Returns (wet[S,...], hydro[S,...], K[S], nparts[S, nz-1], flags[S]); the last three are None when want_partition is
-        False (fully asynchronous for device arrays).  K[s] == 0: build_ray -> None for that slice (its delays are 0)."""
+        False (fully asynchronous for device arrays).  K[s] == 0: build_ray -> None for that slice (its delays are 0).
+        want_nan=True: a sixth element, bool[S] = np.isnan(result[s]).any() as scanned on the device before the download."""
         rays.adopt_stream(self.ctx)
         if rays.ht_min is not None:
             raise ValueError('a batch with per-ray heights is ONE slice: use raytrace()')
@@ -403,9 +435,9 @@ class Cube:
                                                    float(max_seg), ptr(wet), ptr(hyd), ptr(K), ptr(nparts), ld, ptr(flags)), self.ctx.handle)
             # RDR_FLAG_NAN_OUTPUT (np.isnan(result).any() per slice, scanned on the device before the download) is reported apart
             # from the partition flags, which stay what rdr_raytrace returns for the slice
-            self.last_nan_output = (flags & L.FLAG_NAN_OUTPUT) != 0
+            nan_out = (flags & L.FLAG_NAN_OUTPUT) != 0
             flags &= ~np.int32(L.FLAG_NAN_OUTPUT)
-            return wet, hyd, K, nparts, flags
+            return (wet, hyd, K, nparts, flags, nan_out) if want_nan else (wet, hyd, K, nparts, flags)
         check(self.ctx.lib.rdr_raytrace_slices(self.ctx.handle, self.handle, C.byref(rays.struct), ptr(hts), S, int(rays.slices > 0), float(zref),
                                                float(max_seg), ptr(wet), ptr(hyd), None, None, ld, None), self.ctx.handle)
         return wet, hyd, None, None, None
