@@ -80,10 +80,31 @@ def load_parity(tag):
     return None, why
 
 
+def nccl_needs_devices(world, ndev):
+    return (f'bench.py: --backend nccl (RCCL) needs one GPU per rank: {world} ranks asked, {ndev} device(s) visible (RCCL refuses two ranks on one device). '
+            f'Run on a node with {world} GPUs, or use --backend auto: ranks that share a device then go through gloo with device-resident collective tensors '
+            f'(the same pass 1 -> all-reduce -> pass 2 code path; a dry run of the plumbing, not a scaling measurement).')
+
+
+def gather_rank_times(dist, dt, coll_dev, world):
+    """Every rank's own time of the timed region (s), on every rank: one all-gather of a double (outside the timed region; host tensors
+    unless the backend only takes device ones)."""
+    import torch
+    t = torch.tensor([dt], dtype=torch.float64, device=coll_dev if (coll_dev is not None and dist.get_backend() == 'nccl') else 'cpu')
+    out = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(out, t)
+    return [float(o.item()) for o in out]
+
+
 def self_launch(args):
     """`python bench.py --gpus N` invoked plainly: re-exec through torch.distributed.run with N ranks on this node."""
     import socket
     import subprocess
+    if args.backend == 'nccl':          # preflight: ONE clear message here instead of N torchrun tracebacks
+        import torch
+        ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if ndev < args.gpus:
+            raise SystemExit(nccl_needs_devices(args.gpus, ndev))
     with socket.socket() as s_:
         s_.bind(('127.0.0.1', 0)); port = s_.getsockname()[1]
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
@@ -117,12 +138,17 @@ def main():
                                                                 'its own GPU, else gloo with device-resident collective tensors (ranks sharing a GPU: RCCL refuses duplicates)')
     ap.add_argument('--dump', type=str, default='', help='write this rank\'s slab of the hydrostatic / wet delays to <dump>.rank<r>.npz (tests)')
     ap.add_argument('--cpu-sample', type=int, default=640, help='edge of the square ray block timed on the CPU oracle (0 = skip)')
-    ap.add_argument('--workload', choices=('rays', 'c5'), default='rays',
-                    help='rays (default): the ray-traced scene the metric is quoted on (configs[2] / configs[3]).  c5: BASELINE configs[4] - two HRRR-sized '
+    ap.add_argument('--workload', choices=('rays', 'c2', 'c5'), default='rays',
+                    help='rays (default): the ray-traced scene the metric is quoted on (configs[2] / configs[3]); its line also carries `secondary`: the kernel-level '
+                         'figures + parity errors of c2 and c5 (--no-secondary skips them).  c2: BASELINE configs[1] - Conventional slant (inc 39 deg), --points x --points '
+                         'query points with their own heights through the point branch (intermediate delay cube on the AOI grid + one gather + / cos(inc)) on the '
+                         'ERA5-sized f64 totals cube; value = points/s.  c5: BASELINE configs[4] - two HRRR-sized '
                          '1000x1000x50 f32 epochs on the 3-km LCC grid, blended (0.25, 0.75), --stations GNSS station points gathered from the blend; '
                          'N > 1: the epochs go out in two packed broadcasts, every rank blends and gathers its block of the stations (no data-path collective); '
                          'value = stations/s')
     ap.add_argument('--stations', type=int, default=5_000_000, help='--workload c5: station points of the whole job')
+    ap.add_argument('--points', type=int, default=1000, help='--workload c2: edge of the square point set (default 1000 x 1000)')
+    ap.add_argument('--no-secondary', action='store_true', help='default workload: skip the `secondary` c2 / c5 figures')
     args = ap.parse_args()
     if args.scaling == 'auto':
         args.scaling = 'strong' if (args.gpus > 1 and args.rows is None) else 'weak'
@@ -158,6 +184,10 @@ def main():
         args.backend = 'nccl' if world <= ndev else 'gloo'
         if args.backend == 'gloo':
             args.coll_device = True
+    elif args.backend == 'nccl' and world > ndev:      # (ranks started by a launcher other than self_launch: the same message, from rank 0 only)
+        if rank == 0:
+            sys.stderr.write(nccl_needs_devices(world, ndev) + '\n')
+        raise SystemExit(2)
     dist_on = world > 1 or args.force_dist
     if dist_on:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -175,6 +205,8 @@ def main():
     # (raider_amd launches on torch's current stream whenever it is handed device tensors)
     if args.workload == 'c5':
         return run_c5(args, ctx, dev, coll_dev, dist_on, rank, world, ndev, result_fd)
+    if args.workload == 'c2':
+        return run_c2(args, ctx, dev, coll_dev, dist_on, rank, world, ndev, result_fd)
 
     # ---- weather cube: generated on rank 0, sent to every rank in ONE packed broadcast (RCCL over xGMI), packed (y,x,z) on device
     ny, nx, nz = (int(v) for v in args.cube.split('x'))
@@ -284,13 +316,15 @@ def main():
     n_pre, ms_pre = ctx.profile_get(0)
     n_march, ms_march = ctx.profile_get(1)
     ctx.set_profiling(False)
+    rank_s = [dt]
     if dist_on:
+        rank_s = gather_rank_times(dist, dt, coll_dev, world)
         tmax = torch.tensor([dt], dtype=torch.float64, device=coll_dev if coll_dev is not None else 'cpu')
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
     if args.dump:
-        np.savez(f'{args.dump}.rank{rank}.npz', wet=out_w.cpu().numpy(), hydro=out_h.cpu().numpy(), nparts=np.asarray(nparts))
+        np.savez(f'{args.dump}.rank{rank}.npz', wet=out_w.cpu().numpy(), hydro=out_h.cpu().numpy(), nparts=np.asarray(nparts), row0=row0, rows=rows)
     nan_frac = float(torch.isnan(out_h).double().mean().item())
     mean_h = float(torch.nanmean(out_h).item()); mean_w = float(torch.nanmean(out_w).item())
 
@@ -367,6 +401,11 @@ def main():
                                        f'MAX all-reduce of {K}+4 doubles per step, no output collective') if dist_on else 'single GPU',
                        'ranks': world, 'backend': (dist.get_backend() if dist_on else None),
                        'world_size_seen_by_backend': (dist.get_world_size() if dist_on else 1),
+                       # every rank's row block [row0, rows] of the scene and its own time per step (the line's ms_per_step is their maximum)
+                       'shards': ([list(D.shard_rows(total_rows, world, r_)) for r_ in range(world)] if args.scaling == 'strong' else
+                                  [[r_ * rows, rows] for r_ in range(world)]),
+                       'rank_ms_per_step': [t_ / args.steps * 1e3 for t_ in rank_s],
+                       'devices_visible': ndev, 'ranks_per_device': -(-world // ndev),
                        'mean_hydro_m': mean_h, 'mean_wet_m': mean_w, 'nan_fraction': nan_frac},
             # The limiter the SQ counters show is fp64 vector-ALU issue, so THAT is the roofline (frac <= 1 by construction:
             # instructions actually issued / issue slots of the chip).  north_star's ">= 60 % of HBM" is not meetable at S = 178:
@@ -415,9 +454,302 @@ def main():
         if world == 1 and args.cpu_sample > 0:
             pp = (hts_np, cube.ray_levels(rays.ht_min, zref)[2]) if args.per_pixel_ht else None
             res['cpu_baseline'] = cpu_baseline(args, rows, cols, xpts, ypts, inc_cols, hd, nparts, zref, out_w, out_h, pp)
+        if world == 1 and not args.no_secondary and not args.per_pixel_ht:
+            # the two gather workloads of BASELINE.json beside the headline (a few ms of GPU time each; their own lines: --workload c2 / c5)
+            del los_t, out_w, out_h, rays, cube, wet, hyd
+            torch.cuda.empty_cache()
+            sec = {}
+            for name, fn in (('c2', lambda: c2_measure(ctx, dev, n_side=1000, steps=5, warmup=2, oracle_sample=20000)),
+                             ('c5', lambda: c5_measure(ctx, dev, stations=5_000_000, steps=5, warmup=2, oracle_sample=20000))):
+                try:
+                    sec[name] = compact_secondary(fn())
+                except Exception as exc:          # (a diagnostic appendix: the headline line stays valid without it)
+                    sec[name] = {'error': f'{type(exc).__name__}: {exc}'}
+            res['secondary'] = sec
         os.write(result_fd, (json.dumps(res) + '\n').encode())
     if dist_on:
         dist.destroy_process_group()
+
+
+def load_kernel_counters(tag):
+    """profiles/r*_<tag>_counters.json (tools/gather_digest.py: rocprofv3 --kernel-trace + FETCH_SIZE / WRITE_SIZE passes over
+    `bench.py --workload <tag>`) made with the CURRENT kernels; (dict, path) or (None, reason)."""
+    want = kernel_source_hash()
+    why = f'no profiles/r*_{tag}_counters.json'
+    for f in sorted((REPO / 'profiles').glob(f'r*_{tag}_counters.json'), reverse=True):
+        try:
+            d = json.loads(f.read_text())
+        except (OSError, ValueError):
+            continue
+        if d.get('source_hash') != want:
+            why = f'{f.name}: source hash {d.get("source_hash")} != current {want} (stale profile)'
+            continue
+        return d, str(f.relative_to(REPO))
+    return None, why
+
+
+def c2_inputs(n_side):
+    """BASELINE configs[1]: the ERA5-sized 300x300x80 processed model (f64 totals), n_side x n_side query points on the
+    scene of configs[2] (lon -119.5..-115.5, lat 34.5..31.5) with their own heights rng(1).uniform(0, 3000) m, Conventional line of
+    sight with a fixed incidence of 39 deg (heading -167.9 deg: it does not enter delay / cos(inc), losreader.py:130-133).  The
+    intermediate grid is the one tropo_delay lays out for a station AOI: the points' bounding box at the model's own spacing
+    (delay.py:142-151, llreader.py:173-191), every model level."""
+    from raider_amd.synthetic import synthetic_cube, scene_grid
+    from raider_amd.delay import PointsAOI
+    c = synthetic_cube(300, 300, 80, seed=0)
+    xp, yp, _, _ = scene_grid(n_side, n_side)
+    xx, yy = np.meshgrid(xp, yp)
+    lats, lons = np.ascontiguousarray(yy.ravel()), np.ascontiguousarray(xx.ravel())
+    hgts = np.random.default_rng(1).uniform(0.0, 3000.0, lats.size)
+    aoi = PointsAOI(lats, lons, hgts)
+    aoi.set_output_spacing(ll_res=min(np.diff(c['xs']).mean(), np.diff(c['ys']).mean()))
+    aoi.set_output_xygrid(4326)
+    return c, lats, lons, hgts, np.asarray(aoi.xpts), np.asarray(aoi.ypts), np.asarray(c['zs'], dtype=np.float64)
+
+
+def c2_measure(ctx, dev, n_side=1000, steps=20, warmup=3, oracle_sample=200000, block=None, cube_tensors=None, e2e=False):
+    """One step of configs[1] = the point branch of tropo_delay (delay.py:96-128) for this rank's block of the points, inputs resident
+    in HBM: _build_cube of the intermediate delay cube on the AOI grid (rdr_build_cube_to_cube: setup + gather + packing, the cube stays
+    on the device) and ONE gather of both fields at the points with delay / cos(inc) in the same launch (rdr_interp3_project).
+    Returns the raw figures; `block` = (p0, cnt) of the flattened point list (default: all), `cube_tensors` = (wet_total, hydro_total)
+    device tensors when the cube came through a broadcast."""
+    import torch
+    import raider_amd as R
+    c, lats, lons, hgts, xg, yg, zl = c2_inputs(n_side)
+    n_all = lats.size
+    p0, cnt = block if block is not None else (0, n_all)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    wt, ht = cube_tensors if cube_tensors is not None else (torch.from_numpy(c['wet_total']).to(dev), torch.from_numpy(c['hydro_total']).to(dev))
+    tot = R.Cube(c['ys'], c['xs'], c['zs'], wt, ht, order='zyx', ctx=ctx)
+    yt, xt, zt = (torch.from_numpy(np.ascontiguousarray(a[p0:p0 + cnt])).to(dev) for a in (lats, lons, hgts))
+    inc = 39.0
+    out = [None, None]
+    keep = [None]
+
+    def build():
+        keep[0] = tot.build_delay_cube(xg, yg, zl)
+
+    def gather():
+        out[0], out[1] = keep[0].interp_project(yt, xt, zt, inc=inc)
+
+    def step():
+        build(); gather()
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    # the two halves by themselves, HIP events on the stream the kernels run on (the library's own pairs around every launch)
+    ctx.set_profiling(True)
+    for _ in range(steps):
+        build()
+    torch.cuda.synchronize()
+    n_b, ms_b = ctx.profile_get(2)
+    ctx.set_profiling(True)
+    for _ in range(steps):
+        gather()
+    torch.cuda.synchronize()
+    n_g, ms_g = ctx.profile_get(2)
+    ctx.set_profiling(False)
+    nodes = int(xg.size * yg.size * zl.size)
+    r = dict(points_all=n_all, points_this_rank=cnt, p0=p0, nodes=nodes, grid=[int(zl.size), int(yg.size), int(xg.size)], step_s=dt / steps,
+             build_ms=ms_b / steps, build_launches=n_b, gather_ms=ms_g / steps, gather_launches=n_g, inc=inc,
+             wet=out[0], hydro=out[1], has_nan=bool(keep[0].has_nan()),
+             mean_hydro=float(torch.nanmean(out[1]).item()), mean_wet=float(torch.nanmean(out[0]).item()), nan_fraction=float(torch.isnan(out[1]).double().mean().item()))
+    if e2e:       # the same job through the host-buffer entry (rdr_point_delays: points up, delays down, everything between on the device)
+        la, lo, hg = (np.ascontiguousarray(a[p0:p0 + cnt]) for a in (lats, lons, hgts))
+        tot.point_delays(xg, yg, zl, la, lo, hg, inc=inc)
+        reps = 5
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ew, eh, _ = tot.point_delays(xg, yg, zl, la, lo, hg, inc=inc)
+        dte = (time.perf_counter() - t0) / reps
+        r['e2e'] = {'value': cnt / dte, 'unit': 'points/s', 'ms': dte * 1e3, 'h2d_bytes': cnt * 24, 'd2h_bytes': cnt * 16,
+                    'what': 'the same job through rdr_point_delays (NumPy arrays in, NumPy arrays out): points up, intermediate cube built while they travel, one gather, '
+                            'delays down', 'bit_identical_to_device_path': bool(np.array_equal(eh, out[1].cpu().numpy(), equal_nan=True) and np.array_equal(ew, out[0].cpu().numpy(), equal_nan=True))}
+    if oracle_sample:
+        from oracle import raider_oracle as O
+        ns = int(min(cnt, oracle_sample))
+        t0 = time.perf_counter()
+        ip = list(O.getInterpolators(c['xs'], c['ys'], c['zs'], c['wet_total'], c['hydro_total']))
+        cw, ch = O.build_cube(xg, yg, zl, ip)
+        t_build = time.perf_counter() - t0
+        sel = np.linspace(0, cnt - 1, ns).astype(np.int64) + p0
+        t0 = time.perf_counter()
+        ow, oh = O.points_from_cube(lats[sel], lons[sel], hgts[sel], xg, yg, zl, cw, ch)
+        ow, oh = ow / O.cosd(inc), oh / O.cosd(inc)
+        t_pts = time.perf_counter() - t0
+        gw, gh = out[0].cpu().numpy()[sel - p0], out[1].cpu().numpy()[sel - p0]
+        r['oracle'] = {'sample_points': ns, 'build_s': t_build, 'points_s': t_pts,
+                       'points_per_s': ns / (t_build * ns / n_all + t_pts),
+                       'max_abs': float(max(np.nanmax(np.abs(ow - gw)), np.nanmax(np.abs(oh - gh)))),
+                       'nan_masks_equal': bool(np.array_equal(np.isnan(oh), np.isnan(gh)))}
+    return r
+
+
+def c2_roofline(m):
+    """168 B per trilinear query on the f64 totals (8 corners x 16 B + 24 B of coordinates + 16 B of results) - the 10^6 points
+    AND the nodes of the intermediate cube are such queries; the packing of the planar results into the (y,x,z) cube moves 32 B per node."""
+    alg_g = 168.0 * m['points_this_rank']
+    alg_b = (168.0 + 32.0) * m['nodes']
+    kern_ms = m['build_ms'] + m['gather_ms']
+    prof, src = load_kernel_counters('c2')
+    k = (prof or {}).get('kernels', {})
+    traffic = sum(v.get('hbm_read_bytes', 0) + v.get('hbm_write_bytes', 0) for v in k.values() if v.get('per_step')) if k else None
+    return {'bound': 'hbm', 'kernel': 'interp_points_kernel<double2> + build_cube_setup_kernel / build_cube_kernel<double2> (one step of one rank)',
+            'achieved': (alg_g + alg_b) / (kern_ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': (alg_g + alg_b) / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            'traffic': traffic, 'traffic_unit': 'HBM bytes per step, all kernels of the step (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE, separate passes)',
+            'frac_hbm_measured': (traffic / (m['step_s']) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+            'algorithmic_bytes_per_step': alg_g + alg_b, 'gather_ms_per_step': m['gather_ms'], 'build_ms_per_step': m['build_ms'],
+            'gather_algorithmic_GBps': alg_g / (m['gather_ms'] * 1e-3) / 1e9, 'build_algorithmic_GBps': alg_b / (m['build_ms'] * 1e-3) / 1e9,
+            'kernels_ms_per_step': kern_ms, 'launch_and_sync_ms_per_step': m['step_s'] * 1e3 - kern_ms,
+            'note': 'algorithmic bytes over the HIP-event time of the step\'s timed kernels (setup + gather of the intermediate cube, the point gather); the 38 MB '
+                    'intermediate cube and the source cube\'s AOI slab are L2 / Infinity-Cache resident, so the algorithmic rate may exceed the HBM peak - `traffic` is what HBM saw; '
+                    'the step itself is bound by launches and the one synchronisation of the cube\'s NaN verdict (launch_and_sync_ms_per_step), not by bytes',
+            'counters_source': src if prof is not None else None, 'counters_note': None if prof is not None else src,
+            'source_hash': kernel_source_hash()}
+
+
+def compact_secondary(m):
+    """What the default line carries of a gather workload: kernel-level rate, step rate, roofline fraction, parity error."""
+    if 'stations_this_rank' in m:
+        return {'workload': 'configs[4]: 5 M stations, two-epoch blend of 1000x1000x50 f32 cubes', 'value': m['stations_this_rank'] / m['step_s'], 'unit': 'points/s',
+                'ms_per_step': m['step_s'] * 1e3, 'kernels_ms_per_step': m['blend_ms'] + m['interp_ms'], 'roofline_frac': m['alg_bytes'] / ((m['blend_ms'] + m['interp_ms']) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                'roofline_bound': 'hbm', 'gpu_vs_oracle_max_abs': m.get('oracle', {}).get('max_abs'), 'oracle_sample_points': m.get('oracle', {}).get('sample_points'),
+                'route': m['route']}
+    rf = c2_roofline(m)
+    return {'workload': 'configs[1]: Conventional (inc 39 deg), 1000x1000 points, 300x300x80 f64 totals cube', 'value': m['points_this_rank'] / m['step_s'], 'unit': 'points/s',
+            'ms_per_step': m['step_s'] * 1e3, 'kernels_ms_per_step': rf['kernels_ms_per_step'], 'gather_points_per_s_kernel': m['points_this_rank'] / (m['gather_ms'] * 1e-3),
+            'roofline_frac': rf['frac'], 'roofline_bound': 'hbm', 'hbm_traffic_bytes_per_step': rf['traffic'],
+            'gpu_vs_oracle_max_abs_m': m.get('oracle', {}).get('max_abs'), 'oracle_sample_points': m.get('oracle', {}).get('sample_points')}
+
+
+def run_c2(args, ctx, dev, coll_dev, dist_on, rank, world, ndev, result_fd):
+    """BASELINE configs[1]: Conventional slant delay at 1000 x 1000 query points through the ERA5-sized cube (c2_inputs / c2_measure).
+    N > 1: the f64 totals go out in ONE packed broadcast, every rank builds the (small) intermediate cube and gathers its contiguous
+    block of the point list - no data-path collective (the intermediate grid is the job's, not the block's: same bits as one rank)."""
+    import torch
+    import torch.distributed as dist
+    from raider_amd import distributed as D
+    import raider_amd as R
+    n_side = int(args.points)
+    cube_tensors = None
+    t_bcast = 0.0
+    if dist_on:
+        from raider_amd.synthetic import synthetic_cube
+        fields = None
+        if rank == 0:
+            c = synthetic_cube(300, 300, 80, seed=0)
+            fields = dict(ys=c['ys'], xs=c['xs'], zs=c['zs'], wet=c['wet_total'], hydro=c['hydro_total'])
+        torch.cuda.synchronize(); dist.barrier()
+        t0 = time.perf_counter()
+        axes, wt, ht = D.broadcast_cube_packed(fields, src=0, device=coll_dev, header=(300, 300, 80, 1, 80, 300, 300))
+        if coll_dev is None:
+            wt, ht = wt.to(dev), ht.to(dev)
+        torch.cuda.synchronize()
+        t_bcast = time.perf_counter() - t0
+        cube_tensors = (wt, ht)
+    n_all = n_side * n_side
+    p0, cnt = D.shard_rows(n_all, world, rank)
+    if dist_on:
+        dist.barrier()
+    m = c2_measure(ctx, dev, n_side=n_side, steps=args.steps, warmup=args.warmup, oracle_sample=(200000 if (world == 1 and args.cpu_sample > 0) else 0),
+                   block=(p0, cnt), cube_tensors=cube_tensors, e2e=(world == 1 and not args.no_e2e))
+    dt = m['step_s'] * args.steps
+    if dist_on:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=coll_dev if coll_dev is not None else 'cpu')
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    if args.dump:
+        np.savez(f'{args.dump}.rank{rank}.npz', wet=m['wet'].cpu().numpy(), hydro=m['hydro'].cpu().numpy(), p0=p0, cnt=cnt)
+    if rank == 0:
+        res = {'metric': 'query points/sec (Conventional slant delay: intermediate delay cube + wet/hydro gather + 1/cos(inc)) through ERA5 cube; achieved HBM GB/s',
+               'value': n_all * args.steps / dt, 'unit': 'points/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
+               'higher_is_better': True, 'scaling': 'strong' if world > 1 else 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+               'config': {'workload': f'configs[1]: Conventional slant (fixed incidence {m["inc"]} deg, heading -167.9 deg), {n_side}x{n_side} query points with heights '
+                                      f'rng(1).uniform(0, 3000) m, synthetic ERA5-sized 300x300x80 f64 totals cube; one step = the point branch of tropo_delay with inputs '
+                                      f'resident in HBM: _build_cube of the {m["grid"][0]}x{m["grid"][1]}x{m["grid"][2]} intermediate cube (bounding box of the points at the '
+                                      f'model spacing, every model level) + one gather of both fields at the points + delay / cos(inc)',
+                          'points_all_gpus': n_all, 'points_this_rank': cnt, 'intermediate_nodes': m['nodes'], 'cube': '300x300x80 f64 totals',
+                          'parallelism': (f'points sharded x{world} ({args.backend}, {ndev} device(s) visible), cube: one packed broadcast ({t_bcast*1e3:.1f} ms), intermediate cube '
+                                          f'replicated per rank, no data-path collective') if dist_on else 'single GPU',
+                          'ranks': world, 'backend': (dist.get_backend() if dist_on else None), 'world_size_seen_by_backend': (dist.get_world_size() if dist_on else 1),
+                          'mean_hydro_m': m['mean_hydro'], 'mean_wet_m': m['mean_wet'], 'nan_fraction': m['nan_fraction'], 'intermediate_cube_has_nan': m['has_nan']},
+               'roofline': dict(c2_roofline(m), library_source_hash=R.load_library().rdr_source_hash().decode())}
+        if 'e2e' in m:
+            res['end_to_end'] = m['e2e']
+        if 'oracle' in m:
+            o = m['oracle']
+            res['cpu_baseline'] = {'value': o['points_per_s'], 'unit': 'points/s', 'cores': 1, 'kind': 'port',
+                                   'sample': f'NumPy oracle (oracle/raider_oracle.py: getInterpolators + build_cube + points_from_cube + / cosd(inc)), one thread: the intermediate '
+                                             f'cube of the whole job ({o["build_s"]:.2f} s, charged pro rata) + {o["sample_points"]} of the points ({o["points_s"]:.2f} s)',
+                                   'gpu_vs_oracle_max_abs_m': o['max_abs'], 'nan_masks_equal': o['nan_masks_equal']}
+        os.write(result_fd, (json.dumps(res) + '\n').encode())
+    if dist_on:
+        dist.destroy_process_group()
+
+
+def c5_measure(ctx, dev, stations=5_000_000, steps=5, warmup=2, oracle_sample=20000):
+    """One rank's step of configs[4] (run_c5 is the full line with the N > 1 path): blend of the two resident HRRR-sized epochs + gather of
+    the stations, kernel times from HIP events; returns the raw figures for the `secondary` entry of the default line."""
+    import torch
+    import raider_amd as R
+    from raider_amd import distributed as D
+    ny = nx = 1000; nz = 50
+    xs = -1.5e6 + 3000.0 * np.arange(nx); ys = -1.5e6 + 3000.0 * np.arange(ny)
+    zs = np.round(-100.0 + 26100.0 * np.linspace(0, 1, nz) ** 2, 3)
+    ep = [hrrr_epoch(s_, ys, xs, zs) for s_ in (0, 1)]
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    a, b = (R.Cube(ys, xs, zs, torch.from_numpy(e['wet']).to(dev), torch.from_numpy(e['hydro']).to(dev), order='zyx', ctx=ctx) for e in ep)
+    w1, w2 = 0.25, 0.75
+    rng = np.random.default_rng(3)
+    pts_all = np.stack([rng.uniform(-1.4e6, 1.4e6, stations), rng.uniform(-1.4e6, 1.4e6, stations), rng.uniform(0.0, 4000.0, stations)], -1)
+    pts = torch.from_numpy(pts_all).to(dev)
+    fly = D.blend_on_the_fly_pays(a, stations)
+    out = [None, None]
+
+    def step():
+        if fly:
+            out[0], out[1] = a.interp_blend(w1, b, w2, pts)
+        else:
+            out[0], out[1] = a.blend(w1, b, w2).interp(pts)
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    ctx.set_profiling(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    _, ms_int = ctx.profile_get(2)
+    _, ms_bl = ctx.profile_get(3)
+    ctx.set_profiling(False)
+    cells = ny * nx * nz
+    r = dict(stations_this_rank=stations, step_s=dt / steps, interp_ms=ms_int / steps, blend_ms=ms_bl / steps, route='blend at the corners' if fly else 'blended cube + gather',
+             alg_bytes=(168.0 * stations) if fly else (24.0 * cells + 104.0 * stations))
+    if oracle_sample:
+        from oracle import raider_oracle as O
+        ns = int(min(stations, oracle_sample))
+        bw = O.blend_cubes(w1, ep[0]['wet'], w2, ep[1]['wet']); bh = O.blend_cubes(w1, ep[0]['hydro'], w2, ep[1]['hydro'])
+        ip = list(O.getInterpolators(xs, ys, zs, bw, bh))
+        ow, oh = ip[0](pts_all[:ns]), ip[1](pts_all[:ns])
+        r['oracle'] = {'sample_points': ns, 'max_abs': float(max(np.nanmax(np.abs(ow - out[0][:ns].cpu().numpy())), np.nanmax(np.abs(oh - out[1][:ns].cpu().numpy()))))}
+    return r
+
+
+def hrrr_epoch(seed, ys, xs, zs):
+    """Synthetic HRRR-sized epoch of SURVEY 8(d) (configs[4]): (z,y,x) f32 wet / hydro on the 3-km LCC lattice."""
+    rng = np.random.default_rng(seed)
+    ny, nx = ys.size, xs.size
+    gh = rng.standard_normal((ny, nx)).astype(np.float32); gw = rng.standard_normal((ny, nx)).astype(np.float32)
+    z3 = zs[:, None, None]
+    hyd = (np.float32(270.0) * np.exp(-z3 / 8000.0).astype(np.float32) * (1 + np.float32(0.01) * gh[None])).astype(np.float32)
+    wet = (np.float32(60.0) * np.exp(-z3 / 2000.0).astype(np.float32) * (1 + np.float32(0.1) * gw[None])).astype(np.float32)
+    return dict(ys=ys, xs=xs, zs=zs, wet=wet, hydro=hyd)
 
 
 def run_c5(args, ctx, dev, coll_dev, dist_on, rank, world, ndev, result_fd):
@@ -435,14 +767,7 @@ def run_c5(args, ctx, dev, coll_dev, dist_on, rank, world, ndev, result_fd):
     xs = -1.5e6 + 3000.0 * np.arange(nx); ys = -1.5e6 + 3000.0 * np.arange(ny)
     zs = np.round(-100.0 + 26100.0 * np.linspace(0, 1, nz) ** 2, 3)
 
-    def epoch(seed):
-        rng = np.random.default_rng(seed)
-        gh = rng.standard_normal((ny, nx)).astype(np.float32); gw = rng.standard_normal((ny, nx)).astype(np.float32)
-        z3 = zs[:, None, None]
-        hyd = (np.float32(270.0) * np.exp(-z3 / 8000.0).astype(np.float32) * (1 + np.float32(0.01) * gh[None])).astype(np.float32)
-        wet = (np.float32(60.0) * np.exp(-z3 / 2000.0).astype(np.float32) * (1 + np.float32(0.1) * gw[None])).astype(np.float32)
-        return dict(ys=ys, xs=xs, zs=zs, wet=wet, hydro=hyd)
-    epochs = [epoch(0), epoch(1)] if rank == 0 else None
+    epochs = [hrrr_epoch(0, ys, xs, zs), hrrr_epoch(1, ys, xs, zs)] if rank == 0 else None
     w1, w2 = 0.25, 0.75
     t_bcast = 0.0
     if dist_on:
@@ -492,7 +817,9 @@ def run_c5(args, ctx, dev, coll_dev, dist_on, rank, world, ndev, result_fd):
     dt = time.perf_counter() - t0
     n_int, ms_int = ctx.profile_get(2)
     ctx.set_profiling(False)
+    rank_s = [dt]
     if dist_on:
+        rank_s = gather_rank_times(dist, dt, coll_dev, world)
         tmax = torch.tensor([dt], dtype=torch.float64, device=coll_dev if coll_dev is not None else 'cpu')
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -527,6 +854,8 @@ def run_c5(args, ctx, dev, coll_dev, dist_on, rank, world, ndev, result_fd):
                    'parallelism': (f'stations sharded x{world} ({args.backend}, {ndev} device(s) visible), epochs: two packed broadcasts ({t_bcast*1e3:.1f} ms), blend replicated '
                                    f'per rank, no data-path collective') if dist_on else 'single GPU',
                    'ranks': world, 'backend': (dist.get_backend() if dist_on else None), 'world_size_seen_by_backend': (dist.get_world_size() if dist_on else 1),
+                   'shards': [list(D.shard_rows(n_all, world, r_)) for r_ in range(world)], 'rank_ms_per_step': [t_ / args.steps * 1e3 for t_ in rank_s],
+                   'devices_visible': ndev, 'ranks_per_device': -(-world // ndev),
                    'mean_hydro': float(torch.nanmean(hyd_t).item()), 'mean_wet': float(torch.nanmean(wet_t).item()), 'nan_fraction': float(torch.isnan(hyd_t).double().mean().item())},
         'roofline': {'bound': 'hbm', 'kernel': 'interp_points_blend_kernel<float2> (one step of one rank)' if fly else 'blend_kernel<float> + interp_points_kernel<float2> (one step of one rank)',
                      'achieved': alg_bytes / ((blend_ms + interp_ms) * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

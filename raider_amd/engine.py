@@ -238,6 +238,35 @@ class Cube:
         arrays y, x, z of one shape (or y = packed pts[..., 3], x = z = None) and, for a projected line of sight, delay / cosd(inc)
         (`inc`: a scalar or an array of the points' shape, degrees) or delay / `divisor` (an array: cos of the look angle) -
         losreader.py:130-133 - before the values leave the device.  Returns (wet, hydro) f64 of the points' shape."""
+        if _is_dev(y):
+            # device-resident points (three float64 tensors of one shape, or one packed [..., 3]): nothing crosses PCIe, the call is asynchronous
+            import torch
+            if inc is not None and divisor is not None:
+                raise ValueError('give inc= or divisor=, not both')
+            self.ctx.adopt_torch_stream(y)
+            if x is None:
+                if y.shape[-1] != 3:
+                    raise ValueError(f'The requested sample points xi have dimension {y.shape[-1]} but this RegularGridInterpolator has dimension 3')
+                shape, n = tuple(y.shape[:-1]), y.numel() // 3
+                _dev_f64(y, 'pts')
+            else:
+                shape, n = tuple(y.shape), y.numel()
+                for t, what in ((y, 'y'), (x, 'x'), (z, 'z')):
+                    _dev_f64(t, what, n)
+            mode, parr, inc0 = 0, None, 0.0
+            arr = inc if inc is not None else divisor
+            if arr is not None:
+                if _is_dev(arr):
+                    mode, parr = (1 if inc is not None else 3), _dev_f64(arr, 'inc / divisor', n)
+                elif np.ndim(arr) == 0 and inc is not None:
+                    mode, inc0 = 2, float(arr)
+                else:
+                    mode = 1 if inc is not None else 3
+                    parr = torch.from_numpy(f64(np.broadcast_to(np.asarray(arr, dtype=np.float64), shape))).to(y.device)
+            wet = torch.empty(shape, dtype=torch.float64, device=y.device); hyd = torch.empty_like(wet)
+            check(self.ctx.lib.rdr_interp3_project(self.ctx.handle, self.handle, ptr(y), ptr(x), ptr(z), n, mode, ptr(parr), inc0, ptr(wet), ptr(hyd),
+                                                   L.RDR_DEVICE), self.ctx.handle)
+            return wet, hyd
         ya, xa, za, n, shape, mode, parr, inc0 = self._point_args(y, x, z, inc, divisor)
         wet = _pinned.empty((n,)); hyd = _pinned.empty((n,))
         check(self.ctx.lib.rdr_interp3_project(self.ctx.handle, self.handle, ptr(ya), ptr(xa), ptr(za), n, mode, ptr(parr), inc0, ptr(wet), ptr(hyd),

@@ -90,3 +90,84 @@ def test_c5_station_workload_across_two_ranks(tmp_path):
     assert int(b0['cnt']) == 200001 and int(b1['p0']) == 200001 and int(b1['cnt']) == 200000
     assert np.array_equal(a['wet'], np.concatenate([b0['wet'], b1['wet']])) and np.array_equal(a['hydro'], np.concatenate([b0['hydro'], b1['hydro']]))
     assert np.isfinite(a['hydro']).all() and a['hydro'].mean() > 50.0          # (refractivities, not delays: N units)
+
+
+# ---- world = 8 on ONE device (round 5): every branch an 8-GPU node will take, rehearsed --------------------------------------------------
+def _run(tmp_path, tag, *args, timeout=1200):
+    out = subprocess.run([sys.executable, str(ROOT / 'bench.py'), '--steps', '2', '--warmup', '1', '--cpu-sample', '0', '--no-e2e', '--dump', str(tmp_path / tag)] + list(args),
+                         capture_output=True, text=True, timeout=timeout)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-4000:])
+    lines = out.stdout.splitlines()
+    assert len(lines) == 1 and lines[0].startswith('{'), out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def _covers(shards, total):
+    """contiguous blocks, in rank order, covering [0, total) exactly once"""
+    pos = 0
+    for r0, cnt in shards:
+        if r0 != pos or cnt < 0:
+            return False
+        pos += cnt
+    return pos == total
+
+
+def test_world8_strong_scaling_of_one_scene_matches_one_rank(tmp_path):
+    """`python bench.py --gpus 8` as the driver's scaling run launches it (self-launch through torch.distributed.run, eight ranks): BASELINE
+    configs[3] semantics on a reduced 2005 x 4000 scene - uneven row blocks (251 x 5 + 250 x 3), ONE packed cube broadcast, ONE MAX all-reduce
+    of K+4 doubles per step, max-over-ranks timing.  On a one-GPU box the ranks share the device (`--backend auto` -> gloo with device-resident
+    collective tensors: RCCL refuses duplicates); on an 8-GPU node the same command runs over RCCL.  The eight slabs equal the one-rank run of
+    the whole scene bit for bit; the line reports the world the backend saw, every rank's block and every rank's own time."""
+    one = _run(tmp_path, 'one', '--gpus', '1', '--rows', '2005', '--cols', '4000', '--no-secondary')
+    eight = _run(tmp_path, 'eight', '--gpus', '8', '--total-rows', '2005', '--cols', '4000')
+    cfg = eight['config']
+    assert eight['n_gpus'] == 8 and eight['scaling'] == 'strong' and cfg['ranks'] == 8 and cfg['world_size_seen_by_backend'] == 8
+    assert cfg['backend'] in ('nccl', 'gloo') and cfg['ranks_per_device'] * cfg['devices_visible'] >= 8
+    assert 'configs[3]' in cfg['workload'] and cfg['rays_per_step_all_gpus'] == 2005 * 4000
+    assert _covers(cfg['shards'], 2005) and [c for _, c in cfg['shards']] == [251] * 5 + [250] * 3
+    assert len(cfg['rank_ms_per_step']) == 8 and all(t > 0 for t in cfg['rank_ms_per_step'])
+    assert abs(max(cfg['rank_ms_per_step']) - eight['ms_per_step']) < 1e-6 * eight['ms_per_step']       # the line's time IS the slowest rank's
+    assert abs(eight['value'] * eight['ms_per_step'] * 1e-3 - 2005 * 4000) < 1.0
+    assert 'secondary' not in eight                                                                       # (an appendix of the one-GPU line only)
+    a = np.load(tmp_path / 'one.rank0.npz')
+    parts = [np.load(tmp_path / f'eight.rank{r}.npz') for r in range(8)]
+    assert [int(p['row0']) for p in parts] == [r0 for r0, _ in cfg['shards']]
+    assert all(np.array_equal(a['nparts'], p['nparts']) for p in parts)
+    assert np.array_equal(a['hydro'], np.concatenate([p['hydro'] for p in parts])) and np.array_equal(a['wet'], np.concatenate([p['wet'] for p in parts]))
+    assert np.isfinite(a['hydro']).all()
+
+
+def test_world8_station_and_point_workloads_match_one_rank(tmp_path):
+    """`--workload c5` (configs[4]) and `--workload c2` (configs[1]) on eight ranks: the cubes go out in packed broadcasts, every rank takes its
+    contiguous block of the point list, there is no data-path collective; blocks cover the list exactly and equal the one-rank result bit for bit."""
+    one = _run(tmp_path, 'c5one', '--gpus', '1', '--workload', 'c5', '--stations', '400003')
+    eight = _run(tmp_path, 'c5eight', '--gpus', '8', '--workload', 'c5', '--stations', '400003')
+    cfg = eight['config']
+    assert eight['n_gpus'] == 8 and eight['scaling'] == 'strong' and cfg['world_size_seen_by_backend'] == 8 and _covers(cfg['shards'], 400003)
+    assert len(cfg['rank_ms_per_step']) == 8 and abs(eight['value'] * eight['ms_per_step'] * 1e-3 - 400003) < 1.0
+    a = np.load(tmp_path / 'c5one.rank0.npz')
+    parts = [np.load(tmp_path / f'c5eight.rank{r}.npz') for r in range(8)]
+    assert [int(p['p0']) for p in parts] == [r0 for r0, _ in cfg['shards']]
+    assert np.array_equal(a['wet'], np.concatenate([p['wet'] for p in parts])) and np.array_equal(a['hydro'], np.concatenate([p['hydro'] for p in parts]))
+    one = _run(tmp_path, 'c2one', '--gpus', '1', '--workload', 'c2', '--points', '301')
+    eight = _run(tmp_path, 'c2eight', '--gpus', '8', '--workload', 'c2', '--points', '301')
+    assert one['unit'] == 'points/s' and 'configs[1]' in eight['config']['workload'] and eight['config']['world_size_seen_by_backend'] == 8
+    assert eight['config']['points_all_gpus'] == 301 * 301 and abs(eight['value'] * eight['ms_per_step'] * 1e-3 - 301 * 301) < 1.0
+    assert eight['roofline']['bound'] == 'hbm' and eight['roofline']['frac'] > 0
+    a = np.load(tmp_path / 'c2one.rank0.npz')
+    parts = [np.load(tmp_path / f'c2eight.rank{r}.npz') for r in range(8)]
+    assert sum(int(p['cnt']) for p in parts) == 301 * 301
+    assert np.array_equal(a['wet'], np.concatenate([p['wet'] for p in parts])) and np.array_equal(a['hydro'], np.concatenate([p['hydro'] for p in parts]))
+    assert np.isfinite(a['hydro']).all() and 1.5 < a['hydro'].mean() < 4.0                          # metres of slant delay at 39 deg incidence
+
+
+def test_nccl_preflight_is_one_clear_message(tmp_path):
+    """`bench.py --gpus 8 --backend nccl` on a box with fewer than eight devices: ONE sentence saying what is needed, a non-zero exit code, no
+    torchrun stack - the first real 8-GPU run must not die on something a dry run could have told."""
+    import torch
+    if torch.cuda.device_count() >= 8:
+        pytest.skip('eight devices are visible: the nccl path itself runs (test_gpu_rccl.py)')
+    out = subprocess.run([sys.executable, str(ROOT / 'bench.py'), '--gpus', '8', '--backend', 'nccl', '--steps', '1', '--warmup', '0'], capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and out.stdout.strip() == ''
+    assert 'needs one GPU per rank: 8 ranks asked' in out.stderr and '--backend auto' in out.stderr
+    assert 'Traceback' not in out.stderr and 'ChildFailedError' not in out.stderr

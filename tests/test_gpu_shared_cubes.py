@@ -255,7 +255,7 @@ def test_two_level_f64_cube_is_not_staged():
     import raider_amd as R
     from oracle import oracle_c as OC
     ny = nx = 12
-    ys = 30.0 + 0.1 * np.arange(ny); xs = -100.0 + 0.1 * np.arange(nx); zs = np.array([0.0, 3000.0])
+    ys = 30.0 + 0.1 * np.arange(ny); xs = -100.0 + 0.1 * np.arange(nx); zs = np.array([-100.0, 3000.0])       # (below the origins: a first sample ON the lowest node is in or out by round-off, as in the reference)
     rng = np.random.default_rng(7)
     wet = rng.uniform(5, 60, (2, ny, nx)); hyd = rng.uniform(150, 300, (2, ny, nx))
     cube = R.Cube(ys, xs, zs, wet, hyd, order='zyx')
