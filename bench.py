@@ -370,6 +370,13 @@ def main():
         pr_ = 2 if args.per_pixel_ht else 0
         ka_m, ka_c = cube.ray_kernel_attributes(1 + pr_), cube.ray_kernel_attributes(0 + pr_)      # from the loaded code object
         frac_valu = valu_rate / VALU_ISSUE_PEAK if valu_rate else None
+        # MEASURED instruction mix of the march kernel (rocprofv3 SQ class counters, profiles/r*_instr_mix.json through the same digest): what
+        # the issued instructions were, the fp64 flops they executed, and the issue cycles they cost at the per-class rates
+        mix = km.get('instr_mix')
+        waves = n_rays / 64.0
+        executed_fp64 = (mix['fp64_flops_per_lane'] * 64.0 * waves / (march_ms * 1e-3)) if mix else None
+        class_cycles = (mix['issue_cycles_model'] * waves / (march_ms * 1e-3)) if mix else None            # SIMD cycles per second the mix needs
+        simd_cycles = 256 * 4 * 2.4e9
         # how GOOD the kernel is, beside how busy: the reference's arithmetic (SURVEY 8d flop model: 110 fp64 flop per ray and
         # REFERENCE sample, S of them per ray) per second of march time against the fp64 vector peak - a kernel that issues more
         # instructions for the same rays scores lower here and the same in `frac`
@@ -416,6 +423,17 @@ def main():
                          # frac prices every VALU instruction at the fp64 rate and the 2.4 GHz data-sheet clock: it says how BUSY the issue
                          # ports are.  useful_flops_frac (the headline for kernel quality) says how much of the chip's fp64
                          # vector peak goes into the reference's own arithmetic; the clock the chip really ran at is beside it.
+                         # three different things: `frac` = how BUSY the issue ports are (every instruction priced at 4 cycles);
+                         # `useful_flops_frac` = the REFERENCE's arithmetic per second against the fp64 peak (a throughput-equivalent: flops the kernel
+                         # avoids still count); `executed_fp64_flops_frac` = the fp64 flops the kernel actually executed (counted by the SQ) against that
+                         # peak = its EFFICIENCY as an fp64 machine; `frac_class_priced` = issue cycles of the measured mix at the per-class rates
+                         # (fp64 + conversions 4 cycles, f32 / integer 2) over the cycles the chip had at 2.4 GHz
+                         'executed_fp64_flops_frac': (executed_fp64 / FP64_VECTOR_PEAK) if executed_fp64 else None,
+                         'executed_fp64_TFLOPs': (executed_fp64 / 1e12) if executed_fp64 else None,
+                         'frac_class_priced': (class_cycles / simd_cycles) if class_cycles else None,
+                         'valu_mix': ({k: mix[k] / mix['valu'] for k in ('fp64', 'cvt', 'int32', 'int64', 'f32', 'other')} if mix else None),
+                         'valu_mix_per_raywave': mix,
+                         'valu_mix_source': 'rocprofv3 --pmc SQ_INSTS_VALU_{FMA,ADD,MUL,TRANS}_F64 / _CVT / _INT32 / _INT64 / _{FMA,ADD,MUL,TRANS}_F32 (tools/profile_round.sh sq3-sq6)' if mix else None,
                          'useful_flops_frac': useful_flops / FP64_VECTOR_PEAK, 'useful_TFLOPs': useful_flops / 1e12, 'fp64_vector_peak_TFLOPs': FP64_VECTOR_PEAK / 1e12,
                          'flop_model': f'{FLOP_PER_REFERENCE_SAMPLE:.0f} fp64 flop x S = {S} reference samples per ray (SURVEY 8d)',
                          'valu_per_reference_sample': (valu_rw / S) if valu_rw else None,
@@ -561,10 +579,13 @@ def c2_measure(ctx, dev, n_side=1000, steps=20, warmup=3, oracle_sample=200000, 
              mean_hydro=float(torch.nanmean(out[1]).item()), mean_wet=float(torch.nanmean(out[0]).item()), nan_fraction=float(torch.isnan(out[1]).double().mean().item()))
     if e2e:       # the same job through the host-buffer entry (rdr_point_delays: points up, delays down, everything between on the device)
         la, lo, hg = (np.ascontiguousarray(a[p0:p0 + cnt]) for a in (lats, lons, hgts))
-        tot.point_delays(xg, yg, zl, la, lo, hg, inc=inc)
+        for _ in range(3):                            # warm-up: scratch, page-locked result blocks in the recycling pool
+            ew = eh = None
+            ew, eh, _ = tot.point_delays(xg, yg, zl, la, lo, hg, inc=inc)
         reps = 5
         t0 = time.perf_counter()
         for _ in range(reps):
+            ew = eh = None                            # (the caller is done with the previous results: their blocks are recycled)
             ew, eh, _ = tot.point_delays(xg, yg, zl, la, lo, hg, inc=inc)
         dte = (time.perf_counter() - t0) / reps
         r['e2e'] = {'value': cnt / dte, 'unit': 'points/s', 'ms': dte * 1e3, 'h2d_bytes': cnt * 24, 'd2h_bytes': cnt * 16,
@@ -741,6 +762,18 @@ def c5_measure(ctx, dev, stations=5_000_000, steps=5, warmup=2, oracle_sample=20
     return r
 
 
+def c5_traffic(fly):
+    """Measured HBM bytes of one c5 step (blend + gather, or the blend-at-the-corners gather) from the digest at the current source hash; None without one."""
+    prof, _ = load_kernel_counters('c5')
+    if prof is None:
+        return None
+    k = prof.get('kernels', {})
+    names = ('interp_points_blend_kernel',) if fly else ('blend_kernel', 'interp_points_kernel')
+    if not all(n in k and 'hbm_read_bytes' in k[n] for n in names):
+        return None
+    return sum(k[n]['hbm_read_bytes'] + k[n]['hbm_write_bytes'] for n in names)
+
+
 def hrrr_epoch(seed, ys, xs, zs):
     """Synthetic HRRR-sized epoch of SURVEY 8(d) (configs[4]): (z,y,x) f32 wet / hydro on the 3-km LCC lattice."""
     rng = np.random.default_rng(seed)
@@ -859,7 +892,8 @@ def run_c5(args, ctx, dev, coll_dev, dist_on, rank, world, ndev, result_fd):
                    'mean_hydro': float(torch.nanmean(hyd_t).item()), 'mean_wet': float(torch.nanmean(wet_t).item()), 'nan_fraction': float(torch.isnan(hyd_t).double().mean().item())},
         'roofline': {'bound': 'hbm', 'kernel': 'interp_points_blend_kernel<float2> (one step of one rank)' if fly else 'blend_kernel<float> + interp_points_kernel<float2> (one step of one rank)',
                      'achieved': alg_bytes / ((blend_ms + interp_ms) * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                     'frac': alg_bytes / ((blend_ms + interp_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 'traffic': None,
+                     'frac': alg_bytes / ((blend_ms + interp_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     'traffic': c5_traffic(fly), 'traffic_unit': 'HBM bytes per step of one rank holding ALL stations (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE; profiles/r*_c5_counters.json)',
                      'algorithmic_bytes_per_step': alg_bytes, 'blend_ms': blend_ms, 'interp_ms_per_step': interp_ms, 'interp_launches_timed': n_int,
                      'note': ('algorithmic bytes (168 B per station: 8 corners x 2 epochs x 8 B + the point + the two delays, SURVEY 8d) over the kernel\'s HIP-event time; a random '
                               'point touches 8 x 128 B lines for them (4 per epoch)') if fly else

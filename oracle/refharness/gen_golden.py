@@ -62,7 +62,11 @@ EPSG4326 = CRS.from_epsg(4326)
 
 
 def save(name, **arrs):
+    """One fixture.  `_meta` (a JSON string) records what the reference's third-party geometry ran on (ref_import.provenance): the stand-in
+    pyproj of this image, or - the day they are importable - the real pyproj / PROJ and isce3 versions."""
+    import json
     path = GOLD / f'{name}.npz'
+    arrs['_meta'] = np.array(json.dumps(dict(ref_import.provenance(), numpy=np.__version__, generator='oracle/refharness/gen_golden.py')))
     np.savez_compressed(path, **arrs)
     print(f'{name}: {path.stat().st_size/1024:.1f} KiB  keys={list(arrs)}')
 
@@ -575,7 +579,31 @@ def g13():
          wet_aoi=wa, hydro_aoi=ha, wet_model=wm_, hydro_model=hm_)
 
 
+
+def g14():
+    """Raytracing.getLookVectors (losreader.py:219-255: isce3 geo2rdr + orbit.interpolate per pixel) on the reference's own fixture orbit -
+    the eight state vectors of test/test_losreader.py:20-92 = test/orbit_files/S1_orbit_example.EOF - for a 16 x 16 lon/lat grid under the
+    right-looking descending pass, at two heights.  Needs the REAL isce3: generated only when it is importable (it is not in this image;
+    tests/test_gpu_api.py::test_g14_* skips while the fixture is absent).  This is the pin of SURVEY 8(f)1."""
+    prov = ref_import.provenance()
+    if not prov['look_vectors'].startswith('isce3'):
+        print('g14: skipped -', prov['look_vectors'])
+        return
+    orbit = REPO / 'tests' / 'golden' / 'orbit_files' / 'S1_orbit_example.EOF'
+    when = dt.datetime(2018, 11, 12, 23, 0, 32)
+    los_obj = rlos.Raytracing(str(orbit), time=when, pad=600)
+    lon = np.linspace(103.0, 105.5, 16); lat = np.linspace(16.5, 14.5, 16)
+    xx, yy = np.meshgrid(lon, lat)
+    out = {}
+    for ht in (0.0, 1500.0):
+        llh = [xx.copy(), yy.copy(), np.full(yy.shape, ht)]
+        xyz = np.stack(rutil.lla2ecef(llh[1], llh[0], llh[2]), axis=-1)
+        out[f'los_{int(ht)}'] = los_obj.getLookVectors(ht, llh, xyz, yy)
+        out[f'xyz_{int(ht)}'] = xyz
+    save('g14_isce3_look_vectors', lon=lon, lat=lat, hts=np.array([0.0, 1500.0]), when=np.array(when.isoformat()), direction=np.array(los_obj.getSensorDirection()), **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g8', 'g9', 'g10', 'g11', 'g13']   # g12: gen_ref_file_vectors.py; g7: cli.raider needs h5py (absent)
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g8', 'g9', 'g10', 'g11', 'g13', 'g14']   # g14: only with isce3; g12: gen_ref_file_vectors.py; g7: cli.raider needs h5py (absent)
     for w in which:
         globals()[w]()

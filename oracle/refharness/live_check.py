@@ -43,6 +43,7 @@ assert np.array_equal(np.isnan(ow), np.isnan(wet)) and np.isnan(wet).any()
 m = np.isfinite(wet)
 out['zenith_max_rel'] = float(max(np.abs(ow - wet)[m].max() / np.abs(wet[m]).max(), np.abs(oh - hydro)[m].max() / np.abs(hydro[m]).max()))     # of the field maximum
 import scipy          # noqa: E402
+out.update(H.ref_import.provenance())       # geodesy: real pyproj / PROJ or the builder stub; look_vectors: isce3 or absent
 out['python'] = '.'.join(str(v) for v in sys.version_info[:3]); out['numpy'] = np.__version__; out['scipy'] = scipy.__version__
 if not H.HAVE_NATIVES:          # (another interpreter than the one oracle/_ref was built for: the Python path only)
     print(json.dumps(out))

@@ -6,7 +6,7 @@ box).  Recipe = SURVEY.md App. B:
   1. pre-seed sys.modules['RAiDER'] with a bare package whose __path__ points at the reference dir
      (+ oracle/_ref/RAiDER for the two compiled native extensions) - bypasses
      tools/RAiDER/__init__.py:7-10 (importlib.metadata.version of an uninstalled dist);
-  2. put the build-owned stubs of pyproj / xarray / rasterio (absent from this image) on sys.path;
+  2. put the build-owned stubs of pyproj / xarray / rasterio (absent from this image) at the END of sys.path - real packages win;
   3. point the reference logger at a temp dir (logger.py:59-86 would write debug.log into CWD).
 """
 import os
@@ -31,9 +31,11 @@ def import_reference():
         raise RuntimeError(f'reference not present at {REF_PKG}')
     if 'RAiDER' in sys.modules and getattr(sys.modules['RAiDER'], '_oracle_seeded', False):
         return sys.modules['RAiDER']
+    # The stand-ins go to the END of sys.path: a REAL pyproj / xarray / rasterio / isce3, the day the image has one, is found first and
+    # used instead (provenance() then says so, and every fixture and the live-check record carry that string)
     stubs = str(HERE / 'stubs')
     if stubs not in sys.path:
-        sys.path.insert(0, stubs)
+        sys.path.append(stubs)
     pkg = types.ModuleType('RAiDER')
     pkg.__path__ = [str(REF_PKG), str(REF_SO)]
     pkg.__version__ = '0.0-reference-in-place'
@@ -47,3 +49,28 @@ def import_reference():
     models.__path__ = [str(REF_PKG / 'models')]
     sys.modules['RAiDER.models'] = models
     return pkg
+
+
+def provenance():
+    """What the reference's third-party geometry ran on when a fixture was made: {'geodesy': ..., 'look_vectors': ...}.
+    geodesy: 'pyproj <ver> / PROJ <ver>' when the real pyproj is importable, else the builder's stand-in (WGS84 geodetic <-> ECEF
+    restated from PROJ's `cart` conversion: parity of THAT arithmetic is then unpinned, everything downstream is the reference's code).
+    look_vectors: 'isce3 <ver>' when isce3 is importable (Raytracing.getLookVectors = geo2rdr + orbit.interpolate, losreader.py:219-255),
+    else 'absent' (golden g14 cannot be generated; orbit look vectors stay pinned only by closed-form orbits)."""
+    stubs = str(HERE / 'stubs')
+    out = {}
+    try:
+        import pyproj
+        real = not str(getattr(pyproj, '__file__', '')).startswith(stubs)
+        if real:
+            out['geodesy'] = f"pyproj {pyproj.__version__} / PROJ {getattr(pyproj, 'proj_version_str', getattr(pyproj, '__proj_version__', '?'))}"
+        else:
+            out['geodesy'] = 'builder stub oracle/refharness/stubs/pyproj (WGS84 cart conversion restated; PROJ binary parity unpinned)'
+    except ImportError:
+        out['geodesy'] = 'no pyproj at all'
+    try:
+        import isce3
+        out['look_vectors'] = f"isce3 {getattr(isce3, '__version__', '?')}"
+    except ImportError:
+        out['look_vectors'] = 'absent (isce3 not importable: golden g14 not generated)'
+    return out

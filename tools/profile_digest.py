@@ -47,6 +47,28 @@ def sq(dirs, nwaves):
     return out
 
 
+def instr_mix(d):
+    """VALU instructions per 64-ray wave by class, from the SQ class counters of gfx950 (rocprofv3 -L), and what they cost.
+    A wave64 instruction issues over 2 cycles on CDNA4's SIMD-32 (MI355X_MICROARCH.md "Wave scheduling"); fp64 arithmetic runs at half
+    that rate (78.6 TFLOP/s = 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz), i.e. 4 cycles.  Conversions are priced at the fp64 rate
+    (this kernel's are all f32 <-> f64 or f64 <-> i32: v_cvt_f64_f32 of the gathered values, v_cvt_i32_f64 / v_cvt_f64_i32 of the
+    cell search) - an assumption the measured busy cycles check: 4 x SQ_ACTIVE_INST_VALU (quad-cycles) per wave against the model."""
+    g = lambda k: float(d.get(k, 0.0))
+    fma, add, mul, trans = g('SQ_INSTS_VALU_FMA_F64'), g('SQ_INSTS_VALU_ADD_F64'), g('SQ_INSTS_VALU_MUL_F64'), g('SQ_INSTS_VALU_TRANS_F64')
+    f32 = g('SQ_INSTS_VALU_FMA_F32') + g('SQ_INSTS_VALU_ADD_F32') + g('SQ_INSTS_VALU_MUL_F32') + g('SQ_INSTS_VALU_TRANS_F32')
+    cvt, i32, i64, valu = g('SQ_INSTS_VALU_CVT'), g('SQ_INSTS_VALU_INT32'), g('SQ_INSTS_VALU_INT64'), g('SQ_INSTS_VALU')
+    fp64 = fma + add + mul + trans
+    other = valu - (fp64 + f32 + cvt + i32 + i64)
+    m = dict(valu=round(valu, 1), fp64=round(fp64, 1), fp64_fma=round(fma, 1), fp64_add=round(add, 1), fp64_mul=round(mul, 1), fp64_trans=round(trans, 1),
+             cvt=round(cvt, 1), int32=round(i32, 1), int64=round(i64, 1), f32=round(f32, 1), other=round(other, 1),
+             fp64_flops_per_lane=round(2 * fma + add + mul + trans, 1),
+             flops_fp64_counter_per_wave=round(g('SQ_INSTS_VALU_FLOPS_FP64'), 1),
+             issue_cycles_model=round(4 * (fp64 + cvt) + 2 * (f32 + i32 + i64 + max(other, 0.0)), 1),
+             valu_busy_cycles_measured=round(4 * g('SQ_ACTIVE_INST_VALU'), 1),
+             vmem_wr=round(g('SQ_INSTS_VMEM_WR'), 2), smem=round(g('SQ_INSTS_SMEM'), 1), branch=round(g('SQ_INSTS_BRANCH'), 1))
+    return m
+
+
 def pmc(dirpath, counter):
     per = defaultdict(list); cal = None
     for f in glob.glob(str(dirpath) + '/**/*counter_collection.csv', recursive=True):
@@ -73,7 +95,7 @@ def main():
                       'calibration copy in the same pass (gfx950: x2), WRITE_SIZE likewise (x1); SQ counters divided by launches and 64-ray waves',
                kernels={})
     nw = info['sq_scene'][0] * info['sq_scene'][1] / 64.0
-    s = sq([src / 'sq1', src / 'sq2'], nw)
+    s = sq(sorted(p_ for p_ in src.glob('sq*') if p_.is_dir()), nw)
     lines = [f'# rocprofv3 --pmc SQ passes on bench.py --rows {info["sq_scene"][0]} --cols {info["sq_scene"][1]} --cube {info["cube"]}; per launch and per 64-ray wave',
              f'# VALU busy while a wave is resident = {WAVES_PER_SIMD} waves/SIMD x SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES']
     for k, d in sorted(s.items()):
@@ -87,6 +109,8 @@ def main():
             e['wait_inst_any_frac'] = round(d.get('SQ_WAIT_INST_ANY', 0.0) / d['SQ_WAVE_CYCLES'], 4)
         # (registers / LDS / scratch are NOT taken from rocprof's metadata columns - VGPR_Count reads 64 for a 128-register kernel here -
         # bench.py asks the loaded code object: rdr_ray_kernel_attributes)
+        if 'SQ_INSTS_VALU_FMA_F64' in d:
+            e['instr_mix'] = instr_mix(d)
         lines.append(k + ': ' + json.dumps({c: round(v, 1) for c, v in sorted(d.items())}))
     (prof / f'{rnd}_{tag}_sq_counters_per_raywave.txt').write_text('\n'.join(lines) + '\n')
 
@@ -119,6 +143,14 @@ def main():
     if (src / 'bench.json').exists() and (src / 'bench.json').stat().st_size:
         shutil.copy(src / 'bench.json', prof / f'{rnd}_{tag}_bench.json')
     (prof / f'{rnd}_{tag}_counters.json').write_text(json.dumps(res, indent=1, sort_keys=True) + '\n')
+    mix = {k: v['instr_mix'] for k, v in res['kernels'].items() if 'instr_mix' in v}
+    if mix:
+        (prof / f'{rnd}_instr_mix.json').write_text(json.dumps(dict(
+            source_hash=res['source_hash'], tag=tag, cube=res['cube'], scene=res['sq_scene'], unit='VALU instructions per 64-ray wave and launch (rocprofv3 --pmc SQ_INSTS_VALU_* '
+            'class counters, tools/profile_round.sh passes sq3-sq6; per-lane flops = 2 x FMA + ADD + MUL + TRANS)',
+            pricing='wave64 instruction = 2 cycles on the SIMD-32 (f32 / integer), 4 cycles for fp64 arithmetic and f32<->f64 conversions; valu_busy_cycles_measured = 4 x '
+                    'SQ_ACTIVE_INST_VALU (quad-cycles) per wave is the check of that model',
+            kernels=mix), indent=1, sort_keys=True) + '\n')
     print(json.dumps(res, indent=1, sort_keys=True))
 
 
