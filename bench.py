@@ -680,7 +680,9 @@ def run_c2(args, ctx, dev, coll_dev, dist_on, rank, world, ndev, result_fd):
     m = c2_measure(ctx, dev, n_side=n_side, steps=args.steps, warmup=args.warmup, oracle_sample=(200000 if (world == 1 and args.cpu_sample > 0) else 0),
                    block=(p0, cnt), cube_tensors=cube_tensors, e2e=(world == 1 and not args.no_e2e))
     dt = m['step_s'] * args.steps
+    rank_s = [dt]
     if dist_on:
+        rank_s = gather_rank_times(dist, dt, coll_dev, world)
         tmax = torch.tensor([dt], dtype=torch.float64, device=coll_dev if coll_dev is not None else 'cpu')
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -698,6 +700,8 @@ def run_c2(args, ctx, dev, coll_dev, dist_on, rank, world, ndev, result_fd):
                           'parallelism': (f'points sharded x{world} ({args.backend}, {ndev} device(s) visible), cube: one packed broadcast ({t_bcast*1e3:.1f} ms), intermediate cube '
                                           f'replicated per rank, no data-path collective') if dist_on else 'single GPU',
                           'ranks': world, 'backend': (dist.get_backend() if dist_on else None), 'world_size_seen_by_backend': (dist.get_world_size() if dist_on else 1),
+                          'shards': [list(D.shard_rows(n_all, world, r_)) for r_ in range(world)], 'rank_ms_per_step': [t_ / args.steps * 1e3 for t_ in rank_s],
+                          'devices_visible': ndev, 'ranks_per_device': -(-world // ndev),
                           'mean_hydro_m': m['mean_hydro'], 'mean_wet_m': m['mean_wet'], 'nan_fraction': m['nan_fraction'], 'intermediate_cube_has_nan': m['has_nan']},
                'roofline': dict(c2_roofline(m), library_source_hash=R.load_library().rdr_source_hash().decode())}
         if 'e2e' in m:

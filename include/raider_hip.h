@@ -248,7 +248,7 @@ int rdr_interp3_project(rdr_ctx* ctx, const rdr_cube* cube, const double* y, con
  * then reads four 128 B lines per point for 16 B each.  The cube can carry a second, cell-column-major copy ("corner quads",
  * 5.3 x its bytes for f32, 8 x for f64) from which a point's eight corners are ONE line - same values, same arithmetic, 3.3 x less
  * HBM traffic.  mode 1: build it now; mode 0: free it.  Without this call rdr_interp3 builds it by itself from the second call with
- * >= 262144 points on a cube beyond 32 MB - or at the first, when the point set is large enough that the build pays for itself within
+ * >= 262144 points on a cube beyond 192 MB (the Infinity Cache holds smaller ones) - or at the first, when the point set is large enough that the build pays for itself within
  * that call (n x 175 B > the copy's bytes, from the measured rates) - if it fits a quarter of the free memory (env
  * RAIDER_HIP_POINT_INDEX=0 never, =1 at the first such call, =2 second call only).  rdr_cube_point_index_bytes: bytes the copy holds now (0: none). */
 int rdr_cube_point_index(rdr_ctx* ctx, rdr_cube* cube, int mode);

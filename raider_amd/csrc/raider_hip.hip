@@ -540,8 +540,11 @@ int rdr_cube_create(rdr_ctx* c, const double* ys, int64_t ny, const double* xs, 
     if (e != hipSuccess) { rdr_cube_destroy(q); return fail(c, RDR_ERR_HIP, hipGetErrorString(e)); }
 #define RDR_PACK(T, T2, SW) hipLaunchKernelGGL((pack_cube_kernel<T, T2, SW>), dim3(g), dim3(256), 0, c->stream, (const T*)dw, (const T*)dh, \
                                                (T2*)q->d_vals, ny, nx, nz, sy, sx, sz, fy, fx, fz, nf)
-    if (dtype == RDR_F32) { if (swapped) RDR_PACK(float, float2, true); else RDR_PACK(float, float2, false); }
-    else { if (swapped) RDR_PACK(double, double2, true); else RDR_PACK(double, double2, false); }
+    {
+        KTimer t(c, 2);       // (the packing of an intermediate delay cube is part of the point branch's step: bench.py --workload c2 counts it)
+        if (dtype == RDR_F32) { if (swapped) RDR_PACK(float, float2, true); else RDR_PACK(float, float2, false); }
+        else { if (swapped) RDR_PACK(double, double2, true); else RDR_PACK(double, double2, false); }
+    }
 #undef RDR_PACK
     e = hipGetLastError();
     if (e != hipSuccess) { rdr_cube_destroy(q); return fail(c, RDR_ERR_HIP, hipGetErrorString(e)); }
@@ -937,7 +940,7 @@ static int quad_build(rdr_ctx* c, const rdr_cube* q_any) {
 }
 
 // Policy of the automatic build: only for point sets and cubes large enough that the four-lines-per-point gather is what bounds
-// the call (>= 256 k points, a cube beyond 32 MB - smaller ones live in L2 / the Infinity Cache), only when the copy fits a quarter
+// the call (>= 256 k points, a cube beyond 192 MB - smaller ones live in L2 / the 256 MB Infinity Cache), only when the copy fits a quarter
 // of the free memory.  When: by TIME, from the measured rates (profiles/r03_secondary.json, r04_secondary.json: 5 M stations on the
 // 400 MB HRRR-sized cube) - the direct gather moves 572 B per point at 6.5 TB/s (88 ps), the quad gather 168 B at 5.65 TB/s (30 ps),
 // the build writes the copy at 3.0 TB/s: building at the FIRST large call pays when n x 58 ps > bytes / 3.0 TB/s, i.e. n x 175 B >
@@ -950,7 +953,9 @@ static bool quad_wanted(rdr_ctx* c, const rdr_cube* q_any, int64_t n) {
     static const int env = []() { const char* e = std::getenv("RAIDER_HIP_POINT_INDEX"); return e ? std::atoi(e) : -1; }();
     if (env == 0) return false;
     const size_t cube_bytes = (size_t)q->ny * q->nx * q->nz * (q->dtype == RDR_F32 ? 8 : 16);
-    if (n < (1 << 18) || cube_bytes < ((size_t)32 << 20) || q->ny < 2 || q->nx < 2 || q->nz < 2) return false;
+    // (round 5: 32 MB -> 192 MB.  A 38.8 MB f64 cube - the intermediate delay cube of BASELINE configs[1] - is Infinity-Cache resident: 10^6
+    // points from it take 23.7 us directly, 32.0 us from the copy, which also costs 54 us to build; profiles/r05_c2_counters.json at 458657a3)
+    if (n < (1 << 18) || cube_bytes < ((size_t)192 << 20) || q->ny < 2 || q->nx < 2 || q->nz < 2) return false;
     int nblk; const size_t need = quad_need_bytes(q, &nblk);
     const bool pays_now = env != 2 && (double)n * 175.0 > (double)need;
     if (++q->big_point_calls < 2 && env != 1 && !pays_now) return false;

@@ -3,8 +3,8 @@ R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 for lib in "$@"; do
   O=$R/gpurun_out/sqq_$(basename $lib .so); rm -rf $O; mkdir -p $O
-  RAIDER_HIP_LIB=$R/$lib timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $O/sq1 -- python $R/bench.py --rows 2000 --cols 2000 --steps 2 --warmup 1 --cpu-sample 0 > $O/sq1.log 2>&1
-  RAIDER_HIP_LIB=$R/$lib timeout 600 rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAIT_INST_ANY --output-format csv -d $O/sq2 -- python $R/bench.py --rows 2000 --cols 2000 --steps 2 --warmup 1 --cpu-sample 0 > $O/sq2.log 2>&1
+  RAIDER_HIP_LIB=$R/$lib timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $O/sq1 -- python $R/bench.py --rows 2000 --cols 2000 --steps 2 --warmup 1 --cpu-sample 0 --no-e2e --no-secondary > $O/sq1.log 2>&1
+  RAIDER_HIP_LIB=$R/$lib timeout 600 rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAIT_INST_ANY --output-format csv -d $O/sq2 -- python $R/bench.py --rows 2000 --cols 2000 --steps 2 --warmup 1 --cpu-sample 0 --no-e2e --no-secondary > $O/sq2.log 2>&1
   python - $O $lib <<'PY'
 import csv, glob, sys
 from collections import defaultdict
