@@ -51,6 +51,25 @@ def test_bench_line_is_complete_and_self_consistent():
         assert abs(r['frac_at_measured_clock'] - r['frac'] * 2.4 / r['clock_GHz_measured']) < 1e-12 and r['frac_at_measured_clock'] <= 1.02
         assert abs(r['valu_per_reference_sample'] - r['valu_instr_per_raywave'] / S) < 1e-9
         assert r['valu_per_reference_sample'] < r['valu_per_evaluated_sample']             # shared segment ends are evaluated once
+    # round 5: the instruction mix is MEASURED (SQ class counters through the same digest); three different fractions, related as they must be
+    for k in ('executed_fp64_flops_frac', 'executed_fp64_TFLOPs', 'frac_class_priced', 'valu_mix', 'valu_mix_per_raywave', 'valu_mix_source'):
+        assert k in r, k
+    if r['frac'] is not None and r['valu_mix'] is not None:
+        mix = r['valu_mix_per_raywave']
+        assert abs(sum(r['valu_mix'].values()) - 1.0) < 1e-9 and r['valu_mix']['fp64'] > 0.4 and r['valu_mix']['cvt'] > 0.1
+        assert abs(mix['valu'] - r['valu_instr_per_raywave']) < 0.01 * mix['valu']                 # the class passes saw the same kernel as the VALU pass
+        assert abs(mix['fp64_flops_per_lane'] - (2 * mix['fp64_fma'] + mix['fp64_add'] + mix['fp64_mul'] + mix['fp64_trans'])) < 1.0
+        assert abs(mix['flops_fp64_counter_per_wave'] - mix['fp64_flops_per_lane']) < 0.02 * mix['fp64_flops_per_lane']   # SQ_INSTS_VALU_FLOPS_FP64 agrees with the class counts
+        assert 0.0 < r['executed_fp64_flops_frac'] <= r['frac'] + 1e-12                          # executed flops can never exceed issue busy-ness
+        assert r['executed_fp64_flops_frac'] < r['useful_flops_frac']                            # ... and the kernel executes FEWER flops than the reference's algorithm counts
+        assert r['frac_class_priced'] <= r['frac'] + 1e-12                                       # cheaper classes priced at their own rate
+        assert abs(r['executed_fp64_TFLOPs'] * 1e12 - mix['fp64_flops_per_lane'] * n / (r['march_ms_per_step'] * 1e-3)) < 1e-6 * r['executed_fp64_TFLOPs'] * 1e12
+    sec = d['secondary']                                                                    # the two gather workloads beside the headline
+    for wl, unit in (('c2', 'points/s'), ('c5', 'points/s')):
+        assert 'error' not in sec[wl], sec[wl]
+        assert sec[wl]['unit'] == unit and sec[wl]['value'] > 1e8 and sec[wl]['roofline_bound'] == 'hbm' and sec[wl]['roofline_frac'] > 0
+        assert sec[wl]['kernels_ms_per_step'] <= sec[wl]['ms_per_step'] * 1.001
+    assert sec['c2']['gpu_vs_oracle_max_abs_m'] < 1e-12 and sec['c5']['gpu_vs_oracle_max_abs'] < 1e-9    # metres of delay; N-units of refractivity
     p = d['parity']                                                                         # a full-scene record is cited only when made with THESE kernels
     assert p['record'] is None or p['source_hash'] == r['source_hash']
     e = d['end_to_end']
@@ -64,3 +83,26 @@ def test_bench_per_pixel_heights_line():
     assert d['config']['workload'].startswith('c3b') and 'end_to_end' not in d
     assert d['roofline']['kernel'].endswith('true>') and d['roofline']['frac'] is None     # (no counter digest is kept for the secondary workload)
     assert d['cpu_baseline']['gpu_vs_oracle_max_abs_m'] < 1e-6 and d['config']['nan_fraction'] == 0.0
+
+
+def test_c2_line():
+    """`bench.py --workload c2` = BASELINE configs[1] as a driver-runnable line: points/s with the inputs resident in HBM, an HBM roofline on
+    SURVEY 8(d)'s 168 B per query, the host-buffer route beside it (bit-identical), the NumPy oracle timed on the same box."""
+    out = subprocess.run([sys.executable, str(ROOT / 'bench.py'), '--workload', 'c2', '--steps', '5', '--warmup', '2'], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-4000:])
+    lines = out.stdout.splitlines()
+    assert len(lines) == 1 and lines[0].startswith('{'), out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['unit'] == 'points/s' and d['n_gpus'] == 1 and d['dtype'] == 'f64' and 'configs[1]' in d['config']['workload'] and d['vs_baseline'] is None
+    assert d['config']['points_all_gpus'] == 1000 * 1000 and abs(d['value'] * d['ms_per_step'] * 1e-3 - 1e6) < 1.0
+    r = d['roofline']
+    assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12
+    assert abs(r['algorithmic_bytes_per_step'] - (168.0 * 1e6 + 200.0 * d['config']['intermediate_nodes'])) < 1.0
+    assert r['kernels_ms_per_step'] < d['ms_per_step'] and r['source_hash'] == r['library_source_hash']
+    if r['traffic'] is not None:
+        assert r['counters_source'].startswith('profiles/') and 0 < r['frac_hbm_measured'] < 1.0
+    e = d['end_to_end']
+    assert e['bit_identical_to_device_path'] is True and e['value'] < d['value'] and e['h2d_bytes'] == 24_000_000
+    c = d['cpu_baseline']
+    assert c['kind'] == 'port' and c['cores'] == 1 and c['gpu_vs_oracle_max_abs_m'] < 1e-12 and c['nan_masks_equal'] is True
+    assert 1.5 < d['config']['mean_hydro_m'] < 4.0 and d['config']['nan_fraction'] == 0.0
