@@ -525,7 +525,7 @@ def c2_inputs(n_side):
     return c, lats, lons, hgts, np.asarray(aoi.xpts), np.asarray(aoi.ypts), np.asarray(c['zs'], dtype=np.float64)
 
 
-def c2_measure(ctx, dev, n_side=1000, steps=20, warmup=3, oracle_sample=200000, block=None, cube_tensors=None, e2e=False):
+def c2_measure(ctx, dev, n_side=1000, steps=20, warmup=3, oracle_sample=200000, block=None, cube_tensors=None, e2e=False, sync=None):
     """One step of configs[1] = the point branch of tropo_delay (delay.py:96-128) for this rank's block of the points, inputs resident
     in HBM: _build_cube of the intermediate delay cube on the AOI grid (rdr_build_cube_to_cube: setup + gather + packing, the cube stays
     on the device) and ONE gather of both fields at the points with delay / cos(inc) in the same launch (rdr_interp3_project).
@@ -555,10 +555,14 @@ def c2_measure(ctx, dev, n_side=1000, steps=20, warmup=3, oracle_sample=200000, 
     for _ in range(warmup):
         step()
     torch.cuda.synchronize()
+    if sync is not None:
+        sync()                                   # N > 1: every rank enters the timed region together (barrier)
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
     torch.cuda.synchronize()
+    if sync is not None:
+        sync()
     dt = time.perf_counter() - t0
     # the two halves by themselves, HIP events on the stream the kernels run on (the library's own pairs around every launch)
     ctx.set_profiling(True)
@@ -678,7 +682,7 @@ def run_c2(args, ctx, dev, coll_dev, dist_on, rank, world, ndev, result_fd):
     if dist_on:
         dist.barrier()
     m = c2_measure(ctx, dev, n_side=n_side, steps=args.steps, warmup=args.warmup, oracle_sample=(200000 if (world == 1 and args.cpu_sample > 0) else 0),
-                   block=(p0, cnt), cube_tensors=cube_tensors, e2e=(world == 1 and not args.no_e2e))
+                   block=(p0, cnt), cube_tensors=cube_tensors, e2e=(world == 1 and not args.no_e2e), sync=(dist.barrier if dist_on else None))
     dt = m['step_s'] * args.steps
     rank_s = [dt]
     if dist_on:
