@@ -765,7 +765,9 @@ def test_advice_r2_host_fixes():
     # (c)
     cube.set_projection_lcc(38.5, 38.5, 38.5, 262.5)
     d = _build_cube_ray(xp, yp, zpts[:2], los, 4326, 4326, ip, MAX_TROPO_HEIGHT=zref)
-    assert cube.projection is None and np.array_equal(d[0], a[0][:2])
+    # round 5: a call with model_crs = 4326 on a cube that carries a projection works on an UNPROJECTED VIEW of it (rdr_cube_view) - the
+    # caller's cube is not modified (it may be shared), the result is the lon/lat one
+    assert cube.projection is not None and cube.projection['proj'] == 'lcc' and np.array_equal(d[0], a[0][:2])
 
 
 def test_cube_files_are_uploaded_from_the_mapping(tmp_path, caplog):
