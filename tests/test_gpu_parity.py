@@ -414,7 +414,8 @@ def test_point_index_gives_the_same_bits(R):
 def test_point_index_is_built_by_the_second_large_call(R):
     import torch
     rng = np.random.default_rng(3)
-    ny, nx, nz = 210, 200, 110                                             # 37 MB as float2: beyond the 32 MB threshold
+    ny, nx, nz = 520, 500, 110                                             # 229 MB as float2: beyond the 192 MB threshold (round 5: smaller cubes live in the Infinity Cache,
+                                                                            # where the copy LOSES - measured on the 38.8 MB intermediate cube of configs[1])
     ys = np.linspace(30, 40, ny); xs = np.linspace(-120, -110, nx); zs = np.round(-100 + 30000 * np.linspace(0, 1, nz) ** 2, 3)
     dev = torch.device('cuda:0')
     w = torch.randn((ny, nx, nz), dtype=torch.float32, device=dev); h = torch.randn_like(w)
@@ -433,10 +434,10 @@ def test_point_index_is_built_by_the_second_large_call(R):
     torch.cuda.synchronize()
     assert torch.equal(r1[0], r2[0]) and torch.equal(r1[1], r2[1]) and torch.isfinite(r3[0]).all()
     # round 4: a point set so large that the build pays for itself WITHIN the call (by time, from the measured rates: n x 175 B > the
-    # copy's 197 MB here -> from 1.13 M points on) builds it at the FIRST call; same bits as the direct gather
+    # copy's 1.23 GB here -> from 7.0 M points on) builds it at the FIRST call; same bits as the direct gather
     cube2 = R.Cube(ys, xs, zs, w, h, order='yxz')
     held2 = lambda: cube2.ctx.lib.rdr_cube_point_index_bytes(cube2.handle)
-    n2 = 1300000
+    n2 = 7500000
     huge = torch.from_numpy(np.stack([rng.uniform(30, 40, n2), rng.uniform(-120, -110, n2), rng.uniform(0, 9000, n2)], -1)).to(dev)
     direct = cube2.interp(huge[:200000].contiguous())
     assert held2() == 0
