@@ -583,12 +583,14 @@ static void cube_release(rdr_cube* q) {
             if (hipEventRecord(ev, s_) != hipSuccess) { ok = false; break; }
         }
         if (ok) {
+            // (the corner-quad copy is freed, not pooled: wait for the same events first - every stream that may still be reading it)
+            if (q->d_quad) for (auto ev : evs) (void)hipEventSynchronize(ev);
             c->cube_pool.push_back({q->d_vals, q->alloc_bytes, evs});
             c->cube_pool_bytes += q->alloc_bytes;
             pooled = true;
         } else { for (auto ev : evs) (void)hipEventDestroy(ev); (void)hipGetLastError(); }
     }
-    if (!pooled || q->d_quad) { if (foreign || !c || c->ext_overflow || !pooled) (void)hipDeviceSynchronize(); else (void)hipStreamSynchronize(c->stream); }
+    if (!pooled) (void)hipDeviceSynchronize();
     if (!pooled && q->d_vals && q->alloc_bytes > 0) (void)hipFree(q->d_vals);       // (the axes live in the same allocation)
     if (q->d_quad) (void)hipFree(q->d_quad);
     delete q;
