@@ -60,6 +60,7 @@ for wl in ('c2', 'c5'):
         e['hbm_read_bytes'] = f[len(f) // 2] * 2.0 * 1024
         e['hbm_write_bytes'] = w[len(w) // 2] * 1024
         e['per_step'] = k in STEP[wl]
+    res['kernels'] = {k: e for k, e in res['kernels'].items() if 'rocprof_avg_us' in e}      # (gpurun MERGES into gpurun_out: counters of kernels an earlier build launched are not this run's)
     for e in res['kernels'].values():
         e.pop('_tot', None)
     res['step_traffic_bytes'] = sum(e.get('hbm_read_bytes', 0) + e.get('hbm_write_bytes', 0) for e in res['kernels'].values() if e.get('per_step'))
