@@ -37,6 +37,50 @@ __global__ void pack_cube_kernel(const T* __restrict__ wet, const T* __restrict_
     if (nan_flag && __any(bad) && (threadIdx.x & 63) == 0) atomicOr(nan_flag, 1);
 }
 
+// The same for sources whose x axis is contiguous (sx == 1: file order (z, y, x), weatherModel.py:685-693 - and the planar results of
+// _build_cube that become an intermediate delay cube).  The generic kernel above walks the OUTPUT (z fastest), i.e. reads such a source at a
+// stride of ny * nx elements: every 8 B from its own line (measured on the 80 x 151 x 201 intermediate cube of BASELINE configs[1]: 272 MB of
+// HBM reads for a 39 MB cube, 50 us - the longest kernel of that step).  Here a workgroup moves a 32 (x) x 32 (z) tile of one y row through
+// LDS: reads coalesced along x (256 B per half-wave), writes coalesced along z (32 x sizeof(T2) contiguous bytes per half-wave).
+template <typename T, typename T2, bool SWAP>
+__global__ __launch_bounds__(256) void pack_cube_xfast_kernel(const T* __restrict__ wet, const T* __restrict__ hyd, T2* __restrict__ dst,
+                                                              int64_t ny, int64_t nx, int64_t nz, int64_t sy, int64_t sz,
+                                                              int fy, int fx, int fz, int* __restrict__ nan_flag) {
+    __shared__ T2 tile[32][33];                      // [z][x], padded: the transposed read walks a column
+    auto fix = [](T v) -> T {
+        if constexpr (!SWAP) return v;
+        else if constexpr (sizeof(T) == 4) return __uint_as_float(__builtin_bswap32(__float_as_uint(v)));
+        else return __longlong_as_double((long long)__builtin_bswap64((unsigned long long)__double_as_longlong(v)));
+    };
+    const int64_t tx_n = (nx + 31) / 32, tz_n = (nz + 31) / 32, ntiles = ny * tx_n * tz_n;
+    const int lx = threadIdx.x & 31, lr = threadIdx.x >> 5;          // 32 lanes along the fast axis, 8 rows per pass
+    bool bad = false;
+    for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int64_t tz = t % tz_n, r = t / tz_n, tx = r % tx_n, iy = r / tx_n;
+        const int64_t jy = fy ? ny - 1 - iy : iy;
+        const int64_t x0 = tx * 32, z0 = tz * 32;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {                                // read: lanes along x, rows = z
+            const int64_t ix = x0 + lx, iz = z0 + lr + 8 * k;
+            if (ix < nx && iz < nz) {
+                const int64_t jx = fx ? nx - 1 - ix : ix, jz = fz ? nz - 1 - iz : iz;
+                const int64_t src = jy * sy + jx + jz * sz;
+                T2 v; v.x = fix(wet[src]); v.y = fix(hyd[src]);
+                bad |= (v.x != v.x) | (v.y != v.y);
+                tile[lr + 8 * k][lx] = v;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {                                // write: lanes along z, rows = x
+            const int64_t iz = z0 + lx, ix = x0 + lr + 8 * k;
+            if (ix < nx && iz < nz) dst[(iy * nx + ix) * nz + iz] = tile[lx][lr + 8 * k];
+        }
+        __syncthreads();
+    }
+    if (nan_flag && __any(bad) && (threadIdx.x & 63) == 0) atomicOr(nan_flag, 1);
+}
+
 template <typename T, typename T2>
 __global__ void unpack_cube_kernel(const T2* __restrict__ src, T* __restrict__ wet, T* __restrict__ hyd, int64_t total) {
     for (int64_t o = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x) {

@@ -66,6 +66,12 @@ struct rdr_ctx {
     int64_t side_cap = 0;                     // columns of `side` in the current layout
     int* d_sidectr = nullptr;                 // [1] next free column
     int* h_word = nullptr;                    // [16] page-locked host words: flags read back WITHOUT stalling the host before the final sync
+    // cubes made from DEVICE sources are created without a host synchronisation (round 5): their NaN verdict lands in one of these page-locked
+    // words and is read when somebody asks (rdr_cube_has_nan), after the cube's ready event; nan_owner[i] = the cube word i is pending for
+    static constexpr int NAN_SLOTS = 256;
+    int* nan_words = nullptr;
+    const struct rdr_cube* nan_owner[NAN_SLOTS] = {};
+    int nan_next = 0;
     int64_t side_forced = -1;                 // rdr_set_side_capacity
     int64_t last_nslow = 0;                   // generic rays seen by the last pass 1 whose count the host happened to read back
     int wall_khz = 0;                         // rate of the wall counter (rdr_clock_sample_begin)
@@ -93,7 +99,12 @@ struct rdr_cube {
     mutable int quad_nblk = 0;
     mutable int big_point_calls = 0;             // rdr_interp3 calls that would have profited
     mutable std::mutex quad_mutex;               // one builder of the quad copy per cube
-    bool has_nan = false;                        // a NaN among the fields (seen while packing; blends: unknown -> false)
+    mutable bool has_nan = false;                // a NaN among the fields (seen while packing; blends: either source's)
+    // asynchronous creation (device sources): `ready_ev` is recorded on `ready_stream` after the last kernel that writes the buffers; any use
+    // on another stream waits for it (cube_wait); nan_slot >= 0: the packing kernel's verdict is still in ctx->nan_words[nan_slot]
+    mutable hipEvent_t ready_ev = nullptr;
+    hipStream_t ready_stream = nullptr;
+    mutable int nan_slot = -1;
     size_t alloc_bytes = 0;                      // bytes of the ONE allocation behind d_vals (values | axes); 0: not owned (scratch cube, view)
     // views (rdr_cube_view): `base` != NULL marks a handle that shares base's buffers and corner-quad copy and owns only its projection
     const rdr_cube* base = nullptr;
@@ -104,7 +115,23 @@ struct rdr_cube {
 static std::mutex g_view_mutex;
 static inline const rdr_cube* root(const rdr_cube* q) { return q->base ? q->base : q; }
 // every entry point that reads a cube says so: work enqueued by ANOTHER context is not covered by the events the owner records at destroy
-static inline void note_use(const rdr_ctx* c, const rdr_cube* q) { if (c && q && root(q)->ctx != c) root(q)->foreign.store(true, std::memory_order_relaxed); }
+static inline void note_use(const rdr_ctx* c, const rdr_cube* q) {
+    if (!c || !q) return;
+    const rdr_cube* r = root(q);
+    if (r->ctx != c) r->foreign.store(true, std::memory_order_relaxed);
+    // a cube created asynchronously on another stream: this stream's work is ordered after its completion
+    if (r->ready_ev && r->ready_stream != c->stream) { (void)hipStreamWaitEvent(c->stream, r->ready_ev, 0); (void)hipGetLastError(); }
+}
+// the pending NaN verdict of an asynchronously created cube (waits for the cube's ready event: the only host wait of such a cube)
+static void cube_resolve_nan(const rdr_cube* r) {
+    if (r->nan_slot < 0) return;
+    rdr_ctx* c = r->ctx;
+    if (r->ready_ev) (void)hipEventSynchronize(r->ready_ev);
+    r->has_nan = c->nan_words[r->nan_slot] != 0;
+    c->nan_owner[r->nan_slot] = nullptr;
+    r->nan_slot = -1;
+}
+
 
 static int fail(rdr_ctx* ctx, int code, const std::string& msg) {
     g_err = msg;
@@ -120,6 +147,14 @@ static int fail(rdr_ctx* ctx, int code, const std::string& msg) {
             return fail(ctx, _e == hipErrorOutOfMemory ? RDR_ERR_OOM : RDR_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
         }                                                                                           \
     } while (0)
+
+// mark `q` complete-on-stream: everything enqueued on c->stream so far finishes before any other stream touches it
+static int cube_mark_ready(rdr_ctx* c, rdr_cube* q) {
+    HIPCHECK(c, hipEventCreateWithFlags(&q->ready_ev, hipEventDisableTiming));
+    HIPCHECK(c, hipEventRecord(q->ready_ev, c->stream));
+    q->ready_stream = c->stream;
+    return RDR_OK;
+}
 
 static int ensure(rdr_ctx* ctx, int s, size_t bytes, void** out) {
     DevBuf& b = ctx->slot[s];
@@ -249,6 +284,7 @@ int rdr_create(int device, rdr_ctx** out) {
         HIPCHECK(nullptr, hipMalloc((void**)&c->d_sidectr, sizeof(int)));
         HIPCHECK(nullptr, hipMemset(c->d_sidectr, 0, sizeof(int)));
         HIPCHECK(nullptr, hipHostMalloc((void**)&c->h_word, 16 * sizeof(int), hipHostMallocDefault));
+        HIPCHECK(nullptr, hipHostMalloc((void**)&c->nan_words, rdr_ctx::NAN_SLOTS * sizeof(int), hipHostMallocDefault));
         HIPCHECK(nullptr, hipMemset(c->d_nslow, 0, sizeof(int)));
         return RDR_OK;
     }();
@@ -274,6 +310,7 @@ void rdr_destroy(rdr_ctx* c) {
     if (c->side.p) (void)hipFree(c->side.p);
     if (c->d_sidectr) (void)hipFree(c->d_sidectr);
     if (c->h_word) (void)hipHostFree(c->h_word);
+    if (c->nan_words) (void)hipHostFree(c->nan_words);
     for (auto& v : c->evs) for (auto& pr : v) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
@@ -285,6 +322,18 @@ int rdr_set_stream(rdr_ctx* c, void* s) {
     if (!c) return fail(nullptr, RDR_ERR_INVALID, "ctx is NULL");
     // NULL is HIP's legacy default stream (what torch.cuda.current_stream().cuda_stream is unless the caller
     // switched streams); (void*)-1 restores the ctx's private stream
+    const hipStream_t before = c->stream;
+    const hipStream_t want = (s == (void*)(intptr_t)-1) ? c->own_stream : (hipStream_t)s;
+    if (want != before) {
+        // the context's scratch slots, flag words and asynchronously created cubes are shared by whatever stream it launches on: work on the
+        // new stream is ordered after everything enqueued on the old one (one event; calls no longer end with a host synchronisation)
+        hipEvent_t ev = nullptr;
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess) {
+            if (hipEventRecord(ev, before) == hipSuccess) (void)hipStreamWaitEvent(want, ev, 0);
+            (void)hipEventDestroy(ev);
+        }
+        (void)hipGetLastError();
+    }
     if (s == (void*)(intptr_t)-1) c->stream = c->own_stream;
     else {
         c->stream = (hipStream_t)s;
@@ -540,15 +589,38 @@ int rdr_cube_create(rdr_ctx* c, const double* ys, int64_t ny, const double* xs, 
     if (e != hipSuccess) { rdr_cube_destroy(q); return fail(c, RDR_ERR_HIP, hipGetErrorString(e)); }
 #define RDR_PACK(T, T2, SW) hipLaunchKernelGGL((pack_cube_kernel<T, T2, SW>), dim3(g), dim3(256), 0, c->stream, (const T*)dw, (const T*)dh, \
                                                (T2*)q->d_vals, ny, nx, nz, sy, sx, sz, fy, fx, fz, nf)
+    // x-contiguous sources (file order (z, y, x); the planar results behind an intermediate delay cube): the LDS-transposing kernel
+    const bool xfast = sx == 1 && nx >= 8 && nz >= 8;
+    const int gx = (int)std::max<int64_t>(1, std::min<int64_t>(ny * ((nx + 31) / 32) * ((nz + 31) / 32), (int64_t)c->num_cus * 16));
+#define RDR_PACKX(T, T2, SW) hipLaunchKernelGGL((pack_cube_xfast_kernel<T, T2, SW>), dim3(gx), dim3(256), 0, c->stream, (const T*)dw, (const T*)dh, \
+                                                (T2*)q->d_vals, ny, nx, nz, sy, sz, fy, fx, fz, nf)
     {
         KTimer t(c, 2);       // (the packing of an intermediate delay cube is part of the point branch's step: bench.py --workload c2 counts it)
-        if (dtype == RDR_F32) { if (swapped) RDR_PACK(float, float2, true); else RDR_PACK(float, float2, false); }
+        if (xfast) {
+            if (dtype == RDR_F32) { if (swapped) RDR_PACKX(float, float2, true); else RDR_PACKX(float, float2, false); }
+            else { if (swapped) RDR_PACKX(double, double2, true); else RDR_PACKX(double, double2, false); }
+        } else if (dtype == RDR_F32) { if (swapped) RDR_PACK(float, float2, true); else RDR_PACK(float, float2, false); }
         else { if (swapped) RDR_PACK(double, double2, true); else RDR_PACK(double, double2, false); }
     }
+#undef RDR_PACKX
 #undef RDR_PACK
     e = hipGetLastError();
     if (e != hipSuccess) { rdr_cube_destroy(q); return fail(c, RDR_ERR_HIP, hipGetErrorString(e)); }
-    // one-time: the cube must be complete before it is used from any other stream (and the staging slots reused)
+    if (loc == RDR_DEVICE) {
+        // DEVICE sources (intermediate delay cubes, cubes made from tensors): no host synchronisation.  The verdict travels into a page-locked
+        // word and is read when asked for (rdr_cube_has_nan -> cube_resolve_nan); other streams wait for the ready event (note_use).
+        int slot = c->nan_next; c->nan_next = (c->nan_next + 1) % rdr_ctx::NAN_SLOTS;
+        if (c->nan_owner[slot]) cube_resolve_nan(c->nan_owner[slot]);              // (a cube 256 creations ago that nobody asked: settle it now)
+        c->nan_words[slot] = 0;
+        e = hipMemcpyAsync(&c->nan_words[slot], nf, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+        if (e != hipSuccess) { rdr_cube_destroy(q); return fail(c, RDR_ERR_HIP, hipGetErrorString(e)); }
+        rc = cube_mark_ready(c, q);
+        if (rc) { rdr_cube_destroy(q); return rc; }
+        q->nan_slot = slot; c->nan_owner[slot] = q;
+        *out = q;
+        return RDR_OK;
+    }
+    // HOST sources: the staging slots are free again and the cube is complete when the call returns
     int has_nan = 0;
     e = hipMemcpyAsync(&has_nan, nf, sizeof(int), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -567,6 +639,8 @@ static int cone_params(rdr_ctx* c, const char* who, int kind, const double* p, i
 static void cube_release(rdr_cube* q) {
     rdr_ctx* c = q->ctx;
     if (c) (void)hipSetDevice(c->device);
+    if (c && q->nan_slot >= 0) { c->nan_owner[q->nan_slot] = nullptr; q->nan_slot = -1; }     // (nobody asked: the word is free again)
+    if (q->ready_ev) { (void)hipEventDestroy(q->ready_ev); q->ready_ev = nullptr; }
     bool pooled = false;
     const bool foreign = q->foreign.load(std::memory_order_relaxed);
     if (c && q->d_vals && q->alloc_bytes > 0 && !foreign && !c->ext_overflow && c->cube_pool.size() < 6 &&
@@ -625,14 +699,19 @@ int rdr_cube_view(rdr_ctx* c, const rdr_cube* src, int kind, const double* p, in
     v->d_vals = r->d_vals; v->d_axes = r->d_axes; v->ys = r->ys; v->xs = r->xs; v->zs = r->zs;
     for (int i = 0; i < 3; ++i) { v->uni[i] = r->uni[i]; v->inv_d[i] = r->inv_d[i]; }
     v->exact[0] = r->exact[0]; v->exact[1] = r->exact[1];
-    v->proj = L; v->has_nan = r->has_nan; v->alloc_bytes = 0; v->base = r;
+    v->proj = L; v->alloc_bytes = 0; v->base = r;
     note_use(c, r);
     { std::lock_guard<std::mutex> guard(g_view_mutex); ++r->views; }
     *out = v;
     return RDR_OK;
 }
 
-int rdr_cube_has_nan(const rdr_cube* q) { return q ? (q->has_nan ? 1 : 0) : -1; }
+int rdr_cube_has_nan(const rdr_cube* q) {
+    if (!q) return -1;
+    const rdr_cube* r = root(q);                  // (a view's verdict is its source's)
+    cube_resolve_nan(r);
+    return r->has_nan ? 1 : 0;
+}
 
 int rdr_cube_shape(const rdr_cube* q, int64_t* ny, int64_t* nx, int64_t* nz, int* dtype) {
     if (!q) return fail(nullptr, RDR_ERR_INVALID, "cube is NULL");
@@ -756,7 +835,8 @@ int rdr_cube_blend(rdr_ctx* c, const rdr_cube* a, double w1, const rdr_cube* b, 
     HIPCHECK(c, hipSetDevice(c->device));
     rdr_cube* q = new rdr_cube();
     q->ctx = c; q->ny = a->ny; q->nx = a->nx; q->nz = a->nz; q->dtype = a->dtype;
-    q->ys = a->ys; q->xs = a->xs; q->zs = a->zs; q->proj = a->proj; q->has_nan = a->has_nan || b->has_nan;
+    q->ys = a->ys; q->xs = a->xs; q->zs = a->zs; q->proj = a->proj;
+    q->has_nan = rdr_cube_has_nan(a) == 1 || rdr_cube_has_nan(b) == 1;
     int rc = cube_alloc(c, q);
     if (rc) { rdr_cube_destroy(q); return rc; }
     const int64_t nscal = 2 * a->ny * a->nx * a->nz;                  // (wet, hydro) pairs as one flat array
@@ -774,8 +854,9 @@ int rdr_cube_blend(rdr_ctx* c, const rdr_cube* a, double w1, const rdr_cube* b, 
                                (const double*)b->d_vals, w2, (double*)q->d_vals, nscal);
     }
     hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) { rdr_cube_destroy(q); return fail(c, RDR_ERR_HIP, hipGetErrorString(e)); }
+    rc = cube_mark_ready(c, q);                    // (no host synchronisation: device sources, device result - other streams wait for the event)
+    if (rc) { rdr_cube_destroy(q); return rc; }
     *out = q;
     return RDR_OK;
 }
@@ -1288,8 +1369,12 @@ int rdr_point_delays(rdr_ctx* c, const rdr_cube* q, const double* xpts, int64_t 
     rc = build_cube_impl(c, q, xpts, nx, ypts, ny, zpts, nz, nullptr, nullptr, RDR_HOST, planar); if (rc) return rc;
     int* const nf = c->d_flags + MAX_SLICES + 2;
     HIPCHECK(c, hipMemsetAsync(nf, 0, sizeof(int), c->stream));
-    hipLaunchKernelGGL((pack_cube_kernel<double, double2, false>), dim3(grid_for((int64_t)total, 256, c->num_cus * 8)), dim3(256), 0, c->stream,
-                       (const double*)planar[0], (const double*)planar[1], (double2*)dvals, ny, nx, nz, nx, (int64_t)1, ny * nx, fy, fx, fz, nf);
+    if (nx >= 8 && nz >= 8)        // planar (z, y, x) results: x is contiguous - the LDS-transposing packer (cube_kernels.h)
+        hipLaunchKernelGGL((pack_cube_xfast_kernel<double, double2, false>), dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(ny * ((nx + 31) / 32) * ((nz + 31) / 32), (int64_t)c->num_cus * 16))),
+                           dim3(256), 0, c->stream, (const double*)planar[0], (const double*)planar[1], (double2*)dvals, ny, nx, nz, nx, ny * nx, fy, fx, fz, nf);
+    else
+        hipLaunchKernelGGL((pack_cube_kernel<double, double2, false>), dim3(grid_for((int64_t)total, 256, c->num_cus * 8)), dim3(256), 0, c->stream,
+                           (const double*)planar[0], (const double*)planar[1], (double2*)dvals, ny, nx, nz, nx, (int64_t)1, ny * nx, fy, fx, fz, nf);
     HIPCHECK(c, hipGetLastError());
     // (into a page-locked word: a pageable destination would stall the host here until the cube is built - and the upload of the
     // points, which is to run UNDER that build, with it)

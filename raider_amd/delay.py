@@ -479,8 +479,8 @@ def _point_branch_on_device(weather_model_file, wm_proj, aoi, heights, los, crs,
             rays = los.ray_batch_slices(xpts, ypts, zpts)
             dcube, K, _nparts, flags = cube.raytrace_slices_to_cube(rays, zpts, zref, 1000.0)
             _raise_slice_failures(K, flags, zpts, zpts[-1])
-            has_nan = dcube.has_nan()
             wet, hyd = dcube.interp_project(*pts, **kw)
+            has_nan = dcube.has_nan()                                      # (asked AFTER the gather: the cube was made without a host synchronisation)
     except (MemoryError, RuntimeError) as exc:
         # out of DEVICE memory (RDR_ERR_OOM -> _lib.DeviceOutOfMemory, a MemoryError; torch's allocator: torch.OutOfMemoryError, a
         # RuntimeError): the one-call route holds the whole intermediate cube; the host sequence builds it in chunks that are halved

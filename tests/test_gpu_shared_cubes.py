@@ -270,3 +270,53 @@ def test_two_level_f64_cube_is_not_staged():
     cw, ch, _ = OC.build_cube_ray_slice(c, xp, yp, 0.0, los, zref, nparts=nparts)
     np.testing.assert_allclose(w, cw, rtol=0, atol=1e-9)
     np.testing.assert_allclose(h, ch, rtol=0, atol=1e-9)
+
+
+def test_cubes_from_device_sources_are_created_without_a_host_wait_and_still_ordered():
+    """Round 5: rdr_cube_create from DEVICE arrays (tensors, intermediate delay cubes) and rdr_cube_blend no longer end with a host
+    synchronisation - a ready event orders other streams after them, the packing kernel's NaN verdict is read lazily.  (a) a cube made on one
+    torch stream and queried at once from ANOTHER stream gives the values of a synchronous build; (b) the lazy verdict is right for NaN and
+    NaN-free cubes, also after more creations than the context has verdict words (256: unasked ones are settled on recycling); (c) a blend
+    of two fresh cubes, read back immediately, is the host arithmetic bit for bit."""
+    import torch
+    import raider_amd as R
+    dev = torch.device('cuda:0')
+    c = O.synthetic_cube(60, 64, 40, seed=11)
+    rng = np.random.default_rng(2)
+    n = 40000
+    pts = np.stack([rng.uniform(c['ys'][0], c['ys'][-1], n), rng.uniform(c['xs'][0], c['xs'][-1], n), rng.uniform(c['zs'][0], c['zs'][-1], n)], -1)
+    ref = R.Cube(c['ys'], c['xs'], c['zs'], c['wet'], c['hydro'], order='zyx')              # host sources: the synchronous route
+    want = ref.interp(pts)
+    pt = torch.from_numpy(pts).to(dev)
+    s1, s2 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize()
+    for _ in range(20):
+        with torch.cuda.stream(s1):
+            w = torch.from_numpy(c['wet']).to(dev, non_blocking=True); h = torch.from_numpy(c['hydro']).to(dev, non_blocking=True)
+            cube = R.Cube(c['ys'], c['xs'], c['zs'], w, h, order='zyx')                      # packed on s1, nobody waits
+        with torch.cuda.stream(s2):
+            gw, gh = cube.interp(pt)                                                         # ... queried on s2 at once
+        s2.synchronize()
+        assert np.array_equal(gw.cpu().numpy(), want[0], equal_nan=True) and np.array_equal(gh.cpu().numpy(), want[1], equal_nan=True)
+        assert cube.has_nan() is False
+        del cube, w, h
+    # (b) lazy verdicts, more cubes alive than verdict words
+    small = O.synthetic_cube(12, 13, 9, seed=1)
+    wt = torch.from_numpy(small['wet']).to(dev); ht = torch.from_numpy(small['hydro']).to(dev)
+    wn = wt.clone(); wn[3, 4, 5] = float('nan')
+    cubes = []
+    for k in range(300):
+        cubes.append(R.Cube(small['ys'], small['xs'], small['zs'], wn if k % 3 == 0 else wt, ht, order='zyx'))
+    got = [q.has_nan() for q in cubes]
+    assert got == [k % 3 == 0 for k in range(300)]
+    assert cubes[0].view(None).has_nan() is True and cubes[1].view(None).has_nan() is False   # a view's verdict is its source's
+    del cubes
+    # (c) blend of two fresh device cubes, read back at once
+    a = R.Cube(c['ys'], c['xs'], c['zs'], torch.from_numpy(c['wet']).to(dev), torch.from_numpy(c['hydro']).to(dev), order='zyx')
+    c2 = O.synthetic_cube(60, 64, 40, seed=12)
+    b = R.Cube(c['ys'], c['xs'], c['zs'], torch.from_numpy(c2['wet']).to(dev), torch.from_numpy(c2['hydro']).to(dev), order='zyx')
+    m = a.blend(0.25, b, 0.75)
+    mw, mh = m.read()
+    ew = (np.float32(0.25) * c['wet'] + np.float32(0.75) * c2['wet']).transpose(1, 2, 0)
+    assert np.array_equal(mw, O.blend_cubes(0.25, c['wet'], 0.75, c2['wet']).transpose(1, 2, 0)) or np.array_equal(mw, ew)
+    assert m.has_nan() is False

@@ -441,3 +441,22 @@ def test_conic_inverses_against_snyders_worked_examples():
         x, y = O.stere_forward(la, lo, **kw)
         la2, lo2 = O.stere_inverse(x, y, **kw)
         assert np.abs(la2 - la).max() < 1e-12 and np.abs((lo2 - lo + 180) % 360 - 180).max() < 1e-11
+
+
+def test_every_reference_made_fixture_says_what_it_was_made_on(golden):
+    """Round 5: each fixture written by oracle/refharness/gen_golden.py carries `_meta` - what the reference's third-party
+    geometry ran on when it was made (`geodesy`: the builder's pyproj stand-in today, `pyproj <ver> / PROJ <ver>` the day the image has it;
+    `look_vectors`: isce3 or absent).  g12 is a cut of a data file (no geometry), g14 exists only when isce3 made it."""
+    import json
+    from pathlib import Path
+    gold = Path(__file__).resolve().parent / 'golden'
+    made = sorted(p.stem for p in gold.glob('g*.npz') if p.stem != 'g12_gmao_time_interp')
+    assert len(made) >= 12
+    for name in made:
+        g = golden(name)
+        assert '_meta' in g.files, name
+        meta = json.loads(str(g['_meta']))
+        assert set(meta) >= {'geodesy', 'look_vectors', 'numpy', 'generator'} and meta['generator'].endswith('gen_golden.py'), (name, meta)
+        assert meta['geodesy'].startswith(('builder stub', 'pyproj ')) and meta['look_vectors'].startswith(('absent', 'isce3 ')), (name, meta)
+        if name.startswith('g14'):
+            assert meta['look_vectors'].startswith('isce3 ')
