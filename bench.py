@@ -624,16 +624,16 @@ def c2_roofline(m):
     prof, src = load_kernel_counters('c2')
     k = (prof or {}).get('kernels', {})
     traffic = sum(v.get('hbm_read_bytes', 0) + v.get('hbm_write_bytes', 0) for v in k.values() if v.get('per_step')) if k else None
-    return {'bound': 'hbm', 'kernel': 'interp_points_kernel<double2> + build_cube_setup_kernel / build_cube_kernel<double2> (one step of one rank)',
+    return {'bound': 'hbm', 'kernel': 'build_cube_setup_kernel + build_cube_kernel<double2> + pack_cube_xfast_kernel<double> + interp_points_kernel<double2> (one step of one rank)',
             'achieved': (alg_g + alg_b) / (kern_ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': (alg_g + alg_b) / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             'traffic': traffic, 'traffic_unit': 'HBM bytes per step, all kernels of the step (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE, separate passes)',
             'frac_hbm_measured': (traffic / (m['step_s']) / 1e9 / HBM_PEAK_GBS) if traffic else None,
             'algorithmic_bytes_per_step': alg_g + alg_b, 'gather_ms_per_step': m['gather_ms'], 'build_ms_per_step': m['build_ms'],
             'gather_algorithmic_GBps': alg_g / (m['gather_ms'] * 1e-3) / 1e9, 'build_algorithmic_GBps': alg_b / (m['build_ms'] * 1e-3) / 1e9,
             'kernels_ms_per_step': kern_ms, 'launch_and_sync_ms_per_step': m['step_s'] * 1e3 - kern_ms,
-            'note': 'algorithmic bytes over the HIP-event time of the step\'s timed kernels (setup + gather of the intermediate cube, the point gather); the 38 MB '
-                    'intermediate cube and the source cube\'s AOI slab are L2 / Infinity-Cache resident, so the algorithmic rate may exceed the HBM peak - `traffic` is what HBM saw; '
-                    'the step itself is bound by launches and the one synchronisation of the cube\'s NaN verdict (launch_and_sync_ms_per_step), not by bytes',
+            'note': 'algorithmic bytes over the HIP-event time of the step\'s four kernels (setup + gather of the intermediate cube, its packing, the point gather); the 39 MB '
+                    'intermediate cube and the source cube\'s AOI slab are L2 / Infinity-Cache resident, so the algorithmic rate may exceed the HBM peak - `traffic` is what HBM saw. '
+                    'Nothing in the step waits on the host (the intermediate cube is made asynchronously, its NaN verdict read after the loop): launch_and_sync_ms_per_step is launch gaps',
             'counters_source': src if prof is not None else None, 'counters_note': None if prof is not None else src,
             'source_hash': kernel_source_hash()}
 

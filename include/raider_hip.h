@@ -173,8 +173,15 @@ int rdr_cube_create(rdr_ctx* ctx, const double* ys, int64_t ny, const double* xs
                     const double* zs, int64_t nz, const void* wet, const void* hydro, int dtype,
                     int64_t sy, int64_t sx, int64_t sz, int loc, rdr_cube** out);
 void rdr_cube_destroy(rdr_cube* cube);
-/* 1 when a NaN was seen among the two source fields while the cube was packed (what delayFcns.py:50-52 scans for on the host:
- * "Weather model contains NaNs!"), 0 otherwise (also for blended cubes: their sources were scanned), -1 for NULL */
+/* Synchronisation of cube-making entries (round 5).  loc == RDR_HOST: the call returns when the cube is complete (the host arrays may be
+ * reused at once).  loc == RDR_DEVICE - cubes made from device arrays, the intermediate delay cubes of rdr_build_cube_to_cube /
+ * rdr_raytrace_slices_to_cube - and rdr_cube_blend: NO host synchronisation; the cube is complete in stream order on the context's stream,
+ * every entry that reads it from another stream (or another context) first makes that stream wait for the cube's ready event, and the
+ * source device arrays must stay valid in stream order, as for any asynchronous kernel.  rdr_set_stream orders the new stream after
+ * everything enqueued on the previous one (the context's scratch and flag words are shared by them).
+ * rdr_cube_has_nan: 1 when a NaN was seen among the two source fields while the cube was packed (what delayFcns.py:50-52 scans for on the
+ * host: "Weather model contains NaNs!"), 0 otherwise (blended cubes: either source's; a view: its source's), -1 for NULL.  For an
+ * asynchronously made cube this call is where the host waits (for that cube's ready event, once). */
 int rdr_cube_has_nan(const rdr_cube* cube);
 int rdr_cube_shape(const rdr_cube* cube, int64_t* ny, int64_t* nx, int64_t* nz, int* dtype);
 /* ascending copies of the axes as the interpolator's `.grid` exposes them (delay.py:239) */
