@@ -6,7 +6,6 @@ python tools/world8_digest.py r05 | head -4
 python tools/e2e_digest.py gpurun_out/e2e5 r05 > /dev/null
 for t in c3 c3b c4 c5; do cp gpurun_out/parity/$t.json profiles/r05_full_scene_parity_$t.json; done
 cp gpurun_out/parity/points.json profiles/r05_full_batch_parity_points.json
-cp gpurun_out/e2e5/bench.json profiles/r05_bench_measure_run.json
 python - <<'PY'
 import json
 from pathlib import Path
