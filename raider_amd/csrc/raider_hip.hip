@@ -124,6 +124,7 @@ static inline void note_use(const rdr_ctx* c, const rdr_cube* q) {
 }
 // the pending NaN verdict of an asynchronously created cube (waits for the cube's ready event: the only host wait of such a cube)
 static void cube_resolve_nan(const rdr_cube* r) {
+    std::lock_guard<std::mutex> guard(g_view_mutex);         // (a cube may be asked from two contexts' threads at once)
     if (r->nan_slot < 0) return;
     rdr_ctx* c = r->ctx;
     if (r->ready_ev) (void)hipEventSynchronize(r->ready_ev);

@@ -156,3 +156,21 @@ def test_loaded_library_was_built_from_this_tree():
     for which in (0, 1):
         cube_attrs = q.ray_kernel_attributes(which)
         assert 64 < cube_attrs['vgpr'] <= 128 and cube_attrs['scratch'] == 0 and cube_attrs['lds_dynamic'] > 1000, cube_attrs
+
+
+def test_bench_c2_through_one_rank_rccl_group(tmp_path):
+    """BASELINE configs[1] (`bench.py --workload c2`) through the nccl backend on the one GPU of this box: the f64 totals cube in one packed
+    RCCL broadcast, the rank's point block through the intermediate delay cube - bit for bit the plain run."""
+    def run(tag, *args):
+        out = subprocess.run([sys.executable, str(ROOT / 'bench.py'), '--workload', 'c2', '--points', '400', '--steps', '2', '--warmup', '1', '--cpu-sample', '0', '--no-e2e',
+                              '--dump', str(tmp_path / tag)] + list(args), capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-4000:])
+        lines = out.stdout.splitlines()
+        assert len(lines) == 1 and lines[0].startswith('{'), out.stdout[-2000:]
+        return json.loads(lines[0])
+    plain = run('plain')
+    rccl = run('rccl', '--force-dist', '--backend', 'nccl')
+    assert plain['config']['backend'] is None and rccl['config']['backend'] == 'nccl' and rccl['config']['world_size_seen_by_backend'] == 1
+    assert 'one packed broadcast' in rccl['config']['parallelism'] and rccl['config']['shards'] == [[0, 160000]]
+    a, b = np.load(tmp_path / 'plain.rank0.npz'), np.load(tmp_path / 'rccl.rank0.npz')
+    assert np.array_equal(a['wet'], b['wet']) and np.array_equal(a['hydro'], b['hydro']) and np.isfinite(a['hydro']).all()

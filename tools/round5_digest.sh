@@ -14,8 +14,8 @@ h = _lib.source_hash()
 fp = [l for l in Path('gpurun_out/fuzz_parity.txt').read_text().splitlines() if l.startswith('{')][-1]
 fn = [l for l in Path('gpurun_out/fuzz_natives.txt').read_text().splitlines() if l.startswith('{')][-1]
 Path('profiles/r05_fuzz.txt').write_text(f"Randomised sweeps of the round-5 binary (source hash {h}) on the MI355X, inside tools/round5_measure.sh:\n\n"
-    f"tools/fuzz_parity.py 800 5 (ray tracer vs NumPy oracle; DEM trials vs the C oracle)\n{fp}\n\n"
-    f"tools/fuzz_natives.py 800 5 (zenith cube, station queries, interpolate 1-5 D, interpolate_along_axis, makePoints - vs the oracle AND the reference's own compiled extensions)\n{fn}\n")
+    f"tools/fuzz_parity.py 2000 5 (ray tracer vs NumPy oracle; DEM trials vs the C oracle)\n{fp}\n\n"
+    f"tools/fuzz_natives.py 1500 5 (zenith cube, station queries, interpolate 1-5 D, interpolate_along_axis, makePoints - vs the oracle AND the reference's own compiled extensions)\n{fn}\n")
 for t in ('c3', 'c3b', 'c4', 'c5'):
     d = json.load(open(f'profiles/r05_full_scene_parity_{t}.json')); print(t, d.get('source_hash'), d.get('max_abs_hydro_m'), d.get('nparts_equal'), d.get('nan_mask_mismatches'))
 c = json.load(open('profiles/r05_v31_counters.json')); print('counters', c['source_hash'], 'tree', h)

@@ -15,8 +15,8 @@ python tools/full_scene_parity.py 4000 4000 gpurun_out/parity/c3b.json c3b > gpu
 python tools/full_scene_parity.py 4000 4000 gpurun_out/parity/c5.json c5 > gpurun_out/parity/c5.log 2>&1
 python tools/full_scene_parity.py 10000 10000 gpurun_out/parity/c4.json > gpurun_out/parity/c4.log 2>&1
 python tools/full_batch_parity_points.py gpurun_out/parity/points.json > gpurun_out/parity/points.log 2>&1
-python tools/fuzz_parity.py 800 5 > gpurun_out/fuzz_parity.txt 2>&1
-python tools/fuzz_natives.py 800 5 > gpurun_out/fuzz_natives.txt 2>&1
+python tools/fuzz_parity.py 2000 5 > gpurun_out/fuzz_parity.txt 2>&1
+python tools/fuzz_natives.py 1500 5 > gpurun_out/fuzz_natives.txt 2>&1
 mkdir -p gpurun_out/e2e5
 python tools/e2e_points.py c2 > gpurun_out/e2e5/e2e_c2.json 2> gpurun_out/e2e5/e2e_c2.err
 python tools/e2e_points.py c5 > gpurun_out/e2e5/e2e_c5.json 2> gpurun_out/e2e5/e2e_c5.err
