@@ -12,6 +12,20 @@ from collections import defaultdict
 from pathlib import Path
 
 REPO = Path(__file__).resolve().parent.parent
+
+
+def newest(pattern):
+    """gpurun MERGES a call's files into the local gpurun_out/: a pass directory may hold the CSVs of earlier runs beside the last one's
+    (rocprofv3 names them by pid).  Only the newest file per directory is this run's."""
+    import glob as _g
+    import os as _o
+    best = {}
+    for f in _g.glob(pattern, recursive=True):
+        d = _o.path.dirname(f)
+        if d not in best or _o.path.getmtime(f) > _o.path.getmtime(best[d]):
+            best[d] = f
+    return list(best.values())
+
 RND = sys.argv[1] if len(sys.argv) > 1 else 'r05'
 # kernels one step of the workload launches once each (bench.py c2_measure / run_c5)
 STEP = {'c2': ('build_cube_setup_kernel', 'build_cube_kernel', 'pack_cube_kernel', 'pack_cube_xfast_kernel', 'interp_points_kernel'),
@@ -28,7 +42,7 @@ def short(name):
 
 def pmc(d, counter):
     per = defaultdict(list)
-    for f in glob.glob(str(d) + '/**/*counter_collection.csv', recursive=True):
+    for f in newest(str(d) + '/**/*counter_collection.csv'):
         for r in csv.DictReader(open(f)):
             k = short(r['Kernel_Name'])
             if k and r['Counter_Name'] == counter:

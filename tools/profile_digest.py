@@ -19,6 +19,20 @@ from collections import defaultdict
 from pathlib import Path
 
 REPO = Path(__file__).resolve().parent.parent
+
+
+def newest(pattern):
+    """gpurun MERGES a call's files into the local gpurun_out/: a pass directory may hold the CSVs of earlier runs beside the last one's
+    (rocprofv3 names them by pid).  Only the newest file per directory is this run's."""
+    import glob as _g
+    import os as _o
+    best = {}
+    for f in _g.glob(pattern, recursive=True):
+        d = _o.path.dirname(f)
+        if d not in best or _o.path.getmtime(f) > _o.path.getmtime(best[d]):
+            best[d] = f
+    return list(best.values())
+
 WAVES_PER_SIMD = 4          # amdgpu_waves_per_eu of the two light ray kernels
 
 
@@ -33,7 +47,7 @@ def short(name):
 def sq(dirs, nwaves):
     acc = defaultdict(lambda: defaultdict(float)); launches = defaultdict(lambda: defaultdict(set)); meta = {}
     for d in dirs:
-        for f in glob.glob(str(d) + '/**/*counter_collection.csv', recursive=True):
+        for f in newest(str(d) + '/**/*counter_collection.csv'):
             for r in csv.DictReader(open(f)):
                 k = short(r['Kernel_Name'])
                 if not k:
@@ -71,7 +85,7 @@ def instr_mix(d):
 
 def pmc(dirpath, counter):
     per = defaultdict(list); cal = None
-    for f in glob.glob(str(dirpath) + '/**/*counter_collection.csv', recursive=True):
+    for f in newest(str(dirpath) + '/**/*counter_collection.csv'):
         for r in csv.DictReader(open(f)):
             if r['Counter_Name'] != counter:
                 continue

@@ -9,6 +9,20 @@ import sys
 from pathlib import Path
 
 REPO = Path(__file__).resolve().parent.parent
+
+
+def newest(pattern):
+    """gpurun MERGES a call's files into the local gpurun_out/: a pass directory may hold the CSVs of earlier runs beside the last one's
+    (rocprofv3 names them by pid).  Only the newest file per directory is this run's."""
+    import glob as _g
+    import os as _o
+    best = {}
+    for f in _g.glob(pattern, recursive=True):
+        d = _o.path.dirname(f)
+        if d not in best or _o.path.getmtime(f) > _o.path.getmtime(best[d]):
+            best[d] = f
+    return list(best.values())
+
 TAG = sys.argv[1] if len(sys.argv) > 1 else 'r04'        # round prefix of the files written under profiles/
 src = REPO / 'gpurun_out' / 'secondary'
 line = [ln for ln in (src / 'bench.json').read_text().splitlines() if ln.startswith('{')][-1]
@@ -32,7 +46,7 @@ for k, d in res.items():
 # measured HBM bytes per launch: FETCH_SIZE (KiB; gfx950: x2, checked on the calibration copy of tools/profile_round.sh) and WRITE_SIZE (x1)
 def pmc(sub, counter):
     out = {}
-    for f in glob.glob(str(src / sub) + '/**/*counter_collection.csv', recursive=True):
+    for f in newest(str(src / sub) + '/**/*counter_collection.csv'):
         for r in csv.DictReader(open(f)):
             if r['Counter_Name'] == counter:
                 out.setdefault(r['Kernel_Name'], []).append(float(r['Counter_Value']))
@@ -58,7 +72,7 @@ VALU_PEAK = 256 * 4 * 2.4e9 / 4
 
 def sq(sub):
     out = {}
-    for f in glob.glob(str(src / sub) + '/**/*counter_collection.csv', recursive=True):
+    for f in newest(str(src / sub) + '/**/*counter_collection.csv'):
         for r in csv.DictReader(open(f)):
             out.setdefault((r['Kernel_Name'], r['Counter_Name']), []).append(float(r['Counter_Value']))
     return out
