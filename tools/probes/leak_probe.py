@@ -28,7 +28,17 @@ def cycle():
     d = tot.build_delay_cube(xp, yp, np.array([0.0, 100.0, 1000.0, 4000.0])); dw, dh = d.interp_project(pts)
     rc, K2, n2, f2 = cube.raytrace_slices_to_cube(R.Rays.grid(xp, yp, inc=35.0, hd=-167.9), np.array([0.0, 500.0, 2000.0]), zref)
     bw, bh = cube.interp_blend(0.25, cube, 0.75, pts)
-    del cube, tot, m, d, rc, ctx
+    # round 5: views (source destroyed first), device-source cubes made asynchronously with pending verdicts never asked for, trim
+    v = cube.view(dict(proj='lcc', lat_1=38.5, lat_2=38.5, lat_0=38.5, lon_0=262.5, x_0=0.0, y_0=0.0, a=6371229.0, es=0.0)); v2 = v.view(None)
+    dev = torch.device('cuda:0')
+    wt, ht = torch.from_numpy(c['wet']).to(dev), torch.from_numpy(c['hydro']).to(dev)
+    asy = [R.Cube(c['ys'], c['xs'], c['zs'], wt, ht, order='zyx', ctx=ctx) for _ in range(3)]
+    asy[0].has_nan()
+    va, vb = v2.interp(pts)
+    del cube
+    vc = v.interp(pts)
+    ctx.trim(1 << 20)
+    del tot, m, d, rc, v, v2, asy, ctx
 for i in range(3): cycle()
 gc.collect(); torch.cuda.synchronize()
 free0 = torch.cuda.mem_get_info()[0]
