@@ -16,7 +16,7 @@
       ERA-5_2022_08_29_T17_00_01_69N_73N_159W_152W.nc)
       RAW ERA-5 model-level files (NetCDF-3, packed int16 z / t / q / lnsp on 137 levels) whose processed counterparts sit
       beside them: the whole producer chain raw file -> processed cube is replayed against what the real RAiDER wrote.
-  raider_amd/data/ecmwf_l137.npz
+  raider_amd/data/ecmwf_l137.npz, raider_amd/data/hrrr_l50.npz
       ECMWF's published L137 hybrid-level coefficients a, b (138 each) and the 145 output heights every ECMWF model is
       resampled to, as DATA (read off the reference's models/model_levels.py tables A_137_HRES, B_137_HRES,
       LEVELS_137_HEIGHTS by importing it).
@@ -72,6 +72,8 @@ def main():
     (REPO / 'raider_amd' / 'data').mkdir(exist_ok=True)
     np.savez(REPO / 'raider_amd' / 'data' / 'ecmwf_l137.npz', a=np.array(ml.A_137_HRES, dtype=np.float64), b=np.array(ml.B_137_HRES, dtype=np.float64),
              level_heights=np.array(ml.LEVELS_137_HEIGHTS, dtype=np.float64))
+    # HRRR's 50 native levels + the 7 padding levels below the surface (model_levels.py:517-533): the z axis of a processed HRRR model
+    np.savez(REPO / 'raider_amd' / 'data' / 'hrrr_l50.npz', level_heights=np.array(ml.LEVELS_50_HEIGHTS, dtype=np.float64))
     print('g12_gmao_time_interp.npz', (OUT / 'g12_gmao_time_interp.npz').stat().st_size // 1024, 'KiB;', src.name, src.stat().st_size // 1024, 'KiB')
 
 

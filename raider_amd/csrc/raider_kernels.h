@@ -217,26 +217,20 @@ struct PendingSample {
     double ty, tx, tz;
 };
 
-// MODE 0: generic kernels (three-entry z window).  MODE 1 (light march loop, a level's TOP sample or the ray's first sample):
-// index-space x / y on exact axes, two-entry z window.  MODE 2 (light march loop, a sample strictly INSIDE model interval kz):
-// its z cell is kz itself, one table entry, no select.  Any sample whose weight leaves [0,1] takes the exact search.
-template <typename T2, int MODE = 0, bool NOCHECK = false>
-__device__ __forceinline__ void sample_issue(const CubeView<T2>& c, const AxisTabs& m, double y, double x, double z, int kz,
-                                             PendingSample<T2>& s) {
-    const double2* ez = m.ez;
-    int iy, ix, iz;
-    cell_xy<MODE != 0, NOCHECK>(m.ey, c.ny, y, c.y_lo, c.y_hi, c.inv_dy, c.exact_y, c.uni_y, iy, s.ty);
-    cell_xy<MODE != 0, NOCHECK>(m.ex, c.nx, x, c.x_lo, c.x_hi, c.inv_dx, c.exact_x, c.uni_x, ix, s.tx);
-    if (MODE == 2) {
-        const double2 e0 = ez[kz];                                              // kz <= nz-2: slice-uniform address
-        iz = kz;
-        s.tz = (z - e0.x) * e0.y;
-        if (!(s.tz >= 0.0) || !(s.tz <= 1.0)) cell_exact(ez, c.nz, z, iz, s.tz);   // rare
-    } else if (MODE == 1) window2_cell(ez, c.nz, z, kz, c.nz >= 4, iz, s.tz);
-    else window_cell(ez, c.nz, z, kz, c.nz >= 4, iz, s.tz);
+// The horizontal half of a sample: cell search on x / y (cell_xy), the element offset of corner (iy, ix, iz) and the four 16-byte (32-byte
+// for f64 cubes) corner-pair loads.  iz may be slice-uniform (a scalar) or per lane.
+template <typename T2, bool IDX, bool NOCHECK>
+__device__ __forceinline__ void gather_corners(const CubeView<T2>& c, const AxisTabs& m, double y, double x, int iz, PendingSample<T2>& s) {
+    int iy, ix;
+    cell_xy<IDX, NOCHECK>(m.ey, c.ny, y, c.y_lo, c.y_hi, c.inv_dy, c.exact_y, c.uni_y, iy, s.ty);
+    cell_xy<IDX, NOCHECK>(m.ex, c.nx, x, c.x_lo, c.x_hi, c.inv_dx, c.exact_x, c.uni_x, ix, s.tx);
     const T2 *p00, *p01, *p10, *p11;
     if (c.small) {              // one 32-bit element offset against four uniform row bases
-        const unsigned off = (__umul24(__umul24((unsigned)iy, (unsigned)c.nx) + (unsigned)ix, (unsigned)c.nz) + (unsigned)iz) * (unsigned)sizeof(T2);
+        // (iy nx + ix) as ONE full-rate v_mad_u32_u24: left to itself the compiler picks v_mad_u64_u32, a quarter-rate instruction
+        // that holds the vector ALU for four issue slots
+        unsigned col;
+        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(col) : "v"((unsigned)iy), "s"((unsigned)c.nx), "v"((unsigned)ix));
+        const unsigned off = (__umul24(col, (unsigned)c.nz) + (unsigned)iz) * (unsigned)sizeof(T2);
         const char* b = reinterpret_cast<const char*>(c.v);
         const size_t rowx = (size_t)c.nz * sizeof(T2), rowy = (size_t)c.nx * rowx;
         p00 = reinterpret_cast<const T2*>(b + off);
@@ -253,6 +247,24 @@ __device__ __forceinline__ void sample_issue(const CubeView<T2>& c, const AxisTa
     s.v[2] = p01[0]; s.v[3] = p01[1];
     s.v[4] = p10[0]; s.v[5] = p10[1];
     s.v[6] = p11[0]; s.v[7] = p11[1];
+}
+
+// MODE 0: generic kernels (three-entry z window).  MODE 1 (light march loop, a level's TOP sample or the ray's first sample):
+// index-space x / y on exact axes, two-entry z window.  MODE 2 (light march loop, a sample strictly INSIDE model interval kz):
+// its z cell is kz itself, one table entry, no select.  Any sample whose weight leaves [0,1] takes the exact search.
+template <typename T2, int MODE = 0, bool NOCHECK = false>
+__device__ __forceinline__ void sample_issue(const CubeView<T2>& c, const AxisTabs& m, double y, double x, double z, int kz,
+                                             PendingSample<T2>& s) {
+    const double2* ez = m.ez;
+    int iz;
+    if (MODE == 2) {
+        const double2 e0 = ez[kz];                                              // kz <= nz-2: slice-uniform address
+        iz = kz;
+        s.tz = (z - e0.x) * e0.y;
+        if (!(s.tz >= 0.0) || !(s.tz <= 1.0)) cell_exact(ez, c.nz, z, iz, s.tz);   // rare
+    } else if (MODE == 1) window2_cell(ez, c.nz, z, kz, c.nz >= 4, iz, s.tz);
+    else window_cell(ez, c.nz, z, kz, c.nz >= 4, iz, s.tz);
+    gather_corners<T2, MODE != 0, NOCHECK>(c, m, y, x, iz, s);
 }
 
 // Generic kernels: scipy's own summation order, weight = ((1*wy)*wx)*wz over the corners in lexicographic order (_rgi.py:490-498).
@@ -491,11 +503,23 @@ __device__ __forceinline__ int first_level(const double2* ez, int nz, const doub
 // Shared LDS layout of the two ray kernels.  Axis tables are (g[i], 1/(g[i+1]-g[i])) pairs; an x / y axis that is uniform to
 // round-off (CubeView::exact_*) needs no table at all (cell_xy works from g0 and the spacing), so the usual lat/lon or LCC grid
 // costs 16 B per z level only - a CONUS-sized HRRR grid (1059 x 1799 nodes) would otherwise take 69 KB per workgroup.
+// Pass 2's per-level record (slice loop of the light marcher): everything a level needs that is the same for every ray of the slice,
+// packed so that ONE LDS address register serves all the reads of a level (as separate arrays every read cost a v_mov of its own).
+struct __attribute__((aligned(16))) LevelRec {
+    double xv, hs;          // abscissa of the level's top in the crossing polynomial; 0.5e-6/(nParts-1)
+    double step, zmid;      // 1/(nParts-1); node g[zb+1] the level's top sits on, zb = window2_base(nz, kz)
+    double r0, r1;          // 1/(g[zb+1]-g[zb]), 1/(g[zb+2]-g[zb+1]): the two entries of the top sample's z window
+    double gk, rk;          // g[kz], 1/(g[kz+1]-g[kz]): the model interval of the level's interior samples
+    int npkz, pad[3];       // nParts | kz << 17
+};
+static_assert(sizeof(LevelRec) == 80, "LevelRec is read with fixed LDS offsets");
+
 struct RaySmem {
     AxisTabs ax;            // axis tables (ey / ex are null for exact axes)
     double2* tab2;          // backing store of the tables
     double* lo; double* hi; // level table
     unsigned long long* mxcol; // [nz][MXCOLS] per-level running maxima of the workgroup, one column per lane%MXCOLS (pass 1)
+    LevelRec* lev;          // [nz] pass 2 only: the same bytes as mxcol (80 <= 8 * MXCOLS per level)
     double* step;           // [nz] 1/(nParts-1) (pass 2)
     double* hs;             // [nz] 0.5e-6/(nParts-1): half the trapezoid weight per unit of ray length (pass 2)
     double* trig;           // [64] (sin, cos) of the tile's 16 row latitudes, then of its 16 column longitudes (pass 1, GRID rays);
@@ -505,6 +529,7 @@ struct RaySmem {
     int* kz; int* np; int* K;
 };
 constexpr int MXCOLS = 16;
+static_assert(sizeof(LevelRec) <= 8 * MXCOLS, "LevelRec aliases a level's mxcol columns");
 __host__ __device__ inline int64_t table_nodes(int64_t ny, int64_t nx, int64_t nz, int exact_y, int exact_x) {
     return (exact_y ? 0 : ny) + (exact_x ? 0 : nx) + nz;
 }
@@ -518,6 +543,7 @@ __device__ __forceinline__ RaySmem carve_smem(unsigned char* raw, int ny, int nx
     m.lo = reinterpret_cast<double*>(m.tab2 + nyt + nxt + nz);
     m.hi = m.lo + nz;
     m.mxcol = reinterpret_cast<unsigned long long*>(m.hi + nz);
+    m.lev = reinterpret_cast<LevelRec*>(m.mxcol);
     m.step = reinterpret_cast<double*>(m.mxcol + (size_t)nz * MXCOLS);
     m.hs = m.step + nz;
     m.trig = m.hs + nz;
@@ -1013,6 +1039,19 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
                 m.np[k] = np;
                 m.step[k] = 1.0 / ((double)np - 1.0);                    // np.linspace(0,1,np) (delay.py:287)
                 m.hs[k] = 0.5e-6 * m.step[k];                            // delay.py:314-315: end points get half of L*1e-6/(np-1)
+                if constexpr (!SLOW && !PR) {                            // the slice loop's packed record of the level
+                    const int kzk = m.kz[k], last = c.nz - 1;
+                    const int zb = max(window2_base(c.nz, kzk), 0);      // (nz = 2: the window is never trusted, only in-range reads matter)
+                    LevelRec r;
+                    r.xv = m.xv[k]; r.hs = m.hs[k]; r.step = m.step[k];
+                    r.zmid = m.ax.ez[min(zb + 1, last)].x; r.r0 = m.ax.ez[zb].y; r.r1 = m.ax.ez[min(zb + 1, last)].y;
+                    r.gk = m.ax.ez[kzk].x; r.rk = m.ax.ez[kzk].y;
+                    r.npkz = np | (kzk << 17); r.pad[0] = r.pad[1] = r.pad[2] = 0;
+                    m.lev[k] = r;
+                    // one record past the last level (K <= nz-1): the "next level" of the last one repeats its top abscissa with weight 0,
+                    // so the loop computes du1 = X(v) - X(v) = 0 and adds 0 * 0 to the top weight instead of branching on `more`
+                    if (k == K - 1) { r.hs = 0.0; r.npkz = 2 | (kzk << 17); m.lev[K] = r; }
+                }
             }
             __syncthreads();
             const int flags_in = P.flags[sl];
@@ -1069,6 +1108,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
             for (int n = 0; n < PX; ++n) xc[n] = w[(int64_t)(WS_XPOLY + n) * ns];
             const double scale = scale_rec;
             // MODE 1: a level's top sample / the ray's first sample; MODE 2: a sample strictly inside its model interval
+            // lanes whose samples count: a lane of tile padding or a generic ray (its record is not a polynomial) computes garbage that is
+            // never stored, and must not decide a wave-uniform branch
+            const unsigned long long live = __builtin_amdgcn_ballot_w64(active && mine);
             auto run = [&](auto nochk) {
             constexpr bool NC = decltype(nochk)::value;
             auto issue_top = [&](double us, int zbase, bool floor_it, bool ceil_it, PendingSample<T2>& s) {
@@ -1141,9 +1183,14 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
                     }
                 }
             } else {
-            int np = __builtin_amdgcn_readfirstlane(m.np[0]);                        // >= 2 (fill above)
-            int kz = __builtin_amdgcn_readfirstlane(m.kz[0]);
-            double step = m.step[0], hs = m.hs[0];
+            // Everything slice-uniform about a level comes from its packed LDS record through ONE address register (la + fixed offsets).
+            typedef __attribute__((address_space(3))) const LevelRec LdsRec;
+            int la = (int)(size_t)m.lev;                                             // LDS byte address of record 0 (a 32-bit LDS pointer)
+            asm volatile("" : "+v"(la));                                             // (a VGPR once, not a v_mov per read)
+            const LdsRec* rec = (const LdsRec*)(size_t)(unsigned)la;
+            int npkz = __builtin_amdgcn_readfirstlane(rec->npkz);
+            int np = npkz & 0x1ffff, kz = npkz >> 17;                                // np >= 2 (fill above)
+            double hs = rec->hs;
             double u_k = w[(int64_t)WS_U0 * ns];
             double u_last = w[(int64_t)WS_U1 * ns];
             double du = u_last - u_k;
@@ -1151,7 +1198,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
             // two-entry z window must start one interval lower
             if (K > 0) {
                 PendingSample<T2> s;
-                issue_top(fma(0.0 * step, du, u_k), window2_base(c.nz, kz - ((m.lo[0] <= m.ax.ez[kz].x) ? 1 : 0)), clamp_lo, false, s);
+                issue_top(fma(0.0 * rec->step, du, u_k), window2_base(c.nz, kz - ((m.lo[0] <= m.ax.ez[kz].x) ? 1 : 0)), clamp_lo, false, s);
                 finish(s, hs * du);
             }
 #pragma unroll 1
@@ -1160,30 +1207,59 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
                 const bool more = k + 1 < K;
                 // trapezoid weights per unit of u (delay.py:314-315): interior samples, and the top one with both its segments
                 const double w_mid = (2.0 * hs) * du;
+                if (np > 2) {
+                    const double step = rec->step, gk = rec->gk, rk = rec->rk;
 #pragma unroll 1
-                for (int j = 1; j < np - 1; ++j) {                                   // low + frac * (high - low), delay.py:292
-                    PendingSample<T2> s;
-                    issue_mid(fma((double)j * step, du, u_k), kz, s);
-                    finish(s, w_mid);
+                    for (int j = 1; j < np - 1; ++j) {                               // low + frac * (high - low), delay.py:292
+                        PendingSample<T2> s;
+                        const double us = fma((double)j * step, du, u_k);
+                        const double ph = poly5(q.h, us), plat = poly5(q.lat, us), plon = poly5(q.lon, us);
+                        int iz = kz;                                                 // strictly inside model interval kz: one table entry, no select
+                        s.tz = (ph - gk) * rk;
+                        if (!(s.tz >= 0.0) || !(s.tz <= 1.0)) cell_exact(m.ax.ez, c.nz, ph, iz, s.tz);   // rare
+                        gather_corners<T2, true, NC>(c, m.ax, plat, plon, iz, s);
+                        finish(s, w_mid);
+                    }
                 }
                 // top sample: its gathers are issued first, the next level's crossing (7 FMAs that need no memory) is computed
                 // while they are in flight, then the sample is finished with the weight of both its segments
                 PendingSample<T2> top;
-                issue_top(u_k + du, zbase, false, clamp_hi && !more, top);                // fraction exactly 1.0, as np.linspace returns it
-                double du1 = 0.0, hs1 = 0.0;
-                double w_top = hs * du;
-                if (more) {
-                    const double t2 = poly7(xc, m.xv[k + 1]);
-                    du1 = t2 - u_last; u_last = t2; hs1 = m.hs[k + 1];
-                    w_top = fma(hs1, du1, w_top);
+                {
+                    const double us = u_k + du;                                      // fraction exactly 1.0, as np.linspace returns it
+                    double ph = poly5(q.h, us);
+                    const double plat = poly5(q.lat, us), plon = poly5(q.lon, us);   // delay.py:295 through the ray polynomials
+                    if (clamp_hi && !more) { asm volatile("" ::: "memory"); ph = fmin(ph, c.z_hi); }      // delay.py:310-311 (slice-uniform branch)
+                    // z cell: the top sits on node g[zbase+1] within the residual of the three-iteration crossing - ABOVE it for every ray
+                    // whose zenith angle falls with height (profiles/r06_nodetop_ab.txt).  When no live lane of the wave is below the node
+                    // (one compare + a scalar test) the cell index is the scalar zbase+1 and the weight one multiplication; otherwise the
+                    // per-lane two-entry window.  Same values either way.
+                    const double d = ph - rec->zmid;
+                    int iz; bool ok;
+                    if (__builtin_expect((__builtin_amdgcn_ballot_w64(!(d >= 0.0)) & live) == 0ULL, 1)) {
+                        iz = zbase + 1;
+                        top.tz = d * rec->r1;
+                        ok = top.tz <= 1.0;                                                                // (idle lanes: NaN)
+                    } else {
+                        double ds = d;
+                        asm volatile("" : "+v"(ds));                                                       // (nothing of this block is hoisted into the fast path)
+                        const bool up = ds >= 0.0;
+                        iz = zbase + (int)up;
+                        top.tz = fma(ds, up ? rec->r1 : rec->r0, up ? 0.0 : 1.0);
+                        ok = (top.tz >= 0.0) & (top.tz <= 1.0);
+                    }
+                    if (!(ok & (c.nz >= 4))) cell_exact(m.ax.ez, c.nz, ph, iz, top.tz);                  // rare
+                    gather_corners<T2, true, NC>(c, m.ax, plat, plon, iz, top);                          // delay.py:298,319
                 }
+                // (the record after the last level: same abscissa, weight 0 - see the fill above)
+                const double t2 = poly7(xc, rec[1].xv);
+                const double du1 = t2 - u_last, hs1 = rec[1].hs;
+                u_last = t2;
+                const double w_top = fma(hs1, du1, hs * du);
+                npkz = __builtin_amdgcn_readfirstlane(rec[1].npkz);
                 finish(top, w_top);
                 u_k += du; du = du1; hs = hs1;
-                if (more) {
-                    np = __builtin_amdgcn_readfirstlane(m.np[k + 1]);
-                    kz = __builtin_amdgcn_readfirstlane(m.kz[k + 1]);
-                    step = m.step[k + 1];
-                }
+                np = npkz & 0x1ffff; kz = npkz >> 17;
+                ++rec;
             }
             }   // (slice loop)
             };

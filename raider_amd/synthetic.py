@@ -2,12 +2,18 @@
 import numpy as np
 
 
-def synthetic_cube(ny, nx, nz, seed=0, ztop=41000.0, y0=30.0, y1=36.0, x0=-121.0, x1=-113.0):
+def synthetic_cube(ny, nx, nz, seed=0, ztop=41000.0, y0=30.0, y1=36.0, x0=-121.0, x1=-113.0, zs=None):
     """ERA5-like processed weather model: dict(xs, ys, zs, wet, hydro (z,y,x) f32, wet_total,
-    hydro_total (z,y,x) f64) laid out as weatherModel.py:685-693 writes it."""
+    hydro_total (z,y,x) f64) laid out as weatherModel.py:685-693 writes it.  zs: the level heights to use (ascending, nz of them;
+    e.g. a model's real axis, real_level_heights) instead of the quadratic stand-in."""
     ys = np.linspace(y0, y1, ny)
     xs = np.linspace(x0, x1, nx)
-    zs = np.round(-100 + ztop * np.linspace(0, 1, nz) ** 2, 3)
+    if zs is None:
+        zs = np.round(-100 + ztop * np.linspace(0, 1, nz) ** 2, 3)
+    else:
+        zs = np.ascontiguousarray(zs, dtype=np.float64)
+        if zs.shape != (nz,) or not np.all(np.diff(zs) > 0):
+            raise ValueError('synthetic_cube: zs must hold nz ascending heights')
     rng = np.random.default_rng(seed)
     g_h = rng.standard_normal((ny, nx))
     g_w = rng.standard_normal((ny, nx))
@@ -33,3 +39,13 @@ def scene_grid(rows, cols, row0=0, nrows=None, total_rows=None):
     ypts = np.linspace(34.5, 31.5, total_rows)[row0:row0 + nrows]
     inc_cols = 30.0 + 16.0 * (np.arange(cols) / float(cols))
     return xpts, ypts, inc_cols, -167.9
+
+
+def real_level_heights(model):
+    """The z axis of a processed model as the reference lays it out (models/model_levels.py, shipped as data under raider_amd/data):
+    'era5' - the 145 heights every ECMWF model is resampled to (-500 m .. 80.3 km); 'hrrr' - HRRR's 50 native + 7 padding levels
+    (-500 m .. 26.2 km).  Ascending float64."""
+    from pathlib import Path
+    f = {'era5': 'ecmwf_l137.npz', 'hrrr': 'hrrr_l50.npz'}[model]
+    h = np.load(Path(__file__).resolve().parent / 'data' / f)['level_heights']
+    return np.sort(np.asarray(h, dtype=np.float64))

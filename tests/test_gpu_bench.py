@@ -64,7 +64,22 @@ def test_bench_line_is_complete_and_self_consistent():
         assert r['executed_fp64_flops_frac'] < r['useful_flops_frac']                            # ... and the kernel executes FEWER flops than the reference's algorithm counts
         assert r['frac_class_priced'] <= r['frac'] + 1e-12                                       # cheaper classes priced at their own rate
         assert abs(r['executed_fp64_TFLOPs'] * 1e12 - mix['fp64_flops_per_lane'] * n / (r['march_ms_per_step'] * 1e-3)) < 1e-6 * r['executed_fp64_TFLOPs'] * 1e12
+    # round 6: SURVEY 8(d)'s models over the WHOLE step beside the busy-ness figure, which is labelled as what it is
+    for k in ('frac_is', 'survey_flops_frac_step', 'survey_bytes_over_hbm_peak_step', 'survey_bytes_note', 'dependent_chain_note'):
+        assert k in r, k
+    assert r['frac_is'] == 'valu_issue_busy'
+    assert 0 < r['survey_flops_frac_step'] <= r['useful_flops_frac']                       # step time >= march time
+    assert abs(r['survey_bytes_over_hbm_peak_step'] * 8.0e12 * d['ms_per_step'] * 1e-3 - (64 * S + 64) * n) < 1e-6 * (64 * S + 64) * n
+    assert len(d['config']['devices']) == 1 and d['config']['devices'][0]['rank'] == 0 and d['config']['distinct_devices'] == 1
     sec = d['secondary']                                                                    # the two gather workloads beside the headline
+    rl = sec['real_levels']                                                                 # the same scene on the REAL level heights of ERA5 / HRRR
+    for tag, nlev in (('era5_145', 145), ('hrrr_57', 57)):
+        assert 'error' not in rl[tag], rl[tag]
+        e_ = rl[tag]
+        assert e_['levels'] == nlev and e_['K'] < nlev and e_['S'] >= 2 * e_['K'] and e_['evaluated_samples_per_ray'] == e_['S'] - (e_['K'] - 1)
+        assert e_['rays_per_s'] > 1e8 and e_['gpu_vs_oracle_max_abs_m'] < 1e-9 and e_['nan_fraction'] == 0.0
+        assert e_['march_ms_per_step'] + e_['crossings_ms_per_step'] <= e_['ms_per_step'] * 1.001
+    assert rl['era5_145']['S'] > rl['hrrr_57']['S']
     for wl, unit in (('c2', 'points/s'), ('c5', 'points/s')):
         assert 'error' not in sec[wl], sec[wl]
         assert sec[wl]['unit'] == unit and sec[wl]['value'] > 1e8 and sec[wl]['roofline_bound'] == 'hbm' and sec[wl]['roofline_frac'] > 0

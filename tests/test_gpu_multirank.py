@@ -32,6 +32,9 @@ def test_bench_self_launches_two_ranks_and_matches_one_rank(tmp_path):
     assert one['n_gpus'] == 1 and two['n_gpus'] == 2 and two['config']['ranks'] == 2
     assert two['config']['rays_per_gpu'] == 700 * 1200 and two['value'] > 0 and two['scaling'] == 'weak'
     assert two['config']['backend'] in ('nccl', 'gloo')
+    # weak scaling: the one-GPU reference is ONE slab traced alone; efficiency = t1 / tN
+    assert abs(two['scaling_efficiency'] - two['one_gpu_same_scene']['ms_per_step'] / two['ms_per_step']) < 1e-12 and 'strong_scaling_efficiency' not in two
+    assert len(two['config']['devices']) == 2 and two['parity_sample']['max_abs_hydro_m'] < 1e-9
     a = np.load(tmp_path / 'one.rank0.npz')
     b0, b1 = np.load(tmp_path / 'two.rank0.npz'), np.load(tmp_path / 'two.rank1.npz')
     assert np.array_equal(a['nparts'], b0['nparts']) and np.array_equal(a['nparts'], b1['nparts'])
@@ -102,6 +105,22 @@ def _run(tmp_path, tag, *args, timeout=1200):
     return json.loads(lines[0])
 
 
+def _self_contained(line, world, units):
+    """round 6: an N > 1 line carries its own one-GPU reference (same job, same node, same run), the identity of every rank's device and a
+    parity sample - the first real 8-GPU SCALE record must be readable without comparing it with another line."""
+    cfg = line['config']
+    assert len(cfg['devices']) == world and [d['rank'] for d in cfg['devices']] == list(range(world))
+    assert all(set(d) >= {'rank', 'hip_device', 'uuid', 'pci', 'name'} for d in cfg['devices'])
+    assert 1 <= cfg['distinct_devices'] <= world
+    if cfg['backend'] == 'nccl':
+        assert cfg['distinct_devices'] == world                                             # RCCL: one rank per physical GPU
+    one = line['one_gpu_same_scene']
+    assert one['ms_per_step'] > 0 and abs(one['value'] * one['ms_per_step'] * 1e-3 - units) < 1.0 and 1 <= one['steps'] <= 3
+    assert abs(line['strong_scaling_efficiency'] - one['ms_per_step'] / (world * line['ms_per_step'])) < 1e-12
+    assert line['scaling_efficiency'] == line['strong_scaling_efficiency'] and 0 < line['scaling_efficiency'] < 1.5
+    assert 'parity_sample' in line
+
+
 def _covers(shards, total):
     """contiguous blocks, in rank order, covering [0, total) exactly once"""
     pos = 0
@@ -129,6 +148,11 @@ def test_world8_strong_scaling_of_one_scene_matches_one_rank(tmp_path):
     assert abs(max(cfg['rank_ms_per_step']) - eight['ms_per_step']) < 1e-6 * eight['ms_per_step']       # the line's time IS the slowest rank's
     assert abs(eight['value'] * eight['ms_per_step'] * 1e-3 - 2005 * 4000) < 1.0
     assert 'secondary' not in eight                                                                       # (an appendix of the one-GPU line only)
+    _self_contained(eight, 8, 2005 * 4000)
+    assert eight['one_gpu_same_scene']['same_bits_as_sharded_run'] is True
+    ps = eight['parity_sample']
+    assert ps['block'] == [250, 250] and ps['rays_compared_all_ranks'] == 8 * 250 * 250 and len(ps['per_rank_max_abs_m']) == 8
+    assert ps['max_abs_wet_m'] < 1e-9 and ps['max_abs_hydro_m'] < 1e-9 and ps['nan_mask_mismatches'] == 0
     a = np.load(tmp_path / 'one.rank0.npz')
     parts = [np.load(tmp_path / f'eight.rank{r}.npz') for r in range(8)]
     assert [int(p['row0']) for p in parts] == [r0 for r0, _ in cfg['shards']]
@@ -145,6 +169,9 @@ def test_world8_station_and_point_workloads_match_one_rank(tmp_path):
     cfg = eight['config']
     assert eight['n_gpus'] == 8 and eight['scaling'] == 'strong' and cfg['world_size_seen_by_backend'] == 8 and _covers(cfg['shards'], 400003)
     assert len(cfg['rank_ms_per_step']) == 8 and abs(eight['value'] * eight['ms_per_step'] * 1e-3 - 400003) < 1.0
+    _self_contained(eight, 8, 400003)
+    assert eight['one_gpu_same_scene']['same_bits_as_sharded_run'] is True and eight['parity_sample']['max_abs'] < 1e-9
+    assert eight['parity_sample']['points_compared_all_ranks'] == 8 * 2048
     a = np.load(tmp_path / 'c5one.rank0.npz')
     parts = [np.load(tmp_path / f'c5eight.rank{r}.npz') for r in range(8)]
     assert [int(p['p0']) for p in parts] == [r0 for r0, _ in cfg['shards']]
@@ -154,6 +181,8 @@ def test_world8_station_and_point_workloads_match_one_rank(tmp_path):
     assert one['unit'] == 'points/s' and 'configs[1]' in eight['config']['workload'] and eight['config']['world_size_seen_by_backend'] == 8
     assert eight['config']['points_all_gpus'] == 301 * 301 and abs(eight['value'] * eight['ms_per_step'] * 1e-3 - 301 * 301) < 1.0
     assert eight['roofline']['bound'] == 'hbm' and eight['roofline']['frac'] > 0
+    _self_contained(eight, 8, 301 * 301)
+    assert eight['parity_sample']['max_abs_m'] < 1e-12 and eight['parity_sample']['nan_masks_equal'] is True
     a = np.load(tmp_path / 'c2one.rank0.npz')
     parts = [np.load(tmp_path / f'c2eight.rank{r}.npz') for r in range(8)]
     assert sum(int(p['cnt']) for p in parts) == 301 * 301
