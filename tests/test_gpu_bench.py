@@ -33,7 +33,7 @@ def test_bench_line_is_complete_and_self_consistent():
               'source_hash', 'library_source_hash', 'march_ms_per_step', 'crossings_ms_per_step'):
         assert k in r, k
     assert r['source_hash'] == r['library_source_hash'] and len(r['source_hash']) == 16   # the binary that ran is the tree's
-    assert r['vgpr'] == 128 and r['scratch_bytes'] == 0 and 10000 < r['lds_bytes'] < 65536  # from the loaded code object, not a profiler column
+    assert 120 <= r["vgpr"] <= 128 and r['scratch_bytes'] == 0 and 10000 < r['lds_bytes'] < 65536  # from the loaded code object, not a profiler column
     assert 0 < r['march_ms_per_step'] < d['ms_per_step'] and 0 < r['crossings_ms_per_step'] < r['march_ms_per_step']
     if r['frac'] is not None:                                                               # a digest of this source tree is committed
         assert r['frac'] == r['frac_valu'] and 0.1 < r['frac'] <= 1.0 and r['counters_source'].startswith('profiles/')
