@@ -957,7 +957,7 @@ def c5_measure(ctx, dev, stations=5_000_000, steps=5, warmup=2, oracle_sample=20
         if fly:
             out[0], out[1] = a.interp_blend(w1, b, w2, pts)
         else:
-            out[0], out[1] = a.blend(w1, b, w2).interp(pts)
+            out[0], out[1] = a.interp_blend(w1, b, w2, pts, via_cube=True)
     for _ in range(warmup):
         step()
     torch.cuda.synchronize()
@@ -971,7 +971,7 @@ def c5_measure(ctx, dev, stations=5_000_000, steps=5, warmup=2, oracle_sample=20
     _, ms_bl = ctx.profile_get(3)
     ctx.set_profiling(False)
     cells = ny * nx * nz
-    r = dict(stations_this_rank=stations, step_s=dt / steps, interp_ms=ms_int / steps, blend_ms=ms_bl / steps, route='blend at the corners' if fly else 'blended cube + gather',
+    r = dict(stations_this_rank=stations, step_s=dt / steps, interp_ms=ms_int / steps, blend_ms=ms_bl / steps, route='blend at the corners' if fly else 'blended cube (paired x columns, scratch) + gather',
              alg_bytes=(168.0 * stations) if fly else (24.0 * cells + 104.0 * stations))
     if oracle_sample:
         from oracle import raider_oracle as O
@@ -989,7 +989,7 @@ def c5_traffic(fly):
     if prof is None:
         return None
     k = prof.get('kernels', {})
-    names = ('interp_points_blend_kernel',) if fly else ('blend_kernel', 'interp_points_kernel')
+    names = ('interp_points_blend_kernel',) if fly else ('blend_pair_kernel', 'interp_points_pair_kernel')
     if not all(n in k and 'hbm_read_bytes' in k[n] for n in names):
         return None
     return sum(k[n]['hbm_read_bytes'] + k[n]['hbm_write_bytes'] for n in names)
@@ -1052,8 +1052,7 @@ def run_c5(args, ctx, dev, coll_dev, dist_on, rank, world, ndev, result_fd):
         if fly:
             out[0], out[1] = a.interp_blend(w1, b, w2, pts)
         else:
-            m = a.blend(w1, b, w2)
-            out[0], out[1] = m.interp(pts)
+            out[0], out[1] = a.interp_blend(w1, b, w2, pts, via_cube=True)
 
     for _ in range(args.warmup):
         step()
@@ -1070,20 +1069,15 @@ def run_c5(args, ctx, dev, coll_dev, dist_on, rank, world, ndev, result_fd):
         dist.barrier()
     dt = time.perf_counter() - t0
     n_int, ms_int = ctx.profile_get(2)
+    _, ms_bl = ctx.profile_get(3)                 # the blend's own launches (HIP event pairs on the stream the kernels run on); 0 on the corner route
     ctx.set_profiling(False)
+    blend_ms = ms_bl / args.steps
     rank_s = [dt]
     if dist_on:
         rank_s = gather_rank_times(dist, dt, coll_dev, world)
         tmax = torch.tensor([dt], dtype=torch.float64, device=coll_dev if coll_dev is not None else 'cpu')
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    # the blend's own time: HIP events on the stream the kernels run on (torch's current stream here)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    blend_ms = 0.0
-    if not fly:
-        e0.record(); keep = [a.blend(w1, b, w2) for _ in range(3)]; e1.record(); torch.cuda.synchronize()
-        blend_ms = e0.elapsed_time(e1) / 3.0
-        del keep
     wet_t, hyd_t = out
     if args.dump:
         np.savez(f'{args.dump}.rank{rank}.npz', wet=wet_t.cpu().numpy(), hydro=hyd_t.cpu().numpy(), p0=p0, cnt=cnt)
@@ -1114,7 +1108,7 @@ def run_c5(args, ctx, dev, coll_dev, dist_on, rank, world, ndev, result_fd):
             k1 = max(1, min(args.steps, 3))
 
             def step1():
-                return a.interp_blend(w1, b, w2, pts1) if fly1 else a.blend(w1, b, w2).interp(pts1)
+                return a.interp_blend(w1, b, w2, pts1, via_cube=not fly1)
             step1(); torch.cuda.synchronize()
             t1 = time.perf_counter()
             for _ in range(k1):
@@ -1144,23 +1138,23 @@ def run_c5(args, ctx, dev, coll_dev, dist_on, rank, world, ndev, result_fd):
         'config': {'workload': f'configs[4]: HRRR-sized 1000x1000x50 f32 cube on the 3-km LCC grid, two epochs blended ({w1}, {w2}), {n_all} station points '
                                f'(rng(3), h ~ U(0, 4000) m) sharded into {world} contiguous blocks, wet + hydro at every point',
                    'stations_all_gpus': n_all, 'stations_this_rank': cnt, 'cube': '1000x1000x50 x 2 epochs',
-                   'blend': 'at the corners of the rank\'s points (rdr_interp3_blend: no blended cube)' if fly else 'blended cube per step (rdr_cube_blend), then the gather',
+                   'blend': 'at the corners of the rank\'s points (rdr_interp3_blend: no blended cube)' if fly else 'blended cube per step in the context\'s scratch, x columns paired, then the gather (rdr_interp3_blend_cube)',
                    'parallelism': (f'stations sharded x{world} ({args.backend}, {ndev} device(s) visible), epochs: two packed broadcasts ({t_bcast*1e3:.1f} ms), blend replicated '
                                    f'per rank, no data-path collective') if dist_on else 'single GPU',
                    'ranks': world, 'backend': (dist.get_backend() if dist_on else None), 'world_size_seen_by_backend': (dist.get_world_size() if dist_on else 1),
                    'shards': [list(D.shard_rows(n_all, world, r_)) for r_ in range(world)], 'rank_ms_per_step': [t_ / args.steps * 1e3 for t_ in rank_s],
                    'devices_visible': ndev, 'ranks_per_device': -(-world // ndev),
                    'mean_hydro': float(torch.nanmean(hyd_t).item()), 'mean_wet': float(torch.nanmean(wet_t).item()), 'nan_fraction': float(torch.isnan(hyd_t).double().mean().item())},
-        'roofline': {'bound': 'hbm', 'kernel': 'interp_points_blend_kernel<float2> (one step of one rank)' if fly else 'blend_kernel<float> + interp_points_kernel<float2> (one step of one rank)',
+        'roofline': {'bound': 'hbm', 'kernel': 'interp_points_blend_kernel<float2> (one step of one rank)' if fly else 'blend_pair_kernel<float2,2> + interp_points_pair_kernel<float2> (one step of one rank)',
                      'achieved': alg_bytes / ((blend_ms + interp_ms) * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': alg_bytes / ((blend_ms + interp_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      'traffic': c5_traffic(fly), 'traffic_unit': 'HBM bytes per step of one rank holding ALL stations (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE; profiles/r*_c5_counters.json)',
                      'algorithmic_bytes_per_step': alg_bytes, 'blend_ms': blend_ms, 'interp_ms_per_step': interp_ms, 'interp_launches_timed': n_int,
                      'note': ('algorithmic bytes (168 B per station: 8 corners x 2 epochs x 8 B + the point + the two delays, SURVEY 8d) over the kernel\'s HIP-event time; a random '
                               'point touches 8 x 128 B lines for them (4 per epoch)') if fly else
-                             ('algorithmic bytes (24 B per cell of the blend + 104 B per station, SURVEY 8d) over the two kernels\' HIP-event time; the one-shot gather on a '
-                              'FRESH blended cube reads 4 x 128 B lines per point (572 B measured, profiles/r04_secondary.json) - the corner-quad copy only pays from the '
-                              'second query of a cube on (raider_hip.hip quad_wanted)'),
+                             ('algorithmic bytes (24 B per cell of the blend + 104 B per station, SURVEY 8d) over the two kernels\' HIP-event time; the blend writes x columns '
+                              'PAIRED (round 6), so a random point reads 2 lines when its cell starts on an even column and 4 otherwise - 3 on average against the 4 of the '
+                              '(y,x,z) layout (572 B per point measured there, profiles/r05_secondary.json)'),
                      'source_hash': kernel_source_hash(), 'library_source_hash': R.load_library().rdr_source_hash().decode()},
     }
     res['config']['devices'] = devices

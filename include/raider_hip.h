@@ -279,6 +279,13 @@ int rdr_build_cube_to_cube(rdr_ctx* ctx, const rdr_cube* cube, const double* xpt
  * blend is what stops the job from scaling.  Points as rdr_interp3_project (three arrays, or y = packed pts[n,3] with x = z = NULL). */
 int rdr_interp3_blend(rdr_ctx* ctx, const rdr_cube* a, double w1, const rdr_cube* b, double w2, const double* y, const double* x, const double* z,
                       int64_t n, double* wet, double* hydro, int loc);
+/* The same query when the point set is LARGE against the cube (one GPU holding all 5 M stations of BASELINE configs[4]): the blend is made
+ * as a cube after all - 24 B per cell, as rdr_cube_blend - but into the context's scratch and in the layout the gather reads best
+ * (neighbouring x columns paired: 3 cache lines per random point on average instead of 4), then gathered in the same call.  The paired
+ * cube never becomes an rdr_cube, so nothing else can be handed that layout.  Same arithmetic as rdr_cube_blend + rdr_interp3
+ * (cli/raider.py:817-819, delay.py:116-121): the same bits.  Points / outputs as rdr_interp3_blend. */
+int rdr_interp3_blend_cube(rdr_ctx* ctx, const rdr_cube* a, double w1, const rdr_cube* b, double w2, const double* y, const double* x, const double* z,
+                           int64_t n, double* wet, double* hydro, int loc);
 /* tropo_delay's point branch for a zenith / projected line of sight (delay.py:96-128) in ONE call, host arrays in, host arrays out:
  * rdr_build_cube_to_cube on the output grid (xpts[nx], ypts[ny], zpts[nz]) + rdr_interp3_project at the query points, with the
  * intermediate cube in the context's scratch (no allocation per call) and the upload of the points running under its build.  Same

@@ -89,6 +89,7 @@ SYMBOLS = [
     ('rdr_interp3', C.c_int, [_VP, _VP, _VP, C.c_int64, _VP, _VP, C.c_int]),
     ('rdr_interp3_project', C.c_int, [_VP, _VP, _VP, _VP, _VP, C.c_int64, C.c_int, _VP, C.c_double, _VP, _VP, C.c_int]),
     ('rdr_interp3_blend', C.c_int, [_VP, _VP, C.c_double, _VP, C.c_double, _VP, _VP, _VP, C.c_int64, _VP, _VP, C.c_int]),
+    ('rdr_interp3_blend_cube', C.c_int, [_VP, _VP, C.c_double, _VP, C.c_double, _VP, _VP, _VP, C.c_int64, _VP, _VP, C.c_int]),
     ('rdr_build_cube', C.c_int, [_VP, _VP, _VP, C.c_int64, _VP, C.c_int64, _VP, C.c_int64, _VP, _VP, C.c_int]),
     ('rdr_build_cube_to_cube', C.c_int, [_VP, _VP, _VP, C.c_int64, _VP, C.c_int64, _VP, C.c_int64, C.c_int, C.POINTER(_VP)]),
     ('rdr_last_nan_output', C.c_int, [_VP]),

@@ -260,6 +260,105 @@ __global__ __launch_bounds__(256) void interp_points_kernel(CubeView<T2> c, Poin
     }
 }
 
+// ---- the two-epoch blend made FOR the point gather (round 6) -----------------------------------------------------------------------------
+// When the blended cube's only reader is a gather at random points (BASELINE configs[4] on one rank: 5 M stations on a 50 M-cell cube), the
+// blend may as well write the layout the gather wants: neighbouring x columns PAIRED,
+//     P[(iy * npx + px) * nz + iz] = (wet, hydro of column 2 px | wet, hydro of column 2 px + 1),   npx = ceil(nx / 2)
+// so that a point whose cell starts on an even column finds both x columns of a y row in 32 contiguous bytes (z, z+1): 2 cache lines per
+// point instead of 4; an odd cell still reads 4 - 3 on average (measured 470 B per point against 572, tools/probes/pair_layout_probe.hip).
+// Same arithmetic as blend_kernel (the two products rounded separately, then added, in the cube's dtype): the same bits, other addresses.
+// One thread per (row, pair, ZV consecutive z): ZV x 8-byte runs of four source columns in, ZV x 16 contiguous bytes out (f32 cubes).
+template <typename T2, int ZV>
+__global__ __launch_bounds__(256) void blend_pair_kernel(const T2* __restrict__ a, decltype(T2().x) w1, const T2* __restrict__ b, decltype(T2().x) w2,
+                                                         T2* __restrict__ out, int ny, int nx, int nz) {
+    typedef decltype(T2().x) T;
+    const int npx = (nx + 1) >> 1, nzv = nz / ZV;
+    const int64_t total = (int64_t)ny * npx * nzv;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int izv = (int)(i % nzv);
+        const int64_t p = i / nzv;
+        const int px = (int)(p % npx), iy = (int)(p / npx);
+        const int64_t se = ((int64_t)iy * nx + 2 * px) * nz + (int64_t)izv * ZV;      // even column of the pair (source element)
+        const bool has_odd = 2 * px + 1 < nx;
+        // (non-temporal: the epochs are read once; ZV = 2: one 16-byte access per column and epoch, 32 contiguous bytes out)
+        typedef T VZ __attribute__((ext_vector_type(2 * ZV)));
+        typedef T V4 __attribute__((ext_vector_type(4)));
+        const VZ zero = {};
+        const VZ ae = __builtin_nontemporal_load(reinterpret_cast<const VZ*>(a + se)), be = __builtin_nontemporal_load(reinterpret_cast<const VZ*>(b + se));
+        const VZ ao = has_odd ? __builtin_nontemporal_load(reinterpret_cast<const VZ*>(a + se + nz)) : zero;
+        const VZ bo = has_odd ? __builtin_nontemporal_load(reinterpret_cast<const VZ*>(b + se + nz)) : zero;
+        V4* o = reinterpret_cast<V4*>(out + 2 * (p * nz + (int64_t)izv * ZV));
+#pragma unroll
+        for (int k = 0; k < ZV; ++k) {
+#pragma clang fp contract(off)
+            V4 r;
+            { const T p1 = w1 * ae[2 * k], q1 = w2 * be[2 * k]; r[0] = p1 + q1; }
+            { const T p1 = w1 * ae[2 * k + 1], q1 = w2 * be[2 * k + 1]; r[1] = p1 + q1; }
+            { const T p1 = w1 * ao[2 * k], q1 = w2 * bo[2 * k]; r[2] = p1 + q1; }
+            { const T p1 = w1 * ao[2 * k + 1], q1 = w2 * bo[2 * k + 1]; r[3] = p1 + q1; }
+            o[k] = r;
+        }
+    }
+}
+
+// scipy RGI (trilinear<> of raider_kernels.h, the same weights, corner order and sum) on a PAIRED cube
+template <typename T2>
+__global__ __launch_bounds__(256) void interp_points_pair_kernel(CubeView<T2> c, const T2* __restrict__ P, PointQuery Q, int64_t n,
+                                                                 double* __restrict__ wet, double* __restrict__ hyd, int axes_in_lds) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const double* s_y = c.axes;
+    if (axes_in_lds) {
+        double* t = reinterpret_cast<double*>(smem_raw);
+        for (int i = threadIdx.x; i < c.ny + c.nx + c.nz; i += blockDim.x) t[i] = c.axes[i];
+        __syncthreads();
+        s_y = t;
+    }
+    const double* s_x = s_y + c.ny;
+    const double* s_z = s_x + c.nx;
+    const int npx = (c.nx + 1) >> 1;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        double y, x, z;
+        Q.point(i, y, x, z);
+        double sw = qnan(), sh = qnan();
+        const bool inside = (y >= c.y_lo) && (y <= c.y_hi) && (x >= c.x_lo) && (x <= c.x_hi) && (z >= c.z_lo) && (z <= c.z_hi);
+        if (inside) {
+            const int iy = find_cell(s_y, c.ny, y, c.y_lo, c.inv_dy, c.uni_y);
+            const int ix = find_cell(s_x, c.nx, x, c.x_lo, c.inv_dx, c.uni_x);
+            const int iz = find_cell(s_z, c.nz, z, c.z_lo, c.inv_dz, c.uni_z);
+            const double ty = (y - s_y[iy]) / (s_y[iy + 1] - s_y[iy]);
+            const double tx = (x - s_x[ix]) / (s_x[ix + 1] - s_x[ix]);
+            const double tz = (z - s_z[iz]) / (s_z[iz + 1] - s_z[iz]);
+            // Whole 16-byte (f32) pair entries, addressed without a data-dependent pointer (left to per-corner selects of ADDRESSES the compiler
+            // issues sixteen 4-byte loads): entries e, e+1 = levels iz, iz+1 of pair px - both x columns of an even cell; an odd cell takes
+            // their odd halves and the even halves of the next pair's entries (two more loads, for those lanes only).
+            typedef decltype(T2().x) T;
+            typedef T V4 __attribute__((ext_vector_type(4)));
+            const V4* P4 = reinterpret_cast<const V4*>(P);
+            const int px = ix >> 1;
+            const bool even = (ix & 1) == 0;
+            T2 v[8];                                   // corners in (y, x, z) lexicographic order
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int64_t e = ((int64_t)(iy + r) * npx + px) * c.nz + iz;
+                const V4 E0 = P4[e], E1 = P4[e + 1];
+                V4 F0 = E0, F1 = E1;
+                if (!even) { F0 = P4[e + c.nz]; F1 = P4[e + c.nz + 1]; }
+                v[4 * r + 0].x = even ? E0[0] : E0[2]; v[4 * r + 0].y = even ? E0[1] : E0[3];       // (x0, z0)
+                v[4 * r + 1].x = even ? E1[0] : E1[2]; v[4 * r + 1].y = even ? E1[1] : E1[3];       // (x0, z1)
+                v[4 * r + 2].x = even ? E0[2] : F0[0]; v[4 * r + 2].y = even ? E0[3] : F0[1];       // (x1, z0)
+                v[4 * r + 3].x = even ? E1[2] : F1[0]; v[4 * r + 3].y = even ? E1[3] : F1[1];       // (x1, z1)
+            }
+            const double wy0 = 1.0 - ty, wx0 = 1.0 - tx, wz0 = 1.0 - tz;
+            const double a00 = wy0 * wx0, a01 = wy0 * tx, a10 = ty * wx0, a11 = ty * tx;
+            const double k[8] = {a00 * wz0, a00 * tz, a01 * wz0, a01 * tz, a10 * wz0, a10 * tz, a11 * wz0, a11 * tz};
+            sw = 0.0; sh = 0.0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { sw += (double)v[j].x * k[j]; sh += (double)v[j].y * k[j]; }
+        }
+        Q.store(i, sw, sh, wet, hyd);
+    }
+}
+
 // The two-epoch temporal interpolation (cli/raider.py:817-819) applied ON THE FLY at the eight corners of every query point instead of
 // to the whole cube first: corner = w1 * a + w2 * b in the cube's own dtype, the two products rounded separately - exactly blend_kernel's
 // arithmetic - then the gather of trilinear<>: the same bits as blend-then-gather.  Reads eight lines per point instead of four but

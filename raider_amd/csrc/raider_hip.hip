@@ -1068,12 +1068,20 @@ int rdr_cube_point_index(rdr_ctx* c, rdr_cube* q_any, int mode) {
 int64_t rdr_cube_point_index_bytes(const rdr_cube* q) { return q ? (int64_t)root(q)->quad_bytes : -1; }
 
 // a second epoch blended in at the corners (rdr_interp3_blend): vb == NULL for an ordinary gather
-struct BlendSpec { const void* vb = nullptr; double w1 = 1.0, w2 = 0.0; };
+// pair != NULL: the blend was made as a PAIRED cube in the context's scratch (rdr_interp3_blend_cube) - the gather reads that
+struct BlendSpec { const void* vb = nullptr; double w1 = 1.0, w2 = 0.0; const void* pair = nullptr; bool want_pair = false; };
 
 static void launch_interp(rdr_ctx* c, const rdr_cube* q, const PointQuery& Qk, int64_t cnt, double* dwk, double* dhk, bool quad, const BlendSpec& B = BlendSpec()) {
     const int g = grid_for(cnt, 256, c->num_cus * 8);
     KTimer t(c, 2);
-    if (B.vb) {
+    if (B.pair) {
+        if (q->dtype == RDR_F32)
+            hipLaunchKernelGGL((interp_points_pair_kernel<float2>), dim3(g), dim3(256), axes_smem(q), c->stream, make_view<float2>(q), (const float2*)B.pair, Qk, cnt, dwk, dhk,
+                               (int)axes_fit_lds(q));
+        else
+            hipLaunchKernelGGL((interp_points_pair_kernel<double2>), dim3(g), dim3(256), axes_smem(q), c->stream, make_view<double2>(q), (const double2*)B.pair, Qk, cnt, dwk, dhk,
+                               (int)axes_fit_lds(q));
+    } else if (B.vb) {
         if (q->dtype == RDR_F32)
             hipLaunchKernelGGL((interp_points_blend_kernel<float2>), dim3(g), dim3(256), axes_smem(q), c->stream, make_view<float2>(q), (const float2*)B.vb, B.w1, B.w2,
                                Qk, cnt, dwk, dhk, (int)axes_fit_lds(q));
@@ -1170,12 +1178,37 @@ static int point_query_args(rdr_ctx* c, const char* who, const double* y, const 
 // the point query behind rdr_interp3 / rdr_interp3_project: y/x/z three arrays (x != NULL) or y = packed (n,3); pmode / proj / inc0 as
 // PointQuery (cube_kernels.h); either output may be NULL (it is then neither written nor downloaded)
 static int interp3_impl(rdr_ctx* c, const char* who, const rdr_cube* q, const double* y, const double* x, const double* z, int64_t n, int pmode,
-                        const double* proj, double inc0, double* wet, double* hydro, int loc, const BlendSpec& B = BlendSpec()) {
+                        const double* proj, double inc0, double* wet, double* hydro, int loc, const BlendSpec& B_in = BlendSpec()) {
     if (!c || !q) return fail(c, RDR_ERR_INVALID, std::string(who) + ": NULL argument");
     note_use(c, q);
     int rc = point_query_args(c, who, y, x, z, n, pmode, proj, wet, hydro); if (rc) return rc;
     if (n == 0) return RDR_OK;
     HIPCHECK(c, hipSetDevice(c->device));
+    BlendSpec B = B_in;
+    if (B.want_pair) {
+        // the blend as a cube, written ONCE in the layout the gather reads best (blend_pair_kernel), into the context's scratch: it never
+        // becomes an rdr_cube, so no other kernel can be handed the paired layout
+        const size_t esz = q->dtype == RDR_F32 ? 8 : 16;
+        const int64_t npx = (q->nx + 1) / 2;
+        void* dp;
+        rc = ensure(c, SLOT_TMPCUBE, (size_t)q->ny * npx * q->nz * 2 * esz, &dp); if (rc) return rc;
+        const int zv = (q->dtype == RDR_F32 && q->nz % 2 == 0) ? 2 : 1;
+        const int g = grid_for(q->ny * npx * (q->nz / zv), 256, 1 << 22);
+        {
+            KTimer t(c, 3);
+            if (q->dtype == RDR_F32 && zv == 2)
+                hipLaunchKernelGGL((blend_pair_kernel<float2, 2>), dim3(g), dim3(256), 0, c->stream, (const float2*)q->d_vals, (float)B.w1, (const float2*)B.vb, (float)B.w2,
+                                   (float2*)dp, (int)q->ny, (int)q->nx, (int)q->nz);
+            else if (q->dtype == RDR_F32)
+                hipLaunchKernelGGL((blend_pair_kernel<float2, 1>), dim3(g), dim3(256), 0, c->stream, (const float2*)q->d_vals, (float)B.w1, (const float2*)B.vb, (float)B.w2,
+                                   (float2*)dp, (int)q->ny, (int)q->nx, (int)q->nz);
+            else
+                hipLaunchKernelGGL((blend_pair_kernel<double2, 1>), dim3(g), dim3(256), 0, c->stream, (const double2*)q->d_vals, B.w1, (const double2*)B.vb, B.w2,
+                                   (double2*)dp, (int)q->ny, (int)q->nx, (int)q->nz);
+        }
+        HIPCHECK(c, hipGetLastError());
+        B.pair = dp;
+    }
     PointQuery Q; std::memset(&Q, 0, sizeof(Q));
     Q.pmode = pmode; Q.inc0 = inc0;
     const bool has_proj = pmode == 1 || pmode == 3;
@@ -1216,6 +1249,17 @@ int rdr_interp3_blend(rdr_ctx* c, const rdr_cube* a, double w1, const rdr_cube* 
         return fail(c, RDR_ERR_INVALID, "rdr_interp3_blend: the two epochs are not on the same grid / dtype");
     BlendSpec B; B.vb = b->d_vals; B.w1 = w1; B.w2 = w2;
     return interp3_impl(c, "rdr_interp3_blend", a, y, x, z, n, 0, nullptr, 0.0, wet, hydro, loc, B);
+}
+
+int rdr_interp3_blend_cube(rdr_ctx* c, const rdr_cube* a, double w1, const rdr_cube* b, double w2, const double* y, const double* x, const double* z, int64_t n,
+                           double* wet, double* hydro, int loc) {
+    if (!c || !a || !b) return fail(c, RDR_ERR_INVALID, "rdr_interp3_blend_cube: NULL argument");
+    note_use(c, b);
+    if (a->ny != b->ny || a->nx != b->nx || a->nz != b->nz || a->dtype != b->dtype || a->ys != b->ys || a->xs != b->xs || a->zs != b->zs)
+        return fail(c, RDR_ERR_INVALID, "rdr_interp3_blend_cube: the two epochs are not on the same grid / dtype");
+    if (a->ny > INT32_MAX || a->nx > INT32_MAX || a->nz > INT32_MAX) return fail(c, RDR_ERR_INVALID, "rdr_interp3_blend_cube: axis longer than 2^31");
+    BlendSpec B; B.vb = b->d_vals; B.w1 = w1; B.w2 = w2; B.want_pair = true;
+    return interp3_impl(c, "rdr_interp3_blend_cube", a, y, x, z, n, 0, nullptr, 0.0, wet, hydro, loc, B);
 }
 
 int rdr_interp3_project(rdr_ctx* c, const rdr_cube* q, const double* y, const double* x, const double* z, int64_t n, int proj_mode,

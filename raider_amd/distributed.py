@@ -252,10 +252,8 @@ def interp_points_sharded(cube, pts, world=None, rank=None, blend=None):
         wet, hyd = cube.interp(mine)
     else:
         w1, other, w2 = blend
-        if blend_on_the_fly_pays(cube, cnt):
-            wet, hyd = cube.interp_blend(w1, other, w2, mine)
-        else:
-            wet, hyd = cube.blend(w1, other, w2).interp(mine)
+        # (the blended cube has no other reader here: it is made in the gather's own layout, in scratch - Cube.interp_blend(via_cube=True))
+        wet, hyd = cube.interp_blend(w1, other, w2, mine, via_cube=not blend_on_the_fly_pays(cube, cnt))
     return p0, cnt, wet, hyd
 
 

@@ -208,10 +208,13 @@ class Cube:
         check(self.ctx.lib.rdr_interp3(self.ctx.handle, self.handle, ptr(p), p.shape[0], ptr(wet), ptr(hyd), L.RDR_HOST), self.ctx.handle)
         return (None if wet is None else wet.reshape(pts.shape[:-1])), (None if hyd is None else hyd.reshape(pts.shape[:-1]))
 
-    def interp_blend(self, w1, other, w2, pts):
-        """interp() on the temporal blend w1 * self + w2 * other (cli/raider.py:817-819) without making the blended cube: the blend is
-        applied at each point's eight corners (rdr_interp3_blend) - bit for bit what `self.blend(w1, other, w2).interp(pts)` returns.
-        Cheaper than blend-then-gather for point sets below ~5 % of the cube's cells (one rank's station block of a multi-GPU job)."""
+    def interp_blend(self, w1, other, w2, pts, via_cube=False):
+        """interp() on the temporal blend w1 * self + w2 * other (cli/raider.py:817-819) without handing back a blended cube - bit for bit
+        what `self.blend(w1, other, w2).interp(pts)` returns.  via_cube=False: the blend is applied at each point's eight corners
+        (rdr_interp3_blend) - cheaper for point sets below ~5 % of the cube's cells (one rank's station block of a multi-GPU job).
+        via_cube=True: the blend is made as a cube in the context's scratch, in the layout the gather reads best, and gathered in the same
+        call (rdr_interp3_blend_cube) - for point sets large against the cube (distributed.blend_on_the_fly_pays decides)."""
+        entry = self.ctx.lib.rdr_interp3_blend_cube if via_cube else self.ctx.lib.rdr_interp3_blend
         if _is_dev(pts):
             import torch
             if pts.shape[-1] != 3:
@@ -221,7 +224,7 @@ class Cube:
             n = pts.numel() // 3
             wet = torch.empty(pts.shape[:-1], dtype=torch.float64, device=pts.device)
             hyd = torch.empty_like(wet)
-            check(self.ctx.lib.rdr_interp3_blend(self.ctx.handle, self.handle, float(w1), other.handle, float(w2), ptr(pts), None, None, n, ptr(wet), ptr(hyd),
+            check(entry(self.ctx.handle, self.handle, float(w1), other.handle, float(w2), ptr(pts), None, None, n, ptr(wet), ptr(hyd),
                                                  L.RDR_DEVICE), self.ctx.handle)
             return wet, hyd
         pts = np.asarray(pts)
@@ -229,7 +232,7 @@ class Cube:
             raise ValueError(f'The requested sample points xi have dimension {pts.shape[-1]} but this RegularGridInterpolator has dimension 3')
         p = f64(pts).reshape(-1, 3)
         wet = _pinned.empty((p.shape[0],)); hyd = _pinned.empty((p.shape[0],))
-        check(self.ctx.lib.rdr_interp3_blend(self.ctx.handle, self.handle, float(w1), other.handle, float(w2), ptr(p), None, None, p.shape[0], ptr(wet), ptr(hyd),
+        check(entry(self.ctx.handle, self.handle, float(w1), other.handle, float(w2), ptr(p), None, None, p.shape[0], ptr(wet), ptr(hyd),
                                              L.RDR_HOST), self.ctx.handle)
         return wet.reshape(pts.shape[:-1]), hyd.reshape(pts.shape[:-1])
 

@@ -138,14 +138,13 @@ def _points_worker(rank, world, port, q):
         pts = np.arange(3 * 1001, dtype=np.float64).reshape(1001, 3)
         p0, cnt, w, h = D.interp_points_sharded(FakeCube(), pts)
         # the two-epoch blend as part of the query (round 4): the rank's block picks blend-at-the-corners or blended-cube-then-gather by the
-        # byte model; both stand-ins return the same numbers here, which route was taken is recorded
+        # byte model (Cube.interp_blend(via_cube=...)); the stand-in returns the same numbers either way, which route was taken is recorded
         took = []
 
         class FakeEpoch(FakeCube):
             dtype = np.float32
             def __init__(self, shape): self.shape = shape
-            def blend(self, w1, other, w2): took.append('cube'); return self
-            def interp_blend(self, w1, other, w2, p): took.append('corners'); return self.interp(p)
+            def interp_blend(self, w1, other, w2, p, via_cube=False): took.append('cube' if via_cube else 'corners'); return self.interp(p)
         for shape in ((1000, 1000, 50), (10, 10, 5)):         # a big cube (the block is small against it), a tiny one
             b0, bc, bw, bh = D.interp_points_sharded(FakeEpoch(shape), pts, blend=(0.25, FakeEpoch(shape), 0.75))
             assert (b0, bc) == (p0, cnt) and np.array_equal(bw, w) and np.array_equal(bh, h)

@@ -384,6 +384,47 @@ def test_interp_blend_is_blend_then_interp_bit_for_bit():
     assert np.array_equal(w, full[0][p0:p0 + cnt], equal_nan=True) and np.array_equal(h, full[1][p0:p0 + cnt], equal_nan=True)
 
 
+def test_interp_blend_via_paired_cube_is_blend_then_interp_bit_for_bit():
+    """rdr_interp3_blend_cube (round 6): the blend made as a cube in the context's scratch, x columns PAIRED (the layout a random gather reads
+    in 3 lines per point instead of 4), then gathered in the same call == rdr_cube_blend + rdr_interp3 bit for bit: f32 / f64 cubes, odd and
+    even nx and nz (the unpaired last column, the one-z-per-thread blend), descending axes, points ON the last nodes, NaN / outside points, host
+    and device point arrays on both sides of the chunked-transfer threshold; mismatched epochs refused; a NaN in an epoch stays where it was."""
+    import torch
+    import raider_amd as R
+    rng = np.random.default_rng(13)
+    for (ny, nx, nz) in ((37, 41, 19), (20, 24, 12), (5, 2, 2), (4, 3, 7)):
+        ys = np.linspace(30.0, 36.0, ny)[::-1].copy(); xs = np.linspace(-121.0, -113.0, nx); zs = np.round(-100 + 30000 * np.linspace(0, 1, nz) ** 2, 3)
+        for dt_ in (np.float32, np.float64):
+            ea = [rng.normal(100, 30, (nz, ny, nx)).astype(dt_) for _ in range(2)]; eb = [rng.normal(100, 30, (nz, ny, nx)).astype(dt_) for _ in range(2)]
+            if nx == 24:
+                ea[0][3, 7, 9] = np.nan
+            a = R.Cube(ys, xs, zs, ea[0], ea[1], order='zyx'); b = R.Cube(ys, xs, zs, eb[0], eb[1], order='zyx')
+            for w1, w2 in ((0.25, 0.75), (0.6041666666666667, 0.3958333333333333)):
+                m = a.blend(w1, b, w2)
+                for n in (3000, 300_000):
+                    q = np.stack([rng.uniform(29.9, 36.1, n), rng.uniform(-121.0, -113.0, n), rng.uniform(-150, 30100, n)], -1)
+                    q[0] = [np.nan, -117.0, 100.0]
+                    q[1] = [36.0, -113.0, zs[-1]]; q[2] = [30.0, -121.0, zs[0]]; q[3] = [33.0, xs[-1], 500.0]; q[4] = [33.0, xs[-2], 500.0]      # on the last / first nodes
+                    r0 = m.interp(q)
+                    r1 = a.interp_blend(w1, b, w2, q, via_cube=True)
+                    assert np.array_equal(r0[0], r1[0], equal_nan=True) and np.array_equal(r0[1], r1[1], equal_nan=True)
+                    assert np.isnan(r1[0][0]) and np.isfinite(r1[0][1:5]).all() and 0.8 < np.isfinite(r1[0]).mean() < 1.0
+                qd = torch.from_numpy(q).cuda()
+                rd = a.interp_blend(w1, b, w2, qd, via_cube=True)
+                torch.cuda.synchronize()
+                assert np.array_equal(rd[0].cpu().numpy(), r0[0], equal_nan=True) and np.array_equal(rd[1].cpu().numpy(), r0[1], equal_nan=True)
+    other = R.Cube(ys, xs[:-1], zs, ea[0][:, :, :-1].copy(), ea[1][:, :, :-1].copy(), order='zyx')
+    with pytest.raises(ValueError, match='same grid'):
+        a.interp_blend(0.5, other, 0.5, q, via_cube=True)
+    # the sharded station query takes this route when the rank's block is large against the cube - same bits
+    from raider_amd import distributed as D
+    big = np.tile(q, (8, 1))
+    assert not D.blend_on_the_fly_pays(a, big.shape[0])
+    p0, cnt, w, h = D.interp_points_sharded(a, big, world=1, rank=0, blend=(0.25, b, 0.75))
+    full = a.blend(0.25, b, 0.75).interp(big)
+    assert np.array_equal(w, full[0], equal_nan=True) and np.array_equal(h, full[1], equal_nan=True)
+
+
 def test_point_branch_randomised_against_the_two_stage_host_sequence():
     """40 random jobs: model cubes with exact / jittered / descending axes (f64 totals), AOI grids ascending or descending and partly outside
     the model, height lists that leave the model's z range, query points inside / outside / NaN, every projection mode.  The fused call
