@@ -116,6 +116,10 @@ const char* rdr_last_error(rdr_ctx* ctx);
 /* Launch on an external hipStream_t (e.g. torch.cuda.current_stream().cuda_stream).  NULL is HIP's default stream;
  * (void*)-1 goes back to the ctx's private stream.  RDR_DEVICE arrays are only ordered against work on THIS stream. */
 int rdr_set_stream(rdr_ctx* ctx, void* hip_stream);
+/* Tell the context that a stream handed to rdr_set_stream is about to be destroyed: its pending work is waited for if it is still the
+ * current stream (the context then goes back to its private stream) and no event is recorded on it ever again (buffers of destroyed
+ * cubes are recycled behind events on the streams that used them).  Streams that live as long as the process (torch's) need no call. */
+int rdr_forget_stream(rdr_ctx* ctx, void* hip_stream);
 int rdr_synchronize(rdr_ctx* ctx);
 int rdr_device_info(rdr_ctx* ctx, char* name, int name_len, int* compute_units, int64_t* total_mem);
 /* profiling: while on, a HIP event pair brackets every kernel launch on the ctx stream (no sync).
@@ -179,6 +183,11 @@ void rdr_cube_destroy(rdr_cube* cube);
  * every entry that reads it from another stream (or another context) first makes that stream wait for the cube's ready event, and the
  * source device arrays must stay valid in stream order, as for any asynchronous kernel.  rdr_set_stream orders the new stream after
  * everything enqueued on the previous one (the context's scratch and flag words are shared by them).
+ * Small HOST inputs of any entry (the axes of a cube, AOI axes, height lists; up to 1 MiB each) go up through a ring of page-locked
+ * buffers: the caller's array is consumed when the call returns and the host does not wait for work queued earlier on the stream - so the
+ * creation of a cube from device arrays, and rdr_build_cube_to_cube / rdr_raytrace_slices_to_cube with host axes, really are asynchronous
+ * (round 6; before, the pageable copy of the axes waited for the stream).  Larger host inputs are waited for (one event behind their copy):
+ * a host array may be reused as soon as the call that took it returns, whatever memory it lives in.
  * rdr_cube_has_nan: 1 when a NaN was seen among the two source fields while the cube was packed (what delayFcns.py:50-52 scans for on the
  * host: "Weather model contains NaNs!"), 0 otherwise (blended cubes: either source's; a view: its source's), -1 for NULL.  For an
  * asynchronously made cube this call is where the host waits (for that cube's ready event, once). */

@@ -58,6 +58,7 @@ SYMBOLS = [
     ('rdr_destroy', None, [_VP]),
     ('rdr_last_error', C.c_char_p, [_VP]),
     ('rdr_set_stream', C.c_int, [_VP, _VP]),
+    ('rdr_forget_stream', C.c_int, [_VP, _VP]),
     ('rdr_synchronize', C.c_int, [_VP]),
     ('rdr_device_info', C.c_int, [_VP, C.c_char_p, C.c_int, C.POINTER(C.c_int), c_lp]),
     ('rdr_set_profiling', C.c_int, [_VP, C.c_int]),
@@ -280,6 +281,11 @@ class Context:
         """Launch on an external HIP stream (0 / None = HIP's default stream, -1 = the context's private stream)."""
         h = -1 if stream_handle == -1 else (stream_handle or 0)
         check(self.lib.rdr_set_stream(self.handle, C.c_void_p(h)), self.handle)
+
+    def forget_stream(self, stream_handle):
+        """Before DESTROYING a stream once handed to set_stream: the context finishes its work on it and never records an event on it again
+        (rdr_forget_stream).  Streams that live as long as the process - torch's - need no call."""
+        check(self.lib.rdr_forget_stream(self.handle, C.c_void_p(stream_handle or 0)), self.handle)
 
     def adopt_torch_stream(self, tensor):
         """Order this context's kernels with torch work on `tensor`'s device: launch on torch's current stream."""

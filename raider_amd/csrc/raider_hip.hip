@@ -66,6 +66,15 @@ struct rdr_ctx {
     int64_t side_cap = 0;                     // columns of `side` in the current layout
     int* d_sidectr = nullptr;                 // [1] next free column
     int* h_word = nullptr;                    // [16] page-locked host words: flags read back WITHOUT stalling the host before the final sync
+    // Small host inputs (axes, level lists, a cube's three axes) go up through a ring of page-locked buffers: the caller's array is consumed by a
+    // memcpy before the call returns and the device copy is REALLY asynchronous (from pageable memory hipMemcpyAsync first waits for everything
+    // queued on the stream - ADVICE r5).  A slot is reused only after the event recorded behind its last copy.
+    struct PinSlot { void* p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool used = false; };
+    static constexpr int PIN_SLOTS = 16;
+    static constexpr size_t PIN_MAX = (size_t)1 << 20;
+    PinSlot pin[PIN_SLOTS];
+    int pin_next = 0;
+    hipEvent_t staged_ev = nullptr;           // recorded behind a LARGE host input's copy and waited for: the source is consumed when the entry returns
     // cubes made from DEVICE sources are created without a host synchronisation (round 5): their NaN verdict lands in one of these page-locked
     // words and is read when somebody asks (rdr_cube_has_nan), after the cube's ready event; nan_owner[i] = the cube word i is pending for
     static constexpr int NAN_SLOTS = 256;
@@ -111,20 +120,32 @@ struct rdr_cube {
     mutable int views = 0;                       // live views of THIS cube (guarded by g_view_mutex)
     mutable bool doomed = false;                 // destroyed while views were alive: the last view frees the buffers
     mutable std::atomic<bool> foreign{false};    // used from a context other than its own: its buffers are freed synchronously, never pooled
+    // caller streams (rdr_set_stream) this cube was read or written on: its buffers are pooled behind events on THESE streams, not on every
+    // stream the context ever saw (guarded by g_view_mutex; last_stream: the common case - the same stream again - without the lock)
+    mutable std::vector<hipStream_t> used_streams;
+    mutable std::atomic<hipStream_t> last_stream{nullptr};
 };
-static std::mutex g_view_mutex;
+// One lock for the state that a cube shares with its OWNING context and that another context's thread may touch (a cube is usable from any
+// context): view counts, the pending-NaN-verdict slots (nan_owner) and the pool of buffers of destroyed cubes.  Recursive: settling a verdict
+// happens inside a creation.
+static std::recursive_mutex g_view_mutex;
 static inline const rdr_cube* root(const rdr_cube* q) { return q->base ? q->base : q; }
 // every entry point that reads a cube says so: work enqueued by ANOTHER context is not covered by the events the owner records at destroy
 static inline void note_use(const rdr_ctx* c, const rdr_cube* q) {
     if (!c || !q) return;
     const rdr_cube* r = root(q);
     if (r->ctx != c) r->foreign.store(true, std::memory_order_relaxed);
+    if (r->last_stream.load(std::memory_order_relaxed) != c->stream) {
+        std::lock_guard<std::recursive_mutex> guard(g_view_mutex);
+        if (std::find(r->used_streams.begin(), r->used_streams.end(), c->stream) == r->used_streams.end()) r->used_streams.push_back(c->stream);
+        r->last_stream.store(c->stream, std::memory_order_relaxed);
+    }
     // a cube created asynchronously on another stream: this stream's work is ordered after its completion
     if (r->ready_ev && r->ready_stream != c->stream) { (void)hipStreamWaitEvent(c->stream, r->ready_ev, 0); (void)hipGetLastError(); }
 }
 // the pending NaN verdict of an asynchronously created cube (waits for the cube's ready event: the only host wait of such a cube)
 static void cube_resolve_nan(const rdr_cube* r) {
-    std::lock_guard<std::mutex> guard(g_view_mutex);         // (a cube may be asked from two contexts' threads at once)
+    std::lock_guard<std::recursive_mutex> guard(g_view_mutex);         // (a cube may be asked from two contexts' threads at once)
     if (r->nan_slot < 0) return;
     rdr_ctx* c = r->ctx;
     if (r->ready_ev) (void)hipEventSynchronize(r->ready_ev);
@@ -157,27 +178,76 @@ static int cube_mark_ready(rdr_ctx* c, rdr_cube* q) {
     return RDR_OK;
 }
 
+static void pool_drain(rdr_ctx* c);
+// hipMalloc that, when the device is out of memory, first gives back what the context itself is hoarding - the pooled buffers of destroyed
+// cubes (up to 4 GiB) - and tries once more: a job that would fit must not fail on the library's own cache.
+static int dev_malloc(rdr_ctx* ctx, void** p, size_t bytes) {
+    hipError_t e = hipMalloc(p, bytes);
+    if (e == hipErrorOutOfMemory && !ctx->cube_pool.empty()) {
+        (void)hipGetLastError();
+        pool_drain(ctx);
+        e = hipMalloc(p, bytes);
+    }
+    if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); *p = nullptr; return fail(ctx, RDR_ERR_OOM, "out of device memory (" + std::to_string(bytes >> 20) + " MiB asked)"); }
+    if (e != hipSuccess) { *p = nullptr; return fail(ctx, RDR_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e)); }
+    return RDR_OK;
+}
+
 static int ensure(rdr_ctx* ctx, int s, size_t bytes, void** out) {
     DevBuf& b = ctx->slot[s];
     if (bytes > ((size_t)1 << 46)) return fail(ctx, RDR_ERR_INVALID, "a size argument is negative or beyond 64 TiB");
     if (b.cap < bytes) {
         if (b.p) { HIPCHECK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHECK(ctx, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
         size_t cap = std::max(bytes, (size_t)1 << 16);
-        HIPCHECK(ctx, hipMalloc(&b.p, cap));
+        int rc = dev_malloc(ctx, &b.p, cap); if (rc) return rc;
         b.cap = cap;
     }
     *out = b.p;
     return RDR_OK;
 }
 
-// input staging: host -> scratch slot (synchronous w.r.t. host buffer), device -> passthrough
+// Host bytes -> device, stream-ordered, with the source CONSUMED when this returns whatever memory it lives in (pageable or page-locked):
+// up to PIN_MAX through the ring of page-locked buffers (the host never waits for earlier work on the stream); larger ones copied from where
+// they are and waited for (one event behind the copy - which is what a pageable copy costs anyway).
+static int upload(rdr_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    if (bytes == 0) return RDR_OK;
+    if (bytes <= rdr_ctx::PIN_MAX) {
+        rdr_ctx::PinSlot& ps = ctx->pin[ctx->pin_next];
+        ctx->pin_next = (ctx->pin_next + 1) % rdr_ctx::PIN_SLOTS;
+        bool ok = true;
+        if (ps.used) { ok = hipEventSynchronize(ps.ev) == hipSuccess; ps.used = false; }
+        if (ok && ps.cap < bytes) {
+            if (ps.p) { (void)hipHostFree(ps.p); ps.p = nullptr; ps.cap = 0; }
+            const size_t cap = std::max(bytes, (size_t)1 << 14);
+            ok = hipHostMalloc(&ps.p, cap, hipHostMallocDefault) == hipSuccess;
+            if (ok) ps.cap = cap; else ps.p = nullptr;
+        }
+        if (ok && !ps.ev) ok = hipEventCreateWithFlags(&ps.ev, hipEventDisableTiming) == hipSuccess;
+        if (ok) {
+            std::memcpy(ps.p, src, bytes);
+            HIPCHECK(ctx, hipMemcpyAsync(dst, ps.p, bytes, hipMemcpyHostToDevice, ctx->stream));
+            HIPCHECK(ctx, hipEventRecord(ps.ev, ctx->stream));
+            ps.used = true;
+            return RDR_OK;
+        }
+        (void)hipGetLastError();                  // (no page-locked memory to be had: the plain copy below)
+    }
+    HIPCHECK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (!ctx->staged_ev) HIPCHECK(ctx, hipEventCreateWithFlags(&ctx->staged_ev, hipEventDisableTiming));
+    HIPCHECK(ctx, hipEventRecord(ctx->staged_ev, ctx->stream));
+    HIPCHECK(ctx, hipEventSynchronize(ctx->staged_ev));
+    return RDR_OK;
+}
+
+// input staging: host -> scratch slot (the host buffer is consumed when this returns), device -> passthrough
 static int stage_in(rdr_ctx* ctx, int s, const void* src, size_t bytes, int loc, const void** dev) {
     if (!src) { *dev = nullptr; return RDR_OK; }
     if (loc == RDR_DEVICE) { *dev = src; return RDR_OK; }
     void* d;
     int rc = ensure(ctx, s, bytes, &d);
     if (rc) return rc;
-    HIPCHECK(ctx, hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    rc = upload(ctx, d, src, bytes);
+    if (rc) return rc;
     *dev = d;
     return RDR_OK;
 }
@@ -312,6 +382,8 @@ void rdr_destroy(rdr_ctx* c) {
     if (c->d_sidectr) (void)hipFree(c->d_sidectr);
     if (c->h_word) (void)hipHostFree(c->h_word);
     if (c->nan_words) (void)hipHostFree(c->nan_words);
+    for (auto& ps : c->pin) { if (ps.ev) (void)hipEventDestroy(ps.ev); if (ps.p) (void)hipHostFree(ps.p); }
+    if (c->staged_ev) (void)hipEventDestroy(c->staged_ev);
     for (auto& v : c->evs) for (auto& pr : v) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
@@ -338,10 +410,24 @@ int rdr_set_stream(rdr_ctx* c, void* s) {
     if (s == (void*)(intptr_t)-1) c->stream = c->own_stream;
     else {
         c->stream = (hipStream_t)s;
+        std::lock_guard<std::recursive_mutex> guard(g_view_mutex);
         if (std::find(c->ext_streams.begin(), c->ext_streams.end(), c->stream) == c->ext_streams.end()) {
             if (c->ext_streams.size() < 8) c->ext_streams.push_back(c->stream); else c->ext_overflow = true;
         }
     }
+    return RDR_OK;
+}
+
+int rdr_forget_stream(rdr_ctx* c, void* s) {
+    if (!c) return fail(nullptr, RDR_ERR_INVALID, "ctx is NULL");
+    const hipStream_t st = (hipStream_t)s;
+    if (c->stream == st && st != c->own_stream) {           // still the current one: finish its work, go back to the private stream
+        HIPCHECK(c, hipStreamSynchronize(st));
+        c->stream = c->own_stream;
+    }
+    std::lock_guard<std::recursive_mutex> guard(g_view_mutex);
+    c->ext_streams.erase(std::remove(c->ext_streams.begin(), c->ext_streams.end(), st), c->ext_streams.end());
+    if (c->ext_streams.size() < 8) c->ext_overflow = false;
     return RDR_OK;
 }
 
@@ -385,6 +471,19 @@ int rdr_set_workspace_limit(rdr_ctx* c, int64_t bytes) {
     return RDR_OK;
 }
 
+// every pooled buffer back to the device (waits for the events they were retired with)
+static void pool_drain(rdr_ctx* c) {
+    std::lock_guard<std::recursive_mutex> guard(g_view_mutex);
+    while (!c->cube_pool.empty()) {
+        rdr_ctx::PoolEntry e = c->cube_pool.front();
+        c->cube_pool.erase(c->cube_pool.begin());
+        c->cube_pool_bytes -= e.bytes;
+        for (auto ev : e.evs) { (void)hipEventSynchronize(ev); (void)hipEventDestroy(ev); }
+        (void)hipFree(e.p);
+    }
+    (void)hipGetLastError();
+}
+
 int rdr_trim(rdr_ctx* c, int64_t keep_bytes, int64_t* released) {
     if (!c || keep_bytes < 0) return fail(c, RDR_ERR_INVALID, "rdr_trim: NULL context or a negative size");
     HIPCHECK(c, hipSetDevice(c->device));
@@ -399,6 +498,7 @@ int rdr_trim(rdr_ctx* c, int64_t keep_bytes, int64_t* released) {
     if ((c->ws.p && c->ws.cap > keep) || (c->side.p && c->side.cap > keep)) c->wsig.valid = false;      // (the stored ray records go with them)
     drop(c->ws);
     if (c->side.p && c->side.cap > keep) { drop(c->side); c->side_cap = 0; }
+    std::lock_guard<std::recursive_mutex> guard(g_view_mutex);
     while (!c->cube_pool.empty() && c->cube_pool_bytes > keep) {          // oldest first
         rdr_ctx::PoolEntry e = c->cube_pool.front();
         c->cube_pool.erase(c->cube_pool.begin());
@@ -527,6 +627,7 @@ static int cube_alloc(rdr_ctx* c, rdr_cube* q) {
     const size_t vbytes = (total * esz + 255) / 256 * 256;
     const size_t bytes = vbytes + (size_t)(q->ny + q->nx + q->nz) * sizeof(double);
     q->alloc_bytes = bytes;
+    std::unique_lock<std::recursive_mutex> guard(g_view_mutex);
     for (size_t i = 0; i < c->cube_pool.size(); ++i) {
         if (c->cube_pool[i].bytes != bytes) continue;
         const rdr_ctx::PoolEntry e = c->cube_pool[i];
@@ -540,15 +641,16 @@ static int cube_alloc(rdr_ctx* c, rdr_cube* q) {
         q->d_vals = e.p;
         break;
     }
-    if (!q->d_vals) HIPCHECK(c, hipMalloc(&q->d_vals, bytes));
+    if (!q->d_vals) { const int rc = dev_malloc(c, &q->d_vals, bytes); if (rc) { q->alloc_bytes = 0; return rc; } }     // (out of memory: the pool is drained, then once more)
+    guard.unlock();
     q->d_axes = reinterpret_cast<double*>(static_cast<char*>(q->d_vals) + vbytes);
     std::vector<double> ax;
     ax.insert(ax.end(), q->ys.begin(), q->ys.end());
     ax.insert(ax.end(), q->xs.begin(), q->xs.end());
     ax.insert(ax.end(), q->zs.begin(), q->zs.end());
-    // (stream-ordered: a pooled buffer may still be read by work enqueued before the event above; pageable source: the call returns
-    // once the bytes are staged)
-    HIPCHECK(c, hipMemcpyAsync(q->d_axes, ax.data(), ax.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    // (stream-ordered: a pooled buffer may still be read by work enqueued before the event above; through the page-locked ring: the host
+    // does not wait for what the stream is still doing - creation from device sources really is asynchronous)
+    { const int rc = upload(c, q->d_axes, ax.data(), ax.size() * sizeof(double)); if (rc) return rc; }
     axis_uniformity(q->ys, &q->uni[0], &q->inv_d[0], &q->exact[0]);
     axis_uniformity(q->xs, &q->uni[1], &q->inv_d[1], &q->exact[1]);
     axis_uniformity(q->zs, &q->uni[2], &q->inv_d[2]);
@@ -610,13 +712,14 @@ int rdr_cube_create(rdr_ctx* c, const double* ys, int64_t ny, const double* xs, 
     if (loc == RDR_DEVICE) {
         // DEVICE sources (intermediate delay cubes, cubes made from tensors): no host synchronisation.  The verdict travels into a page-locked
         // word and is read when asked for (rdr_cube_has_nan -> cube_resolve_nan); other streams wait for the ready event (note_use).
+        std::unique_lock<std::recursive_mutex> guard(g_view_mutex);                // (the slots are also released by whoever destroys a cube)
         int slot = c->nan_next; c->nan_next = (c->nan_next + 1) % rdr_ctx::NAN_SLOTS;
         if (c->nan_owner[slot]) cube_resolve_nan(c->nan_owner[slot]);              // (a cube 256 creations ago that nobody asked: settle it now)
         c->nan_words[slot] = 0;
         e = hipMemcpyAsync(&c->nan_words[slot], nf, sizeof(int), hipMemcpyDeviceToHost, c->stream);
-        if (e != hipSuccess) { rdr_cube_destroy(q); return fail(c, RDR_ERR_HIP, hipGetErrorString(e)); }
+        if (e != hipSuccess) { guard.unlock(); rdr_cube_destroy(q); return fail(c, RDR_ERR_HIP, hipGetErrorString(e)); }
         rc = cube_mark_ready(c, q);
-        if (rc) { rdr_cube_destroy(q); return rc; }
+        if (rc) { guard.unlock(); rdr_cube_destroy(q); return rc; }
         q->nan_slot = slot; c->nan_owner[slot] = q;
         *out = q;
         return RDR_OK;
@@ -640,14 +743,19 @@ static int cone_params(rdr_ctx* c, const char* who, int kind, const double* p, i
 static void cube_release(rdr_cube* q) {
     rdr_ctx* c = q->ctx;
     if (c) (void)hipSetDevice(c->device);
+    // (may run on a thread of ANOTHER context - the last view of a destroyed source: the owner's slots and pool are under the shared lock)
+    std::lock_guard<std::recursive_mutex> guard(g_view_mutex);
     if (c && q->nan_slot >= 0) { c->nan_owner[q->nan_slot] = nullptr; q->nan_slot = -1; }     // (nobody asked: the word is free again)
     if (q->ready_ev) { (void)hipEventDestroy(q->ready_ev); q->ready_ev = nullptr; }
     bool pooled = false;
     const bool foreign = q->foreign.load(std::memory_order_relaxed);
     if (c && q->d_vals && q->alloc_bytes > 0 && !foreign && !c->ext_overflow && c->cube_pool.size() < 6 &&
         c->cube_pool_bytes + q->alloc_bytes <= c->cube_pool_limit) {
+        // the context's own three streams, and of the caller streams only those this cube was used on AND the context still knows
+        // (rdr_forget_stream drops a stream the caller is about to destroy: no event is ever recorded on a dead handle)
         std::vector<hipStream_t> st = {c->own_stream, c->copy_stream, c->down_stream};
-        for (auto s_ : c->ext_streams) st.push_back(s_);
+        for (auto s_ : c->ext_streams)
+            if (std::find(q->used_streams.begin(), q->used_streams.end(), s_) != q->used_streams.end()) st.push_back(s_);
         if (std::find(st.begin(), st.end(), c->stream) == st.end()) st.push_back(c->stream);
         std::vector<hipEvent_t> evs;
         bool ok = true;
@@ -675,7 +783,7 @@ void rdr_cube_destroy(rdr_cube* q) {
     if (!q) return;
     const rdr_cube* dead_root = nullptr;
     {
-        std::lock_guard<std::mutex> guard(g_view_mutex);
+        std::lock_guard<std::recursive_mutex> guard(g_view_mutex);
         if (q->base) {                                  // a view: only the handle goes; the last view of a destroyed source frees the buffers
             const rdr_cube* r = q->base;
             delete q;
@@ -702,7 +810,7 @@ int rdr_cube_view(rdr_ctx* c, const rdr_cube* src, int kind, const double* p, in
     v->exact[0] = r->exact[0]; v->exact[1] = r->exact[1];
     v->proj = L; v->alloc_bytes = 0; v->base = r;
     note_use(c, r);
-    { std::lock_guard<std::mutex> guard(g_view_mutex); ++r->views; }
+    { std::lock_guard<std::recursive_mutex> guard(g_view_mutex); ++r->views; }
     *out = v;
     return RDR_OK;
 }
@@ -1008,7 +1116,7 @@ static int quad_build(rdr_ctx* c, const rdr_cube* q_any) {
     int nblk = 0;
     const size_t need = quad_need_bytes(q, &nblk);
     void* dq = nullptr;
-    HIPCHECK(c, hipMalloc(&dq, need));
+    { const int rc_ = dev_malloc(c, &dq, need); if (rc_) return rc_; }
     struct Pub { const rdr_cube* q; void* p; size_t need; int nblk; bool ok = false;
                  ~Pub() { if (ok) { q->quad_bytes = need; q->quad_nblk = nblk; q->d_quad = p; } else (void)hipFree(p); } } pub{q, dq, need, nblk};
     const int64_t parts = (int64_t)(need / 16);
@@ -1618,7 +1726,7 @@ static int ws_reserve(rdr_ctx* c, int64_t tiles, int K, RayParams& P) {
     const size_t need = (size_t)tiles * ws_tile_bytes();
     if (c->ws.cap < need) {
         if (c->ws.p) { HIPCHECK(c, hipStreamSynchronize(c->stream)); HIPCHECK(c, hipFree(c->ws.p)); c->ws.p = nullptr; c->ws.cap = 0; }
-        HIPCHECK(c, hipMalloc(&c->ws.p, need));
+        { const int rc_ = dev_malloc(c, &c->ws.p, need); if (rc_) return rc_; }
         c->ws.cap = need;
     }
     const size_t budget = ws_budget(c);
@@ -1626,7 +1734,7 @@ static int ws_reserve(rdr_ctx* c, int64_t tiles, int K, RayParams& P) {
     const size_t sneed = (size_t)cols * (K + 1) * sizeof(double);
     if (c->side.cap < sneed) {
         if (c->side.p) { HIPCHECK(c, hipStreamSynchronize(c->stream)); HIPCHECK(c, hipFree(c->side.p)); c->side.p = nullptr; c->side.cap = 0; }
-        HIPCHECK(c, hipMalloc(&c->side.p, sneed));
+        { const int rc_ = dev_malloc(c, &c->side.p, sneed); if (rc_) return rc_; }
         c->side.cap = sneed;
     }
     c->side_cap = cols;

@@ -341,7 +341,7 @@ class Cube:
             _dev_f64(wet, 'out[0]', nx * ny * nz); _dev_f64(hyd, 'out[1]', nx * ny * nz)
             check(self.ctx.lib.rdr_build_cube(self.ctx.handle, self.handle, ptr(xpts), nx, ptr(ypts), ny, ptr(zpts), nz,
                                               ptr(wet), ptr(hyd), L.RDR_DEVICE), self.ctx.handle)
-            return wet, hyd
+            return (wet, hyd, None) if want_nan else (wet, hyd)       # (device results are not scanned: the call stays asynchronous)
         x, y, z = f64(xpts).ravel(), f64(ypts).ravel(), f64(np.atleast_1d(zpts)).ravel()
         # (large cubes in recycled page-locked memory: the 640 MB of a 1000 x 1000 x 40 zenith cube come down in 12 ms instead of 40-120 ms
         # into freshly mapped pageable pages - _pinned.py)

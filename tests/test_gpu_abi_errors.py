@@ -93,7 +93,7 @@ def test_every_entry_point_survives_null_and_zero_arguments():
     assert res['bad'] == []
     assert res['finite']
     # RDR_OK on all-zero arguments is legal only where "nothing to do" is a meaning: setters, queries, empty batches
-    legal_ok = {'rdr_host_free', 'rdr_set_stream', 'rdr_synchronize', 'rdr_set_profiling', 'rdr_set_side_capacity', 'rdr_cube_has_nan',
+    legal_ok = {'rdr_host_free', 'rdr_set_stream', 'rdr_forget_stream', 'rdr_synchronize', 'rdr_set_profiling', 'rdr_set_side_capacity', 'rdr_cube_has_nan',
                 'rdr_last_nan_output', 'rdr_cube_point_index', 'rdr_trim',      # (rdr_trim(ctx, 0, NULL): free everything, report nothing)
                 # every output pointer of these queries is optional; kind 0 CLEARS a projection; n = 0 points is an empty batch
                 'rdr_cube_axes', 'rdr_cube_shape', 'rdr_device_info', 'rdr_ray_kernel_attributes', 'rdr_cube_set_projection', 'rdr_interp3', 'rdr_interp3_project', 'rdr_interp3_blend', 'rdr_interp3_blend_cube',

@@ -320,3 +320,65 @@ def test_cubes_from_device_sources_are_created_without_a_host_wait_and_still_ord
     ew = (np.float32(0.25) * c['wet'] + np.float32(0.75) * c2['wet']).transpose(1, 2, 0)
     assert np.array_equal(mw, O.blend_cubes(0.25, c['wet'], 0.75, c2['wet']).transpose(1, 2, 0)) or np.array_equal(mw, ew)
     assert m.has_nan() is False
+
+
+def test_cube_creation_does_not_wait_for_the_stream_and_forgotten_streams_are_left_alone():
+    """Round 6: (a) the axes of a new cube go up through the context's page-locked ring, so making a cube from DEVICE arrays returns
+    while a long kernel queued earlier on the same stream is still running (a pageable hipMemcpyAsync first waits for the stream), and the host
+    axes arrays may be overwritten at once; (b) rdr_forget_stream: a caller stream that is about to be destroyed is dropped from the set the
+    context records events on - cubes used on it are still recycled correctly afterwards; (c) out of memory in a cube allocation drains the
+    context's own pool of retired buffers before giving up (rdr_trim reports what is left)."""
+    import time
+    import torch
+    import raider_amd as R
+    from raider_amd.synthetic import synthetic_cube, scene_grid
+    dev = torch.device('cuda:0')
+    ctx = R.Context.default()
+    c = synthetic_cube(300, 300, 80, seed=0)
+    big = R.Cube(c['ys'], c['xs'], c['zs'], c['wet'], c['hydro'], order='zyx')
+    zref = float(c['zs'].max() - 1.0)
+    xp, yp, inc_cols, hd = scene_grid(4000, 4000)
+    xt, yt = torch.from_numpy(xp).to(dev), torch.from_numpy(yp).to(dev)
+    inc = torch.from_numpy(np.ascontiguousarray(np.broadcast_to(inc_cols, (4000, 4000)))).to(dev)
+    rays = R.Rays.grid(xt, yt, inc=inc, hd=torch.full((4000, 4000), hd, dtype=torch.float64, device=dev))
+    ow = torch.empty((4000, 4000), dtype=torch.float64, device=dev); oh = torch.empty_like(ow)
+    big.raytrace(rays, 0.0, zref, out=(ow, oh), want_nparts=False)            # warm-up (workspace)
+    torch.cuda.synchronize()
+    small = synthetic_cube(40, 44, 20, seed=3)
+    wt, ht = torch.from_numpy(small['wet']).to(dev), torch.from_numpy(small['hydro']).to(dev)
+    ref = R.Cube(small['ys'], small['xs'], small['zs'], small['wet'], small['hydro'], order='zyx')
+    q = np.stack([np.linspace(30.5, 35.5, 500), np.linspace(-120.5, -113.5, 500), np.linspace(0.0, 30000.0, 500)], -1)
+    want = ref.interp(q)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        big.raytrace(rays, 0.0, zref, out=(ow, oh), want_nparts=False)        # ~30 ms of queued kernels
+    t_enq = time.perf_counter() - t0
+    ys = small['ys'].copy(); xs = small['xs'].copy(); zs = small['zs'].copy()
+    t0 = time.perf_counter()
+    cube = R.Cube(ys, xs, zs, wt, ht, order='zyx')                             # device sources: axes through the ring, packing kernel queued
+    t_make = time.perf_counter() - t0
+    ys[:] = 0.0; xs[:] = 0.0; zs[:] = 0.0                                     # the axes were consumed by the call
+    torch.cuda.synchronize()
+    t_all = time.perf_counter() - t0
+    assert t_all > 0.010, (t_enq, t_make, t_all)                              # the queue really was long ...
+    assert t_make < 0.5 * t_all, (t_enq, t_make, t_all)                       # ... and the creation did not wait for it
+    got = cube.interp(q)
+    assert np.array_equal(got[0], want[0], equal_nan=True) and np.array_equal(got[1], want[1], equal_nan=True)
+    # (b) a short-lived caller stream
+    h = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(h):
+        qt = torch.from_numpy(q).to(dev)
+        c2 = R.Cube(small['ys'], small['xs'], small['zs'], wt, ht, order='zyx')
+        gw, gh = c2.interp(qt)
+    h.synchronize()
+    assert np.array_equal(gw.cpu().numpy(), want[0], equal_nan=True)
+    ctx.forget_stream(h.cuda_stream)
+    del c2                                                                    # retired: no event may be recorded on the forgotten stream
+    c3 = R.Cube(small['ys'], small['xs'], small['zs'], wt, ht, order='zyx')    # picks the pooled buffer up again
+    g3 = c3.interp(q)
+    assert np.array_equal(g3[0], want[0], equal_nan=True)
+    ctx.forget_stream(h.cuda_stream)                                          # (idempotent)
+    # (c) the pool is the context's to give back
+    del c3, cube
+    freed = ctx.trim(0)
+    assert freed > 0

@@ -26,15 +26,15 @@ def newest(pattern):
             best[d] = f
     return list(best.values())
 
-RND = sys.argv[1] if len(sys.argv) > 1 else 'r05'
+RND = sys.argv[1] if len(sys.argv) > 1 else 'r06'
 # kernels one step of the workload launches once each (bench.py c2_measure / run_c5)
 STEP = {'c2': ('build_cube_setup_kernel', 'build_cube_kernel', 'pack_cube_kernel', 'pack_cube_xfast_kernel', 'interp_points_kernel'),
-        'c5': ('blend_kernel', 'interp_points_kernel', 'interp_points_blend_kernel', 'interp_points_quad_kernel')}
+        'c5': ('blend_kernel', 'blend_pair_kernel', 'interp_points_kernel', 'interp_points_pair_kernel', 'interp_points_blend_kernel', 'interp_points_quad_kernel')}
 
 
 def short(name):
-    for k in ('build_cube_setup_kernel', 'build_cube_kernel', 'pack_cube_xfast_kernel', 'pack_cube_kernel', 'interp_points_blend_kernel', 'interp_points_quad_kernel', 'interp_points_kernel',
-              'blend_kernel', 'quad_build_kernel', 'nan_scan_kernel'):
+    for k in ('build_cube_setup_kernel', 'build_cube_kernel', 'pack_cube_xfast_kernel', 'pack_cube_kernel', 'interp_points_blend_kernel', 'interp_points_quad_kernel', 'interp_points_pair_kernel',
+              'interp_points_kernel', 'blend_pair_kernel', 'blend_kernel', 'quad_build_kernel', 'nan_scan_kernel'):
         if k in name:
             return k
     return None
