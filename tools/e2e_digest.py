@@ -11,7 +11,7 @@ REPO = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(REPO))
 from raider_amd import _lib       # noqa: E402
 
-src = Path(sys.argv[1]); rnd = sys.argv[2] if len(sys.argv) > 2 else 'r04'
+src = Path(sys.argv[1]); rnd = sys.argv[2] if len(sys.argv) > 2 else 'r06'
 
 
 def last_json(name):

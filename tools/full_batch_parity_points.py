@@ -55,6 +55,9 @@ t0 = time.perf_counter()
 py, px = m.project(lat, lon)
 gw, gh = m.interp(np.stack([py, px, hgt], -1))
 t_gpu = time.perf_counter() - t0
+pw, ph = a.interp_blend(0.25, b, 0.75, np.stack([py, px, hgt], -1), via_cube=True)        # round 6: the blend made for the gather (paired x columns, scratch)
+pair_same = bool(np.array_equal(pw, gw, equal_nan=True) and np.array_equal(ph, gh, equal_nan=True))
+del pw, ph
 t0 = time.perf_counter()
 ox, oy = O.lcc_forward(lat, lon, **HRRR)
 iw, ih = O.getInterpolators(xs, ys, zs, bw, bh)
@@ -67,7 +70,7 @@ for s0 in range(0, n, 500000):
         worst[j] = max(worst[j], float(np.nanmax(np.abs(gg - o))))
 res['c5'] = dict(points=n, what='configs[4]: 5 M stations (lon/lat, projected on the device) on the blend of two 1000x1000x50 f32 LCC epochs',
                  max_abs_wet=worst[0], max_abs_hydro=worst[1], max_abs_projection_m=float(max(np.abs(px - ox).max(), np.abs(py - oy).max())),
-                 nan_mask_mismatches=nanmis, gpu_call_s=t_gpu, oracle_s=time.perf_counter() - t0,
+                 nan_mask_mismatches=nanmis, gpu_call_s=t_gpu, oracle_s=time.perf_counter() - t0, paired_blend_route_same_bits=pair_same,
                  note='the field differences are the projection difference (device libm vs NumPy) times the field gradient')
 print(json.dumps(res['c5']), flush=True)
 if out_path:

@@ -66,6 +66,15 @@ os.environ['RAIDER_HIP_POINT_INDEX'] = '0'          # (read once by the library:
 t = timed(lambda: m.interp(pts))
 res['interp_points_kernel'] = dict(what='configs[4]: 5 M random station points on the blended 1000x1000x50 f32 cube, gathered from the (y,x,z) cube', units=npt, unit='points', bytes_per_unit=104,
                                    wall_ms=t * 1e3, reps=REPS + 1)
+# round 6: the same query with the blend made FOR the gather - x columns paired, in scratch (rdr_interp3_blend_cube: blend_pair_kernel + interp_points_pair_kernel)
+t = timed(lambda: a.interp_blend(0.25, b, 0.75, pts, via_cube=True))
+res['blend_pair_kernel'] = dict(what='configs[4]: blend of two 1000x1000x50 f32 epochs written pair-interleaved into the context scratch', units=cells, unit='cells', bytes_per_unit=24,
+                                wall_ms=t * 1e3, reps=REPS + 1, note='wall time is the whole rdr_interp3_blend_cube call (blend + gather)')
+res['interp_points_pair_kernel'] = dict(what='configs[4]: 5 M random station points gathered from the pair-interleaved blend (2 lines per point from an even cell, 4 from an odd one)',
+                                        units=npt, unit='points', bytes_per_unit=104, wall_ms=t * 1e3, reps=REPS + 1, note='wall time is the whole rdr_interp3_blend_cube call (blend + gather)')
+rp = a.interp_blend(0.25, b, 0.75, pts, via_cube=True); rq = m.interp(pts)
+res['pair_route_same_bits'] = bool(torch.equal(rp[0], rq[0]) and torch.equal(rp[1], rq[1]))
+del rp, rq
 tb = timed(lambda: (m.point_index(build=False), m.point_index()), reps=2)
 res['quad_build_kernel'] = dict(what='corner-quad copy of the 1000x1000x50 f32 cube (built once per cube)', units=cells, unit='cells', bytes_per_unit=8 + 128.0 / 3.0,
                                 wall_ms=tb * 1e3, reps=3, note='wall time includes hipMalloc / hipFree of the 2.2 GB copy')

@@ -23,7 +23,7 @@ def newest(pattern):
             best[d] = f
     return list(best.values())
 
-TAG = sys.argv[1] if len(sys.argv) > 1 else 'r04'        # round prefix of the files written under profiles/
+TAG = sys.argv[1] if len(sys.argv) > 1 else 'r06'        # round prefix of the files written under profiles/
 src = REPO / 'gpurun_out' / 'secondary'
 line = [ln for ln in (src / 'bench.json').read_text().splitlines() if ln.startswith('{')][-1]
 res = json.loads(line)

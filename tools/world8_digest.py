@@ -7,7 +7,7 @@ import sys
 from pathlib import Path
 
 REPO = Path(__file__).resolve().parent.parent
-RND = sys.argv[1] if len(sys.argv) > 1 else 'r05'
+RND = sys.argv[1] if len(sys.argv) > 1 else 'r06'
 src = REPO / 'gpurun_out' / 'world8'
 
 
