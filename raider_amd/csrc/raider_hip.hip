@@ -209,6 +209,26 @@ static int ensure(rdr_ctx* ctx, int s, size_t bytes, void** out) {
 // Host bytes -> device, stream-ordered, with the source CONSUMED when this returns whatever memory it lives in (pageable or page-locked):
 // up to PIN_MAX through the ring of page-locked buffers (the host never waits for earlier work on the stream); larger ones copied from where
 // they are and waited for (one event behind the copy - which is what a pageable copy costs anyway).
+// (several host pieces that land back to back on the device go up as ONE copy: every copy is a packet of its own on the stream - four of
+// them per step showed as +20 us on the 0.13 ms step of BASELINE configs[1])
+struct HostPart { const void* p; size_t bytes; };
+static int upload(rdr_ctx* ctx, void* dst, const void* src, size_t bytes);
+static int upload_parts(rdr_ctx* ctx, void* dst, const HostPart* parts, int nparts) {
+    size_t bytes = 0;
+    for (int i = 0; i < nparts; ++i) bytes += parts[i].bytes;
+    if (bytes == 0) return RDR_OK;
+    if (bytes > rdr_ctx::PIN_MAX) {               // too large for the ring: piece by piece
+        size_t o = 0;
+        for (int i = 0; i < nparts; ++i) { const int rc = upload(ctx, static_cast<char*>(dst) + o, parts[i].p, parts[i].bytes); if (rc) return rc; o += parts[i].bytes; }
+        return RDR_OK;
+    }
+    std::vector<char> tmp;                        // (small: at most PIN_MAX; the ring path of upload() consumes it before returning)
+    tmp.resize(bytes);
+    size_t o = 0;
+    for (int i = 0; i < nparts; ++i) { std::memcpy(tmp.data() + o, parts[i].p, parts[i].bytes); o += parts[i].bytes; }
+    return upload(ctx, dst, tmp.data(), bytes);
+}
+
 static int upload(rdr_ctx* ctx, void* dst, const void* src, size_t bytes) {
     if (bytes == 0) return RDR_OK;
     if (bytes <= rdr_ctx::PIN_MAX) {
@@ -620,7 +640,20 @@ static CubeView<T2> make_view(const rdr_cube* q) {
 static bool axes_fit_lds(const rdr_cube* q) { return (size_t)(q->ny + q->nx + q->nz) * sizeof(double) <= (48u << 10); }
 static size_t axes_smem(const rdr_cube* q) { return axes_fit_lds(q) ? (size_t)(q->ny + q->nx + q->nz) * sizeof(double) : 0; }
 
-static int cube_alloc(rdr_ctx* c, rdr_cube* q) {
+// The three axes of a cube from DEVICE copies of the arrays they were given as (any of them possibly descending): one tiny launch instead of
+// one more host copy on the stream (rdr_build_cube_to_cube: the AOI axes went up for the build already).
+struct DevAxes { const double* y = nullptr; const double* x = nullptr; const double* z = nullptr; int fy = 0, fx = 0, fz = 0; };
+__global__ void axes_from_device_kernel(DevAxes a, int ny, int nx, int nz, double* __restrict__ out) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ny + nx + nz; i += gridDim.x * blockDim.x) {
+        double v;
+        if (i < ny) v = a.y[a.fy ? ny - 1 - i : i];
+        else if (i < ny + nx) { const int j = i - ny; v = a.x[a.fx ? nx - 1 - j : j]; }
+        else { const int j = i - ny - nx; v = a.z[a.fz ? nz - 1 - j : j]; }
+        out[i] = v;
+    }
+}
+
+static int cube_alloc(rdr_ctx* c, rdr_cube* q, const DevAxes* dev_axes = nullptr) {
     const size_t esz = q->dtype == RDR_F32 ? 8 : 16;
     const size_t total = (size_t)q->ny * q->nx * q->nz;
     // ONE allocation: the values, then (256 B aligned) the three axes
@@ -650,16 +683,30 @@ static int cube_alloc(rdr_ctx* c, rdr_cube* q) {
     ax.insert(ax.end(), q->zs.begin(), q->zs.end());
     // (stream-ordered: a pooled buffer may still be read by work enqueued before the event above; through the page-locked ring: the host
     // does not wait for what the stream is still doing - creation from device sources really is asynchronous)
-    { const int rc = upload(c, q->d_axes, ax.data(), ax.size() * sizeof(double)); if (rc) return rc; }
+    if (dev_axes && dev_axes->y) {
+        hipLaunchKernelGGL(axes_from_device_kernel, dim3((unsigned)((ax.size() + 255) / 256)), dim3(256), 0, c->stream, *dev_axes, (int)q->ny, (int)q->nx, (int)q->nz, q->d_axes);
+        HIPCHECK(c, hipGetLastError());
+    } else { const int rc = upload(c, q->d_axes, ax.data(), ax.size() * sizeof(double)); if (rc) return rc; }
     axis_uniformity(q->ys, &q->uni[0], &q->inv_d[0], &q->exact[0]);
     axis_uniformity(q->xs, &q->uni[1], &q->inv_d[1], &q->exact[1]);
     axis_uniformity(q->zs, &q->uni[2], &q->inv_d[2]);
     return RDR_OK;
 }
 
+static int cube_create_impl(rdr_ctx* c, const double* ys, int64_t ny, const double* xs, int64_t nx, const double* zs, int64_t nz,
+                            const void* wet, const void* hydro, int dtype, int64_t sy, int64_t sx, int64_t sz, int loc,
+                            rdr_cube** out, const double* const* dev_yxz);
+
 int rdr_cube_create(rdr_ctx* c, const double* ys, int64_t ny, const double* xs, int64_t nx, const double* zs, int64_t nz,
                     const void* wet, const void* hydro, int dtype, int64_t sy, int64_t sx, int64_t sz, int loc,
                     rdr_cube** out) {
+    return cube_create_impl(c, ys, ny, xs, nx, zs, nz, wet, hydro, dtype, sy, sx, sz, loc, out, nullptr);
+}
+
+// dev_yxz: device copies of the three axis arrays AS GIVEN (before any flip), or NULL: the axes go up from the host
+static int cube_create_impl(rdr_ctx* c, const double* ys, int64_t ny, const double* xs, int64_t nx, const double* zs, int64_t nz,
+                            const void* wet, const void* hydro, int dtype, int64_t sy, int64_t sx, int64_t sz, int loc,
+                            rdr_cube** out, const double* const* dev_yxz) {
     if (!c || !out || !ys || !xs || !zs || !wet || !hydro) return fail(c, RDR_ERR_INVALID, "rdr_cube_create: NULL argument");
     const bool swapped = (dtype & RDR_BYTESWAPPED) != 0;       // the source fields are in the other byte order (NetCDF-3: big-endian)
     dtype &= ~RDR_BYTESWAPPED;
@@ -676,7 +723,9 @@ int rdr_cube_create(rdr_ctx* c, const double* ys, int64_t ny, const double* xs, 
     if (fy) std::reverse(q->ys.begin(), q->ys.end());
     if (fx) std::reverse(q->xs.begin(), q->xs.end());
     if (fz) std::reverse(q->zs.begin(), q->zs.end());
-    int rc = cube_alloc(c, q);
+    DevAxes da;
+    if (dev_yxz) { da.y = dev_yxz[0]; da.x = dev_yxz[1]; da.z = dev_yxz[2]; da.fy = fy; da.fx = fx; da.fz = fz; }
+    int rc = cube_alloc(c, q, dev_yxz ? &da : nullptr);
     if (rc) { rdr_cube_destroy(q); return rc; }
     const size_t total = (size_t)ny * nx * nz;
     const size_t esz = dtype == RDR_F32 ? 4 : 8;
@@ -1378,7 +1427,7 @@ int rdr_interp3_project(rdr_ctx* c, const rdr_cube* q, const double* y, const do
 // _build_cube (delay.py:196-216).  keep == NULL: the public entry (results to the caller's wet / hydro at `loc`); keep != NULL: the results
 // stay in the context's scratch (planar (z,y,x), keep[0] = wet, keep[1] = hydro) for rdr_build_cube_to_cube, nothing is downloaded.
 static int build_cube_impl(rdr_ctx* c, const rdr_cube* q, const double* xpts, int64_t nx, const double* ypts, int64_t ny,
-                           const double* zpts, int64_t nz, double* wet, double* hydro, int loc, double** keep) {
+                           const double* zpts, int64_t nz, double* wet, double* hydro, int loc, double** keep, const double** dev_yxz = nullptr) {
     if (!c || !q || !xpts || !ypts || !zpts || (!keep && (!wet || !hydro))) return fail(c, RDR_ERR_INVALID, "rdr_build_cube: NULL argument");
     note_use(c, q);
     if (nx < 0 || ny < 0 || nz < 0) return fail(c, RDR_ERR_INVALID, "rdr_build_cube: negative count");
@@ -1387,9 +1436,15 @@ static int build_cube_impl(rdr_ctx* c, const rdr_cube* q, const double* xpts, in
     if (n == 0) return RDR_OK;
     HIPCHECK(c, hipSetDevice(c->device));
     const void *dx, *dy, *dz; void *dw, *dh;
-    int rc = stage_in(c, SLOT_IN0, xpts, (size_t)nx * 8, loc, &dx); if (rc) return rc;
-    rc = stage_in(c, SLOT_IN1, ypts, (size_t)ny * 8, loc, &dy); if (rc) return rc;
-    rc = stage_in(c, SLOT_IN2, zpts, (size_t)nz * 8, loc, &dz); if (rc) return rc;
+    int rc;
+    if (loc == RDR_HOST) {                        // the three axes in one slot, one copy
+        void* d;
+        rc = ensure(c, SLOT_IN0, (size_t)(nx + ny + nz) * 8, &d); if (rc) return rc;
+        const HostPart parts[3] = {{xpts, (size_t)nx * 8}, {ypts, (size_t)ny * 8}, {zpts, (size_t)nz * 8}};
+        rc = upload_parts(c, d, parts, 3); if (rc) return rc;
+        dx = d; dy = static_cast<const double*>(d) + nx; dz = static_cast<const double*>(d) + nx + ny;
+    } else { dx = xpts; dy = ypts; dz = zpts; }
+    if (dev_yxz) { dev_yxz[0] = (const double*)dy; dev_yxz[1] = (const double*)dx; dev_yxz[2] = (const double*)dz; }
     rc = stage_out(c, SLOT_OUT0, wet, (size_t)n * 8, keep ? RDR_HOST : loc, &dw); if (rc) return rc;
     rc = stage_out(c, SLOT_OUT1, hydro, (size_t)n * 8, keep ? RDR_HOST : loc, &dh); if (rc) return rc;
     // Setup kernel: per-node and per-height records (24 B / 16 B) into scratch; then the gather: 64 x 4-node tiles x chunks of
@@ -1474,11 +1529,12 @@ int rdr_build_cube_to_cube(rdr_ctx* c, const rdr_cube* q, const double* xpts, in
     rc = axis_to_host(c, ypts, ny, loc, hy); if (rc) return rc;
     rc = axis_to_host(c, zpts, nz, loc, hz); if (rc) return rc;
     double* planar[2] = {nullptr, nullptr};
-    rc = build_cube_impl(c, q, xpts, nx, ypts, ny, zpts, nz, nullptr, nullptr, loc, planar); if (rc) return rc;
+    const double* dev_yxz[3] = {nullptr, nullptr, nullptr};       // the axes as the build has them on the device (scratch slot / the caller's arrays)
+    rc = build_cube_impl(c, q, xpts, nx, ypts, ny, zpts, nz, nullptr, nullptr, loc, planar, dev_yxz); if (rc) return rc;
     // planar (z,y,x) results -> interleaved (y,x,z) cube with axes (ypts, xpts, zpts): what getInterpolators(ds, 'ztd') builds from the
     // Dataset of writeResultsToXarray (delay.py:113, delayFcns.py:40-41), descending axes flipped as scipy does; its NaN scan
     // (delayFcns.py:50-52 on this cube == np.isnan(result).any(), delay.py:187) comes with the packing
-    return rdr_cube_create(c, hy.data(), ny, hx.data(), nx, hz.data(), nz, planar[0], planar[1], RDR_F64, nx, 1, ny * nx, RDR_DEVICE, out);
+    return cube_create_impl(c, hy.data(), ny, hx.data(), nx, hz.data(), nz, planar[0], planar[1], RDR_F64, nx, 1, ny * nx, RDR_DEVICE, out, dev_yxz);
 }
 
 

@@ -32,7 +32,7 @@ subprocess.run([sys.executable, str(REPO / 'tools' / 'rocprof_summary.py'), stat
                 'tools/secondary_bench.py: configs 2 / 5 sizes, producer, orbit look vectors'], check=True, stdout=subprocess.DEVNULL)
 rows = list(csv.DictReader(open(stats)))
 for k, d in res.items():
-    if 'units' not in d:
+    if not isinstance(d, dict) or 'units' not in d:
         continue
     cand = [r for r in rows if k in r['Name']]
     if not cand:
@@ -55,7 +55,7 @@ def pmc(sub, counter):
 
 fetch, write = pmc('fetch', 'FETCH_SIZE'), pmc('write', 'WRITE_SIZE')
 for k, d in res.items():
-    if 'units' not in d:
+    if not isinstance(d, dict) or 'units' not in d:
         continue
     fr = [v for name, vals in fetch.items() if k in name for v in vals]
     wr = [v for name, vals in write.items() if k in name for v in vals]
@@ -83,7 +83,7 @@ for sub in ('sq1', 'sq2'):
     for (name, cn), vals in sq(sub).items():
         sqc.setdefault(name, {})[cn] = sorted(vals)[len(vals) // 2]
 for k, d in res.items():
-    if 'units' not in d:
+    if not isinstance(d, dict) or 'units' not in d:
         continue
     hit = [v for name, v in sqc.items() if k in name]
     if not hit or 'rocprof_avg_us' not in d:
