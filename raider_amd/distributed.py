@@ -223,11 +223,12 @@ def raytrace_heights_sharded(cube, rays_for, hts, zref, max_seg=1000.0, world=No
 
 
 def blend_on_the_fly_pays(cube, npoints):
-    """The two ways to interpolate the two-epoch blend at `npoints` points of one rank: make the blended cube (24 B per cell of HBM
-    traffic, the SAME on every rank) and gather from it (4 lines = 572 B per random point, measured), or blend at the corners
-    (Cube.interp_blend: 8 lines per point, no cube).  On the fly pays when the extra 572 B per point stay below the blend's bytes."""
+    """The two ways to interpolate the two-epoch blend at `npoints` points of one rank: apply it at the corners (Cube.interp_blend: 8 cache
+    lines = 1144 B per random point, no cube), or make the blended cube for the gather - 26 B per cell measured, the SAME on every rank,
+    written pair-interleaved into scratch - and gather from it (3 lines = 463 B per point measured; profiles/r06_secondary.json).  On the
+    fly pays when its extra 681 B per point stay below the blend's bytes: below ~1.9 M points on a 50 M-cell f32 cube."""
     ny, nx, nz = cube.shape
-    return 572.0 * npoints < 24.0 * ny * nx * nz * (1.0 if cube.dtype == np.float32 else 2.0)
+    return 681.0 * npoints < 26.0 * ny * nx * nz * (1.0 if cube.dtype == np.float32 else 2.0)
 
 
 def interp_points_sharded(cube, pts, world=None, rank=None, blend=None):

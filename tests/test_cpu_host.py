@@ -335,7 +335,7 @@ def test_round4_host_logic_without_a_gpu(tmp_path, monkeypatch):
         shape = (1000, 1000, 50); dtype = np.float32
     assert blend_on_the_fly_pays(_C, 625_000) and not blend_on_the_fly_pays(_C, 5_000_000)
     _C.dtype = np.float64
-    assert blend_on_the_fly_pays(_C, 4_000_000)             # an f64 blend moves twice the bytes per cell
+    assert blend_on_the_fly_pays(_C, 3_500_000)             # an f64 blend moves twice the bytes per cell
 
     monkeypatch.delenv('RAIDER_HIP_PINNED_POOL_BYTES', raising=False)
     monkeypatch.setenv('LOCAL_WORLD_SIZE', '8')
@@ -348,3 +348,37 @@ def test_round4_host_logic_without_a_gpu(tmp_path, monkeypatch):
     assert isinstance(r, list) and r.has_nan is None and len(r) == 2 and h[0] == 1.0
     r.has_nan = True
     assert r.has_nan is True and _Result().has_nan is None  # (per instance, not shared)
+
+
+def test_round6_host_logic_without_a_gpu():
+    """Round 6, the parts that need no GPU: the real level axes shipped as data (models/model_levels.py: ERA5's 145 heights, HRRR's 50 + 7), a
+    synthetic cube on a given z axis, the byte model that routes a two-epoch station query, and the scaling-efficiency arithmetic of an N > 1
+    bench line."""
+    import importlib.util
+    from raider_amd.synthetic import synthetic_cube, real_level_heights
+    from raider_amd import distributed as D
+    e, h = real_level_heights('era5'), real_level_heights('hrrr')
+    assert e.shape == (145,) and h.shape == (57,) and np.all(np.diff(e) > 0) and np.all(np.diff(h) > 0)
+    assert e[0] == -500.0 and e[-1] == 80301.65 and h[0] == -500.0 and abs(h[-1] - 26158.0385) < 1e-9 and 0.0 in e and 0.0 in h
+    c = synthetic_cube(6, 7, h.size, seed=0, zs=h)
+    assert c['wet'].shape == (57, 6, 7) and c['wet'].dtype == np.float32 and np.array_equal(c['zs'], h)
+    assert np.allclose(c['hydro_total'][-1], 0.0) and (np.diff(c['hydro_total'], axis=0) < 0).all()      # totals integrate downwards from the top
+    with pytest.raises(ValueError):
+        synthetic_cube(6, 7, 5, zs=h)                          # nz must match
+    with pytest.raises(ValueError):
+        synthetic_cube(6, 7, 57, zs=h[::-1])                   # ascending
+    assert np.array_equal(synthetic_cube(5, 5, 8, seed=3)['zs'], np.round(-100 + 41000.0 * np.linspace(0, 1, 8) ** 2, 3))      # the default axis is unchanged
+
+    class Shape:
+        def __init__(self, shape, dtype): self.shape, self.dtype = shape, dtype
+    hrrr = Shape((1000, 1000, 50), np.float32)
+    assert D.blend_on_the_fly_pays(hrrr, 625_000) and D.blend_on_the_fly_pays(hrrr, 1_800_000) and not D.blend_on_the_fly_pays(hrrr, 2_000_000)
+    assert not D.blend_on_the_fly_pays(hrrr, 5_000_000)                                                   # one GPU holding all of configs[4]: the paired cube
+    assert D.blend_on_the_fly_pays(Shape((1000, 1000, 50), np.float64), 3_500_000)                        # f64 cells cost twice as much to blend
+
+    spec = importlib.util.spec_from_file_location('bench_for_test', Path(__file__).resolve().parent.parent / 'bench.py')
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    one, eff = bench.scaling_reference('strong', 40.0, 1.0e8, 8, 5.5, 3, 'x')
+    assert abs(eff - 40.0 / (8 * 5.5)) < 1e-15 and abs(one['value'] - 1.0e8 / 0.040) < 1e-3 and one['steps'] == 3
+    one, eff = bench.scaling_reference('weak', 6.0, 1.6e7, 8, 6.3, 3, 'x')
+    assert abs(eff - 6.0 / 6.3) < 1e-15 and abs(one['value'] - 1.6e7 / 0.006) < 1e-3
