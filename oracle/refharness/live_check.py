@@ -33,6 +33,21 @@ for seed in (101, 102, 103, 104):
     assert np.isfinite(hydro).all()
     worst = max(worst, float(np.abs(ow - wet).max()), float(np.abs(oh - hydro).max()))
 out['ray_max_abs_m'] = worst
+# An origin ABOVE zref inside zref's own model interval (round 6): the reference's level tests leave ONE reversed segment (losreader.py:785-808),
+# integrated with its positive length (np.linalg.norm, :821) - the quirk the GPU kernels got wrong until the fuzz drew it; an origin above the
+# interval's top node has no level.  The unmodified reference against the oracle on exactly that.
+cube = O.synthetic_cube(18, 17, 6, seed=5, ztop=15000.0)          # zs = -100, 500, 2300, 5300, 9500, 14900
+xpts = np.linspace(cube['xs'][5], cube['xs'][11], 7); ypts = np.linspace(cube['ys'][12], cube['ys'][5], 6)
+rng = np.random.default_rng(9)
+inc = rng.uniform(5, 60, (6, 7)); hd = rng.uniform(-180, 180, (6, 7))
+zpts = np.array([8000.0, 8941.5, 9000.0, 9400.0, 9499.0, 9600.0])
+wet, hydro, nparts = H.run_ray(cube, xpts, ypts, zpts, inc, hd, 8940.0, 400.0)
+ip = list(O.getInterpolators(cube['xs'], cube['ys'], cube['zs'], cube['wet'], cube['hydro']))
+look = lambda ht, llh, xyz, yy: O.look_vectors_from_inc_hd(inc, hd, llh[1], llh[0], llh[2])
+(ow, oh), onp = O.build_cube_ray(xpts, ypts, zpts, look, ip, MAX_SEGMENT_LENGTH=400.0, MAX_TROPO_HEIGHT=8940.0, return_nparts=True)
+assert all((a is None and b is None) or np.array_equal(a, b) for a, b in zip(nparts, onp)), 'nParts (reversed segment)'
+assert (hydro[1:5] > 0).all() and (hydro[5] == 0).all() and np.isfinite(hydro).all()
+out['reversed_segment_max_abs_m'] = float(max(np.abs(ow - wet).max(), np.abs(oh - hydro).max()))
 
 rng = np.random.default_rng(7)
 cube = O.synthetic_cube(30, 28, 25, seed=77)

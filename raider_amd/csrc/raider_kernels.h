@@ -848,7 +848,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
                 double t_lo = t_hi;
                 if (k == k0) t_lo = toa_newton_t(ox, oy, oz, lx, ly, lz, lo, 10, 1.0);
                 t_hi = toa_newton_t(ox, oy, oz, lx, ly, lz, hi, k == k0 ? 10 : 3, inv_cosf);
-                const double L = (t_hi - t_lo) * nl;
+                const double L = fabs(t_hi - t_lo) * nl;                                   // np.linalg.norm(high - low) (losreader.py:821): positive also for the
+                                                                                            // reversed segment of an origin ABOVE zref inside zref's model interval
                 if (k == k0) inv_cosf = L / (hi - lo);                                      // 1/cos_factor, losreader.py:824-825
                 if (sd) {
                     if (k == k0) sd[0] = t_lo;
@@ -871,8 +872,11 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
             // ---- light rays: fit h(u), lat(u), lon(u) once, then everything is polynomial arithmetic.
             // Range of the ray parameter any Newton iterate / sample can take: iterates start at t0 = level height
             // (>= ht) and move monotonically to the crossing, which lies in [0, (zref - ht)/cos(inc)].
-            const double t_a = fmin(0.0, hti) - 1.0;
-            const double t_b = fmax(P.zref, (P.zref - hti) / (cosi * nl)) + 1.0;
+            // (an origin ABOVE zref inside zref's model interval - the reference's one reversed segment, low_ht = ht > high_ht = zref - starts its
+            // iterates at t0 = ht and ends them at a NEGATIVE ray parameter: both belong to the range.  Unchanged for ht <= zref.)
+            const double t_end = (P.zref - hti) / (cosi * nl);
+            const double t_a = fmin(fmin(0.0, hti), t_end) - 1.0;
+            const double t_b = fmax(fmax(P.zref, hti), t_end) + 1.0;
             const double half = 0.5 * (t_b - t_a), mid = 0.5 * (t_b + t_a);
             const double su = 1.0 / half, ou = -mid * su;
             RayPoly q;
@@ -914,7 +918,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
                     u_lo = fma(lo - poly5(q.h, u_lo), su, u_lo);
                     u_hi = fma(hi - poly5(q.h, u_hi), su, u_hi);
                 }
-                const double L = (u_hi - u_lo) * scale;
+                const double L = fabs(u_hi - u_lo) * scale;                                    // a norm (losreader.py:821): an origin above zref in zref's own model
+                                                                                               // interval gives ONE reversed segment (low_ht = ht > high_ht = zref) of positive length
                 last_len = L;
                 gain = su * (L / (hi - lo));                                                   // su / cos_factor, losreader.py:824-825
                 if (w && mine) { w[(int64_t)WS_U0 * ns] = u_lo; w[(int64_t)WS_U1 * ns] = u_hi; }
@@ -954,7 +959,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
                         const double st = poly7(xm, m.xv[k]);
                         const double L = st - (k == k0 + 1 ? s_first : s_hi);
                         s_hi = st;
-                        atomicMax(&mxc[k * MXCOLS], (unsigned long long)__double_as_longlong(k > k0 ? fmax(L, 0.0) : 0.0));
+                        atomicMax(&mxc[k * MXCOLS], (unsigned long long)__double_as_longlong(k > k0 ? fmax(fabs(L), 0.0) : 0.0));
                     }
                 }
                 for (; k + 2 <= K; k += 2) {
@@ -962,14 +967,14 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
                     const double sa = poly7(xm, v0), sb = poly7(xm, v1);
                     const double La = sa - s_hi, Lb = sb - sa;
                     s_hi = sb;
-                    atomicMax(&mxc[k * MXCOLS], (unsigned long long)__double_as_longlong(fmax(La, 0.0)));
-                    atomicMax(&mxc[(k + 1) * MXCOLS], (unsigned long long)__double_as_longlong(fmax(Lb, 0.0)));
+                    atomicMax(&mxc[k * MXCOLS], (unsigned long long)__double_as_longlong(fmax(fabs(La), 0.0)));
+                    atomicMax(&mxc[(k + 1) * MXCOLS], (unsigned long long)__double_as_longlong(fmax(fabs(Lb), 0.0)));
                 }
                 for (; k < K; ++k) {
                     const double st = poly7(xm, m.xv[k]);
                     const double L = st - s_hi;
                     s_hi = st;
-                    atomicMax(&mxc[k * MXCOLS], (unsigned long long)__double_as_longlong(fmax(L, 0.0)));
+                    atomicMax(&mxc[k * MXCOLS], (unsigned long long)__double_as_longlong(fmax(fabs(L), 0.0)));
                 }
                 if (PR ? (k0 + 1 < K) : (K > 1)) last_len = u_end * scale;                    // (only its NaN-ness is used)
                 if (K > 0 && cnt && !(poly5(q.h, u_end) > c.z_hi)) my_flags |= 8;              // last sample of the ray
@@ -1152,7 +1157,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
                     const int kzf = m.kz[kf];
                     PendingSample<T2> s;
                     issue_top(fma(0.0 * m.step[kf], du, u_k), window2_base(c.nz, kzf - ((lo_first <= m.ax.ez[kzf].x) ? 1 : 0)), clamp_lo, false, s);
-                    if (has) finish(s, m.hs[kf] * du);
+                    if (has) finish(s, m.hs[kf] * fabs(du));
                 }
 #pragma unroll 1
                 for (int k = kmin; k < K; ++k) {
@@ -1162,7 +1167,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
                     const bool more = k + 1 < K;
                     if (k >= k0) {
                         const int zbase = window2_base(c.nz, kz);
-                        const double w_mid = (2.0 * hs) * du;
+                        const double w_mid = (2.0 * hs) * fabs(du);
 #pragma unroll 1
                         for (int j = 1; j < np - 1; ++j) {
                             PendingSample<T2> s;
@@ -1172,11 +1177,11 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
                         PendingSample<T2> top;
                         issue_top(u_k + du, zbase, false, clamp_hi && !more, top);
                         double du1 = 0.0;
-                        double w_top = hs * du;
+                        double w_top = hs * fabs(du);
                         if (more) {
                             const double t2 = poly7(xc, m.xv[k + 1]);
                             du1 = t2 - u_last; u_last = t2;
-                            w_top = fma(m.hs[k + 1], du1, w_top);
+                            w_top = fma(m.hs[k + 1], fabs(du1), w_top);
                         }
                         finish(top, w_top);
                         u_k += du; du = du1;
@@ -1199,14 +1204,15 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
             if (K > 0) {
                 PendingSample<T2> s;
                 issue_top(fma(0.0 * rec->step, du, u_k), window2_base(c.nz, kz - ((m.lo[0] <= m.ax.ez[kz].x) ? 1 : 0)), clamp_lo, false, s);
-                finish(s, hs * du);
+                finish(s, hs * fabs(du));
             }
 #pragma unroll 1
             for (int k = 0; k < K; ++k) {
                 const int zbase = window2_base(c.nz, kz);                            // first table entry of the two-entry z window
                 const bool more = k + 1 < K;
-                // trapezoid weights per unit of u (delay.py:314-315): interior samples, and the top one with both its segments
-                const double w_mid = (2.0 * hs) * du;
+                // trapezoid weights per unit of u (delay.py:314-315): interior samples, and the top one with both its segments.  The weight is the
+                // segment's LENGTH (a norm, losreader.py:821): |du| - an origin above zref in zref's model interval walks its one segment downwards
+                const double w_mid = (2.0 * hs) * fabs(du);
                 if (np > 2) {
                     const double step = rec->step, gk = rec->gk, rk = rec->rk;
 #pragma unroll 1
@@ -1254,7 +1260,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
                 const double t2 = poly7(xc, rec[1].xv);
                 const double du1 = t2 - u_last, hs1 = rec[1].hs;
                 u_last = t2;
-                const double w_top = fma(hs1, du1, hs * du);
+                const double w_top = fma(hs1, fabs(du1), hs * fabs(du));
                 npkz = __builtin_amdgcn_readfirstlane(rec[1].npkz);
                 finish(top, w_top);
                 u_k += du; du = du1; hs = hs1;
@@ -1357,13 +1363,13 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
                     const double plat = poly5(q.lat, fma(0.0 * step, du, u_k)), plon = poly5(q.lon, fma(0.0 * step, du, u_k));
                     if (clamp_lo) { asm volatile("" ::: "memory"); ph = fmax(ph, c.z_lo); }
                     sample_issue<T2, 1, true>(c, m.ax, plat, plon, ph, window2_base(c.nz, kz - ((m.lo[0] <= m.ax.ez[kz].x) ? 1 : 0)), s0);
-                    finish(s0, hs * du);
+                    finish(s0, hs * fabs(du));
                 }
 #pragma unroll 1
                 for (int k = 0; k < K; ++k) {
                     zb = window2_base(c.nz, kz);
                     const bool more = k + 1 < K;
-                    const double w_mid = (2.0 * hs) * du;
+                    const double w_mid = (2.0 * hs) * fabs(du);
                     // the level's TOP sample first: its cell places the staged block
                     PendingSample<T2> top;
                     double ph = poly5(q.h, u_k + du);
@@ -1397,11 +1403,11 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
                     }
                     fetch(iy, ix, iz, top);
                     double du1 = 0.0, hs1 = 0.0;
-                    double w_top = hs * du;
+                    double w_top = hs * fabs(du);
                     if (more) {
                         const double t2 = poly7(xc, m.xv[k + 1]);
                         du1 = t2 - u_last; u_last = t2; hs1 = m.hs[k + 1];
-                        w_top = fma(hs1, du1, w_top);
+                        w_top = fma(hs1, fabs(du1), w_top);
                     }
                     finish(top, w_top);
                     u_k += du; du = du1; hs = hs1;
@@ -1443,12 +1449,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SLOW ? 1 
                     if (k + 2 <= K) t_next = sd[(int64_t)(k + 2) * P.side_cap];
                 } else if (mine) {
                     t_hi = toa_newton_t(ox, oy, oz, lx, ly, lz, m.hi[k], k == k0 ? 10 : 3, inv_cosf);
-                    if (k == k0) inv_cosf = ((t_hi - t_lo) * scale) / (m.hi[k0] - lo_first);   // losreader.py:824-825, as in pass 1
+                    if (k == k0) inv_cosf = (fabs(t_hi - t_lo) * scale) / (m.hi[k0] - lo_first);   // losreader.py:824-825, as in pass 1
                 }
                 const double dt = t_hi - t_lo;
                 const int np = m.np[k];
                 const double step = m.step[k];
-                const double segw = (dt * scale * 1.0e-6) * step;    // delay.py:315: L*1e-6/(np-1), L = |high-low| (losreader.py:821)
+                const double segw = (fabs(dt) * scale * 1.0e-6) * step;    // delay.py:315: L*1e-6/(np-1), L = |high-low| (losreader.py:821)
                 const double dts = dt * step;                        // sample spacing: low + (j*step)*(high-low), delay.py:292
                 const int kz = m.kz[k];
                 // j = 0 of this segment is the SAME point as j = np-1 of the previous one (low_xyz is high_xyz,

@@ -476,3 +476,70 @@ def test_f64_cube_marcher_lds_staging_gives_the_f32_kernels_bits(R):
                 assert np.array_equal(a[2], b[2]), (name, inc, ht)
                 assert np.array_equal(a[0], b[0], equal_nan=True) and np.array_equal(a[1], b[1], equal_nan=True), (name, inc, ht)
                 assert np.isfinite(a[1]).mean() > (0.3 if name == 'corner' else 0.9)
+
+
+def test_origin_above_zref_walks_its_one_segment_downwards(R):
+    """Round 6, found by new fuzz seeds in a path round 5 already shipped: an origin ABOVE zref but inside zref's own model interval gets ONE
+    segment from the reference's level tests (losreader.py:785-808: low_ht = ht > high_ht = zref, |high - low| >= 1 m) - walked downwards, with
+    a POSITIVE length (np.linalg.norm, losreader.py:821) and hence positive trapezoid weights and nParts = ceil(|L| / 1000) + 1.  The kernels took
+    the signed difference of the two crossings: negative weights (delays of the wrong sign) and a zero slice maximum.  Slices, per-pixel heights
+    straddling zref, point lists, the generic-geodesy kernels (polar scene) and both cube dtypes against the oracle; an origin above the
+    interval's top node still has no level at all."""
+    from oracle import oracle_c as OC
+    c = O.synthetic_cube(18, 17, 6, seed=5, ztop=15000.0)             # zs = -100, 500, 2300, 5300, 9500, 14900
+    assert list(c['zs']) == [-100.0, 500.0, 2300.0, 5300.0, 9500.0, 14900.0]
+    zref = 8940.0
+    cube = R.Cube(c['ys'], c['xs'], c['zs'], c['wet'], c['hydro'], order='zyx')
+    ip = list(O.getInterpolators(c['xs'], c['ys'], c['zs'], c['wet'], c['hydro']))
+    xpts = np.linspace(c['xs'][5], c['xs'][11], 19); ypts = np.linspace(c['ys'][12], c['ys'][5], 14)
+    xx, yy = np.meshgrid(xpts, ypts)
+    for inc in (12.0, 38.0, 61.0):
+        look = lambda ht, llh, xyz, yy_: O.look_vectors_from_inc_hd(np.full(yy_.shape, inc), np.full(yy_.shape, -167.9), llh[1], llh[0], llh[2])
+        for ht in (8000.0, 8939.5, 8941.5, 9000.0, 9400.0, 9499.0):
+            (ow, oh), onp = O.build_cube_ray(xpts, ypts, np.array([ht]), look, ip, MAX_TROPO_HEIGHT=zref, return_nparts=True)
+            rays = R.Rays.grid(xpts, ypts, inc=inc, hd=-167.9)
+            if onp[0] is None:                                         # |zref - ht| < 1 m: no level, zero delay (a top slice)
+                with pytest.raises(R.NoLevels):
+                    cube.raytrace(rays, ht, zref)
+                continue
+            wet, hyd, nparts, _ = cube.raytrace(rays, ht, zref)
+            assert np.array_equal(nparts, onp[0]) and (hyd > 0).all() and (oh[0] > 0).all(), (inc, ht, nparts, onp[0])
+            np.testing.assert_allclose(wet, ow[0], rtol=0, atol=TIGHT)
+            np.testing.assert_allclose(hyd, oh[0], rtol=0, atol=TIGHT)
+            # the same rays as a point list with ECEF look vectors
+            los = O.look_vectors_from_inc_hd(np.full(yy.shape, inc), np.full(yy.shape, -167.9), yy, xx, ht)
+            pw, ph, pn, _ = cube.raytrace(R.Rays.points(lat=yy.ravel().copy(), lon=xx.ravel().copy(), los=np.ascontiguousarray(los).reshape(-1, 3)), ht, zref)
+            assert np.array_equal(pn, nparts)
+            np.testing.assert_allclose(ph.reshape(yy.shape), oh[0], rtol=0, atol=TIGHT)
+    with pytest.raises(R.NoLevels):                                     # above the interval's top node: zref's interval is skipped (high_ht < ht), the next starts above zref
+        cube.raytrace(R.Rays.grid(xpts, ypts, inc=38.0, hd=-167.9), 9600.0, zref)
+    # a long reversed segment: the slice maximum is the REVERSED rays' length (nParts = 3 at 61 deg from 9499 m with 400 m segments)
+    look = lambda ht, llh, xyz, yy_: O.look_vectors_from_inc_hd(np.full(yy_.shape, 61.0), np.full(yy_.shape, -167.9), llh[1], llh[0], llh[2])
+    (ow, oh), onp = O.build_cube_ray(xpts, ypts, np.array([9499.0]), look, ip, MAX_SEGMENT_LENGTH=400.0, MAX_TROPO_HEIGHT=zref, return_nparts=True)
+    wet, hyd, nparts, _ = cube.raytrace(R.Rays.grid(xpts, ypts, inc=61.0, hd=-167.9), 9499.0, zref, max_seg=400.0)
+    assert np.array_equal(nparts, onp[0]) and nparts[0] >= 4
+    np.testing.assert_allclose(hyd, oh[0], rtol=0, atol=TIGHT)
+    # per-pixel heights on both sides of zref (the fuzz case): against the C oracle's per-ray rule
+    rng = np.random.default_rng(8)
+    hts = rng.uniform(5400.0, 9490.0, yy.shape)
+    hts[0, :4] = [8939.7, 8940.4, 8941.2, 9499.9]
+    los = O.look_vectors_from_inc_hd(np.full(yy.shape, 33.0), np.full(yy.shape, -167.9), yy, xx, hts)
+    cc = dict(c, ys=c['ys'], wet=c['wet'], hydro=c['hydro'])
+    qw, qh, qnp = OC.build_cube_ray_per_pixel(cc, yy, xx, hts, los, zref, max_seg=700.0)
+    pw, ph, pnp, _ = cube.raytrace(R.Rays.grid(xpts, ypts, los=np.ascontiguousarray(los), hts=hts), None, zref, 700.0)
+    kzt = cube.ray_levels(float(hts.min()), zref)[2]
+    assert np.array_equal(pnp, qnp[kzt]) and (hts > zref).sum() > 20
+    np.testing.assert_allclose(pw, qw, rtol=0, atol=TIGHT)
+    np.testing.assert_allclose(ph, qh, rtol=0, atol=TIGHT)
+    # the generic-geodesy kernels (a polar scene: every ray is classified generic) and an f64 cube
+    cp = O.synthetic_cube(12, 40, 6, seed=6, ztop=15000.0, y0=86.0, y1=89.9, x0=-60.0, x1=60.0)
+    for dt_ in (np.float32, np.float64):
+        cubep = R.Cube(cp['ys'], cp['xs'], cp['zs'], cp['wet'].astype(dt_), cp['hydro'].astype(dt_), order='zyx')
+        ipp = list(O.getInterpolators(cp['xs'], cp['ys'], cp['zs'], cp['wet'].astype(dt_), cp['hydro'].astype(dt_)))
+        xp = np.linspace(-20.0, 20.0, 9); yp = np.linspace(88.9, 88.0, 7)
+        look = lambda ht, llh, xyz, yy_: O.look_vectors_from_inc_hd(np.full(yy_.shape, 30.0), np.full(yy_.shape, -167.9), llh[1], llh[0], llh[2])
+        (ow, oh), onp = O.build_cube_ray(xp, yp, np.array([9300.0]), look, ipp, MAX_TROPO_HEIGHT=zref, return_nparts=True)
+        wet, hyd, nparts, _ = cubep.raytrace(R.Rays.grid(xp, yp, inc=30.0, hd=-167.9), 9300.0, zref)
+        assert np.array_equal(nparts, onp[0]) and (cubep.ctx.generic_ray_count() > 0 or dt_ is np.float64)
+        np.testing.assert_allclose(wet, ow[0], rtol=0, atol=5 * TIGHT)
+        np.testing.assert_allclose(hyd, oh[0], rtol=0, atol=5 * TIGHT)

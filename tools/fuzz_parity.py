@@ -16,6 +16,7 @@ from oracle import raider_oracle as O       # noqa: E402
 ntrials = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 rng = np.random.default_rng(seed)
+rng2 = np.random.default_rng(seed + 1_000_003)
 worst = dict(wet=0.0, hydro=0.0)
 bad = []
 stats = dict(trials=0, lcc_trials=0, stere_trials=0, dateline_trials=0, all_nan_slices=0, no_level_slices=0, nan_rays=0, rays=0)
@@ -65,6 +66,13 @@ for trial in range(ntrials):
     xpts = np.linspace(lon_c - f * dlon, lon_c + f * dlon, gx)
     ht = float(rng.choice([0.0, -80.0, 250.0, 1234.5, 3000.0, float(c['zs'][3]), float(c['zs'].max() + 5.0)]))
     zref = float(min(rng.choice([c['zs'].max() - 1, 0.6 * c['zs'].max(), c['zs'].max() + 500.0]), c['zs'].max() - 1))     # delay.py:86-93
+    # (round 6) an origin ABOVE zref inside zref's own model interval: the reference's one reversed segment (losreader.py:785-808,821).  Drawn from
+    # a second generator so that the trials of earlier seeds stay what they were.
+    if rng2.random() < 0.12:
+        kt = int(np.searchsorted(c['zs'], zref, side='right'))
+        if kt < len(c['zs']) and c['zs'][kt] - zref > 3.0:
+            ht = float(zref + rng2.uniform(1.2, c['zs'][kt] - zref - 0.5))
+            stats['above_zref_trials'] = stats.get('above_zref_trials', 0) + 1
     max_seg = float(rng.choice([1000.0, 1000.0, 400.0, 2500.0]))
     inc = rng.uniform(0, 70, (gy, gx)) if rng.random() < 0.8 else np.full((gy, gx), rng.uniform(15, 50))
     hd = rng.uniform(-180, 180, (gy, gx)) if rng.random() < 0.5 else np.full((gy, gx), -167.9)
