@@ -45,7 +45,7 @@ wet, hydro, nparts = H.run_ray(cube, xpts, ypts, zpts, inc, hd, 8940.0, 400.0)
 ip = list(O.getInterpolators(cube['xs'], cube['ys'], cube['zs'], cube['wet'], cube['hydro']))
 look = lambda ht, llh, xyz, yy: O.look_vectors_from_inc_hd(inc, hd, llh[1], llh[0], llh[2])
 (ow, oh), onp = O.build_cube_ray(xpts, ypts, zpts, look, ip, MAX_SEGMENT_LENGTH=400.0, MAX_TROPO_HEIGHT=8940.0, return_nparts=True)
-assert all((a is None and b is None) or np.array_equal(a, b) for a, b in zip(nparts, onp)), 'nParts (reversed segment)'
+assert all((np.size(a) == 0 and b is None) or (b is not None and np.array_equal(a, b)) for a, b in zip(nparts, onp)), 'nParts (reversed segment)'
 assert (hydro[1:5] > 0).all() and (hydro[5] == 0).all() and np.isfinite(hydro).all()
 out['reversed_segment_max_abs_m'] = float(max(np.abs(ow - wet).max(), np.abs(oh - hydro).max()))
 

@@ -20,6 +20,7 @@ def test_oracle_against_the_live_reference():
     assert out.returncode == 0, out.stderr[-3000:]
     res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
     assert res['ray_max_abs_m'] < 1e-11 and res['zenith_max_rel'] < 1e-15 and res['natives_bit_exact'] and res['makepoints_bit_exact'], res
+    assert res['reversed_segment_max_abs_m'] < 1e-11, res        # (round 6) an origin above zref inside zref's model interval: one reversed segment, positive length
 
 
 OLD_PY = '/opt/conda/bin/python3.9'
@@ -38,4 +39,4 @@ def test_the_reference_in_its_own_generation_of_libraries_gives_the_same_numbers
         pytest.skip('the second interpreter lacks a module: ' + out.stderr.strip().splitlines()[-1])
     assert out.returncode == 0, out.stderr[-3000:]
     res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
-    assert res['numpy'].startswith('1.') and res['ray_max_abs_m'] < 1e-14 and res['zenith_max_rel'] < 1e-15, res
+    assert res['numpy'].startswith('1.') and res['ray_max_abs_m'] < 1e-14 and res['zenith_max_rel'] < 1e-15 and res['reversed_segment_max_abs_m'] < 1e-14, res
