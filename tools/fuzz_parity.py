@@ -17,6 +17,9 @@ ntrials = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 rng = np.random.default_rng(seed)
 rng2 = np.random.default_rng(seed + 1_000_003)
+import os as _os
+MAX_INC = float(_os.environ.get('FUZZ_MAX_INC', '70'))       # incidence range of the per-pixel look vectors (default: the 0-70 deg of rounds 1-5)
+SHORT_SEG = _os.environ.get('FUZZ_SHORT_SEG', '') not in ('', '0')
 worst = dict(wet=0.0, hydro=0.0)
 bad = []
 stats = dict(trials=0, lcc_trials=0, stere_trials=0, dateline_trials=0, all_nan_slices=0, no_level_slices=0, nan_rays=0, rays=0)
@@ -74,7 +77,9 @@ for trial in range(ntrials):
             ht = float(zref + rng2.uniform(1.2, c['zs'][kt] - zref - 0.5))
             stats['above_zref_trials'] = stats.get('above_zref_trials', 0) + 1
     max_seg = float(rng.choice([1000.0, 1000.0, 400.0, 2500.0]))
-    inc = rng.uniform(0, 70, (gy, gx)) if rng.random() < 0.8 else np.full((gy, gx), rng.uniform(15, 50))
+    if SHORT_SEG and rng2.random() < 0.3:
+        max_seg = float(rng2.choice([37.0, 90.0, 150.0]))          # many integration points per level (nParts up to ~100)
+    inc = rng.uniform(0, MAX_INC, (gy, gx)) if rng.random() < 0.8 else np.full((gy, gx), rng.uniform(15, 50))
     hd = rng.uniform(-180, 180, (gy, gx)) if rng.random() < 0.5 else np.full((gy, gx), -167.9)
     nan_los = rng.random() < 0.15
     look = lambda ht_, llh, xyz, yy: O.look_vectors_from_inc_hd(inc, hd, llh[1], llh[0], llh[2])
