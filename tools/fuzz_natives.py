@@ -85,6 +85,22 @@ for trial in range(ntrials):
     pts[rng.random(n) < 0.02] = np.nan
     gw, gh = cube.interp(pts)
     note('interp wet', gw, ip[0](pts), 1e-13, tag); note('interp hydro', gh, ip[1](pts), 1e-13, tag)
+    # ---- the two-epoch station query (cli/raider.py:817-819 + delay.py:116-121), three routes: the blended cube + gather, the blend at the
+    # corners (rdr_interp3_blend), the blend made for the gather with paired x columns (rdr_interp3_blend_cube) - bit-identical to each other,
+    # the first against the oracle's f32 / f64 blend arithmetic
+    if trial % 3 == 0:
+        dt_ = np.float32 if rng.random() < 0.6 else np.float64
+        ea = (wet.astype(dt_), hyd.astype(dt_)); eb = (rng.uniform(0, 0.4, wet.shape).astype(dt_), rng.uniform(1.0, 2.5, hyd.shape).astype(dt_))
+        w1 = float(rng.choice([0.25, 0.5, 0.6041666666666667])); w2 = 1.0 - w1
+        ca = R.Cube(ys, xs, zs, ea[0], ea[1], order='zyx'); cb = R.Cube(ys, xs, zs, eb[0], eb[1], order='zyx')
+        r0 = ca.blend(w1, cb, w2).interp(pts)
+        ipb = list(O.getInterpolators(xs, ys, zs, O.blend_cubes(w1, ea[0], w2, eb[0]), O.blend_cubes(w1, ea[1], w2, eb[1])))
+        note('blend + interp wet', r0[0], ipb[0](pts), 1e-13, tag); note('blend + interp hydro', r0[1], ipb[1](pts), 1e-13, tag)
+        for route, via in (('corners', False), ('paired cube', True)):
+            r1 = ca.interp_blend(w1, cb, w2, pts, via_cube=via)
+            if not (np.array_equal(r0[0], r1[0], equal_nan=True) and np.array_equal(r0[1], r1[1], equal_nan=True)):
+                bad.append(dict(tag, what=f'two-epoch query, {route}', kind='not the bits of blend + interp', dtype=str(np.dtype(dt_))))
+        worst['two-epoch routes (bit identity)'] = 0.0
     # ---- native `interpolate` ------------------------------------------------------------------------------------------------
     nd = int(rng.integers(1, 6))                       # 1-D ... 5-D (test_interpolator.py goes to 4-D)
     shape = tuple(int(rng.integers(2, 24 if nd < 4 else 9)) for _ in range(nd))
