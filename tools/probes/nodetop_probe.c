@@ -15,7 +15,6 @@ void probe_nodetop(const double* lat, const double* lon, const double* los, int6
         double o[3], low[3], high[3], cosf = 1.0, dw = 0.0, dh = 0.0, dmax = 0.0, dlast = 0.0;
         lla2ecef(lat[i], lon[i], ht, &o[0], &o[1], &o[2]);
         const double* l = los + 3 * i;
-        double Lprev = 0.0; int np_prev = 2;
         for (int k = 0; k < K; ++k) {
             if (k == 0) toa(o, l, lo[0], 10, 1.0, low); else { low[0] = high[0]; low[1] = high[1]; low[2] = high[2]; }
             toa(o, l, hi[k], k == 0 ? 10 : 3, cosf, high);
@@ -25,8 +24,6 @@ void probe_nodetop(const double* lat, const double* lon, const double* los, int6
             /* the top sample of level k: is hi[k] a model node? */
             int node = 0;
             for (int z = 0; z < nz; ++z) if (zs[z] == hi[k]) node = 1;
-            if (node && k + 1 < K) {      /* shared top: weight of both segments; computed when the NEXT level's length is known -> do it lagged */ }
-            (void)Lprev; (void)np_prev;
             double plon, plat, ph;
             ecef2lla(high[0], high[1], high[2], &plon, &plat, &ph);
             if (node) {

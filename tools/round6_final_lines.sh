@@ -1,3 +1,5 @@
+# gpurun -- 'bash tools/round6_final_lines.sh'  AFTER tools/round6_digest.sh was run here and its profiles/r06_* committed: the bench lines of the final tree with
+# counters / mix / parity record filled (the digests are keyed by the source hash) + the rocprofv3 --kernel-trace --stats summary of the driver's default command
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/final6
 python bench.py > gpurun_out/final6/bench.json 2> gpurun_out/final6/bench.err
@@ -5,7 +7,6 @@ python bench.py --workload c2 > gpurun_out/final6/bench_c2.json 2> gpurun_out/fi
 python bench.py --workload c5 > gpurun_out/final6/bench_c5.json 2> gpurun_out/final6/bench_c5.err
 python bench.py --per-pixel-ht --no-e2e > gpurun_out/final6/bench_c3b.json 2> gpurun_out/final6/bench_c3b.err
 (cd /tmp && TMPDIR=/tmp timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/final6/kt -- python $GRAFT_REPO_ROOT/bench.py > $GRAFT_REPO_ROOT/gpurun_out/final6/bench_under_rocprof.json 2> $GRAFT_REPO_ROOT/gpurun_out/final6/kt.err)
-bash tools/ab_identity.sh raider_amd/libraider_hip.so raider_amd/libraider_hip.so > /dev/null 2>&1
 python -c "
 import json
 d=json.load(open('gpurun_out/final6/bench.json')); r=d['roofline']
