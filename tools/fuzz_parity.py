@@ -22,6 +22,7 @@ MAX_INC = float(_os.environ.get('FUZZ_MAX_INC', '70'))       # incidence range o
 SHORT_SEG = _os.environ.get('FUZZ_SHORT_SEG', '') not in ('', '0')
 NAN_CUBE = _os.environ.get('FUZZ_NAN_CUBE', '') not in ('', '0')
 TINY_NZ = _os.environ.get('FUZZ_TINY_NZ', '') not in ('', '0')
+DESC_ZX = _os.environ.get('FUZZ_DESC_ZX', '') not in ('', '0')
 worst = dict(wet=0.0, hydro=0.0)
 bad = []
 stats = dict(trials=0, lcc_trials=0, stere_trials=0, dateline_trials=0, all_nan_slices=0, no_level_slices=0, nan_rays=0, rays=0)
@@ -64,6 +65,14 @@ for trial in range(ntrials):
     if proj is None and rng.random() < 0.25:          # latitude axis stored north to south (scipy's RGI flips descending axes, _rgi.py:280-281)
         c['ys'] = c['ys'][::-1].copy(); c['wet'] = c['wet'][:, ::-1, :].copy(); c['hydro'] = c['hydro'][:, ::-1, :].copy()
         axes_kind = str(axes_kind) + '+descending_y'
+    if DESC_ZX and proj is None and rng2.random() < 0.4:       # (round 6) x and / or z axes stored descending too (scipy's RGI flips them, _rgi.py `_check_points`; rdr_cube_create does)
+        if rng2.random() < 0.6:
+            c['zs'] = c['zs'][::-1].copy(); c['wet'] = c['wet'][::-1].copy(); c['hydro'] = c['hydro'][::-1].copy()
+            axes_kind = str(axes_kind) + '+descending_z'
+        if rng2.random() < 0.6:
+            c['xs'] = c['xs'][::-1].copy(); c['wet'] = c['wet'][:, :, ::-1].copy(); c['hydro'] = c['hydro'][:, :, ::-1].copy()
+            axes_kind = str(axes_kind) + '+descending_x'
+        stats['descending_zx_trials'] = stats.get('descending_zx_trials', 0) + 1
     if rng.random() < 0.2:           # float64 fields (the double2 instantiations of the ray kernels)
         c['wet'] = c['wet'].astype(np.float64) * (1 + 1e-9 * rng.standard_normal(c['wet'].shape)); c['hydro'] = c['hydro'].astype(np.float64) * (1 + 1e-9 * rng.standard_normal(c['hydro'].shape))
         axes_kind = str(axes_kind) + '+f64'
@@ -76,9 +85,10 @@ for trial in range(ntrials):
     # (round 6) an origin ABOVE zref inside zref's own model interval: the reference's one reversed segment (losreader.py:785-808,821).  Drawn from
     # a second generator so that the trials of earlier seeds stay what they were.
     if rng2.random() < 0.12:
-        kt = int(np.searchsorted(c['zs'], zref, side='right'))
-        if kt < len(c['zs']) and c['zs'][kt] - zref > 3.0:
-            ht = float(zref + rng2.uniform(1.2, c['zs'][kt] - zref - 0.5))
+        zasc = np.sort(c['zs'])
+        kt = int(np.searchsorted(zasc, zref, side='right'))
+        if kt < len(zasc) and zasc[kt] - zref > 3.0:
+            ht = float(zref + rng2.uniform(1.2, zasc[kt] - zref - 0.5))
             stats['above_zref_trials'] = stats.get('above_zref_trials', 0) + 1
     max_seg = float(rng.choice([1000.0, 1000.0, 400.0, 2500.0]))
     if SHORT_SEG and rng2.random() < 0.3:
@@ -196,7 +206,7 @@ for trial in range(ntrials):
         bad.append(dict(tag, kind='value', d_wet=dw, d_hydro=dh, max_inc=float(inc.max())))
     # the same scene on a DEM: per-pixel origin heights (rdr_rays.hts) against the oracle's per-ray restatement (lon/lat cubes:
     # the C oracle has no projected-model branch); every fourth of these with all heights equal = the slice result, bit for bit
-    if proj is None and not nan_los and trial % 2 == 0:
+    if proj is None and not nan_los and trial % 2 == 0 and 'descending_z' not in str(axes_kind) and 'descending_x' not in str(axes_kind):      # (the C oracle takes ascending x / z)
         from oracle import oracle_c as OC
         equal = trial % 8 == 0
         hts = np.full((gy, gx), ht) if equal else ht + rng.uniform(0.0, rng.choice([30.0, 800.0, 4000.0]), (gy, gx))
