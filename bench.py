@@ -557,7 +557,7 @@ def main():
                          'survey_bytes_note': 'SURVEY 8(d) gather bytes (64 S + 64 per ray) per second of step time over the HBM peak: above 1 because the gathers are '
                                               'cache-served (L1 / L2 / Infinity Cache) - a model rate, not a utilisation; the measured HBM fraction is hbm.step_measured_frac',
                          'dependent_chain_note': 'figures of merit are VALU instructions and dependent-chain length PER EVALUATED SAMPLE (one sample in flight per lane, 4 waves per '
-                                                 'SIMD): round-5/6 A/Bs - 4.2 % fewer VALU bought 1.3 % (pk-diff), 9 % fewer (32-bit ops) bought 4 % (LDS level records) - the kernel '
+                                                 'SIMD): round-5/6 A/Bs - 4.2 % fewer VALU bought 1.3 % (pk-diff), 6.3 % fewer (32-bit bookkeeping) bought 1-4 % box to box (LDS level records), 8.6 % fewer through LDS tiles LOST 7 % - the kernel '
                                                  'is co-limited by the one-sample chain, so only fewer fp64-rate operations per sample or a shorter chain move it',
                          'vgpr': ka_m['vgpr'], 'lds_bytes': ka_m['lds_static'] + ka_m['lds_dynamic'], 'scratch_bytes': ka_m['scratch'],
                          'resources_source': 'hipFuncGetAttributes on the loaded code object + the launch\'s dynamic LDS size',
